@@ -1,0 +1,180 @@
+/*
+ * rabitq_hip.h -- C ABI of librabitq_hip.so, the MI355X (gfx950) engine for the RaBitQ build/query
+ * hot path of kemingy/rabitq.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * The reference has no FFI seam of its own; the seam is cut at the public
+ * methods of `RaBitQ` (src/lib.rs:12), which is exactly what a Rust `extern "C"` block would bind
+ * (INTEGRATION.md shows that binding).  Every entry point cites the reference interface it
+ * replaces as file:line relative to the reference repository root.
+ *
+ * Conventions
+ *   - All functions return rq_status (0 = RQ_OK).  The reference panics (`expect`/`assert!`,
+ *     release profile panic = "abort", Cargo.toml:43) where these return an error; a Rust wrapper
+ *     keeps that behaviour by `expect()`-ing the status.  rq_last_error() gives the message.
+ *   - "host" pointers are ordinary CPU memory; "_device" variants take HIP device pointers
+ *     (hipMalloc) and enqueue on an internal stream, returning after the results are complete.
+ *   - Query entry points are safe to call concurrently on one index (read-only index, per-call
+ *     workspace + stream), as `RaBitQ::query(&self)` is (src/rabitq.rs:268); build/load/dump/free
+ *     are single-caller.
+ *   - Matrices are row-major.  `dim` is the dimension padded to a multiple of 64
+ *     (src/rabitq.rs:168-179).  Ids and positions are u32 (src/rabitq.rs:64-65).
+ */
+#ifndef RABITQ_HIP_H
+#define RABITQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t rq_status;
+enum {
+    RQ_OK = 0,
+    RQ_ERR_INVALID = -1,      /* bad argument (null pointer, probe == 0, topk == 0 ...)            */
+    RQ_ERR_DIM_MISMATCH = -2, /* src/rabitq.rs:165 / :275 assert failures                          */
+    RQ_ERR_IO = -3,           /* src/rabitq.rs:73-155 `expect("open ... error")`                    */
+    RQ_ERR_HIP = -4,          /* a HIP runtime call failed                                         */
+    RQ_ERR_NO_DEVICE = -5,    /* no gfx950 device visible: there is NO CPU fallback                */
+    RQ_ERR_UNSUPPORTED = -6,  /* size outside the engine's limits (documented per function)        */
+    RQ_ERR_EMPTY = -7,        /* heuristic ranker produced no candidate (src/rerank.rs:173 panics) */
+    RQ_ERR_OOM = -8
+};
+
+/* Opaque index handle: the device-resident state of `RaBitQ` (src/rabitq.rs:57-68). */
+typedef struct rq_index rq_index;
+
+/* `Factor`, src/rabitq.rs:21-32 (repr(C), 16 bytes, same field order). */
+typedef struct {
+    float factor_ip, factor_ppc, error_bound, center_distance_square;
+} rq_factor_t;
+
+/* `Metrics`, src/metrics.rs:7-18: process-global counters. */
+typedef struct {
+    uint64_t rough, precise, query, miss;
+} rq_metrics_t;
+
+typedef struct {
+    uint32_t dim;          /* padded dimension */
+    uint32_t k;            /* number of clusters */
+    uint64_t n;            /* number of vectors */
+    uint32_t max_list_len; /* longest IVF list */
+    uint32_t reserved;
+} rq_info_t;
+
+/* ---- library ------------------------------------------------------------------------------- */
+const char *rq_version(void);
+const char *rq_last_error(void);              /* thread-local message of the last failure        */
+rq_status rq_init(int device);                /* select the HIP device for this process          */
+
+/* ---- build: RaBitQ::from_path, src/rabitq.rs:159-265 ---------------------------------------- */
+/* `orthogonal` is the dim x dim rotation P (row-major, P[r][c]); the reference draws it from an
+ * unseeded RNG (src/utils.rs:16-20), so for reproducibility it is an input.  NULL = generate a
+ * Gaussian-QR orthogonal matrix from `seed` (same construction, seeded). */
+rq_status rq_build(const float *base, uint64_t n, uint32_t d, const float *centroids, uint32_t k,
+                   const float *orthogonal, uint64_t seed, rq_index **out);
+/* Same with base/centroids already in device memory (n x d and k x d, row-major f32).  `base` is
+ * only read; the index keeps its own cluster-ordered copy (src/rabitq.rs:245-247). */
+rq_status rq_build_device(const float *d_base, uint64_t n, uint32_t d, const float *d_centroids,
+                          uint32_t k, const float *orthogonal_host, uint64_t seed, rq_index **out);
+/* From .fvecs files exactly as RaBitQ::from_path(base_path, centroid_path). */
+rq_status rq_build_from_path(const char *base_fvecs, const char *centroid_fvecs,
+                             const float *orthogonal, uint64_t seed, rq_index **out);
+
+/* ---- persistence: load_from_dir / dump_to_dir, src/rabitq.rs:84-156 -------------------------- */
+/* Byte-compatible with the crate's five-file directory (vecs framing: src/utils.rs:280-364). */
+rq_status rq_load_dir(const char *dir, rq_index **out);
+rq_status rq_dump_dir(const rq_index *idx, const char *dir);
+void rq_free(rq_index *idx);
+
+/* Construct an index from the reference's in-memory arrays (what load_from_dir ends up with):
+ * base n x dim (cluster order, un-rotated), orthogonal dim x dim, centroids k x dim (rotated;
+ * row j = centroid j), offsets k+1, map_ids n, codes n x dim/64 u64, factors n x 4 f32. */
+rq_status rq_from_arrays(uint32_t dim, uint64_t n, uint32_t k, const float *base,
+                         const float *orthogonal, const float *centroids, const uint32_t *offsets,
+                         const uint32_t *map_ids, const uint64_t *codes, const rq_factor_t *factors,
+                         rq_index **out);
+
+rq_status rq_info(const rq_index *idx, rq_info_t *out);
+/* Copy one array of the index back to host memory (sizes as in rq_from_arrays). */
+enum { RQ_ARR_BASE = 0, RQ_ARR_ORTHOGONAL, RQ_ARR_CENTROIDS, RQ_ARR_OFFSETS, RQ_ARR_MAP_IDS,
+       RQ_ARR_CODES, RQ_ARR_FACTORS };
+rq_status rq_get_array(const rq_index *idx, int which, void *dst, uint64_t dst_bytes);
+/* Device pointer of one array (valid until rq_free); for zero-copy hand-over to a caller that
+ * already lives on the GPU. */
+rq_status rq_get_device_ptr(const rq_index *idx, int which, const void **out_ptr, uint64_t *out_bytes);
+
+/* ---- query: RaBitQ::query, src/rabitq.rs:268-333 --------------------------------------------- */
+/* One query of `len` floats (dim must equal ceil(len/64)*64, :275).  out_dist/out_id need room for
+ * topk entries; *out_n receives the number written (<= topk).  Heap ranker results come in the
+ * reference's heap-internal order (src/rerank.rs:108-113); heuristic results sorted ascending. */
+rq_status rq_query(const rq_index *idx, const float *query, uint32_t len, uint32_t probe,
+                   uint32_t topk, int heuristic_rank, float *out_dist, uint32_t *out_id,
+                   uint32_t *out_n);
+/* B independent queries (row-major B x len); the form the GPU wants.  Results of query b are at
+ * out_dist/out_id[b*topk ...], count in out_n[b].  Each query's result is identical to rq_query's. */
+rq_status rq_query_batch(const rq_index *idx, const float *queries, uint32_t nq, uint32_t len,
+                         uint32_t probe, uint32_t topk, int heuristic_rank, float *out_dist,
+                         uint32_t *out_id, uint32_t *out_n);
+/* Same with queries and outputs in device memory. */
+rq_status rq_query_batch_device(const rq_index *idx, const float *d_queries, uint32_t nq,
+                                uint32_t len, uint32_t probe, uint32_t topk, int heuristic_rank,
+                                float *d_out_dist, uint32_t *d_out_id, uint32_t *d_out_n);
+
+/* ---- metrics: METRICS, src/metrics.rs:65 ------------------------------------------------------ */
+rq_status rq_metrics(rq_metrics_t *out);
+rq_status rq_metrics_reset(void);
+
+/* ---- per-stage entry points (each hot kernel testable in isolation; all host pointers) -------- */
+/* Rotation X' = X P in the reference's `project` order (src/utils.rs:237-258, src/simd.rs:257-314):
+ * x is n x dim, out is n x dim.  use_mfma = 1 runs the MFMA kernel (bit-identical by construction),
+ * 0 the VALU kernel. */
+rq_status rq_rotate(const float *x, uint64_t n, uint32_t dim, const float *orthogonal, int use_mfma,
+                    float *out);
+/* Nearest rotated centroid + residual sign-pack + factors for already-rotated vectors
+ * (src/utils.rs:261-277, :53-67; src/rabitq.rs:203-229): out_label n, out_dist n,
+ * out_codes n x dim/64, out_factors n. */
+rq_status rq_quantize_pack(const float *x_rot, uint64_t n, uint32_t dim, const float *centroids_rot,
+                           uint32_t k, uint32_t *out_label, float *out_dist, uint64_t *out_codes,
+                           rq_factor_t *out_factors);
+/* Rotate + coarse-rank a query batch (src/rabitq.rs:282-297): out_y nq x dim (may be NULL),
+ * out_cluster / out_dist nq x min(probe,k). */
+rq_status rq_coarse_rank(const rq_index *idx, const float *queries, uint32_t nq, uint32_t len,
+                         uint32_t probe, float *out_y, uint32_t *out_cluster, float *out_dist);
+/* Per-(query,cluster) query quantisation (src/rabitq.rs:304-317; src/simd.rs:117-247, :83-107):
+ * y is nq x dim rotated queries, cluster[i] is the cluster paired with y row i.
+ * out_planes nq x 4*dim/64 u64. */
+rq_status rq_query_prep(const rq_index *idx, const float *y, uint32_t nq, const uint32_t *cluster,
+                        float *out_lower, float *out_delta, uint32_t *out_sum, uint64_t *out_planes);
+/* calculate_rough_distance (src/rabitq.rs:336-367) for the whole list of `cluster` with the
+ * given query-side scalars and bit planes; out_rough needs list-length floats. */
+rq_status rq_scan(const rq_index *idx, uint32_t cluster, float y_c_distance_square,
+                  const uint64_t *planes, float lower_bound, float scalar_sum, float delta,
+                  float *out_rough);
+/* Exact f32 L2 rerank distance (src/simd.rs:14-73 order) of the padded, un-rotated query against
+ * base rows at cluster-order positions pos[0..m) (src/rerank.rs:85-90). */
+rq_status rq_rerank(const rq_index *idx, const float *query_padded, const uint32_t *pos, uint32_t m,
+                    float *out_accurate);
+
+/* ---- instrumentation ------------------------------------------------------------------------- */
+/* Per-kernel device time of the LAST rq_query_batch* call on this thread, measured with HIP events
+ * on the stream the kernels ran on.  Names: "rotate", "coarse", "select", "prep", "scan",
+ * "rerank", "sort", "replay", "total".  Also the algorithmic bytes the scan launches covered
+ * (sum over probed lists of len * (dim/8 + 16)) and the number of scan launches. */
+typedef struct {
+    float ms_rotate, ms_coarse, ms_select, ms_prep, ms_group, ms_scan, ms_rerank, ms_sort, ms_replay,
+        ms_total;
+    uint64_t scan_bytes;       /* algorithmic bytes over all scan launches of the call */
+    uint64_t scan_candidates;  /* (query, candidate) pairs scanned                      */
+    uint64_t rerank_candidates;/* accurate distances computed (superset of `precise`)   */
+    uint32_t scan_launches;
+    uint32_t retries;          /* queries re-run because a survivor buffer overflowed   */
+} rq_profile_t;
+rq_status rq_set_profiling(int enabled);
+rq_status rq_last_profile(rq_profile_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

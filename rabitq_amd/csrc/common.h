@@ -1,0 +1,77 @@
+// common.h -- shared device helpers for the gfx950 RaBitQ kernels.
+//
+// Parity rules (SURVEY.md section 7 "hard parts" 3): the reference evaluates every f32 expression
+// left to right with one rounding per operation (rustc never contracts), uses FMA only where
+// src/simd.rs calls _mm256_fmadd_ps, and IEEE sqrt/div.  This translation unit is therefore built
+// with -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt, keeps f32 subnormals (hipcc
+// default), and writes fmaf() explicitly where -- and only where -- the reference fuses.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+#define RQ_WAVE 64
+
+// ---- src/ord32.rs:12-26: monotone f32 <-> i32 key ----------------------------------------------
+__host__ __device__ __forceinline__ int32_t ord32_from_f32(float x) {
+    int32_t bits = __builtin_bit_cast(int32_t, x);
+    uint32_t mask = ((uint32_t)(bits >> 31)) >> 1;
+    return bits ^ (int32_t)mask;
+}
+__host__ __device__ __forceinline__ float ord32_to_f32(int32_t key) {
+    uint32_t mask = ((uint32_t)(key >> 31)) >> 1;
+    return __builtin_bit_cast(float, key ^ (int32_t)mask);
+}
+// unsigned-sortable form of the same key (for radix select / u64 composite keys)
+__host__ __device__ __forceinline__ uint32_t ord32_biased(float x) {
+    return (uint32_t)ord32_from_f32(x) ^ 0x80000000u;
+}
+__host__ __device__ __forceinline__ float ord32_unbias(uint32_t u) {
+    return ord32_to_f32((int32_t)(u ^ 0x80000000u));
+}
+
+// ---- src/simd.rs:52-63: fold 8 AVX lanes held by 8 consecutive GPU lanes -------------------------
+// ((a0+a4)+(a1+a5)) + ((a2+a6)+(a3+a7)); float add is commutative, so an xor butterfly in the
+// order 4, 1, 2 leaves the exact AVX result in all 8 lanes.
+__device__ __forceinline__ float reduce8_lanes(float acc) {
+    acc = acc + __shfl_xor(acc, 4, 8);
+    acc = acc + __shfl_xor(acc, 1, 8);
+    acc = acc + __shfl_xor(acc, 2, 8);
+    return acc;
+}
+// same fold for 8 accumulators held in one thread
+__device__ __forceinline__ float reduce8_regs(const float (&a)[8]) {
+    float c0 = a[0] + a[4], c1 = a[1] + a[5], c2 = a[2] + a[6], c3 = a[3] + a[7];
+    return (c0 + c1) + (c2 + c3);
+}
+
+// _mm256_cvtps_epi32 (src/simd.rs:215): round to nearest even; NaN / out of range -> 0x80000000
+__device__ __forceinline__ int32_t cvtps_epi32(float x) {
+    if (x >= -2147483648.0f && x < 2147483648.0f) return (int32_t)rintf(x);
+    return (int32_t)0x80000000;
+}
+
+// Survivor record produced by the scan kernel and consumed by rerank / sort / replay.
+struct __attribute__((aligned(16))) SurvRec {
+    uint32_t pos;    // cluster-order position j (src/rabitq.rs:348)
+    uint32_t slot;   // rank of the list in the query's probe order (src/rabitq.rs:304)
+    float rough;     // src/rabitq.rs:352-363
+    float accurate;  // filled by the rerank kernel (src/rerank.rs:85-90)
+};
+__device__ __forceinline__ uint64_t surv_key(const SurvRec &r) {
+    return ((uint64_t)r.slot << 32) | r.pos;
+}
+
+// Per-(query, probe slot) scalars written by the prep kernel, 32 bytes so a wave can fetch them
+// with one s_load_dwordx8.
+struct __attribute__((aligned(32))) PairScalars {
+    float lower;      // lower_bound                      (src/rabitq.rs:305)
+    float delta;      // (hi - lo) * SCALAR               (:307)
+    float sumq;       // scalar_sum as f32                (:322)
+    float ycd;        // y_c_distance_square              (:319)
+    float ycd_sqrt;   // dist_sqrt                        (:346)
+    uint32_t row;         // query row b of this pair (pair id p = row * nprobe + slot)
+    uint32_t list_begin;  // offsets[cluster]
+    uint32_t list_len;
+};

@@ -1,0 +1,359 @@
+// kernels_build.h -- gfx950 kernels for RaBitQ::from_path (src/rabitq.rs:159-265).
+#pragma once
+#include "common.h"
+#include "kernels_query.h"
+
+#pragma clang fp contract(off)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------
+// Rotation X' = X P on the matrix cores (src/rabitq.rs:188-189; query side src/utils.rs:237-258).
+//
+// Bit-exact with the reference's AVX2 `vector_dot_product` order (src/simd.rs:257-314) BY
+// CONSTRUCTION: that routine keeps 8 independent accumulators, lane l running the fused chain
+//     acc_l = fma(x[8c+l], P[8c+l][j], acc_l)   for c = 0, 1, ...
+// and folds them as ((a0+a4)+(a1+a5)) + ((a2+a6)+(a3+a7)).  v_mfma_f32_32x32x2_f32 computes, per
+// output element, D = fma(A[i][1], B[1][j], fma(A[i][0], B[0][j], C)) -- a k-ordered f32 fmaf
+// chain with one rounding per product.  So each AVX lane l gets its OWN 32x32 accumulator tile,
+// fed with k = 8c + l for consecutive chunk pairs (c, c+1); eight tiles (128 accumulator VGPRs)
+// are folded in the AVX order in the epilogue.  Same flops as a plain GEMM (2*dim per output).
+//
+// block = 256 threads = 4 waves as 2(M) x 2(N); block tile 64 rows x 64 cols; K streamed through
+// LDS in slabs of 64 (X slab padded to 65 floats per row: conflict-free ds_read_b32 down a column).
+// ------------------------------------------------------------------------------------------------
+#define ROT_BM 64
+#define ROT_BN 64
+#define ROT_BK 64
+__global__ __launch_bounds__(256) void rotate_mfma_kernel(const float *__restrict__ x,
+                                                          const float *__restrict__ P,
+                                                          float *__restrict__ out, uint64_t n,
+                                                          uint32_t dim) {
+    __shared__ float Xs[ROT_BM][ROT_BK + 1];
+    __shared__ __attribute__((aligned(16))) float Ps[ROT_BK][ROT_BN];
+    const uint32_t ncol_tiles = dim / ROT_BN;
+    const uint64_t row_tile = blockIdx.x / ncol_tiles;
+    const uint32_t col_tile = blockIdx.x - row_tile * ncol_tiles;
+    const uint64_t row0 = row_tile * ROT_BM;
+    const uint32_t col0 = col_tile * ROT_BN;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t wr = wave >> 1, wc = wave & 1;
+    const uint32_t li = lane & 31, kk = lane >> 5;
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int l = 0; l < 8; ++l)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[l][r] = 0.0f;
+
+    for (uint32_t k0 = 0; k0 < dim; k0 += ROT_BK) {
+        // stage X[row0..+64][k0..+64] and P[k0..+64][col0..+64]
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            uint32_t idx = tid + 256 * it;  // 0..1023 float4 slots
+            uint32_t rr = idx >> 4, c4 = (idx & 15) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + rr < n) v = *reinterpret_cast<const float4 *>(x + (row0 + rr) * dim + k0 + c4);
+            Xs[rr][c4] = v.x, Xs[rr][c4 + 1] = v.y, Xs[rr][c4 + 2] = v.z, Xs[rr][c4 + 3] = v.w;
+            float4 p = *reinterpret_cast<const float4 *>(P + (uint64_t)(k0 + rr) * dim + col0 + c4);
+            *reinterpret_cast<float4 *>(&Ps[rr][c4]) = p;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int cp = 0; cp < ROT_BK / 16; ++cp) {
+            const uint32_t kbase = 8 * (2 * cp + kk);  // this half-wave's chunk inside the slab
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                float a = Xs[wr * 32 + li][kbase + l];
+                float b = Ps[kbase + l][wc * 32 + li];
+                acc[l] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[l], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // epilogue: AVX fold per element; C/D map: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float c0 = acc[0][r] + acc[4][r], c1 = acc[1][r] + acc[5][r];
+        float c2 = acc[2][r] + acc[6][r], c3 = acc[3][r] + acc[7][r];
+        float v = (c0 + c1) + (c2 + c3);
+        uint64_t row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (row < n) out[row * dim + col0 + wc * 32 + li] = v;
+    }
+}
+
+// transpose k x dim -> dim x k (rotated centroids for the coalesced lane<->centroid kernels)
+__global__ void transpose_kernel(const float *__restrict__ in, float *__restrict__ out, uint32_t rows,
+                                 uint32_t cols) {
+    __shared__ float t[32][33];
+    uint32_t c = blockIdx.x * 32 + threadIdx.x, r = blockIdx.y * 32 + threadIdx.y;
+    for (int i = 0; i < 32; i += 8)
+        if (r + i < rows && c < cols) t[threadIdx.y + i][threadIdx.x] = in[(uint64_t)(r + i) * cols + c];
+    __syncthreads();
+    uint32_t oc = blockIdx.y * 32 + threadIdx.x, orow = blockIdx.x * 32 + threadIdx.y;
+    for (int i = 0; i < 32; i += 8)
+        if (orow + i < cols && oc < rows) out[(uint64_t)(orow + i) * rows + oc] = t[threadIdx.x][threadIdx.y + i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// kmeans_nearest_cluster (src/utils.rs:261-277): label = first argmin_j l2_squared_distance(c'_j, x')
+// with strict `<` from (0, f32::MAX), every distance in the exact order of src/simd.rs:14-73.
+//
+// Fast path, dim <= 128: lane <-> vector with the whole rotated vector in VGPRs; centroids are
+// streamed through LDS in tiles and read as wave-uniform broadcasts, so the inner loop is pure
+// VALU (v_sub + v_fma per element) and each lane sees centroids in ascending j, which gives the
+// reference's first-minimum tie-break with no cross-lane traffic at all.
+// ------------------------------------------------------------------------------------------------
+#define ASSIGN_CT 32
+template <int DIM>
+__global__ __launch_bounds__(256) void assign_regs_kernel(const float *__restrict__ xrot,
+                                                          const float *__restrict__ centroids, uint64_t n,
+                                                          uint32_t k, uint32_t *__restrict__ label,
+                                                          float *__restrict__ dist) {
+    __shared__ __attribute__((aligned(16))) float cs[ASSIGN_CT][DIM];
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n;
+    float xv[DIM];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(xrot + (live ? i : 0) * DIM);
+#pragma unroll
+        for (int e = 0; e < DIM / 4; ++e) {
+            float4 v = src[e];
+            xv[4 * e] = v.x, xv[4 * e + 1] = v.y, xv[4 * e + 2] = v.z, xv[4 * e + 3] = v.w;
+        }
+    }
+    float best = 3.402823466e+38f;
+    uint32_t lab = 0;
+    for (uint32_t j0 = 0; j0 < k; j0 += ASSIGN_CT) {
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < ASSIGN_CT * DIM / 4; t += 256) {
+            uint32_t row = t / (DIM / 4), c4 = t - row * (DIM / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j0 + row < k) v = reinterpret_cast<const float4 *>(centroids + (uint64_t)(j0 + row) * DIM)[c4];
+            reinterpret_cast<float4 *>(&cs[row][0])[c4] = v;
+        }
+        __syncthreads();
+        const uint32_t lim = (k - j0) < ASSIGN_CT ? (k - j0) : ASSIGN_CT;
+        for (uint32_t ct = 0; ct < lim; ++ct) {
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < DIM; c += 8) {
+#pragma unroll
+                for (int l = 0; l < 8; ++l) {
+                    float d = cs[ct][c + l] - xv[c + l];
+                    acc[l] = fmaf(d, d, acc[l]);
+                }
+            }
+            float dd = reduce8_regs(acc);
+            if (dd < best) {
+                best = dd;
+                lab = j0 + ct;
+            }
+        }
+    }
+    if (live) {
+        label[i] = lab;
+        dist[i] = best;
+    }
+}
+
+// Generic path (any dim): lane <-> centroid over the transposed centroids, VT vectors per block in
+// LDS, block-wide argmin on the unique composite key (biased Ord32(dist) << 32 | j): the minimum
+// of that key is the first minimum.
+template <int VT>
+__global__ __launch_bounds__(256) void assign_generic_kernel(const float *__restrict__ xrot,
+                                                             const float *__restrict__ cent_t, uint64_t n,
+                                                             uint32_t k, uint32_t dim,
+                                                             uint32_t *__restrict__ label,
+                                                             float *__restrict__ dist) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // VT * dim
+    __shared__ unsigned long long red[VT][4];
+    const uint64_t i0 = (uint64_t)blockIdx.x * VT;
+    for (uint32_t t = threadIdx.x; t < VT * dim; t += 256) {
+        uint32_t v = t / dim, e = t - v * dim;
+        xs[t] = (i0 + v < n) ? xrot[(i0 + v) * dim + e] : 0.0f;
+    }
+    __syncthreads();
+    unsigned long long bestkey[VT];
+#pragma unroll
+    for (int v = 0; v < VT; ++v) bestkey[v] = ((unsigned long long)ord32_biased(3.402823466e+38f) << 32);
+    for (uint32_t j = threadIdx.x; j < k; j += 256) {
+        float acc[VT][8];
+#pragma unroll
+        for (int v = 0; v < VT; ++v)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) acc[v][l] = 0.0f;
+        for (uint32_t c = 0; c < dim; c += 8) {
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                float ce = cent_t[(uint64_t)(c + l) * k + j];
+#pragma unroll
+                for (int v = 0; v < VT; ++v) {
+                    float d = ce - xs[v * dim + c + l];
+                    acc[v][l] = fmaf(d, d, acc[v][l]);
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            float dd = reduce8_regs(acc[v]);
+            // strict `<` against f32::MAX start: NaN and >= MAX never win (utils.rs:271)
+            if (dd < 3.402823466e+38f) {
+                unsigned long long key = ((unsigned long long)ord32_biased(dd) << 32) | j;
+                bestkey[v] = key < bestkey[v] ? key : bestkey[v];
+            }
+        }
+    }
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+        unsigned long long key = bestkey[v];
+        for (int o = 32; o >= 1; o >>= 1) {
+            unsigned long long other = __shfl_xor(key, o, 64);
+            key = other < key ? other : key;
+        }
+        if (lane == 0) red[v][wave] = key;
+    }
+    __syncthreads();
+    if (threadIdx.x < VT && i0 + threadIdx.x < n) {
+        unsigned long long key = red[threadIdx.x][0];
+        for (int w = 1; w < 4; ++w) key = red[threadIdx.x][w] < key ? red[threadIdx.x][w] : key;
+        label[i0 + threadIdx.x] = (uint32_t)key;
+        dist[i0 + threadIdx.x] = ord32_unbias((uint32_t)(key >> 32));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Residual sign-pack + factors (src/rabitq.rs:205-229, src/utils.rs:53-67).  8 lanes per vector,
+// lane l <-> AVX lane l (elements 8c + l):
+//   sq   = l2_squared_distance(x', c')           (faer norm_l2 at :206 -> sqrtf of the AVX-ordered sum)
+//   code bit e = (x'_e - c'_e > 0)               (strict, utils.rs:56)
+//   num  = <r, sign(r)> in vector_dot_product order (faer inner product at :212)
+//   ip   = num / (norm*sqrt(dim)) if that norm is_normal else 0.8          (:210-215)
+//   error_bound = (2*1.9/sqrt(dim-1)) * sqrt((norm/ip)^2 - norm^2), factor_ip = -2/sqrt(dim) * norm/ip,
+//   factor_ppc = factor_ip * (2*popcount - dim)                            (:220-229)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void quantize_kernel(const float *__restrict__ xrot,
+                                                       const float *__restrict__ centroids,
+                                                       const uint32_t *__restrict__ label, uint64_t n,
+                                                       uint32_t dim, uint64_t *__restrict__ codes,
+                                                       float4 *__restrict__ factors) {
+    const uint32_t l = threadIdx.x & 7;
+    const uint64_t i = (uint64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    if (i >= n) return;
+    const float *x = xrot + i * dim;
+    const float *c = centroids + (uint64_t)label[i] * dim;
+    const uint32_t W = dim >> 6;
+    float acc_sq = 0.0f, acc_dot = 0.0f;
+    uint32_t pop = 0;
+    for (uint32_t w = 0; w < W; ++w) {
+        uint32_t lo32 = 0, hi32 = 0;
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+            uint32_t e = 64 * w + 8 * cc + l;
+            float xe = x[e], ce = c[e];
+            float r = xe - ce;  // rabitq.rs:205
+            acc_sq = fmaf(r, r, acc_sq);
+            bool posv = r > 0.0f;
+            float sg = posv ? 1.0f : -1.0f;
+            acc_dot = fmaf(r, sg, acc_dot);
+            uint32_t bit = posv ? 1u : 0u;
+            pop += bit;
+            if (cc < 4) lo32 |= bit << (8 * cc + l);
+            else hi32 |= bit << (8 * (cc - 4) + l);
+        }
+        for (int o = 1; o < 8; o <<= 1) {
+            lo32 |= __shfl_xor(lo32, o, 8);
+            hi32 |= __shfl_xor(hi32, o, 8);
+        }
+        if (l == 0) codes[i * W + w] = ((uint64_t)hi32 << 32) | lo32;
+    }
+    float sq = reduce8_lanes(acc_sq);
+    float num = reduce8_lanes(acc_dot);
+    for (int o = 1; o < 8; o <<= 1) pop += __shfl_xor(pop, o, 8);
+    if (l == 0) {
+        const float dim_sqrt = sqrtf((float)dim);
+        float norm = sqrtf(sq);
+        float cds = norm * norm;
+        float nd = norm * dim_sqrt;
+        float and_ = fabsf(nd);
+        bool normal = (and_ >= 1.17549435e-38f) && (and_ <= 3.402823466e+38f);  // f32::is_normal
+        float ip = normal ? num / nd : 0.8f;
+        float over = norm / ip;
+        const float error_base = 2.0f * 1.9f / sqrtf((float)dim - 1.0f);
+        float4 f;
+        f.z = error_base * sqrtf(over * over - cds);     // error_bound
+        f.x = -2.0f / dim_sqrt * over;                   // factor_ip
+        f.y = f.x * (float)(2 * (int)pop - (int)dim);    // factor_ppc
+        f.w = cds;                                       // center_distance_square
+        factors[i] = f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cluster ordering (src/rabitq.rs:232-252): per-list stable sort by centroid distance (ties keep
+// ascending original id), offsets = prefix sum, gather base/codes/factors.  The composite key
+// (biased Ord32(dist) << 32 | id) is unique, so bucketing with atomics followed by an ordinary
+// per-list sort of that key yields exactly the stable order.
+// ------------------------------------------------------------------------------------------------
+__global__ void label_hist_kernel(const uint32_t *__restrict__ label, uint64_t n, uint32_t *__restrict__ cnt) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&cnt[label[i]], 1u);
+}
+
+__global__ void label_scatter_kernel(const uint32_t *__restrict__ label, const float *__restrict__ dist,
+                                     uint64_t n, uint64_t id0, const uint32_t *__restrict__ offsets,
+                                     uint32_t *__restrict__ cursor, unsigned long long *__restrict__ keys) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t c = label[i];
+    uint32_t at = atomicAdd(&cursor[c], 1u);
+    keys[(uint64_t)offsets[c] + at] = ((unsigned long long)ord32_biased(dist[i]) << 32) | (uint32_t)(id0 + i);
+}
+
+#define RQ_LISTSORT_LDS 8192
+__global__ __launch_bounds__(1024) void list_sort_kernel(unsigned long long *__restrict__ keys,
+                                                         const uint32_t *__restrict__ offsets) {
+    __shared__ unsigned long long lds[RQ_LISTSORT_LDS];
+    const uint32_t c = blockIdx.x;
+    const uint32_t b = offsets[c], n = offsets[c + 1] - b;
+    if (n < 2) return;
+    unsigned long long *seg = keys + b;
+    auto key = [](unsigned long long v) { return v; };
+    if (n <= RQ_LISTSORT_LDS) {
+        for (uint32_t i = threadIdx.x; i < n; i += 1024) lds[i] = seg[i];
+        __syncthreads();
+        bitonic_sort_block(lds, n, key);
+        for (uint32_t i = threadIdx.x; i < n; i += 1024) seg[i] = lds[i];
+    } else {
+        bitonic_sort_block(seg, n, key);
+    }
+}
+
+// gather into cluster order: one wave per destination position
+__global__ __launch_bounds__(256) void gather_kernel(const unsigned long long *__restrict__ keys, uint64_t n,
+                                                     const float *__restrict__ base_in, uint32_t d,
+                                                     uint32_t dim, const uint64_t *__restrict__ codes_in,
+                                                     const float4 *__restrict__ factors_in,
+                                                     float *__restrict__ base_out,
+                                                     uint64_t *__restrict__ codes_out,
+                                                     float4 *__restrict__ factors_out,
+                                                     uint32_t *__restrict__ map_ids) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t p = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= n) return;
+    const uint32_t id = (uint32_t)keys[p];
+    const uint32_t W = dim >> 6;
+    for (uint32_t e = lane; e < dim; e += 64)
+        base_out[p * dim + e] = e < d ? base_in[(uint64_t)id * d + e] : 0.0f;
+    for (uint32_t w = lane; w < W; w += 64) codes_out[p * W + w] = codes_in[(uint64_t)id * W + w];
+    if (lane == 0) {
+        factors_out[p] = factors_in[id];
+        map_ids[p] = id;
+    }
+}
+
+__global__ void max_list_len_kernel(const uint32_t *__restrict__ offsets, uint32_t k, uint32_t *__restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k) atomicMax(out, offsets[i + 1] - offsets[i]);
+}

@@ -1,0 +1,869 @@
+// kernels_query.h -- gfx950 kernels for RaBitQ::query (src/rabitq.rs:268-367, src/rerank.rs).
+//
+// Mapping (MI355X-first, not a translation of the reference's per-vector SIMD loop):
+//   * candidates live one-per-lane in VGPRs (code words + Factor), queries stream through the
+//     scalar unit: every per-query operand (bit planes, lower/delta/sum, threshold) is
+//     wave-uniform, so it is fetched with s_load and fed to VALU ops as an SGPR operand.  A list is
+//     read from HBM once per launch and scored against every query of the batch that probes it.
+//   * the scan filters against the per-query re-rank threshold in-kernel and emits only
+//     survivors; exact f32 distances are computed for survivors only; an ordered replay of the
+//     reference's heap logic over (rough, accurate) pairs reproduces its result id-for-id.
+#pragma once
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+// ------------------------------------------------------------------------------------------------
+// zero-pad queries to the padded dimension (src/rabitq.rs:277-280)
+// ------------------------------------------------------------------------------------------------
+__global__ void pad_rows_kernel(const float *__restrict__ in, float *__restrict__ out, uint64_t n,
+                                uint32_t len, uint32_t dim) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * dim) return;
+    uint64_t r = i / dim;
+    uint32_t c = (uint32_t)(i - r * dim);
+    out[i] = c < len ? in[r * len + c] : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Rotation, VALU form: out[r][j] = vector_dot_product(x[r], P[:, j]) in the exact AVX2 order
+// (src/utils.rs:237-258 -> src/simd.rs:257-314): 8 accumulators acc[l] = fma(x[8c+l], P[8c+l][j],
+// acc[l]) over chunks c, then the fixed fold.  block (64,4): lane <-> column j (coalesced P reads),
+// x[r][*] is a wave-uniform broadcast.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rotate_valu_kernel(const float *__restrict__ x,
+                                                          const float *__restrict__ P,
+                                                          float *__restrict__ out, uint64_t n,
+                                                          uint32_t dim) {
+    uint64_t r = (uint64_t)blockIdx.x * 4 + threadIdx.y;
+    uint32_t j = blockIdx.y * 64 + threadIdx.x;
+    if (r >= n) return;
+    const float *xr = x + r * dim;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t c = 0; c < dim; c += 8) {
+#pragma unroll
+        for (int l = 0; l < 8; ++l) acc[l] = fmaf(xr[c + l], P[(uint64_t)(c + l) * dim + j], acc[l]);
+    }
+    out[r * dim + j] = reduce8_regs(acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Coarse distances (src/rabitq.rs:285-293): dist[q][j] = l2_squared_distance(centroid_j, y_q) in
+// the exact order of src/simd.rs:14-73 (diff rounded, then fused square-accumulate per AVX lane).
+// lane <-> centroid j over the TRANSPOSED rotated centroids cent_t[dim][k] (coalesced; this is also
+// the reference's on-disk centroids.fvecs layout), QT queries per thread held in LDS (broadcast).
+// ------------------------------------------------------------------------------------------------
+template <int QT>
+__global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restrict__ cent_t,
+                                                          const float *__restrict__ y,
+                                                          float *__restrict__ dist, uint32_t k,
+                                                          uint32_t dim, uint32_t nq) {
+    extern __shared__ __attribute__((aligned(16))) float ys[];  // QT * dim
+    const uint32_t q0 = blockIdx.x * QT;
+    const uint32_t j = blockIdx.y * 256 + threadIdx.x;
+    for (uint32_t i = threadIdx.x; i < QT * dim; i += 256) {
+        uint32_t v = i / dim, e = i - v * dim;
+        ys[i] = (q0 + v < nq) ? y[(uint64_t)(q0 + v) * dim + e] : 0.0f;
+    }
+    __syncthreads();
+    float acc[QT][8];
+#pragma unroll
+    for (int v = 0; v < QT; ++v)
+#pragma unroll
+        for (int l = 0; l < 8; ++l) acc[v][l] = 0.0f;
+    const bool live = j < k;
+    for (uint32_t c = 0; c < dim; c += 8) {
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            float ce = live ? cent_t[(uint64_t)(c + l) * k + j] : 0.0f;
+#pragma unroll
+            for (int v = 0; v < QT; ++v) {
+                float d = ce - ys[v * dim + c + l];
+                acc[v][l] = fmaf(d, d, acc[v][l]);
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int v = 0; v < QT; ++v)
+            if (q0 + v < nq) dist[(uint64_t)(q0 + v) * k + j] = reduce8_regs(acc[v]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bitonic sort (flip / disperse form: every compare-exchange puts the smaller element at the lower
+// index, so elements at index >= n can be treated as +inf and are never touched).
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename KeyFn>
+__device__ __forceinline__ void bitonic_sort_block(T *a, uint32_t n, KeyFn key) {
+    if (n < 2) return;
+    uint32_t p2 = 1;
+    while (p2 < n) p2 <<= 1;
+    const uint32_t half = p2 >> 1;
+    for (uint32_t k = 2; k <= p2; k <<= 1) {
+        // flip
+        for (uint32_t t = threadIdx.x; t < half; t += blockDim.x) {
+            uint32_t hk = k >> 1;
+            uint32_t blk = t / hk, off = t - blk * hk;
+            uint32_t i = blk * k + off, j = blk * k + k - 1 - off;
+            if (j < n) {
+                T ai = a[i], aj = a[j];
+                if (key(aj) < key(ai)) {
+                    a[i] = aj;
+                    a[j] = ai;
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t s = k >> 2; s >= 1; s >>= 1) {
+            for (uint32_t t = threadIdx.x; t < half; t += blockDim.x) {
+                uint32_t i = (t / s) * (2 * s) + (t % s), j = i + s;
+                if (j < n) {
+                    T ai = a[i], aj = a[j];
+                    if (key(aj) < key(ai)) {
+                        a[i] = aj;
+                        a[j] = ai;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Probe selection (src/rabitq.rs:294-297): the `nprobe` smallest (distance, cluster id) pairs in
+// ascending order.  total_cmp order == Ord32 order; the composite u64 (biased Ord32 << 32 | id) is
+// unique, so an 8-bit-per-pass radix select finds the nprobe-th key exactly, then the selected keys
+// are bitonic-sorted in LDS.  Exactly-equal distances are ordered by cluster id (the reference's
+// select_nth_unstable leaves that order unspecified).  One 256-thread block per query.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void select_probe_kernel(const float *__restrict__ dist, uint32_t k,
+                                                           uint32_t nprobe,
+                                                           uint32_t *__restrict__ out_cluster,
+                                                           float *__restrict__ out_dist) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint64_t *keys = reinterpret_cast<uint64_t *>(smem_raw);  // nprobe entries
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t s_sel, s_want, s_done, s_cnt;
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const float *d = dist + (uint64_t)b * k;
+
+    uint64_t prefix = 0, mask = 0, T = ~0ull;
+    uint32_t want = nprobe;  // rank (1-based) of the wanted key inside the current prefix group
+    bool done = false;
+    for (int pass = 7; pass >= 0 && !done; --pass) {
+        const int shift = pass * 8;
+        hist[tid] = 0;
+        __syncthreads();
+        for (uint32_t j = tid; j < k; j += 256) {
+            uint64_t key = ((uint64_t)ord32_biased(d[j]) << 32) | j;
+            if ((key & mask) == prefix) atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {  // wave 0: locate the bin holding rank `want`
+            uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            uint32_t s = h0 + h1 + h2 + h3, incl = s;
+            for (int o = 1; o < 64; o <<= 1) {
+                uint32_t up = __shfl_up(incl, o, 64);
+                if ((int)tid >= o) incl += up;
+            }
+            uint32_t excl = incl - s;
+            if (excl < want && want <= incl) {
+                uint32_t r = want - excl, sel, cntbin;
+                if (r <= h0) { sel = 0; cntbin = h0; }
+                else if (r <= h0 + h1) { sel = 1; r -= h0; cntbin = h1; }
+                else if (r <= h0 + h1 + h2) { sel = 2; r -= h0 + h1; cntbin = h2; }
+                else { sel = 3; r -= h0 + h1 + h2; cntbin = h3; }
+                s_sel = 4 * tid + sel;
+                s_want = r;
+                s_done = (cntbin == r) ? 1u : 0u;  // the whole bin is taken: lower bits don't matter
+            }
+        }
+        __syncthreads();
+        prefix |= (uint64_t)s_sel << shift;
+        mask |= 0xFFull << shift;
+        want = s_want;
+        if (s_done) {
+            T = prefix | ~mask;
+            done = true;
+        }
+        __syncthreads();
+    }
+    if (!done) T = prefix;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    for (uint32_t j = tid; j < k; j += 256) {
+        uint64_t key = ((uint64_t)ord32_biased(d[j]) << 32) | j;
+        if (key <= T) {
+            uint32_t p = atomicAdd(&s_cnt, 1u);
+            if (p < nprobe) keys[p] = key;
+        }
+    }
+    __syncthreads();
+    bitonic_sort_block(keys, nprobe, [](uint64_t v) { return v; });
+    for (uint32_t i = tid; i < nprobe; i += 256) {
+        uint64_t key = keys[i];
+        out_cluster[(uint64_t)b * nprobe + i] = (uint32_t)key;
+        out_dist[(uint64_t)b * nprobe + i] = ord32_unbias((uint32_t)(key >> 32));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-(query, probed list) query quantisation (src/rabitq.rs:304-317):
+//   residual = y - c (src/simd.rs:138), (lo, hi) (:143-157), delta = (hi - lo) * (1/15),
+//   q = cvtps_epi32((res - lo) * (1/delta)) (:215, sub then mul, RNE, no bias), sum of q,
+//   4 bit planes, bit b of word w <-> dimension 64w + b (:103).
+// One wave per pair; lane holds dimensions {lane, 64+lane, ...}; a plane word is one __ballot.
+// `pair_cluster[p]` is the list paired with rotated query row `pair_row[p]` (or p / nprobe).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ y,
+                                                   const float *__restrict__ centroids,
+                                                   const uint32_t *__restrict__ offsets,
+                                                   const uint32_t *__restrict__ pair_cluster,
+                                                   const float *__restrict__ pair_ycd, uint32_t npairs,
+                                                   uint32_t pairs_per_row, uint32_t dim,
+                                                   PairScalars *__restrict__ scal,
+                                                   uint64_t *__restrict__ planes,
+                                                   uint32_t *__restrict__ out_sum_u32,
+                                                   unsigned long long *__restrict__ rough_count) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= npairs) return;
+    const uint32_t row = p / pairs_per_row;
+    const uint32_t c = pair_cluster[p];
+    const float *yr = y + (uint64_t)row * dim;
+    const float *cr = centroids + (uint64_t)c * dim;
+    const uint32_t W = dim >> 6;
+    float mn = 3.402823466e+38f, mx = -3.402823466e+38f;
+    for (uint32_t w = 0; w < W; ++w) {
+        float r = yr[64 * w + lane] - cr[64 * w + lane];
+        mn = r < mn ? r : mn;
+        mx = r > mx ? r : mx;
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        float a = __shfl_xor(mn, o, 64), bb = __shfl_xor(mx, o, 64);
+        mn = a < mn ? a : mn;
+        mx = bb > mx ? bb : mx;
+    }
+    const float scalar = 1.0f / 15.0f;          // consts.rs:10
+    const float delta = (mx - mn) * scalar;     // rabitq.rs:307
+    const float one_over_delta = 1.0f / delta;  // :308 f32::recip
+    uint32_t sum = 0;
+    uint64_t *pl = planes + (uint64_t)p * 4 * W;
+    for (uint32_t w = 0; w < W; ++w) {
+        float r = yr[64 * w + lane] - cr[64 * w + lane];
+        int32_t q = cvtps_epi32((r - mn) * one_over_delta);
+        sum += (uint32_t)q;
+#pragma unroll
+        for (int bit = 0; bit < 4; ++bit) {
+            uint64_t word = __ballot((q >> bit) & 1);
+            if (lane == 0) pl[bit * W + w] = word;
+        }
+    }
+    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) {
+        PairScalars s;
+        float ycd = pair_ycd[p];
+        s.lower = mn;
+        s.delta = delta;
+        s.sumq = (float)sum;  // rabitq.rs:322 `scalar_sum as f32`
+        s.ycd = ycd;
+        s.ycd_sqrt = sqrtf(ycd);  // :346
+        s.row = row;
+        s.list_begin = offsets[c];
+        s.list_len = offsets[c + 1] - offsets[c];
+        scal[p] = s;
+        if (out_sum_u32) out_sum_u32[p] = sum;
+        if (rough_count) atomicAdd(rough_count + row, (unsigned long long)s.list_len);  // rerank.rs:105
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Work-list construction for a stage: the (query, slot) pairs with slot in [slot_lo, slot_hi).
+// pair-major: one group per pair.  cluster-major: pairs bucketed by list so that a list is read
+// from HBM once and scored against every query probing it.
+// ------------------------------------------------------------------------------------------------
+__global__ void enumerate_pairs_kernel(uint32_t nq, uint32_t nprobe, uint32_t slot_lo, uint32_t ns,
+                                       uint32_t *__restrict__ pair_list) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq * ns) return;
+    uint32_t b = i / ns, s = slot_lo + (i - b * ns);
+    pair_list[i] = b * nprobe + s;
+}
+
+__global__ void group_count_kernel(const uint32_t *__restrict__ probe_cluster, uint32_t nq, uint32_t nprobe,
+                                   uint32_t slot_lo, uint32_t ns, uint32_t *__restrict__ grp_cnt) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq * ns) return;
+    uint32_t b = i / ns, s = slot_lo + (i - b * ns);
+    atomicAdd(&grp_cnt[probe_cluster[b * nprobe + s]], 1u);
+}
+
+// exclusive scan of cnt[0..k) into start[0..k]; single block, any k.  Also zeroes cnt for the
+// fill pass (cnt is reused as the per-list cursor).
+__global__ __launch_bounds__(1024) void group_scan_kernel(uint32_t *__restrict__ cnt, uint32_t k,
+                                                          uint32_t *__restrict__ start) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < k; base += 1024) {
+        uint32_t i = base + tid;
+        uint32_t v = i < k ? cnt[i] : 0, incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t up = __shfl_up(incl, o, 64);
+            if ((int)lane >= o) incl += up;
+        }
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t w = 0; w < wid; ++w) woff += wsum[w];
+        uint32_t c0 = carry;
+        if (i < k) {
+            start[i] = c0 + woff + incl - v;
+            cnt[i] = 0;
+        }
+        __syncthreads();
+        if (tid == 1023) carry = c0 + woff + incl;
+        __syncthreads();
+    }
+    if (tid == 0) start[k] = carry;
+}
+
+__global__ void group_fill_kernel(const uint32_t *__restrict__ probe_cluster, uint32_t nq, uint32_t nprobe,
+                                  uint32_t slot_lo, uint32_t ns, const uint32_t *__restrict__ grp_start,
+                                  uint32_t *__restrict__ grp_cursor, uint32_t *__restrict__ pair_list) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq * ns) return;
+    uint32_t b = i / ns, s = slot_lo + (i - b * ns);
+    uint32_t p = b * nprobe + s;
+    uint32_t c = probe_cluster[p];
+    uint32_t at = atomicAdd(&grp_cursor[c], 1u);
+    pair_list[grp_start[c] + at] = p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// THE SCAN: calculate_rough_distance (src/rabitq.rs:336-367) + asymmetric_binary_dot_product
+// (src/utils.rs:113-135) + binary_dot_product (src/simd.rs:326-384), fused with the re-rank gate
+// `rough < threshold` (src/rerank.rs:84).
+//
+//   s      = sum_p popcount(code & plane_p) << p                      (u32, exact)
+//   rough  = ((cds + ycd) + lo*ppc) + (((2*s - sumq) * fip) * delta) - eb * sqrt(ycd)
+//            evaluated left to right, one rounding per op, no contraction.
+//
+// One 256-thread block = one tile of 256*CPL consecutive list positions of one group.  Each lane
+// keeps CPL candidates (W u64 code words + the 16-byte Factor) in registers; the block then loops
+// over the group's (query, slot) pairs, whose operands are wave-uniform (SGPR / scalar loads).
+// HBM traffic is the list itself: D/8 + 16 bytes per candidate, 16 B/lane coalesced loads at D=128.
+// ------------------------------------------------------------------------------------------------
+struct ScanArgs {   // scalars only; pointers are explicit __restrict__ kernel parameters so the
+                    // compiler may keep the wave-uniform operand fetches on the scalar unit (s_load)
+    uint32_t nprobe, cap, pos_lo, pos_hi, tiles_per_group, ngroups, cluster_major;
+};
+struct ScanPtrs {   // host-side bundle only
+    const uint32_t *codes;        // n * 2W dwords (x_binary_vec, src/rabitq.rs:66)
+    const float4 *factors;        // n (src/rabitq.rs:67): x=factor_ip y=factor_ppc z=error_bound w=cds
+    const uint32_t *grp_start;    // cluster-major: k+1 offsets into pair_list
+    const uint32_t *pair_list;    // flattened pair ids p = b * nprobe + slot
+    const PairScalars *scal;      // per pair
+    const uint32_t *planes;       // per pair 8W dwords (4 planes x W u64)
+    const float *thr;             // per query
+    SurvRec *surv;                // per query `cap` records
+    uint32_t *surv_cnt;           // per query
+};
+#define SCAN_PARAMS                                                                                  \
+    const uint32_t *__restrict__ codes, const float4 *__restrict__ factors,                          \
+        const uint32_t *__restrict__ grp_start, const uint32_t *__restrict__ pair_list,              \
+        const PairScalars *__restrict__ scal, const uint32_t *__restrict__ planes,                   \
+        const float *__restrict__ thr_of_query, SurvRec *__restrict__ surv, uint32_t *__restrict__ surv_cnt,  \
+        const ScanArgs a
+
+template <int W>
+__device__ __forceinline__ uint32_t asym_dot(const uint32_t (&code)[2 * W],
+                                             const uint32_t *__restrict__ pl) {
+    uint32_t s = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int i = 0; i < 2 * W; ++i) t += __popc(code[i] & pl[p * 2 * W + i]);
+        s += t << p;
+    }
+    return s;
+}
+
+__device__ __forceinline__ float rough_distance(uint32_t s, const float4 &f, float lower, float delta,
+                                                float sumq, float ycd, float ycd_sqrt) {
+    float sf = (float)s;
+    float t = f.w + ycd;                    // center_distance_square + y_c_distance_square
+    t = t + lower * f.y;                    // + lower_bound * factor_ppc
+    float u = (2.0f * sf - sumq) * f.x;     // (2 * dot - scalar_sum) * factor_ip
+    t = t + u * delta;                      //   ... * delta
+    return t - f.z * ycd_sqrt;              // - error_bound * dist_sqrt
+}
+
+template <int W, int CPL>
+__global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
+    const uint32_t g = blockIdx.x / a.tiles_per_group;
+    const uint32_t tile = blockIdx.x - g * a.tiles_per_group;
+    uint32_t pb, pe;
+    if (a.cluster_major) {
+        pb = grp_start[g];
+        pe = grp_start[g + 1];
+    } else {
+        pb = g;
+        pe = g + 1;
+    }
+    if (pb >= pe) return;
+    const uint32_t lane = threadIdx.x & 63;
+    // the list of this group (all its pairs share it)
+    const uint32_t p0 = __builtin_amdgcn_readfirstlane(pair_list[pb]);
+    const uint32_t list_begin = scal[p0].list_begin, list_len = scal[p0].list_len;
+    const uint32_t lo = a.pos_lo < list_len ? a.pos_lo : list_len;
+    const uint32_t hi = a.pos_hi < list_len ? a.pos_hi : list_len;
+    const uint32_t first = lo + tile * (256 * CPL);
+    if (first >= hi) return;
+
+    uint32_t code[CPL][2 * W];
+    float4 fac[CPL];
+    uint32_t pos[CPL];
+    bool valid[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        uint32_t local = first + c * 256 + threadIdx.x;
+        valid[c] = local < hi;
+        pos[c] = list_begin + (valid[c] ? local : lo);
+        const uint32_t *cp = codes + (uint64_t)pos[c] * (2 * W);
+        if constexpr ((2 * W) % 4 == 0) {
+#pragma unroll
+            for (int i = 0; i < 2 * W; i += 4) {
+                uint4 v = *reinterpret_cast<const uint4 *>(cp + i);
+                code[c][i] = v.x, code[c][i + 1] = v.y, code[c][i + 2] = v.z, code[c][i + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2 * W; i += 2) {
+                uint2 v = *reinterpret_cast<const uint2 *>(cp + i);
+                code[c][i] = v.x, code[c][i + 1] = v.y;
+            }
+        }
+        fac[c] = factors[pos[c]];
+    }
+
+    for (uint32_t i = pb; i < pe; ++i) {
+        const uint32_t p = __builtin_amdgcn_readfirstlane(pair_list[i]);
+        const PairScalars *sp = scal + p;
+        const uint32_t b = sp->row;
+        const uint32_t slot = p - b * a.nprobe;
+        const float lower = sp->lower, delta = sp->delta, sumq = sp->sumq, ycd = sp->ycd,
+                    ycd_sqrt = sp->ycd_sqrt;
+        const float thr = thr_of_query[b];
+        const uint32_t *pl = planes + (uint64_t)p * (8 * W);
+        bool pass[CPL];
+        float rough[CPL];
+        uint32_t total = 0;
+        uint64_t m[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            uint32_t s = asym_dot<W>(code[c], pl);
+            rough[c] = rough_distance(s, fac[c], lower, delta, sumq, ycd, ycd_sqrt);
+            pass[c] = valid[c] && (rough[c] < thr);
+            m[c] = __ballot(pass[c]);
+            total += (uint32_t)__popcll(m[c]);
+        }
+        if (total) {  // wave-uniform
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(surv_cnt + b, total);
+            base = __builtin_amdgcn_readfirstlane(base);
+            SurvRec *out = surv + (uint64_t)b * a.cap;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                if (pass[c]) {
+                    uint32_t at = base + (uint32_t)__popcll(m[c] & ((1ull << lane) - 1ull));
+                    if (at < a.cap) {
+                        SurvRec r;
+                        r.pos = pos[c];
+                        r.slot = slot;
+                        r.rough = rough[c];
+                        r.accurate = 0.0f;
+                        out[at] = r;
+                    }
+                }
+                base += (uint32_t)__popcll(m[c]);
+            }
+        }
+    }
+}
+
+// generic-W fallback (dim/64 not in the templated set): code words re-read per query (L1-resident)
+__global__ __launch_bounds__(256) void scan_generic_kernel(SCAN_PARAMS, uint32_t W) {
+    const uint32_t g = blockIdx.x / a.tiles_per_group;
+    const uint32_t tile = blockIdx.x - g * a.tiles_per_group;
+    uint32_t pb, pe;
+    if (a.cluster_major) {
+        pb = grp_start[g];
+        pe = grp_start[g + 1];
+    } else {
+        pb = g;
+        pe = g + 1;
+    }
+    if (pb >= pe) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t p0 = __builtin_amdgcn_readfirstlane(pair_list[pb]);
+    const uint32_t list_begin = scal[p0].list_begin, list_len = scal[p0].list_len;
+    const uint32_t lo = a.pos_lo < list_len ? a.pos_lo : list_len;
+    const uint32_t hi = a.pos_hi < list_len ? a.pos_hi : list_len;
+    const uint32_t local = lo + tile * 256 + threadIdx.x;
+    if (lo + tile * 256 >= hi) return;
+    const bool valid = local < hi;
+    const uint32_t pos = list_begin + (valid ? local : lo);
+    const uint32_t *cp = codes + (uint64_t)pos * (2 * W);
+    const float4 fac = factors[pos];
+    for (uint32_t i = pb; i < pe; ++i) {
+        const uint32_t p = __builtin_amdgcn_readfirstlane(pair_list[i]);
+        const PairScalars *sp = scal + p;
+        const uint32_t b = sp->row, slot = p - b * a.nprobe;
+        const uint32_t *pl = planes + (uint64_t)p * (8 * W);
+        uint32_t s = 0;
+        for (int pp = 0; pp < 4; ++pp) {
+            uint32_t t = 0;
+            for (uint32_t w = 0; w < 2 * W; ++w) t += __popc(cp[w] & pl[pp * 2 * W + w]);
+            s += t << pp;
+        }
+        float rough = rough_distance(s, fac, sp->lower, sp->delta, sp->sumq, sp->ycd, sp->ycd_sqrt);
+        bool pass = valid && rough < thr_of_query[b];
+        uint64_t m = __ballot(pass);
+        if (m) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(surv_cnt + b, (uint32_t)__popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (pass) {
+                uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (at < a.cap) {
+                    SurvRec r;
+                    r.pos = pos, r.slot = slot, r.rough = rough, r.accurate = 0.0f;
+                    surv[(uint64_t)b * a.cap + at] = r;
+                }
+            }
+        }
+    }
+}
+
+// Dense variant for the per-stage test entry rq_scan: rough distance of every member of one list
+// for one (query, list) pair; same device functions as the fused kernel.
+__global__ __launch_bounds__(256) void scan_dense_kernel(const uint32_t *__restrict__ codes,
+                                                         const float4 *__restrict__ factors,
+                                                         uint32_t list_begin, uint32_t list_len,
+                                                         uint32_t W, const uint32_t *__restrict__ pl,
+                                                         float lower, float delta, float sumq, float ycd,
+                                                         float *__restrict__ out) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= list_len) return;
+    const uint32_t *cp = codes + (uint64_t)(list_begin + i) * (2 * W);
+    uint32_t s = 0;
+    for (int p = 0; p < 4; ++p) {
+        uint32_t t = 0;
+        for (uint32_t w = 0; w < 2 * W; ++w) t += __popc(cp[w] & pl[p * 2 * W + w]);
+        s += t << p;
+    }
+    out[i] = rough_distance(s, factors[list_begin + i], lower, delta, sumq, ycd, sqrtf(ycd));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Rerank distances (src/rerank.rs:85-90 -> src/simd.rs:14-73): accurate = ||base[pos] - q||^2 in
+// the ORIGINAL space, exact AVX2 order.  8 GPU lanes play the 8 AVX lanes of one candidate (lane l
+// runs the fused chain over elements 8c + l), so a wave reranks 8 survivors at a time and each
+// 32-byte sector of the 4*dim-byte row is consumed by exactly one load.
+// grid (gx, nq); block 256.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void accurate_kernel(SurvRec *__restrict__ surv,
+                                                       const uint32_t *__restrict__ surv_cnt,
+                                                       uint32_t cap, const float *__restrict__ base,
+                                                       const float *__restrict__ qpad, uint32_t dim) {
+    const uint32_t b = blockIdx.y;
+    uint32_t n = surv_cnt[b];
+    n = n < cap ? n : cap;
+    const uint32_t l = threadIdx.x & 7, grp = threadIdx.x >> 3;
+    const float *q = qpad + (uint64_t)b * dim;
+    SurvRec *recs = surv + (uint64_t)b * cap;
+    for (uint32_t i = blockIdx.x * 32 + grp; i < n; i += gridDim.x * 32) {
+        const float *x = base + (uint64_t)recs[i].pos * dim;
+        float acc = 0.0f;
+        for (uint32_t c = 0; c < dim; c += 8) {
+            float d = x[c + l] - q[c + l];
+            acc = fmaf(d, d, acc);
+        }
+        acc = reduce8_lanes(acc);
+        if (l == 0) recs[i].accurate = acc;
+    }
+}
+
+// flat variant for the per-stage test entry rq_rerank: positions given directly
+__global__ __launch_bounds__(256) void accurate_flat_kernel(const uint32_t *__restrict__ pos, uint32_t m,
+                                                            const float *__restrict__ base,
+                                                            const float *__restrict__ q, uint32_t dim,
+                                                            float *__restrict__ out) {
+    const uint32_t l = threadIdx.x & 7;
+    uint32_t i = blockIdx.x * 32 + (threadIdx.x >> 3);
+    if (i >= m) return;
+    const float *x = base + (uint64_t)pos[i] * dim;
+    float acc = 0.0f;
+    for (uint32_t c = 0; c < dim; c += 8) {
+        float d = x[c + l] - q[c + l];
+        acc = fmaf(d, d, acc);
+    }
+    acc = reduce8_lanes(acc);
+    if (l == 0) out[i] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Restore the reference's visiting order among a query's survivors: ascending (slot, position)
+// (src/rabitq.rs:304 outer loop, :348 inner loop).  One block per query; LDS when it fits.
+// ------------------------------------------------------------------------------------------------
+#define RQ_SORT_LDS_RECS 2048
+__global__ __launch_bounds__(256) void sort_survivors_kernel(SurvRec *__restrict__ surv,
+                                                             const uint32_t *__restrict__ surv_cnt,
+                                                             uint32_t cap) {
+    __shared__ SurvRec lds[RQ_SORT_LDS_RECS];
+    const uint32_t b = blockIdx.x;
+    uint32_t n = surv_cnt[b];
+    n = n < cap ? n : cap;
+    if (n < 2) return;
+    SurvRec *recs = surv + (uint64_t)b * cap;
+    auto key = [](const SurvRec &r) { return surv_key(r); };
+    if (n <= RQ_SORT_LDS_RECS) {
+        for (uint32_t i = threadIdx.x; i < n; i += 256) lds[i] = recs[i];
+        __syncthreads();
+        bitonic_sort_block(lds, n, key);
+        for (uint32_t i = threadIdx.x; i < n; i += 256) recs[i] = lds[i];
+    } else {
+        __syncthreads();
+        bitonic_sort_block(recs, n, key);  // in global memory (L2), rare
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ordered replay of the re-rankers over (rough, accurate) pairs: HeapReRanker::rank_batch
+// (src/rerank.rs:81-106) and HeuristicReRanker::rank_batch (:143-168), with Rust's
+// std BinaryHeap push / pop (sift_up; sift_down_to_bottom + sift_up) on (Ord32, AlwaysEqual) items
+// so that evictions among equal keys match.  One wave per query; survivors are taken 64 at a time
+// and only lanes with rough < threshold are visited (ballot), the threshold being re-applied after
+// every change.  State persists across stages in global memory.
+// ------------------------------------------------------------------------------------------------
+struct ReplayState {
+    float *thr;              // nq
+    uint32_t *heap_len;      // nq
+    int32_t *heap_key;       // nq * topk
+    uint32_t *heap_id;       // nq * topk
+    uint32_t *precise;       // nq   (rerank.rs:91 / :153)
+    uint32_t *need;          // nq   max survivor count seen (overflow detection)
+    uint32_t *nsurv;         // nq   survivors replayed (= accurate distances computed)
+    // heuristic ranker
+    float *recent_max;       // nq
+    uint32_t *win_count;     // nq
+    uint32_t *arr_len;       // nq   accepted so far (may exceed hcap -> overflow)
+    SurvRec *arr;            // nq * hcap : {pos = arrival index, slot = biased Ord32(acc), accurate = id bits}
+    uint32_t hcap;
+};
+
+#define RQ_MAX_TOPK 2048
+
+template <bool HEURISTIC>
+__global__ __launch_bounds__(64) void replay_kernel(const SurvRec *__restrict__ surv,
+                                                    uint32_t *__restrict__ surv_cnt, uint32_t cap,
+                                                    const uint32_t *__restrict__ map_ids, uint32_t topk,
+                                                    ReplayState st) {
+    __shared__ int32_t hkey[HEURISTIC ? 1 : RQ_MAX_TOPK];
+    __shared__ uint32_t hid[HEURISTIC ? 1 : RQ_MAX_TOPK];
+    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+    const uint32_t cnt = surv_cnt[b];
+    const uint32_t n = cnt < cap ? cnt : cap;
+    if (lane == 0) {
+        if (cnt > st.need[b]) st.need[b] = cnt;
+        st.nsurv[b] += n;
+        surv_cnt[b] = 0;  // ready for the next stage
+    }
+    if (n == 0) return;
+    float thr = st.thr[b];
+    uint32_t precise = 0;
+    uint32_t hlen = 0, wcount = 0, alen = 0;
+    float recent = 0.0f;
+    if constexpr (!HEURISTIC) {
+        hlen = st.heap_len[b];
+        for (uint32_t i = lane; i < hlen; i += 64) {
+            hkey[i] = st.heap_key[(uint64_t)b * topk + i];
+            hid[i] = st.heap_id[(uint64_t)b * topk + i];
+        }
+        __syncthreads();
+    } else {
+        recent = st.recent_max[b];
+        wcount = st.win_count[b];
+        alen = st.arr_len[b];
+    }
+    const SurvRec *recs = surv + (uint64_t)b * cap;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const bool have = base + lane < n;
+        SurvRec r;
+        if (have) r = recs[base + lane];
+        else r.pos = 0, r.slot = 0, r.rough = 0.0f, r.accurate = 0.0f;
+        uint64_t m = __ballot(have && r.rough < thr);  // rerank.rs:84 / :146
+        while (m) {
+            const int i = __builtin_ctzll(m);
+            m &= m - 1;
+            const float acc = __shfl(r.accurate, i, 64);
+            const uint32_t pos = __shfl(r.pos, i, 64);
+            ++precise;
+            if (!(acc < thr)) continue;  // rerank.rs:92 / :154
+            const uint32_t id = map_ids[pos];
+            if constexpr (!HEURISTIC) {
+                // push: append + sift_up(0, old_len)
+                int32_t key = ord32_from_f32(acc);
+                uint32_t p = hlen++;
+                while (p > 0) {
+                    uint32_t parent = (p - 1) >> 1;
+                    int32_t pk = hkey[parent];
+                    if (key <= pk) break;
+                    uint32_t pid = hid[parent];
+                    hkey[p] = pk, hid[p] = pid;
+                    p = parent;
+                }
+                hkey[p] = key, hid[p] = id;
+                if (hlen > topk) {  // pop: last -> root, sift_down_to_bottom(0), sift_up
+                    --hlen;
+                    int32_t hk = hkey[hlen];
+                    uint32_t hi = hid[hlen];
+                    if (hlen > 0) {
+                        const uint32_t end = hlen;
+                        uint32_t q = 0, child = 1;
+                        while (child + 1 < end) {
+                            int32_t kl = hkey[child], kr = hkey[child + 1];
+                            if (kl <= kr) child += 1;
+                            int32_t ck = hkey[child];
+                            uint32_t ci = hid[child];
+                            hkey[q] = ck, hid[q] = ci;
+                            q = child;
+                            child = 2 * q + 1;
+                        }
+                        if (child == end - 1) {
+                            int32_t ck = hkey[child];
+                            uint32_t ci = hid[child];
+                            hkey[q] = ck, hid[q] = ci;
+                            q = child;
+                        }
+                        while (q > 0) {  // sift_up(0, q) of the hole element
+                            uint32_t parent = (q - 1) >> 1;
+                            int32_t pk = hkey[parent];
+                            if (hk <= pk) break;
+                            uint32_t pid = hid[parent];
+                            hkey[q] = pk, hid[q] = pid;
+                            q = parent;
+                        }
+                        hkey[q] = hk, hid[q] = hi;
+                    }
+                }
+                if (hlen == topk) thr = ord32_to_f32(hkey[0]);  // rerank.rs:98-100
+            } else {
+                if (alen < st.hcap && lane == 0) {
+                    SurvRec e;
+                    e.pos = alen;
+                    e.slot = ord32_biased(acc);
+                    e.rough = acc;
+                    e.accurate = __builtin_bit_cast(float, id);
+                    st.arr[(uint64_t)b * st.hcap + alen] = e;
+                }
+                ++alen;
+                ++wcount;
+                recent = (acc > recent || recent != recent) ? acc : recent;  // f32::max
+                if (wcount >= 12) {                                          // consts.rs:12
+                    thr = recent;
+                    wcount = 0;
+                    recent = -3.402823466e+38f;
+                }
+            }
+            m &= __ballot(have && r.rough < thr);
+        }
+    }
+    if constexpr (!HEURISTIC) {
+        __syncthreads();
+        for (uint32_t i = lane; i < hlen; i += 64) {
+            st.heap_key[(uint64_t)b * topk + i] = hkey[i];
+            st.heap_id[(uint64_t)b * topk + i] = hid[i];
+        }
+        if (lane == 0) st.heap_len[b] = hlen;
+    } else if (lane == 0) {
+        st.recent_max[b] = recent;
+        st.win_count[b] = wcount;
+        st.arr_len[b] = alen;
+    }
+    if (lane == 0) {
+        st.thr[b] = thr;
+        st.precise[b] += precise;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Results (src/rerank.rs:108-113 heap Vec order; :170-176 the topk smallest, here sorted).
+// ------------------------------------------------------------------------------------------------
+__global__ void finalize_heap_kernel(const ReplayState st, uint32_t nq, uint32_t topk,
+                                     const uint32_t *__restrict__ row_map, float *__restrict__ out_dist,
+                                     uint32_t *__restrict__ out_id, uint32_t *__restrict__ out_n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq * topk) return;
+    uint32_t b = i / topk, e = i - b * topk;
+    uint32_t ob = row_map ? row_map[b] : b;
+    uint32_t len = st.heap_len[b];
+    if (e < len) {
+        out_dist[(uint64_t)ob * topk + e] = ord32_to_f32(st.heap_key[(uint64_t)b * topk + e]);
+        out_id[(uint64_t)ob * topk + e] = st.heap_id[(uint64_t)b * topk + e];
+    }
+    if (e == 0) out_n[ob] = len;
+}
+
+__global__ void finalize_heuristic_kernel(const ReplayState st, uint32_t nq, uint32_t topk,
+                                          const uint32_t *__restrict__ row_map,
+                                          float *__restrict__ out_dist, uint32_t *__restrict__ out_id,
+                                          uint32_t *__restrict__ out_n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq * topk) return;
+    uint32_t b = i / topk, e = i - b * topk;
+    uint32_t ob = row_map ? row_map[b] : b;
+    uint32_t len = st.arr_len[b];
+    len = len < st.hcap ? len : st.hcap;
+    uint32_t take = len < topk ? len : topk;
+    if (e < take) {
+        const SurvRec &r = st.arr[(uint64_t)b * st.hcap + e];
+        out_dist[(uint64_t)ob * topk + e] = r.rough;
+        out_id[(uint64_t)ob * topk + e] = __builtin_bit_cast(uint32_t, r.accurate);
+    }
+    if (e == 0) out_n[ob] = take;
+}
+
+// per-batch totals for METRICS (src/metrics.rs:44-53): sums of the per-query counters.
+// out4 = {rough, precise (queries without overflow only), #overflowed queries, accurate distances computed}
+__global__ __launch_bounds__(256) void metrics_sum_kernel(const unsigned long long *__restrict__ rough,
+                                                          const uint32_t *__restrict__ precise,
+                                                          const uint32_t *__restrict__ need,
+                                                          const uint32_t *__restrict__ arr_len,
+                                                          const uint32_t *__restrict__ nsurv, uint32_t nq,
+                                                          uint32_t cap, uint32_t hcap,
+                                                          unsigned long long *__restrict__ out4) {
+    __shared__ unsigned long long s[4];
+    if (threadIdx.x < 4) s[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned long long r = 0, p = 0, o = 0, a = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) {
+        const bool ok = need[i] <= cap && (!arr_len || arr_len[i] <= hcap);
+        r += rough[i];
+        p += ok ? precise[i] : 0;
+        o += ok ? 0 : 1;
+        a += nsurv[i];
+    }
+    atomicAdd(&s[0], r);
+    atomicAdd(&s[1], p);
+    atomicAdd(&s[2], o);
+    atomicAdd(&s[3], a);
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd(&out4[threadIdx.x], s[threadIdx.x]);
+}

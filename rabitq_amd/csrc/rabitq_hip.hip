@@ -1,0 +1,1239 @@
+// rabitq_hip.hip -- host side of librabitq_hip.so: index state, build / query orchestration,
+// persistence and the extern "C" boundary declared in include/rabitq_hip.h.
+//
+// There is NO CPU fallback anywhere in this file: every arithmetic step of the path runs in the
+// gfx950 kernels of kernels_query.h / kernels_build.h, and every entry point fails with
+// RQ_ERR_NO_DEVICE / RQ_ERR_HIP when no device is usable.
+#include "../../include/rabitq_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <random>
+#include <string>
+#include <vector>
+#include <sys/stat.h>
+
+#include "common.h"
+#include "kernels_build.h"
+#include "kernels_query.h"
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static rq_status fail(rq_status s, const std::string &msg) {
+    g_err = msg;
+    return s;
+}
+#define HIPC(expr)                                                                                   \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess)                                                                        \
+            return fail(_e == hipErrorOutOfMemory ? RQ_ERR_OOM : RQ_ERR_HIP,                         \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                          \
+    } while (0)
+#define RQC(expr)                        \
+    do {                                 \
+        rq_status _s = (expr);           \
+        if (_s != RQ_OK) return _s;      \
+    } while (0)
+
+static rq_status ensure_device() {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail(RQ_ERR_NO_DEVICE, "no HIP device visible (librabitq_hip has no CPU fallback)");
+    return RQ_OK;
+}
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t count = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        count = 0;
+    }
+    rq_status alloc(size_t n) {
+        release();
+        count = n;
+        if (n == 0) n = 1;
+        hipError_t e = hipMalloc((void **)&p, n * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            count = 0;
+            return fail(RQ_ERR_OOM, "hipMalloc of " + std::to_string(n * sizeof(T)) + " bytes failed: " +
+                                        hipGetErrorString(e));
+        }
+        return RQ_OK;
+    }
+    rq_status ensure(size_t n) { return n <= count && p ? RQ_OK : alloc(n); }
+};
+
+static inline uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+static inline uint32_t pow2_ceil(uint32_t v) {
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// metrics (src/metrics.rs:65: process-global relaxed atomics)
+// ------------------------------------------------------------------------------------------------
+static std::atomic<uint64_t> g_rough{0}, g_precise{0}, g_query{0}, g_miss{0};
+
+// ------------------------------------------------------------------------------------------------
+// profiling
+// ------------------------------------------------------------------------------------------------
+enum { PF_ROTATE = 0, PF_COARSE, PF_SELECT, PF_PREP, PF_GROUP, PF_SCAN, PF_RERANK, PF_SORT, PF_REPLAY, PF_TOTAL, PF_N };
+static std::atomic<int> g_profiling{0};
+static thread_local rq_profile_t g_profile;
+
+struct Prof {
+    bool on = false;
+    hipStream_t stream = nullptr;
+    struct Span {
+        hipEvent_t a, b;
+        int cat;
+    };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    hipEvent_t get() {
+        if (used == pool.size()) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            pool.push_back(e);
+        }
+        return pool[used++];
+    }
+    void begin(int cat) {
+        if (!on) return;
+        Span s{get(), get(), cat};
+        (void)hipEventRecord(s.a, stream);
+        spans.push_back(s);
+    }
+    void end() {
+        if (!on) return;
+        (void)hipEventRecord(spans.back().b, stream);
+    }
+    void reset(bool enable, hipStream_t st) {
+        on = enable;
+        stream = st;
+        spans.clear();
+        used = 0;
+    }
+    void collect(float *ms /*PF_N*/) {
+        for (auto &s : spans) {
+            float t = 0;
+            (void)hipEventElapsedTime(&t, s.a, s.b);
+            ms[s.cat] += t;
+        }
+    }
+    ~Prof() {
+        for (auto e : pool) (void)hipEventDestroy(e);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// query workspace
+// ------------------------------------------------------------------------------------------------
+struct Workspace {
+    hipStream_t stream = nullptr;
+    bool busy = false;
+    DevBuf<float> qpad, y, dist, probe_dist, thr, recent;
+    DevBuf<uint32_t> probe_cluster, pair_list, grp_cnt, grp_start, surv_cnt, heap_len, heap_id, precise, need,
+        nsurv, win_count, arr_len, row_map;
+    DevBuf<int32_t> heap_key;
+    DevBuf<PairScalars> scal;
+    DevBuf<uint64_t> planes;
+    DevBuf<unsigned long long> rough_cnt, totals;
+    DevBuf<SurvRec> surv, arr;
+    unsigned long long *h_totals = nullptr;  // pinned, 4
+    Prof prof;
+    ~Workspace() {
+        if (h_totals) (void)hipHostFree(h_totals);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+struct rq_index {
+    uint32_t dim = 0, k = 0, W = 0, max_list_len = 0;
+    uint64_t n = 0;
+    DevBuf<float> base, P, centroids, cent_t;
+    DevBuf<uint32_t> offsets, map_ids;
+    DevBuf<uint64_t> codes;
+    DevBuf<float4> factors;
+    std::mutex ws_mu;
+    std::vector<std::unique_ptr<Workspace>> ws_pool;
+};
+
+// ------------------------------------------------------------------------------------------------
+// small init kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void fill_f32_kernel(float *p, float v, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void gather_rows_kernel(const float *__restrict__ in, const uint32_t *__restrict__ rows,
+                                   uint32_t nrows, uint32_t len, float *__restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)nrows * len) return;
+    uint32_t r = (uint32_t)(i / len), c = (uint32_t)(i - (uint64_t)r * len);
+    out[i] = in[(uint64_t)rows[r] * len + c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// rotation launcher (MFMA kernel for bulk, VALU kernel for a handful of rows; bit-identical)
+// ------------------------------------------------------------------------------------------------
+static void launch_rotate(const float *x, const float *P, float *out, uint64_t n, uint32_t dim, bool mfma,
+                          hipStream_t st) {
+    if (n == 0) return;
+    if (mfma) {
+        uint64_t blocks = (uint64_t)ceil_div(n, ROT_BM) * (dim / ROT_BN);
+        rotate_mfma_kernel<<<dim3((uint32_t)blocks), dim3(256), 0, st>>>(x, P, out, n, dim);
+    } else {
+        rotate_valu_kernel<<<dim3(ceil_div(n, 4), dim / 64), dim3(64, 4), 0, st>>>(x, P, out, n, dim);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scan dispatch on W = dim / 64
+// ------------------------------------------------------------------------------------------------
+#define SCAN_ARGS p.codes, p.factors, p.grp_start, p.pair_list, p.scal, p.planes, p.thr, p.surv, p.surv_cnt, a
+static void launch_scan(const ScanPtrs &p, const ScanArgs &a, uint32_t W, hipStream_t st) {
+    const uint64_t blocks = (uint64_t)a.ngroups * a.tiles_per_group;
+    if (blocks == 0) return;
+    dim3 g((uint32_t)blocks), b(256);
+    switch (W) {
+        case 1: scan_kernel<1, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
+        case 2: scan_kernel<2, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
+        case 3: scan_kernel<3, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
+        case 4: scan_kernel<4, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
+        case 6: scan_kernel<6, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
+        case 8: scan_kernel<8, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
+        case 12: scan_kernel<12, 1><<<g, b, 0, st>>>(SCAN_ARGS); break;
+        case 16: scan_kernel<16, 1><<<g, b, 0, st>>>(SCAN_ARGS); break;
+        default: scan_generic_kernel<<<g, b, 0, st>>>(SCAN_ARGS, W); break;
+    }
+}
+static uint32_t scan_tile(uint32_t W) {
+    switch (W) {
+        case 1: case 2: case 3: case 4: case 6: case 8: return 512;
+        default: return 256;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the query pipeline
+// ------------------------------------------------------------------------------------------------
+struct QueryParams {
+    uint32_t nq, len, probe, topk;
+    bool heuristic;
+    uint32_t cap, hcap;  // survivor / heuristic-array capacity per query (powers of two)
+};
+
+#define RQ_DEFAULT_CAP 4096u
+#define RQ_MAX_NQ_PER_PASS 16384u
+#define RQ_MAX_PROBE 16384u
+
+static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParams &qp) {
+    const uint32_t nprobe = std::min(qp.probe, idx->k);
+    const uint64_t nq = qp.nq, npairs = nq * nprobe;
+    if (!ws.stream) HIPC(hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking));
+    if (!ws.h_totals) HIPC(hipHostMalloc((void **)&ws.h_totals, 4 * sizeof(unsigned long long)));
+    RQC(ws.qpad.ensure(nq * idx->dim));
+    RQC(ws.y.ensure(nq * idx->dim));
+    RQC(ws.dist.ensure(nq * idx->k));
+    RQC(ws.probe_dist.ensure(npairs));
+    RQC(ws.probe_cluster.ensure(npairs));
+    RQC(ws.scal.ensure(npairs));
+    RQC(ws.planes.ensure(npairs * 4 * idx->W));
+    RQC(ws.rough_cnt.ensure(nq));
+    RQC(ws.totals.ensure(4));
+    RQC(ws.pair_list.ensure(npairs));
+    RQC(ws.grp_cnt.ensure(idx->k + 1));
+    RQC(ws.grp_start.ensure(idx->k + 1));
+    RQC(ws.thr.ensure(nq));
+    RQC(ws.surv.ensure(nq * qp.cap));
+    RQC(ws.surv_cnt.ensure(nq));
+    RQC(ws.heap_len.ensure(nq));
+    RQC(ws.heap_key.ensure(nq * qp.topk));
+    RQC(ws.heap_id.ensure(nq * qp.topk));
+    RQC(ws.precise.ensure(nq));
+    RQC(ws.need.ensure(nq));
+    RQC(ws.nsurv.ensure(nq));
+    RQC(ws.recent.ensure(nq));
+    RQC(ws.win_count.ensure(nq));
+    RQC(ws.arr_len.ensure(nq));
+    RQC(ws.row_map.ensure(nq));
+    if (qp.heuristic) RQC(ws.arr.ensure(nq * qp.hcap));
+    return RQ_OK;
+}
+
+struct PassResult {
+    uint64_t rough = 0, precise = 0, overflowed = 0;
+};
+
+// Runs one pass over nq queries already resident at d_q (nq x len).  Results go to row
+// row_map[b] (or b) of the output arrays.  On return the stream is synchronised.
+static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, const QueryParams &qp,
+                          const uint32_t *d_row_map, float *d_out_dist, uint32_t *d_out_id, uint32_t *d_out_n,
+                          PassResult *res, rq_profile_t *prof_acc) {
+    const uint32_t dim = idx->dim, k = idx->k, W = idx->W;
+    const uint32_t nq = qp.nq, nprobe = std::min(qp.probe, k), topk = qp.topk;
+    const uint32_t npairs = nq * nprobe;
+    hipStream_t st = ws.stream;
+    Prof &pf = ws.prof;
+    pf.reset(g_profiling.load() != 0, st);
+    pf.begin(PF_TOTAL);
+    size_t total_span = pf.spans.size() ? pf.spans.size() - 1 : 0;
+
+    // 1. pad (rabitq.rs:277-280) + rotate (:282)
+    pf.begin(PF_ROTATE);
+    const float *qpad = d_q;
+    if (qp.len != dim) {
+        pad_rows_kernel<<<ceil_div((uint64_t)nq * dim, 256), 256, 0, st>>>(d_q, ws.qpad.p, nq, qp.len, dim);
+        qpad = ws.qpad.p;
+    }
+    launch_rotate(qpad, idx->P.p, ws.y.p, nq, dim, nq >= 32, st);
+    pf.end();
+
+    // 2. coarse distances + probe selection (:283-297)
+    pf.begin(PF_COARSE);
+    coarse_dist_kernel<4><<<dim3(ceil_div(nq, 4), ceil_div(k, 256)), 256, 4 * dim * sizeof(float), st>>>(
+        idx->cent_t.p, ws.y.p, ws.dist.p, k, dim, nq);
+    pf.end();
+    pf.begin(PF_SELECT);
+    select_probe_kernel<<<nq, 256, (size_t)nprobe * 8, st>>>(ws.dist.p, k, nprobe, ws.probe_cluster.p,
+                                                              ws.probe_dist.p);
+    pf.end();
+
+    // 3. per-pair query quantisation (:304-317)
+    pf.begin(PF_PREP);
+    HIPC(hipMemsetAsync(ws.rough_cnt.p, 0, nq * sizeof(unsigned long long), st));
+    prep_kernel<<<ceil_div(npairs, 4), 256, 0, st>>>(ws.y.p, idx->centroids.p, idx->offsets.p, ws.probe_cluster.p,
+                                                     ws.probe_dist.p, npairs, nprobe, dim, ws.scal.p, ws.planes.p,
+                                                     nullptr, ws.rough_cnt.p);
+    // 4. ranker state (rerank.rs:70-77, :129-139)
+    fill_f32_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(ws.thr.p, 3.402823466e+38f, nq);
+    fill_f32_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(ws.recent.p, -3.402823466e+38f, nq);
+    HIPC(hipMemsetAsync(ws.surv_cnt.p, 0, nq * 4, st));
+    HIPC(hipMemsetAsync(ws.heap_len.p, 0, nq * 4, st));
+    HIPC(hipMemsetAsync(ws.precise.p, 0, nq * 4, st));
+    HIPC(hipMemsetAsync(ws.need.p, 0, nq * 4, st));
+    HIPC(hipMemsetAsync(ws.nsurv.p, 0, nq * 4, st));
+    HIPC(hipMemsetAsync(ws.win_count.p, 0, nq * 4, st));
+    HIPC(hipMemsetAsync(ws.arr_len.p, 0, nq * 4, st));
+    HIPC(hipMemsetAsync(ws.totals.p, 0, 4 * sizeof(unsigned long long), st));
+    pf.end();
+
+    ReplayState rs;
+    rs.thr = ws.thr.p, rs.heap_len = ws.heap_len.p, rs.heap_key = ws.heap_key.p, rs.heap_id = ws.heap_id.p;
+    rs.precise = ws.precise.p, rs.need = ws.need.p, rs.nsurv = ws.nsurv.p, rs.recent_max = ws.recent.p, rs.win_count = ws.win_count.p;
+    rs.arr_len = ws.arr_len.p, rs.arr = ws.arr.p, rs.hcap = qp.hcap;
+
+    // 5. stages.  A stage scans positions [pos_lo, pos_hi) of the lists at probe slots
+    // [slot_lo, slot_hi) with the threshold each query's ranker holds at the start of the stage
+    // (an upper bound of the reference's threshold everywhere in the stage, since it never rises),
+    // then replays the survivors in the reference's order.  Stage 0 has threshold f32::MAX.
+    struct Stage {
+        uint32_t slot_lo, slot_hi, pos_lo, pos_hi;
+    };
+    std::vector<Stage> stages;
+    {
+        const uint32_t INF = 0xFFFFFFFFu;
+        uint64_t lo = 0, hi = std::max<uint32_t>(topk, 1);
+        while (true) {
+            bool last = hi >= idx->max_list_len;
+            stages.push_back({0, 1, (uint32_t)lo, last ? INF : (uint32_t)hi});
+            if (last) break;
+            lo = hi;
+            hi = std::min<uint64_t>(hi * 16, 0xFFFFFFF0ull);
+        }
+        if (nprobe > 1) stages.push_back({1, nprobe, 0, INF});
+    }
+    const uint32_t tile = scan_tile(W);
+    for (const Stage &sg : stages) {
+        const uint32_t ns = std::min(sg.slot_hi, nprobe) - sg.slot_lo;
+        const uint32_t np = nq * ns;
+        const uint32_t phi = std::min(sg.pos_hi, idx->max_list_len);
+        if (np == 0 || phi <= sg.pos_lo) continue;
+        const bool cluster_major = np >= k / 2 && np > 64;
+        pf.begin(PF_GROUP);
+        ScanArgs a;
+        ScanPtrs sp;
+        a.cluster_major = cluster_major ? 1u : 0u;
+        if (cluster_major) {
+            HIPC(hipMemsetAsync(ws.grp_cnt.p, 0, (k + 1) * 4, st));
+            group_count_kernel<<<ceil_div(np, 256), 256, 0, st>>>(ws.probe_cluster.p, nq, nprobe, sg.slot_lo, ns,
+                                                                  ws.grp_cnt.p);
+            group_scan_kernel<<<1, 1024, 0, st>>>(ws.grp_cnt.p, k, ws.grp_start.p);
+            group_fill_kernel<<<ceil_div(np, 256), 256, 0, st>>>(ws.probe_cluster.p, nq, nprobe, sg.slot_lo, ns,
+                                                                 ws.grp_start.p, ws.grp_cnt.p, ws.pair_list.p);
+            a.ngroups = k;
+        } else {
+            enumerate_pairs_kernel<<<ceil_div(np, 256), 256, 0, st>>>(nq, nprobe, sg.slot_lo, ns, ws.pair_list.p);
+            a.ngroups = np;
+        }
+        pf.end();
+        sp.codes = reinterpret_cast<const uint32_t *>(idx->codes.p);
+        sp.factors = idx->factors.p;
+        sp.grp_start = ws.grp_start.p;
+        sp.pair_list = ws.pair_list.p;
+        sp.scal = ws.scal.p;
+        sp.planes = reinterpret_cast<const uint32_t *>(ws.planes.p);
+        sp.thr = ws.thr.p;
+        sp.surv = ws.surv.p;
+        sp.surv_cnt = ws.surv_cnt.p;
+        a.nprobe = nprobe, a.cap = qp.cap, a.pos_lo = sg.pos_lo, a.pos_hi = sg.pos_hi;
+        a.tiles_per_group = ceil_div(phi - sg.pos_lo, tile);
+        pf.begin(PF_SCAN);
+        launch_scan(sp, a, W, st);
+        pf.end();
+        if (prof_acc) prof_acc->scan_launches++;
+        pf.begin(PF_RERANK);
+        const uint32_t gx = std::max(1u, std::min(64u, 8192u / std::max(nq, 1u)));
+        accurate_kernel<<<dim3(gx, nq), 256, 0, st>>>(ws.surv.p, ws.surv_cnt.p, qp.cap, idx->base.p, qpad, dim);
+        pf.end();
+        pf.begin(PF_SORT);
+        sort_survivors_kernel<<<nq, 256, 0, st>>>(ws.surv.p, ws.surv_cnt.p, qp.cap);
+        pf.end();
+        pf.begin(PF_REPLAY);
+        if (qp.heuristic)
+            replay_kernel<true><<<nq, 64, 0, st>>>(ws.surv.p, ws.surv_cnt.p, qp.cap, idx->map_ids.p, topk, rs);
+        else
+            replay_kernel<false><<<nq, 64, 0, st>>>(ws.surv.p, ws.surv_cnt.p, qp.cap, idx->map_ids.p, topk, rs);
+        pf.end();
+    }
+
+    // 6. results
+    pf.begin(PF_REPLAY);
+    if (qp.heuristic) {
+        sort_survivors_kernel<<<nq, 256, 0, st>>>(ws.arr.p, ws.arr_len.p, qp.hcap);
+        finalize_heuristic_kernel<<<ceil_div((uint64_t)nq * topk, 256), 256, 0, st>>>(rs, nq, topk, d_row_map,
+                                                                                       d_out_dist, d_out_id, d_out_n);
+    } else {
+        finalize_heap_kernel<<<ceil_div((uint64_t)nq * topk, 256), 256, 0, st>>>(rs, nq, topk, d_row_map, d_out_dist,
+                                                                                  d_out_id, d_out_n);
+    }
+    metrics_sum_kernel<<<std::min(256u, ceil_div(nq, 256)), 256, 0, st>>>(
+        ws.rough_cnt.p, ws.precise.p, ws.need.p, qp.heuristic ? ws.arr_len.p : nullptr, ws.nsurv.p, nq, qp.cap, qp.hcap,
+        ws.totals.p);
+    pf.end();
+    if (pf.on) (void)hipEventRecord(pf.spans[total_span].b, st);
+    HIPC(hipMemcpyAsync(ws.h_totals, ws.totals.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    HIPC(hipGetLastError());
+    res->rough = ws.h_totals[0];
+    res->precise = ws.h_totals[1];
+    res->overflowed = ws.h_totals[2];
+    if (pf.on && prof_acc) {
+        float ms[PF_N] = {0};
+        pf.collect(ms);
+        prof_acc->ms_rotate += ms[PF_ROTATE], prof_acc->ms_coarse += ms[PF_COARSE];
+        prof_acc->ms_select += ms[PF_SELECT], prof_acc->ms_prep += ms[PF_PREP], prof_acc->ms_group += ms[PF_GROUP];
+        prof_acc->ms_scan += ms[PF_SCAN], prof_acc->ms_rerank += ms[PF_RERANK], prof_acc->ms_sort += ms[PF_SORT];
+        prof_acc->ms_replay += ms[PF_REPLAY], prof_acc->ms_total += ms[PF_TOTAL];
+    }
+    if (prof_acc) {
+        prof_acc->scan_candidates += res->rough;
+        prof_acc->scan_bytes += res->rough * (uint64_t)(dim / 8 + 16);
+        prof_acc->rerank_candidates += ws.h_totals[3];
+    }
+    return RQ_OK;
+}
+
+static Workspace *ws_acquire(rq_index *idx) {
+    std::lock_guard<std::mutex> g(idx->ws_mu);
+    for (auto &w : idx->ws_pool)
+        if (!w->busy) {
+            w->busy = true;
+            return w.get();
+        }
+    idx->ws_pool.emplace_back(new Workspace());
+    idx->ws_pool.back()->busy = true;
+    return idx->ws_pool.back().get();
+}
+static void ws_release(rq_index *idx, Workspace *w) {
+    std::lock_guard<std::mutex> g(idx->ws_mu);
+    w->busy = false;
+}
+
+// queries/outputs in device memory
+static rq_status query_device(rq_index *idx, const float *d_q, uint32_t nq, uint32_t len, uint32_t probe,
+                              uint32_t topk, bool heuristic, float *d_out_dist, uint32_t *d_out_id,
+                              uint32_t *d_out_n) {
+    RQC(ensure_device());
+    if (!idx || !d_q || !d_out_dist || !d_out_id || !d_out_n) return fail(RQ_ERR_INVALID, "null argument");
+    if (idx->dim != (len + 63) / 64 * 64)  // rabitq.rs:275
+        return fail(RQ_ERR_DIM_MISMATCH, "query length " + std::to_string(len) + " does not pad to index dim " +
+                                             std::to_string(idx->dim));
+    if (probe == 0 || idx->k == 0) return fail(RQ_ERR_INVALID, "probe == 0 (the reference panics at rabitq.rs:295)");
+    if (topk == 0 || topk > RQ_MAX_TOPK) return fail(RQ_ERR_UNSUPPORTED, "topk must be in [1, 2048]");
+    if (std::min(probe, idx->k) > RQ_MAX_PROBE) return fail(RQ_ERR_UNSUPPORTED, "probe > 16384 not supported");
+    if (idx->dim > 4096) return fail(RQ_ERR_UNSUPPORTED, "dim > 4096 not supported");
+    if (nq == 0) return RQ_OK;
+    rq_profile_t prof;
+    memset(&prof, 0, sizeof prof);
+    Workspace *ws = ws_acquire(idx);
+    struct Rel {
+        rq_index *i;
+        Workspace *w;
+        ~Rel() { ws_release(i, w); }
+    } rel{idx, ws};
+    uint64_t tot_rough = 0, tot_precise = 0;
+    bool any_empty = false;
+    std::vector<uint32_t> h_need, h_alen, over_rows;
+    for (uint32_t q0 = 0; q0 < nq; q0 += RQ_MAX_NQ_PER_PASS) {
+        QueryParams qp{std::min(nq - q0, RQ_MAX_NQ_PER_PASS), len, probe, topk, heuristic, RQ_DEFAULT_CAP,
+                       RQ_DEFAULT_CAP};
+        RQC(ws_prepare(idx, *ws, qp));
+        PassResult pr;
+        RQC(run_pass(idx, *ws, d_q + (uint64_t)q0 * len, qp, nullptr, d_out_dist + (uint64_t)q0 * topk,
+                     d_out_id + (uint64_t)q0 * topk, d_out_n + q0, &pr, &prof));
+        tot_rough += pr.rough;
+        tot_precise += pr.precise;
+        // survivor-buffer overflow: re-run exactly those queries with the capacity they asked for
+        uint32_t cap = qp.cap, hcap = qp.hcap;
+        if (pr.overflowed) {
+            h_need.resize(qp.nq);
+            h_alen.resize(qp.nq);
+            HIPC(hipMemcpy(h_need.data(), ws->need.p, qp.nq * 4, hipMemcpyDeviceToHost));
+            HIPC(hipMemcpy(h_alen.data(), ws->arr_len.p, qp.nq * 4, hipMemcpyDeviceToHost));
+            over_rows.clear();
+            uint32_t max_need = 0, max_alen = 0;
+            for (uint32_t b = 0; b < qp.nq; ++b)
+                if (h_need[b] > cap || (heuristic && h_alen[b] > hcap)) {
+                    over_rows.push_back(b);
+                    max_need = std::max(max_need, h_need[b]);
+                    max_alen = std::max(max_alen, h_alen[b]);
+                }
+            int guard = 0;
+            while (!over_rows.empty() && guard++ < 8) {
+                prof.retries += (uint32_t)over_rows.size();
+                uint32_t ncap = std::max(cap * 2, pow2_ceil(max_need));
+                uint32_t nhcap = heuristic ? std::max(hcap * 2, pow2_ceil(std::max(max_alen, max_need))) : hcap;
+                // bound the retry workspace to ~4 GiB of survivor records
+                uint32_t chunk = (uint32_t)std::max<uint64_t>(1, (4ull << 30) / ((uint64_t)(ncap + nhcap) * sizeof(SurvRec)));
+                std::vector<uint32_t> still;
+                Workspace rws;
+                DevBuf<float> sub_q;
+                DevBuf<uint32_t> sub_rows;
+                for (size_t o = 0; o < over_rows.size(); o += chunk) {
+                    uint32_t m = (uint32_t)std::min<size_t>(chunk, over_rows.size() - o);
+                    QueryParams rq{m, len, probe, topk, heuristic, ncap, nhcap};
+                    RQC(ws_prepare(idx, rws, rq));
+                    RQC(sub_q.ensure((uint64_t)m * len));
+                    RQC(sub_rows.ensure(m));
+                    HIPC(hipMemcpy(sub_rows.p, over_rows.data() + o, m * 4, hipMemcpyHostToDevice));
+                    gather_rows_kernel<<<ceil_div((uint64_t)m * len, 256), 256, 0, rws.stream>>>(
+                        d_q + (uint64_t)q0 * len, sub_rows.p, m, len, sub_q.p);
+                    PassResult rr;
+                    RQC(run_pass(idx, rws, sub_q.p, rq, sub_rows.p, d_out_dist + (uint64_t)q0 * topk,
+                                 d_out_id + (uint64_t)q0 * topk, d_out_n + q0, &rr, nullptr));
+                    tot_precise += rr.precise;
+                    if (rr.overflowed) {
+                        std::vector<uint32_t> n2(m), a2(m);
+                        HIPC(hipMemcpy(n2.data(), rws.need.p, m * 4, hipMemcpyDeviceToHost));
+                        HIPC(hipMemcpy(a2.data(), rws.arr_len.p, m * 4, hipMemcpyDeviceToHost));
+                        for (uint32_t b = 0; b < m; ++b)
+                            if (n2[b] > ncap || (heuristic && a2[b] > nhcap)) {
+                                still.push_back(over_rows[o + b]);
+                                max_need = std::max(max_need, n2[b]);
+                                max_alen = std::max(max_alen, a2[b]);
+                            }
+                    }
+                }
+                cap = ncap, hcap = nhcap;
+                over_rows.swap(still);
+            }
+            if (!over_rows.empty()) return fail(RQ_ERR_OOM, "survivor buffers kept overflowing");
+        }
+    }
+    if (heuristic) {  // rerank.rs:171-173: an empty array panics in the reference
+        std::vector<uint32_t> h_n(nq);
+        HIPC(hipMemcpy(h_n.data(), d_out_n, nq * 4, hipMemcpyDeviceToHost));
+        for (uint32_t v : h_n) any_empty |= (v == 0);
+    }
+    g_rough.fetch_add(tot_rough, std::memory_order_relaxed);      // rerank.rs:105
+    g_precise.fetch_add(tot_precise, std::memory_order_relaxed);  // rerank.rs:104
+    g_query.fetch_add(nq, std::memory_order_relaxed);             // rabitq.rs:331
+    g_profile = prof;
+    if (any_empty) return fail(RQ_ERR_EMPTY, "heuristic ranker accepted no candidate for at least one query");
+    return RQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// index construction helpers
+// ------------------------------------------------------------------------------------------------
+static rq_status finish_index(rq_index *idx) {
+    // derived state: transposed centroids, longest list
+    idx->W = idx->dim / 64;
+    RQC(idx->cent_t.alloc((size_t)idx->dim * idx->k));
+    static std::once_flag once;
+    std::call_once(once, [] {  // kernels whose dynamic LDS can exceed the 64 KiB default
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(select_probe_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(coarse_dist_kernel<4>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(assign_generic_kernel<8>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    });
+    if (idx->k)
+        transpose_kernel<<<dim3(ceil_div(idx->dim, 32), ceil_div(idx->k, 32)), dim3(32, 8)>>>(
+            idx->centroids.p, idx->cent_t.p, idx->k, idx->dim);
+    DevBuf<uint32_t> mx;
+    RQC(mx.alloc(1));
+    HIPC(hipMemset(mx.p, 0, 4));
+    if (idx->k) max_list_len_kernel<<<ceil_div(idx->k, 256), 256>>>(idx->offsets.p, idx->k, mx.p);
+    HIPC(hipMemcpy(&idx->max_list_len, mx.p, 4, hipMemcpyDeviceToHost));
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipGetLastError());
+    return RQ_OK;
+}
+
+// Gaussian-QR orthogonal matrix (src/utils.rs:16-20), seeded: Householder QR in f64 of a
+// dim x dim N(0,1) matrix; Q returned row-major in f32.
+static void gen_orthogonal(uint32_t dim, uint64_t seed, std::vector<float> &out) {
+    std::mt19937_64 rng(seed);
+    std::normal_distribution<double> nd(0.0, 1.0);
+    const size_t D = dim;
+    std::vector<double> A(D * D), Q(D * D, 0.0), v(D);
+    for (auto &a : A) a = nd(rng);
+    std::vector<std::vector<double>> vs;
+    vs.reserve(D);
+    for (size_t j = 0; j < D; ++j) {
+        double norm = 0;
+        for (size_t i = j; i < D; ++i) norm += A[i * D + j] * A[i * D + j];
+        norm = std::sqrt(norm);
+        std::vector<double> h(D, 0.0);
+        double alpha = A[j * D + j] > 0 ? -norm : norm;
+        for (size_t i = j; i < D; ++i) h[i] = A[i * D + j];
+        h[j] -= alpha;
+        double hn = 0;
+        for (size_t i = j; i < D; ++i) hn += h[i] * h[i];
+        if (hn > 0) {
+            for (size_t c = j; c < D; ++c) {
+                double dot = 0;
+                for (size_t i = j; i < D; ++i) dot += h[i] * A[i * D + c];
+                dot = 2 * dot / hn;
+                for (size_t i = j; i < D; ++i) A[i * D + c] -= dot * h[i];
+            }
+        }
+        vs.push_back(std::move(h));
+    }
+    for (size_t i = 0; i < D; ++i) Q[i * D + i] = 1.0;
+    for (size_t jj = D; jj-- > 0;) {  // Q = H_0 H_1 ... H_{D-1}
+        const auto &h = vs[jj];
+        double hn = 0;
+        for (size_t i = jj; i < D; ++i) hn += h[i] * h[i];
+        if (hn == 0) continue;
+        for (size_t c = 0; c < D; ++c) {
+            double dot = 0;
+            for (size_t i = jj; i < D; ++i) dot += h[i] * Q[i * D + c];
+            dot = 2 * dot / hn;
+            for (size_t i = jj; i < D; ++i) Q[i * D + c] -= dot * h[i];
+        }
+    }
+    out.resize(D * D);
+    for (size_t i = 0; i < D * D; ++i) out[i] = (float)Q[i];
+}
+
+static void launch_assign(const float *xrot, const rq_index *idx, uint64_t n, uint32_t *label, float *dist,
+                          hipStream_t st) {
+    if (n == 0) return;
+    if (idx->dim == 128)
+        assign_regs_kernel<128><<<ceil_div(n, 256), 256, 0, st>>>(xrot, idx->centroids.p, n, idx->k, label, dist);
+    else if (idx->dim == 64)
+        assign_regs_kernel<64><<<ceil_div(n, 256), 256, 0, st>>>(xrot, idx->centroids.p, n, idx->k, label, dist);
+    else
+        assign_generic_kernel<8><<<ceil_div(n, 8), 256, 8 * idx->dim * sizeof(float), st>>>(
+            xrot, idx->cent_t.p, n, idx->k, idx->dim, label, dist);
+}
+
+static rq_status build_device(const float *d_base, uint64_t n, uint32_t d, const float *d_centroids, uint32_t k,
+                              const float *orthogonal_host, uint64_t seed, rq_index **out) {
+    RQC(ensure_device());
+    if (!out) return fail(RQ_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    if ((n && !d_base) || !d_centroids || d == 0 || k == 0) return fail(RQ_ERR_INVALID, "bad build arguments");
+    if (n >= 0xFFFFFFFFull) return fail(RQ_ERR_UNSUPPORTED, "n must fit u32 ids (rabitq.rs:64-65)");
+    const uint32_t dim = (d + 63) / 64 * 64;  // rabitq.rs:168-179
+    if (dim > 4096) return fail(RQ_ERR_UNSUPPORTED, "dim > 4096 not supported");
+    std::unique_ptr<rq_index> idx(new rq_index());
+    idx->dim = dim, idx->k = k, idx->n = n, idx->W = dim / 64;
+
+    std::vector<float> Pgen;
+    if (!orthogonal_host) {
+        gen_orthogonal(dim, seed, Pgen);  // utils.rs:16-20, seeded
+        orthogonal_host = Pgen.data();
+    }
+    RQC(idx->P.alloc((size_t)dim * dim));
+    HIPC(hipMemcpy(idx->P.p, orthogonal_host, (size_t)dim * dim * 4, hipMemcpyHostToDevice));
+
+    // centroids: pad, rotate (rabitq.rs:189), transpose for the lane<->centroid kernels
+    DevBuf<float> cpad;
+    RQC(cpad.alloc((size_t)k * dim));
+    pad_rows_kernel<<<ceil_div((uint64_t)k * dim, 256), 256>>>(d_centroids, cpad.p, k, d, dim);
+    RQC(idx->centroids.alloc((size_t)k * dim));
+    launch_rotate(cpad.p, idx->P.p, idx->centroids.p, k, dim, true, nullptr);
+    RQC(idx->cent_t.alloc((size_t)dim * k));
+    transpose_kernel<<<dim3(ceil_div(dim, 32), ceil_div(k, 32)), dim3(32, 8)>>>(idx->centroids.p, idx->cent_t.p, k, dim);
+    cpad.release();
+
+    // per-vector pass in chunks: rotate (:188) -> nearest list (:203) -> sign-pack + factors (:205-229)
+    DevBuf<uint32_t> label;
+    DevBuf<float> mind;
+    DevBuf<uint64_t> codes_tmp;
+    DevBuf<float4> factors_tmp;
+    RQC(label.alloc(n));
+    RQC(mind.alloc(n));
+    RQC(codes_tmp.alloc(n * idx->W));
+    RQC(factors_tmp.alloc(n));
+    const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(n, 1), 1ull << 20);
+    DevBuf<float> xpad, xrot;
+    if (d != dim) RQC(xpad.alloc(chunk * dim));
+    RQC(xrot.alloc(chunk * dim));
+    for (uint64_t i0 = 0; i0 < n; i0 += chunk) {
+        const uint64_t m = std::min(chunk, n - i0);
+        const float *src = d_base + i0 * d;
+        if (d != dim) {
+            pad_rows_kernel<<<ceil_div(m * dim, 256), 256>>>(src, xpad.p, m, d, dim);
+            src = xpad.p;
+        }
+        launch_rotate(src, idx->P.p, xrot.p, m, dim, true, nullptr);
+        launch_assign(xrot.p, idx.get(), m, label.p + i0, mind.p + i0, nullptr);
+        quantize_kernel<<<ceil_div(m, 32), 256>>>(xrot.p, idx->centroids.p, label.p + i0, m, dim,
+                                                  codes_tmp.p + i0 * idx->W, factors_tmp.p + i0);
+    }
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipGetLastError());
+    xpad.release();
+    xrot.release();
+
+    // cluster ordering (rabitq.rs:232-252)
+    DevBuf<uint32_t> cnt;
+    DevBuf<unsigned long long> keys;
+    RQC(cnt.alloc((size_t)k + 1));
+    RQC(idx->offsets.alloc((size_t)k + 1));
+    RQC(keys.alloc(n));
+    HIPC(hipMemset(cnt.p, 0, ((size_t)k + 1) * 4));
+    if (n) label_hist_kernel<<<ceil_div(n, 256), 256>>>(label.p, n, cnt.p);
+    group_scan_kernel<<<1, 1024>>>(cnt.p, k, idx->offsets.p);  // also zeroes cnt -> cursor
+    if (n) label_scatter_kernel<<<ceil_div(n, 256), 256>>>(label.p, mind.p, n, 0, idx->offsets.p, cnt.p, keys.p);
+    list_sort_kernel<<<k, 1024>>>(keys.p, idx->offsets.p);
+    RQC(idx->base.alloc(n * dim));
+    RQC(idx->codes.alloc(n * idx->W));
+    RQC(idx->factors.alloc(n));
+    RQC(idx->map_ids.alloc(n));
+    if (n)
+        gather_kernel<<<ceil_div(n, 4), 256>>>(keys.p, n, d_base, d, dim, codes_tmp.p, factors_tmp.p, idx->base.p,
+                                               idx->codes.p, idx->factors.p, idx->map_ids.p);
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipGetLastError());
+    RQC(finish_index(idx.get()));
+    *out = idx.release();
+    return RQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// "vecs" files (src/utils.rs:280-364): records [u32 LE count][count x elem LE]
+// ------------------------------------------------------------------------------------------------
+struct VecsFile {
+    std::vector<unsigned char> data;  // concatenated payloads
+    std::vector<uint32_t> lens;       // per-record element counts
+};
+static rq_status read_vecs_file(const std::string &path, size_t elem, VecsFile &out) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return fail(RQ_ERR_IO, "cannot open " + path);
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<unsigned char> raw((size_t)sz);
+    if (sz && fread(raw.data(), 1, (size_t)sz, f) != (size_t)sz) {
+        fclose(f);
+        return fail(RQ_ERR_IO, "short read on " + path);
+    }
+    fclose(f);
+    out.data.clear();
+    out.lens.clear();
+    out.data.reserve((size_t)sz);
+    size_t off = 0;
+    while (off + 4 <= (size_t)sz) {
+        uint32_t cnt;
+        memcpy(&cnt, raw.data() + off, 4);
+        off += 4;
+        size_t bytes = (size_t)cnt * elem;
+        if (off + bytes > (size_t)sz) return fail(RQ_ERR_IO, "truncated record in " + path);
+        out.data.insert(out.data.end(), raw.begin() + off, raw.begin() + off + bytes);
+        out.lens.push_back(cnt);
+        off += bytes;
+    }
+    return RQ_OK;
+}
+static rq_status write_record(FILE *f, const void *data, uint32_t count, size_t elem, const std::string &path) {
+    if (fwrite(&count, 4, 1, f) != 1 || (count && fwrite(data, elem, count, f) != count))
+        return fail(RQ_ERR_IO, "write error on " + path);
+    return RQ_OK;
+}
+
+static rq_status from_arrays(uint32_t dim, uint64_t n, uint32_t k, const float *base, const float *orthogonal,
+                             const float *centroids, const uint32_t *offsets, const uint32_t *map_ids,
+                             const uint64_t *codes, const rq_factor_t *factors, rq_index **out) {
+    RQC(ensure_device());
+    if (!out) return fail(RQ_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    if (dim == 0 || dim % 64 != 0) return fail(RQ_ERR_DIM_MISMATCH, "dim must be a non-zero multiple of 64 (rabitq.rs:109)");
+    if (!orthogonal || !centroids || !offsets || (n && (!base || !map_ids || !codes || !factors)))
+        return fail(RQ_ERR_INVALID, "null array");
+    if (n >= 0xFFFFFFFFull) return fail(RQ_ERR_UNSUPPORTED, "n must fit u32");
+    std::unique_ptr<rq_index> idx(new rq_index());
+    idx->dim = dim, idx->n = n, idx->k = k, idx->W = dim / 64;
+    RQC(idx->base.alloc(n * dim));
+    RQC(idx->P.alloc((size_t)dim * dim));
+    RQC(idx->centroids.alloc((size_t)k * dim));
+    RQC(idx->offsets.alloc((size_t)k + 1));
+    RQC(idx->map_ids.alloc(n));
+    RQC(idx->codes.alloc(n * idx->W));
+    RQC(idx->factors.alloc(n));
+    if (n) {
+        HIPC(hipMemcpy(idx->base.p, base, n * dim * 4, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(idx->map_ids.p, map_ids, n * 4, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(idx->codes.p, codes, n * idx->W * 8, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(idx->factors.p, factors, n * 16, hipMemcpyHostToDevice));
+    }
+    HIPC(hipMemcpy(idx->P.p, orthogonal, (size_t)dim * dim * 4, hipMemcpyHostToDevice));
+    if (k) HIPC(hipMemcpy(idx->centroids.p, centroids, (size_t)k * dim * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(idx->offsets.p, offsets, ((size_t)k + 1) * 4, hipMemcpyHostToDevice));
+    RQC(finish_index(idx.get()));
+    *out = idx.release();
+    return RQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// extern "C"
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *rq_version(void) { return "rabitq_hip 0.1.0 (gfx950)"; }
+const char *rq_last_error(void) { return g_err.c_str(); }
+
+rq_status rq_init(int device) {
+    RQC(ensure_device());
+    HIPC(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPC(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+        return fail(RQ_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is gfx950-only");
+    return RQ_OK;
+}
+
+rq_status rq_build_device(const float *d_base, uint64_t n, uint32_t d, const float *d_centroids, uint32_t k,
+                          const float *orthogonal_host, uint64_t seed, rq_index **out) {
+    return build_device(d_base, n, d, d_centroids, k, orthogonal_host, seed, out);
+}
+
+rq_status rq_build(const float *base, uint64_t n, uint32_t d, const float *centroids, uint32_t k,
+                   const float *orthogonal, uint64_t seed, rq_index **out) {
+    RQC(ensure_device());
+    if ((n && !base) || !centroids) return fail(RQ_ERR_INVALID, "null argument");
+    DevBuf<float> db, dc;
+    RQC(db.alloc(n * d));
+    RQC(dc.alloc((size_t)k * d));
+    if (n) HIPC(hipMemcpy(db.p, base, n * d * 4, hipMemcpyHostToDevice));
+    if (k) HIPC(hipMemcpy(dc.p, centroids, (size_t)k * d * 4, hipMemcpyHostToDevice));
+    return build_device(db.p, n, d, dc.p, k, orthogonal, seed, out);
+}
+
+rq_status rq_build_from_path(const char *base_fvecs, const char *centroid_fvecs, const float *orthogonal,
+                             uint64_t seed, rq_index **out) {
+    if (!base_fvecs || !centroid_fvecs) return fail(RQ_ERR_INVALID, "null path");
+    VecsFile b, c;
+    RQC(read_vecs_file(base_fvecs, 4, b));      // rabitq.rs:160
+    RQC(read_vecs_file(centroid_fvecs, 4, c));  // :163
+    if (b.lens.empty() || c.lens.empty()) return fail(RQ_ERR_IO, "empty fvecs file");
+    uint32_t d = b.lens[0];
+    if (c.lens[0] != d) return fail(RQ_ERR_DIM_MISMATCH, "base and centroid dimensions differ (rabitq.rs:165)");
+    for (uint32_t l : b.lens)
+        if (l != d) return fail(RQ_ERR_IO, "ragged base.fvecs");
+    for (uint32_t l : c.lens)
+        if (l != d) return fail(RQ_ERR_IO, "ragged centroids.fvecs");
+    return rq_build(reinterpret_cast<const float *>(b.data.data()), b.lens.size(), d,
+                    reinterpret_cast<const float *>(c.data.data()), (uint32_t)c.lens.size(), orthogonal, seed, out);
+}
+
+rq_status rq_from_arrays(uint32_t dim, uint64_t n, uint32_t k, const float *base, const float *orthogonal,
+                         const float *centroids, const uint32_t *offsets, const uint32_t *map_ids,
+                         const uint64_t *codes, const rq_factor_t *factors, rq_index **out) {
+    return from_arrays(dim, n, k, base, orthogonal, centroids, offsets, map_ids, codes, factors, out);
+}
+
+// rabitq.rs:84-125
+rq_status rq_load_dir(const char *dir, rq_index **out) {
+    if (!dir || !out) return fail(RQ_ERR_INVALID, "null argument");
+    const std::string d(dir);
+    VecsFile ortho, cent, oi, fac, bin, base;
+    RQC(read_vecs_file(d + "/orthogonal.fvecs", 4, ortho));
+    RQC(read_vecs_file(d + "/centroids.fvecs", 4, cent));
+    RQC(read_vecs_file(d + "/offsets_ids.ivecs", 4, oi));
+    RQC(read_vecs_file(d + "/factors.fvecs", 4, fac));
+    RQC(read_vecs_file(d + "/x_binary_vec.u64vecs", 8, bin));
+    RQC(read_vecs_file(d + "/base.fvecs", 4, base));
+    const uint32_t dim = (uint32_t)ortho.lens.size();  // :108 dim = orthogonal.nrows()
+    if (dim == 0 || dim % 64 != 0) return fail(RQ_ERR_DIM_MISMATCH, "orthogonal.fvecs: dim % 64 != 0 (rabitq.rs:109)");
+    if (cent.lens.size() != dim || oi.lens.empty()) return fail(RQ_ERR_IO, "malformed index directory");
+    const uint32_t k = cent.lens[0];
+    // centroids.fvecs holds the dim x k matrix row-wise: un-transpose to k x dim
+    std::vector<float> c((size_t)k * dim);
+    const float *ct = reinterpret_cast<const float *>(cent.data.data());
+    for (uint32_t r = 0; r < dim; ++r)
+        for (uint32_t j = 0; j < k; ++j) c[(size_t)j * dim + r] = ct[(size_t)r * k + j];
+    const uint32_t *oip = reinterpret_cast<const uint32_t *>(oi.data.data());
+    const uint32_t first = oi.lens.front(), last = oi.lens.back();
+    size_t total = 0;
+    for (uint32_t l : oi.lens) total += l;
+    if (first != k + 1) return fail(RQ_ERR_IO, "offsets record length != k + 1");
+    const uint64_t n = last;
+    if (fac.data.size() != n * 16 || bin.data.size() != n * (dim / 64) * 8 || base.data.size() != n * dim * 4)
+        return fail(RQ_ERR_IO, "index arrays disagree on n");
+    return from_arrays(dim, n, k, reinterpret_cast<const float *>(base.data.data()),
+                       reinterpret_cast<const float *>(ortho.data.data()), c.data(), oip, oip + (total - last),
+                       reinterpret_cast<const uint64_t *>(bin.data.data()),
+                       reinterpret_cast<const rq_factor_t *>(fac.data.data()), out);
+}
+
+rq_status rq_get_array(const rq_index *idx, int which, void *dst, uint64_t dst_bytes);
+
+// rabitq.rs:128-156
+rq_status rq_dump_dir(const rq_index *idx, const char *dir) {
+    if (!idx || !dir) return fail(RQ_ERR_INVALID, "null argument");
+    mkdir(dir, 0777);
+    const std::string d(dir);
+    const uint32_t dim = idx->dim, k = idx->k;
+    const uint64_t n = idx->n;
+    if (4 * n > 0xFFFFFFFFull || n * (dim / 64) > 0xFFFFFFFFull)
+        return fail(RQ_ERR_UNSUPPORTED, "single-record files need 4n and n*dim/64 to fit the u32 header (rabitq.rs:141-155)");
+    auto open = [&](const char *name, FILE **f) -> rq_status {
+        *f = fopen((d + "/" + name).c_str(), "wb");
+        return *f ? RQ_OK : fail(RQ_ERR_IO, "cannot create " + d + "/" + name);
+    };
+    FILE *f;
+    {  // base.fvecs: n records of dim (cluster order), streamed in chunks
+        RQC(open("base.fvecs", &f));
+        const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / (dim * 4));
+        std::vector<float> buf(std::min<uint64_t>(chunk, std::max<uint64_t>(n, 1)) * dim);
+        for (uint64_t i0 = 0; i0 < n; i0 += chunk) {
+            uint64_t m = std::min(chunk, n - i0);
+            if (hipMemcpy(buf.data(), idx->base.p + i0 * dim, m * dim * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+                fclose(f);
+                return fail(RQ_ERR_HIP, "copy base failed");
+            }
+            for (uint64_t i = 0; i < m; ++i) {
+                rq_status s = write_record(f, buf.data() + i * dim, dim, 4, "base.fvecs");
+                if (s != RQ_OK) {
+                    fclose(f);
+                    return s;
+                }
+            }
+        }
+        fclose(f);
+    }
+    std::vector<float> P((size_t)dim * dim), C((size_t)k * dim), row(std::max<uint32_t>(k, 1));
+    std::vector<uint32_t> off((size_t)k + 1), ids(n);
+    std::vector<float> fac(n * 4);
+    std::vector<uint64_t> codes(n * (dim / 64));
+    RQC(rq_get_array(idx, RQ_ARR_ORTHOGONAL, P.data(), P.size() * 4));
+    RQC(rq_get_array(idx, RQ_ARR_CENTROIDS, C.data(), C.size() * 4));
+    RQC(rq_get_array(idx, RQ_ARR_OFFSETS, off.data(), off.size() * 4));
+    RQC(rq_get_array(idx, RQ_ARR_MAP_IDS, ids.data(), ids.size() * 4));
+    RQC(rq_get_array(idx, RQ_ARR_FACTORS, fac.data(), fac.size() * 4));
+    RQC(rq_get_array(idx, RQ_ARR_CODES, codes.data(), codes.size() * 8));
+    rq_status s = RQ_OK;
+    RQC(open("orthogonal.fvecs", &f));
+    for (uint32_t r = 0; r < dim && s == RQ_OK; ++r) s = write_record(f, P.data() + (size_t)r * dim, dim, 4, "orthogonal.fvecs");
+    fclose(f);
+    RQC(s);
+    RQC(open("centroids.fvecs", &f));  // dim records of k values (rotated, transposed)
+    for (uint32_t r = 0; r < dim && s == RQ_OK; ++r) {
+        for (uint32_t j = 0; j < k; ++j) row[j] = C[(size_t)j * dim + r];
+        s = write_record(f, row.data(), k, 4, "centroids.fvecs");
+    }
+    fclose(f);
+    RQC(s);
+    RQC(open("offsets_ids.ivecs", &f));
+    s = write_record(f, off.data(), k + 1, 4, "offsets_ids.ivecs");
+    if (s == RQ_OK) s = write_record(f, ids.data(), (uint32_t)n, 4, "offsets_ids.ivecs");
+    fclose(f);
+    RQC(s);
+    RQC(open("factors.fvecs", &f));
+    s = write_record(f, fac.data(), (uint32_t)(4 * n), 4, "factors.fvecs");
+    fclose(f);
+    RQC(s);
+    RQC(open("x_binary_vec.u64vecs", &f));
+    s = write_record(f, codes.data(), (uint32_t)(n * (dim / 64)), 8, "x_binary_vec.u64vecs");
+    fclose(f);
+    return s;
+}
+
+void rq_free(rq_index *idx) { delete idx; }
+
+rq_status rq_info(const rq_index *idx, rq_info_t *out) {
+    if (!idx || !out) return fail(RQ_ERR_INVALID, "null argument");
+    out->dim = idx->dim, out->k = idx->k, out->n = idx->n, out->max_list_len = idx->max_list_len, out->reserved = 0;
+    return RQ_OK;
+}
+
+rq_status rq_get_device_ptr(const rq_index *idx, int which, const void **out_ptr, uint64_t *out_bytes) {
+    if (!idx || !out_ptr || !out_bytes) return fail(RQ_ERR_INVALID, "null argument");
+    switch (which) {
+        case RQ_ARR_BASE: *out_ptr = idx->base.p, *out_bytes = idx->n * idx->dim * 4; break;
+        case RQ_ARR_ORTHOGONAL: *out_ptr = idx->P.p, *out_bytes = (uint64_t)idx->dim * idx->dim * 4; break;
+        case RQ_ARR_CENTROIDS: *out_ptr = idx->centroids.p, *out_bytes = (uint64_t)idx->k * idx->dim * 4; break;
+        case RQ_ARR_OFFSETS: *out_ptr = idx->offsets.p, *out_bytes = ((uint64_t)idx->k + 1) * 4; break;
+        case RQ_ARR_MAP_IDS: *out_ptr = idx->map_ids.p, *out_bytes = idx->n * 4; break;
+        case RQ_ARR_CODES: *out_ptr = idx->codes.p, *out_bytes = idx->n * idx->W * 8; break;
+        case RQ_ARR_FACTORS: *out_ptr = idx->factors.p, *out_bytes = idx->n * 16; break;
+        default: return fail(RQ_ERR_INVALID, "unknown array id");
+    }
+    return RQ_OK;
+}
+
+rq_status rq_get_array(const rq_index *idx, int which, void *dst, uint64_t dst_bytes) {
+    const void *p;
+    uint64_t bytes;
+    RQC(rq_get_device_ptr(idx, which, &p, &bytes));
+    if (!dst || dst_bytes < bytes) return fail(RQ_ERR_INVALID, "destination too small");
+    if (bytes) HIPC(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
+    return RQ_OK;
+}
+
+rq_status rq_query_batch_device(const rq_index *idx, const float *d_queries, uint32_t nq, uint32_t len,
+                                uint32_t probe, uint32_t topk, int heuristic_rank, float *d_out_dist,
+                                uint32_t *d_out_id, uint32_t *d_out_n) {
+    return query_device(const_cast<rq_index *>(idx), d_queries, nq, len, probe, topk, heuristic_rank != 0, d_out_dist,
+                        d_out_id, d_out_n);
+}
+
+rq_status rq_query_batch(const rq_index *idx, const float *queries, uint32_t nq, uint32_t len, uint32_t probe,
+                         uint32_t topk, int heuristic_rank, float *out_dist, uint32_t *out_id, uint32_t *out_n) {
+    RQC(ensure_device());
+    if (!idx || !queries || !out_dist || !out_id || !out_n) return fail(RQ_ERR_INVALID, "null argument");
+    if (nq == 0) return RQ_OK;
+    if (topk == 0) return fail(RQ_ERR_UNSUPPORTED, "topk must be in [1, 2048]");
+    DevBuf<float> dq, dd;
+    DevBuf<uint32_t> di, dn;
+    RQC(dq.alloc((uint64_t)nq * len));
+    RQC(dd.alloc((uint64_t)nq * topk));
+    RQC(di.alloc((uint64_t)nq * topk));
+    RQC(dn.alloc(nq));
+    HIPC(hipMemcpy(dq.p, queries, (uint64_t)nq * len * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemset(dn.p, 0, nq * 4));
+    rq_status s = query_device(const_cast<rq_index *>(idx), dq.p, nq, len, probe, topk, heuristic_rank != 0, dd.p, di.p,
+                               dn.p);
+    if (s != RQ_OK && s != RQ_ERR_EMPTY) return s;
+    HIPC(hipMemcpy(out_dist, dd.p, (uint64_t)nq * topk * 4, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(out_id, di.p, (uint64_t)nq * topk * 4, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(out_n, dn.p, nq * 4, hipMemcpyDeviceToHost));
+    return s;
+}
+
+rq_status rq_query(const rq_index *idx, const float *query, uint32_t len, uint32_t probe, uint32_t topk,
+                   int heuristic_rank, float *out_dist, uint32_t *out_id, uint32_t *out_n) {
+    return rq_query_batch(idx, query, 1, len, probe, topk, heuristic_rank, out_dist, out_id, out_n);
+}
+
+rq_status rq_metrics(rq_metrics_t *out) {
+    if (!out) return fail(RQ_ERR_INVALID, "null argument");
+    out->rough = g_rough.load(), out->precise = g_precise.load(), out->query = g_query.load(), out->miss = g_miss.load();
+    return RQ_OK;
+}
+rq_status rq_metrics_reset(void) {
+    g_rough = 0, g_precise = 0, g_query = 0, g_miss = 0;
+    return RQ_OK;
+}
+
+rq_status rq_set_profiling(int enabled) {
+    g_profiling = enabled;
+    return RQ_OK;
+}
+rq_status rq_last_profile(rq_profile_t *out) {
+    if (!out) return fail(RQ_ERR_INVALID, "null argument");
+    *out = g_profile;
+    return RQ_OK;
+}
+
+// ---- per-stage entry points --------------------------------------------------------------------
+rq_status rq_rotate(const float *x, uint64_t n, uint32_t dim, const float *orthogonal, int use_mfma, float *out) {
+    RQC(ensure_device());
+    if (!x || !orthogonal || !out) return fail(RQ_ERR_INVALID, "null argument");
+    if (dim == 0 || dim % 64) return fail(RQ_ERR_DIM_MISMATCH, "dim must be a multiple of 64");
+    DevBuf<float> dx, dp, dout;
+    RQC(dx.alloc(n * dim));
+    RQC(dp.alloc((size_t)dim * dim));
+    RQC(dout.alloc(n * dim));
+    HIPC(hipMemcpy(dx.p, x, n * dim * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(dp.p, orthogonal, (size_t)dim * dim * 4, hipMemcpyHostToDevice));
+    launch_rotate(dx.p, dp.p, dout.p, n, dim, use_mfma != 0, nullptr);
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpy(out, dout.p, n * dim * 4, hipMemcpyDeviceToHost));
+    return RQ_OK;
+}
+
+rq_status rq_quantize_pack(const float *x_rot, uint64_t n, uint32_t dim, const float *centroids_rot, uint32_t k,
+                           uint32_t *out_label, float *out_dist, uint64_t *out_codes, rq_factor_t *out_factors) {
+    RQC(ensure_device());
+    if (!x_rot || !centroids_rot || !out_label || !out_dist || !out_codes || !out_factors)
+        return fail(RQ_ERR_INVALID, "null argument");
+    if (dim == 0 || dim % 64 || k == 0) return fail(RQ_ERR_DIM_MISMATCH, "dim must be a multiple of 64, k > 0");
+    rq_index tmp;
+    tmp.dim = dim, tmp.k = k, tmp.W = dim / 64;
+    DevBuf<float> dx, dd;
+    DevBuf<uint32_t> dl;
+    DevBuf<uint64_t> dc;
+    DevBuf<float4> df;
+    RQC(dx.alloc(n * dim));
+    RQC(tmp.centroids.alloc((size_t)k * dim));
+    RQC(tmp.cent_t.alloc((size_t)k * dim));
+    RQC(dd.alloc(n));
+    RQC(dl.alloc(n));
+    RQC(dc.alloc(n * tmp.W));
+    RQC(df.alloc(n));
+    HIPC(hipMemcpy(dx.p, x_rot, n * dim * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(tmp.centroids.p, centroids_rot, (size_t)k * dim * 4, hipMemcpyHostToDevice));
+    transpose_kernel<<<dim3(ceil_div(dim, 32), ceil_div(k, 32)), dim3(32, 8)>>>(tmp.centroids.p, tmp.cent_t.p, k, dim);
+    launch_assign(dx.p, &tmp, n, dl.p, dd.p, nullptr);
+    if (n) quantize_kernel<<<ceil_div(n, 32), 256>>>(dx.p, tmp.centroids.p, dl.p, n, dim, dc.p, df.p);
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipGetLastError());
+    if (n) {
+        HIPC(hipMemcpy(out_label, dl.p, n * 4, hipMemcpyDeviceToHost));
+        HIPC(hipMemcpy(out_dist, dd.p, n * 4, hipMemcpyDeviceToHost));
+        HIPC(hipMemcpy(out_codes, dc.p, n * tmp.W * 8, hipMemcpyDeviceToHost));
+        HIPC(hipMemcpy(out_factors, df.p, n * 16, hipMemcpyDeviceToHost));
+    }
+    return RQ_OK;
+}
+
+rq_status rq_coarse_rank(const rq_index *idx, const float *queries, uint32_t nq, uint32_t len, uint32_t probe,
+                         float *out_y, uint32_t *out_cluster, float *out_dist) {
+    RQC(ensure_device());
+    if (!idx || !queries || !out_cluster || !out_dist) return fail(RQ_ERR_INVALID, "null argument");
+    if (idx->dim != (len + 63) / 64 * 64) return fail(RQ_ERR_DIM_MISMATCH, "query length does not pad to dim");
+    if (probe == 0) return fail(RQ_ERR_INVALID, "probe == 0");
+    const uint32_t dim = idx->dim, k = idx->k, nprobe = std::min(probe, k);
+    if (nprobe > RQ_MAX_PROBE) return fail(RQ_ERR_UNSUPPORTED, "probe > 16384");
+    DevBuf<float> dq, qpad, y, dist, pd;
+    DevBuf<uint32_t> pc;
+    RQC(dq.alloc((uint64_t)nq * len));
+    RQC(qpad.alloc((uint64_t)nq * dim));
+    RQC(y.alloc((uint64_t)nq * dim));
+    RQC(dist.alloc((uint64_t)nq * k));
+    RQC(pd.alloc((uint64_t)nq * nprobe));
+    RQC(pc.alloc((uint64_t)nq * nprobe));
+    HIPC(hipMemcpy(dq.p, queries, (uint64_t)nq * len * 4, hipMemcpyHostToDevice));
+    pad_rows_kernel<<<ceil_div((uint64_t)nq * dim, 256), 256>>>(dq.p, qpad.p, nq, len, dim);
+    launch_rotate(qpad.p, idx->P.p, y.p, nq, dim, nq >= 32, nullptr);
+    coarse_dist_kernel<4><<<dim3(ceil_div(nq, 4), ceil_div(k, 256)), 256, 4 * dim * sizeof(float)>>>(
+        idx->cent_t.p, y.p, dist.p, k, dim, nq);
+    select_probe_kernel<<<nq, 256, (size_t)nprobe * 8>>>(dist.p, k, nprobe, pc.p, pd.p);
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipGetLastError());
+    if (out_y) HIPC(hipMemcpy(out_y, y.p, (uint64_t)nq * dim * 4, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(out_cluster, pc.p, (uint64_t)nq * nprobe * 4, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(out_dist, pd.p, (uint64_t)nq * nprobe * 4, hipMemcpyDeviceToHost));
+    return RQ_OK;
+}
+
+rq_status rq_query_prep(const rq_index *idx, const float *y, uint32_t nq, const uint32_t *cluster, float *out_lower,
+                        float *out_delta, uint32_t *out_sum, uint64_t *out_planes) {
+    RQC(ensure_device());
+    if (!idx || !y || !cluster || !out_lower || !out_delta || !out_sum || !out_planes)
+        return fail(RQ_ERR_INVALID, "null argument");
+    const uint32_t dim = idx->dim, W = idx->W;
+    for (uint32_t i = 0; i < nq; ++i)
+        if (cluster[i] >= idx->k) return fail(RQ_ERR_INVALID, "cluster id out of range");
+    DevBuf<float> dy, ycd;
+    DevBuf<uint32_t> dc, dsum;
+    DevBuf<PairScalars> scal;
+    DevBuf<uint64_t> planes;
+    RQC(dy.alloc((uint64_t)nq * dim));
+    RQC(ycd.alloc(nq));
+    RQC(dc.alloc(nq));
+    RQC(dsum.alloc(nq));
+    RQC(scal.alloc(nq));
+    RQC(planes.alloc((uint64_t)nq * 4 * W));
+    HIPC(hipMemcpy(dy.p, y, (uint64_t)nq * dim * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(dc.p, cluster, nq * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemset(ycd.p, 0, nq * 4));
+    prep_kernel<<<ceil_div(nq, 4), 256>>>(dy.p, idx->centroids.p, idx->offsets.p, dc.p, ycd.p, nq, 1, dim, scal.p,
+                                          planes.p, dsum.p, nullptr);
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipGetLastError());
+    std::vector<PairScalars> hs(nq);
+    HIPC(hipMemcpy(hs.data(), scal.p, nq * sizeof(PairScalars), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < nq; ++i) out_lower[i] = hs[i].lower, out_delta[i] = hs[i].delta;
+    HIPC(hipMemcpy(out_sum, dsum.p, nq * 4, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(out_planes, planes.p, (uint64_t)nq * 4 * W * 8, hipMemcpyDeviceToHost));
+    return RQ_OK;
+}
+
+rq_status rq_scan(const rq_index *idx, uint32_t cluster, float y_c_distance_square, const uint64_t *planes,
+                  float lower_bound, float scalar_sum, float delta, float *out_rough) {
+    RQC(ensure_device());
+    if (!idx || !planes || !out_rough) return fail(RQ_ERR_INVALID, "null argument");
+    if (cluster >= idx->k) return fail(RQ_ERR_INVALID, "cluster id out of range");
+    uint32_t off[2];
+    HIPC(hipMemcpy(off, idx->offsets.p + cluster, 8, hipMemcpyDeviceToHost));
+    const uint32_t len = off[1] - off[0];
+    if (len == 0) return RQ_OK;
+    DevBuf<uint64_t> dpl;
+    DevBuf<float> dout;
+    RQC(dpl.alloc(4 * idx->W));
+    RQC(dout.alloc(len));
+    HIPC(hipMemcpy(dpl.p, planes, 4 * idx->W * 8, hipMemcpyHostToDevice));
+    scan_dense_kernel<<<ceil_div(len, 256), 256>>>(reinterpret_cast<const uint32_t *>(idx->codes.p), idx->factors.p,
+                                                   off[0], len, idx->W, reinterpret_cast<const uint32_t *>(dpl.p),
+                                                   lower_bound, delta, scalar_sum, y_c_distance_square, dout.p);
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpy(out_rough, dout.p, len * 4, hipMemcpyDeviceToHost));
+    return RQ_OK;
+}
+
+rq_status rq_rerank(const rq_index *idx, const float *query_padded, const uint32_t *pos, uint32_t m,
+                    float *out_accurate) {
+    RQC(ensure_device());
+    if (!idx || !query_padded || !pos || !out_accurate) return fail(RQ_ERR_INVALID, "null argument");
+    for (uint32_t i = 0; i < m; ++i)
+        if (pos[i] >= idx->n) return fail(RQ_ERR_INVALID, "position out of range");
+    if (m == 0) return RQ_OK;
+    DevBuf<float> dq, dout;
+    DevBuf<uint32_t> dp;
+    RQC(dq.alloc(idx->dim));
+    RQC(dout.alloc(m));
+    RQC(dp.alloc(m));
+    HIPC(hipMemcpy(dq.p, query_padded, idx->dim * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(dp.p, pos, m * 4, hipMemcpyHostToDevice));
+    accurate_flat_kernel<<<ceil_div(m, 32), 256>>>(dp.p, m, idx->base.p, dq.p, idx->dim, dout.p);
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpy(out_accurate, dout.p, m * 4, hipMemcpyDeviceToHost));
+    return RQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,209 @@
+"""`RaBitQ`: host-side mirror of the reference's index type (src/rabitq.rs:57-68, :70-333).
+
+Same method names, argument meaning and error behaviour as the crate: where the reference panics
+(`expect` / `assert!`), these raise `RabitqError`.  Everything is delegated to librabitq_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import Info, MetricsT, ProfileT, check, lib
+
+ARR_BASE, ARR_ORTHOGONAL, ARR_CENTROIDS, ARR_OFFSETS, ARR_MAP_IDS, ARR_CODES, ARR_FACTORS = range(7)
+
+
+def _addr(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class RaBitQ:
+    """Device-resident RaBitQ index.  Construct with `from_path`, `build`, `load_from_dir` or
+    `from_arrays`; query with `query` (one vector, like the crate) or `query_batch`."""
+
+    def __init__(self, handle):
+        self._h = handle
+        info = Info()
+        check(lib().rq_info(self._h, C.byref(info)))
+        self.dim, self.k, self.n, self.max_list_len = int(info.dim), int(info.k), int(info.n), int(info.max_list_len)
+
+    # ---- RaBitQ::from_path (src/rabitq.rs:159) ------------------------------------------------
+    @classmethod
+    def from_path(cls, base_path, centroid_path, orthogonal=None, seed: int = 0) -> "RaBitQ":
+        """Build from base.fvecs + centroids.fvecs.  `orthogonal` (dim x dim, P[r][c]) fixes the
+        rotation the reference draws unseeded (src/utils.rs:16-20); None = seeded Gaussian-QR."""
+        h = C.c_void_p()
+        P = _f32(orthogonal) if orthogonal is not None else None
+        check(lib().rq_build_from_path(os.fsencode(base_path), os.fsencode(centroid_path), _addr(P), seed, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def build(cls, base, centroids, orthogonal=None, seed: int = 0) -> "RaBitQ":
+        """from_path on in-memory arrays (base n x d, centroids k x d)."""
+        base, centroids = _f32(base), _f32(centroids)
+        if base.ndim != 2 or centroids.ndim != 2 or base.shape[1] != centroids.shape[1]:
+            raise _lib.RabitqError(-2, "base and centroids must be 2-D with the same dimension (rabitq.rs:165)")
+        P = _f32(orthogonal) if orthogonal is not None else None
+        h = C.c_void_p()
+        check(lib().rq_build(_addr(base), base.shape[0], base.shape[1], _addr(centroids), centroids.shape[0], _addr(P),
+                             seed, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def build_device(cls, base_ptr: int, n: int, d: int, centroids_ptr: int, k: int, orthogonal=None,
+                     seed: int = 0) -> "RaBitQ":
+        """Build from device-resident arrays (raw HIP device addresses, e.g. torch.Tensor.data_ptr())."""
+        P = _f32(orthogonal) if orthogonal is not None else None
+        h = C.c_void_p()
+        check(lib().rq_build_device(C.c_void_p(base_ptr), n, d, C.c_void_p(centroids_ptr), k, _addr(P), seed, C.byref(h)))
+        return cls(h)
+
+    # ---- load_from_dir / dump_to_dir (src/rabitq.rs:84, :128) ---------------------------------
+    @classmethod
+    def load_from_dir(cls, path) -> "RaBitQ":
+        h = C.c_void_p()
+        check(lib().rq_load_dir(os.fsencode(path), C.byref(h)))
+        return cls(h)
+
+    def dump_to_dir(self, path) -> None:
+        check(lib().rq_dump_dir(self._h, os.fsencode(path)))
+
+    @classmethod
+    def from_arrays(cls, base, orthogonal, centroids, offsets, map_ids, codes, factors) -> "RaBitQ":
+        """From the reference's in-memory arrays (what load_from_dir produces)."""
+        base, orthogonal, centroids, factors = _f32(base), _f32(orthogonal), _f32(centroids), _f32(factors)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+        map_ids = np.ascontiguousarray(map_ids, dtype=np.uint32)
+        codes = np.ascontiguousarray(codes, dtype=np.uint64)
+        h = C.c_void_p()
+        check(lib().rq_from_arrays(orthogonal.shape[0], map_ids.size, offsets.size - 1, _addr(base), _addr(orthogonal),
+                                   _addr(centroids), _addr(offsets), _addr(map_ids), _addr(codes), _addr(factors),
+                                   C.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rq_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- arrays (copies to host) ----------------------------------------------------------------
+    def _get(self, which, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        check(lib().rq_get_array(self._h, which, _addr(out), out.nbytes))
+        return out
+
+    @property
+    def base(self):
+        return self._get(ARR_BASE, (self.n, self.dim), np.float32)
+
+    @property
+    def orthogonal(self):
+        return self._get(ARR_ORTHOGONAL, (self.dim, self.dim), np.float32)
+
+    @property
+    def centroids(self):
+        return self._get(ARR_CENTROIDS, (self.k, self.dim), np.float32)
+
+    @property
+    def offsets(self):
+        return self._get(ARR_OFFSETS, (self.k + 1,), np.uint32)
+
+    @property
+    def map_ids(self):
+        return self._get(ARR_MAP_IDS, (self.n,), np.uint32)
+
+    @property
+    def codes(self):
+        return self._get(ARR_CODES, (self.n, self.dim // 64), np.uint64)
+
+    @property
+    def factors(self):
+        return self._get(ARR_FACTORS, (self.n, 4), np.float32)
+
+    def device_ptr(self, which):
+        p, nbytes = C.c_void_p(), C.c_uint64()
+        check(lib().rq_get_device_ptr(self._h, which, C.byref(p), C.byref(nbytes)))
+        return p.value, nbytes.value
+
+    # ---- RaBitQ::query (src/rabitq.rs:268) ------------------------------------------------------
+    def query(self, query, probe: int, topk: int, heuristic_rank: bool = False):
+        """-> list of (distance, original id), at most topk, in the reference's (unspecified,
+        heap-internal) order."""
+        q = _f32(query).reshape(-1)
+        d = np.empty(max(topk, 1), dtype=np.float32)
+        ids = np.empty(max(topk, 1), dtype=np.uint32)
+        n = C.c_uint32()
+        check(lib().rq_query(self._h, _addr(q), q.size, probe, topk, int(heuristic_rank), _addr(d), _addr(ids),
+                             C.cast(C.byref(n), C.c_void_p)))
+        return [(float(d[i]), int(ids[i])) for i in range(n.value)]
+
+    def query_batch(self, queries, probe: int, topk: int, heuristic_rank: bool = False):
+        """B queries at once -> (dist B x topk f32, ids B x topk u32, counts B u32)."""
+        q = _f32(queries)
+        if q.ndim != 2:
+            raise _lib.RabitqError(-1, "queries must be 2-D")
+        B = q.shape[0]
+        d = np.full((B, max(topk, 1)), np.nan, dtype=np.float32)
+        ids = np.full((B, max(topk, 1)), 0xFFFFFFFF, dtype=np.uint32)
+        cnt = np.zeros(B, dtype=np.uint32)
+        st = lib().rq_query_batch(self._h, _addr(q), B, q.shape[1], probe, topk, int(heuristic_rank), _addr(d),
+                                  _addr(ids), _addr(cnt))
+        if st != _lib.RQ_ERR_EMPTY:
+            check(st)
+        return d, ids, cnt
+
+    def query_batch_device(self, q_ptr: int, nq: int, length: int, probe: int, topk: int, out_dist_ptr: int,
+                           out_id_ptr: int, out_n_ptr: int, heuristic_rank: bool = False):
+        """Queries and outputs already in device memory (raw addresses)."""
+        check(lib().rq_query_batch_device(self._h, C.c_void_p(q_ptr), nq, length, probe, topk, int(heuristic_rank),
+                                          C.c_void_p(out_dist_ptr), C.c_void_p(out_id_ptr), C.c_void_p(out_n_ptr)))
+
+
+# ---- METRICS (src/metrics.rs) --------------------------------------------------------------------
+def metrics() -> dict:
+    m = MetricsT()
+    check(lib().rq_metrics(C.byref(m)))
+    return {"query": m.query, "rough": m.rough, "precise": m.precise, "miss": m.miss}
+
+
+def metrics_reset() -> None:
+    check(lib().rq_metrics_reset())
+
+
+def metrics_str() -> str:
+    """Metrics::to_str, src/metrics.rs:30-41."""
+    m = metrics()
+    ratio = m["rough"] / m["precise"] if m["precise"] else float("nan")
+    return (f"query: {m['query']}, rough: {m['rough']}, precise: {m['precise']}, ratio: {ratio:.2f}, "
+            f"cache miss: {m['miss']}")
+
+
+def set_profiling(enabled: bool) -> None:
+    check(lib().rq_set_profiling(int(enabled)))
+
+
+def last_profile() -> dict:
+    p = ProfileT()
+    check(lib().rq_last_profile(C.byref(p)))
+    return {name: getattr(p, name) for name, _ in ProfileT._fields_}
+
+
+def calculate_recall(truth, res, topk: int) -> float:
+    """src/utils.rs:367-379 (host-side bookkeeping of the CLI harness, crates/cli/src/main.rs:73-74)."""
+    res = list(res)
+    assert len(res) == topk
+    t = list(truth)[:topk]
+    return sum(1 for r in res if r in t) / topk

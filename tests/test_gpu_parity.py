@@ -1,0 +1,301 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle and the
+committed golden fixtures.  Bit-exact everywhere (integer work AND f32 work: the kernels reproduce
+the reference's operation order), so no tolerances appear below except where stated.
+
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+IDS = [os.path.basename(p)[:-4] for p in GOLDEN]
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint8)
+
+
+def assert_bits_equal(a, b, what=""):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype, (what, a.shape, b.shape, a.dtype, b.dtype)
+    if not np.array_equal(bits(a), bits(b)):
+        bad = np.nonzero(a.reshape(-1).view(np.uint8 if a.dtype.itemsize == 1 else f"u{a.dtype.itemsize}") !=
+                         b.reshape(-1).view(np.uint8 if b.dtype.itemsize == 1 else f"u{b.dtype.itemsize}"))[0]
+        raise AssertionError(f"{what}: {bad.size} of {a.size} elements differ; first at {bad[:5]}: "
+                             f"{a.reshape(-1)[bad[:5]]} vs {b.reshape(-1)[bad[:5]]}")
+
+
+@pytest.fixture(scope="module")
+def rq():
+    import rabitq_amd
+    from rabitq_amd import _lib
+    assert os.path.exists(_lib.SO_PATH), "librabitq_hip.so must be built in-tree"
+    _lib.check(_lib.lib().rq_init(0))
+    return rabitq_amd
+
+
+# ---- a5: rotation -------------------------------------------------------------------------------
+@pytest.mark.parametrize("dim,n", [(64, 70), (128, 333), (256, 65), (768, 130)])
+def test_rotate_bit_exact_both_kernels(rq, oracle, dim, n):
+    rng = np.random.default_rng(dim)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    P = synth.random_orthogonal(dim, seed=dim + 1)
+    want = oracle.project_rows(x, P)
+    assert_bits_equal(rq.ops.rotate(x, P, use_mfma=False), want, "valu rotate")
+    assert_bits_equal(rq.ops.rotate(x, P, use_mfma=True), want, "mfma rotate")
+
+
+def test_rotate_asymmetric_matrix_catches_transposes(rq, oracle):
+    dim = 128
+    P = (np.arange(dim * dim, dtype=np.float32).reshape(dim, dim) % 17 - 8) / 4   # not symmetric
+    x = np.eye(dim, dtype=np.float32)[:40] * 3
+    want = oracle.project_rows(x, P)
+    assert_bits_equal(rq.ops.rotate(x, P, use_mfma=True), want, "mfma rotate, x = rows of 3I")
+    assert np.array_equal(want[5], 3 * P[5])
+
+
+# ---- a6-a8: assign + sign-pack + factors --------------------------------------------------------
+@pytest.mark.parametrize("path", GOLDEN, ids=IDS)
+def test_quantize_pack_matches_oracle(rq, oracle, path):
+    g = np.load(path)
+    label, dist, codes, factors = rq.ops.quantize_pack(g["rotated"], g["centroids"])
+    ids, off = g["map_ids"], g["offsets"]
+    want_label = np.empty(ids.size, np.uint32)
+    for c in range(off.size - 1):
+        want_label[ids[off[c]:off[c + 1]]] = c
+    assert np.array_equal(label, want_label)
+    for i in (0, 1, ids.size - 1):
+        lab, d = oracle.kmeans_nearest_cluster(g["centroids"], g["rotated"][i])
+        assert lab == label[i] and np.float32(d).tobytes() == dist[i].tobytes()
+    assert_bits_equal(codes[ids], g["codes"], "codes")
+    assert_bits_equal(factors[ids], g["factors"], "factors")
+
+
+# ---- a3-a9: whole build -------------------------------------------------------------------------
+@pytest.mark.parametrize("path", GOLDEN, ids=IDS)
+def test_build_matches_golden(rq, path):
+    g = np.load(path)
+    idx = rq.RaBitQ.build(g["base_in"], g["centroids_in"], g["orthogonal"])
+    assert idx.dim == g["orthogonal"].shape[0] and idx.n == g["base_in"].shape[0]
+    assert_bits_equal(idx.centroids, g["centroids"], "centroids")
+    assert np.array_equal(idx.offsets, g["offsets"])
+    assert np.array_equal(idx.map_ids, g["map_ids"])
+    assert_bits_equal(idx.codes, g["codes"], "codes")
+    assert_bits_equal(idx.factors, g["factors"], "factors")
+    pad = np.pad(g["base_in"], ((0, 0), (0, idx.dim - g["base_in"].shape[1])))
+    assert_bits_equal(idx.base, pad[g["map_ids"]], "base")
+    assert_bits_equal(idx.orthogonal, g["orthogonal"], "orthogonal")
+    assert idx.max_list_len == int(np.diff(g["offsets"].astype(np.int64)).max())
+    idx.close()
+
+
+# ---- a10-a16: query stages ----------------------------------------------------------------------
+@pytest.mark.parametrize("path", GOLDEN, ids=IDS)
+def test_query_stages_match_golden(rq, path):
+    g = np.load(path)
+    pad = np.pad(g["base_in"], ((0, 0), (0, g["orthogonal"].shape[0] - g["base_in"].shape[1])))
+    idx = rq.RaBitQ.from_arrays(pad[g["map_ids"]], g["orthogonal"], g["centroids"], g["offsets"], g["map_ids"],
+                                g["codes"], g["factors"])
+    k = idx.k
+    y, cl, cd = rq.ops.coarse_rank(idx, g["queries"], k)
+    assert_bits_equal(y, g["y"], "rotated queries")
+    assert np.array_equal(cl, g["coarse_cluster"])
+    assert_bits_equal(cd, g["coarse_dist"], "coarse distances")
+    y2, cl2, cd2 = rq.ops.coarse_rank(idx, g["queries"], 2)          # partial selection
+    assert np.array_equal(cl2, g["coarse_cluster"][:, :2]) and np.array_equal(bits(cd2), bits(g["coarse_dist"][:, :2]))
+    lo, delta, s, planes = rq.ops.query_prep(idx, g["y"], g["coarse_cluster"][:, 0])
+    assert_bits_equal(lo, g["prep_lower"], "lower")
+    assert_bits_equal(delta, g["prep_delta"], "delta")
+    assert np.array_equal(s, g["prep_sum"])
+    assert_bits_equal(planes, g["prep_planes"], "bit planes")
+    at = 0
+    off = g["offsets"]
+    for qi in range(g["queries"].shape[0]):
+        c = int(g["coarse_cluster"][qi, 0])
+        n = int(g["rough_nearest_len"][qi])
+        rough = rq.ops.scan(idx, c, g["coarse_dist"][qi, 0], g["prep_planes"][qi], g["prep_lower"][qi],
+                            np.float32(g["prep_sum"][qi]), g["prep_delta"][qi], n)
+        assert_bits_equal(rough, g["rough_nearest"][at:at + n], f"rough distances q{qi}")
+        at += n
+        assert n == off[c + 1] - off[c]
+    idx.close()
+
+
+def test_rerank_distances_exact(rq, oracle):
+    g = np.load(GOLDEN[0])
+    pad = np.pad(g["base_in"], ((0, 0), (0, g["orthogonal"].shape[0] - g["base_in"].shape[1])))
+    base = pad[g["map_ids"]]
+    idx = rq.RaBitQ.from_arrays(base, g["orthogonal"], g["centroids"], g["offsets"], g["map_ids"], g["codes"],
+                                g["factors"])
+    q = np.zeros(idx.dim, np.float32)
+    q[:g["queries"].shape[1]] = g["queries"][1]
+    pos = np.array([0, 5, 17, idx.n - 1, 3, 3, 100, 101, 102], dtype=np.uint32)
+    got = rq.ops.rerank(idx, q, pos)
+    want = np.array([oracle.l2_squared_distance(base[p], q) for p in pos], np.float32)
+    assert_bits_equal(got, want, "accurate distances")
+    idx.close()
+
+
+# ---- whole query: ids, order, distances and the METRICS counters ---------------------------------
+@pytest.mark.parametrize("path", GOLDEN, ids=IDS)
+def test_query_matches_golden(rq, path):
+    g = np.load(path)
+    idx = rq.RaBitQ.build(g["base_in"], g["centroids_in"], g["orthogonal"])
+    ci = 0
+    while f"q{ci}_cfg" in g:
+        probe, topk, heur = (int(v) for v in g[f"q{ci}_cfg"])
+        want_n = g[f"q{ci}_n"]
+        # one at a time, like the crate's CLI loop (crates/cli/src/main.rs:69-75)
+        for qi, q in enumerate(g["queries"]):
+            rq.metrics_reset()
+            res = idx.query(q, probe, topk, bool(heur))
+            n = int(want_n[qi])
+            assert len(res) == n
+            assert [i for _, i in res] == g[f"q{ci}_ids"][qi, :n].tolist(), (ci, qi)
+            assert_bits_equal(np.array([d for d, _ in res], np.float32), g[f"q{ci}_dist"][qi, :n], "distances")
+            m = rq.metrics()
+            assert (m["rough"], m["precise"], m["query"]) == (int(g[f"q{ci}_counts"][qi, 0]),
+                                                              int(g[f"q{ci}_counts"][qi, 1]), 1)
+        # and as one batch
+        rq.metrics_reset()
+        d, ids, cnt = idx.query_batch(g["queries"], probe, topk, bool(heur))
+        assert np.array_equal(cnt, want_n)
+        for qi in range(len(cnt)):
+            n = int(cnt[qi])
+            assert np.array_equal(ids[qi, :n], g[f"q{ci}_ids"][qi, :n])
+            assert_bits_equal(d[qi, :n], g[f"q{ci}_dist"][qi, :n], "batch distances")
+        m = rq.metrics()
+        assert m["rough"] == int(g[f"q{ci}_counts"][:, 0].sum()) and m["precise"] == int(g[f"q{ci}_counts"][:, 1].sum())
+        assert m["query"] == len(cnt)
+        ci += 1
+    idx.close()
+
+
+def _compare_with_oracle(rq, oracle, oidx, gidx, queries, probe, topk, heur):
+    rq.metrics_reset()
+    d, ids, cnt = gidx.query_batch(queries, probe, topk, heur)
+    tot_r = tot_p = 0
+    for qi, q in enumerate(queries):
+        oracle.metrics_reset()
+        od, oi = oidx.query(q, probe, topk, heur)
+        m = oracle.metrics()
+        tot_r += m["rough"]
+        tot_p += m["precise"]
+        n = int(cnt[qi])
+        assert n == oi.size, (qi, n, oi.size)
+        assert np.array_equal(ids[qi, :n], oi), (qi, ids[qi, :n], oi)
+        assert np.array_equal(bits(d[qi, :n]), bits(od)), qi
+    m = rq.metrics()
+    assert (m["rough"], m["precise"], m["query"]) == (tot_r, tot_p, len(queries))
+
+
+@pytest.mark.parametrize("n,d,k,sigma,nq,cfgs", [
+    (20000, 128, 32, 0.8, 96, [(8, 10, False), (32, 1, False), (64, 100, False), (5, 10, True)]),
+    (6000, 64, 300, 1.0, 300, [(20, 10, False), (300, 5, False)]),       # cluster-major path, tiny lists
+    (3000, 256, 8, 0.7, 40, [(8, 10, False), (3, 30, True)]),
+    (2500, 960, 6, 0.7, 20, [(6, 10, False)]),                           # W = 15: generic scan kernel
+])
+def test_random_indexes_match_oracle(rq, oracle, n, d, k, sigma, nq, cfgs):
+    x, centres, _ = synth.mixture(n, d, k, sigma=sigma, seed=n + d, centre_scale=0.6)
+    P = synth.random_orthogonal((d + 63) // 64 * 64, seed=d)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    gidx = rq.RaBitQ.build(x, centres, P)
+    assert np.array_equal(gidx.map_ids, oidx.map_ids) and np.array_equal(gidx.offsets, oidx.offsets)
+    assert_bits_equal(gidx.codes, oidx.codes, "codes")
+    assert_bits_equal(gidx.factors, oidx.factors, "factors")
+    queries, _, _ = synth.mixture(nq, d, k, sigma=sigma, seed=n + d + 1, centre_scale=0.6)
+    queries[1] = x[17]
+    for probe, topk, heur in cfgs:
+        _compare_with_oracle(rq, oracle, oidx, gidx, queries, probe, topk, heur)
+    gidx.close()
+    oidx.close()
+
+
+def test_survivor_overflow_retry_is_exact(rq, oracle):
+    # one huge list and a large topk: the second stage's survivors exceed the default per-query
+    # buffer, which must trigger the exact-capacity re-run and still match the reference id for id
+    n, d = 24000, 64
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    centres = np.zeros((1, d), np.float32)
+    P = synth.random_orthogonal(d, seed=3)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    gidx = rq.RaBitQ.build(x, centres, P)
+    queries = rng.standard_normal((6, d)).astype(np.float32) * 0.2
+    rq.set_profiling = None
+    _compare_with_oracle(rq, oracle, oidx, gidx, queries, 1, 400, False)
+    _compare_with_oracle(rq, oracle, oidx, gidx, queries, 1, 400, True)
+    from rabitq_amd import index as ix
+    assert ix.last_profile()["retries"] > 0
+    gidx.close()
+
+
+def test_edge_cases(rq, oracle):
+    d, k = 64, 6
+    x, centres, _ = synth.mixture(40, d, 3, sigma=0.5, seed=9)
+    centres = np.concatenate([centres, centres[:1] + 100.0, centres[:1] - 100.0, centres[1:2] + 50.0])  # empty lists
+    P = np.eye(d, dtype=np.float32)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    gidx = rq.RaBitQ.build(x, centres, P)
+    assert np.array_equal(gidx.offsets, oidx.offsets) and (np.diff(oidx.offsets.astype(np.int64)) == 0).any()
+    qs = np.stack([x[0], centres[0], np.zeros(d, np.float32), x[5] * 1.5])  # query == centroid: delta = 0 edge
+    for probe, topk in ((k, 10), (2, 64), (1, 3), (100, 1)):                # topk > n in list, probe > k
+        _compare_with_oracle(rq, oracle, oidx, gidx, qs, probe, topk, False)
+    # fewer candidates than topk
+    d_, ids_, cnt_ = gidx.query_batch(qs, k, 64)
+    assert cnt_.tolist() == [40, 40, 40, 40]
+    # error behaviour mirrors the reference's panics
+    with pytest.raises(rq.RabitqError) as e:
+        gidx.query(np.zeros(65, np.float32), 2, 5)       # rabitq.rs:275
+    assert e.value.status == -2
+    with pytest.raises(rq.RabitqError):
+        gidx.query(x[0], 0, 5)                           # rabitq.rs:295
+    with pytest.raises(rq.RabitqError):
+        rq.RaBitQ.build(x, centres[:, :32], P)           # rabitq.rs:165
+    # short query is zero padded (rabitq.rs:277-280): d = 40 pads to 64
+    x2 = x[:, :40].copy()
+    o2 = oracle.OracleIndex.build(x2, centres[:, :40], P)
+    g2 = rq.RaBitQ.build(x2, centres[:, :40], P)
+    _compare_with_oracle(rq, oracle, o2, g2, x2[:5], 3, 5, False)
+    gidx.close()
+    g2.close()
+
+
+# ---- persistence: byte-compatible with the crate's directory -------------------------------------
+def test_dump_is_byte_identical_and_loads(rq, oracle, tmp_path):
+    g = np.load(GOLDEN[1])   # d = 100 -> padded to 128
+    oidx = oracle.OracleIndex.build(g["base_in"], g["centroids_in"], g["orthogonal"])
+    gidx = rq.RaBitQ.build(g["base_in"], g["centroids_in"], g["orthogonal"])
+    oidx.dump_to_dir(str(tmp_path / "o"))
+    gidx.dump_to_dir(str(tmp_path / "g"))
+    for name in ("base.fvecs", "orthogonal.fvecs", "centroids.fvecs", "offsets_ids.ivecs", "factors.fvecs",
+                 "x_binary_vec.u64vecs"):
+        assert (tmp_path / "o" / name).read_bytes() == (tmp_path / "g" / name).read_bytes(), name
+    back = rq.RaBitQ.load_from_dir(str(tmp_path / "o"))
+    for name in ("base", "orthogonal", "centroids", "offsets", "map_ids", "codes", "factors"):
+        assert np.array_equal(bits(getattr(back, name)), bits(getattr(gidx, name))), name
+    q = g["queries"][2]
+    assert back.query(q, 3, 7) == gidx.query(q, 3, 7)
+    with pytest.raises(rq.RabitqError) as e:
+        rq.RaBitQ.load_from_dir(str(tmp_path / "missing"))
+    assert e.value.status == -3
+    # from_path on fvecs files
+    from rabitq_amd import vecs
+    vecs.write_vecs(tmp_path / "b.fvecs", g["base_in"])
+    vecs.write_vecs(tmp_path / "c.fvecs", g["centroids_in"])
+    fp = rq.RaBitQ.from_path(tmp_path / "b.fvecs", tmp_path / "c.fvecs", orthogonal=g["orthogonal"])
+    assert np.array_equal(fp.map_ids, gidx.map_ids) and np.array_equal(bits(fp.factors), bits(gidx.factors))
+    # generated rotation (orthogonal = None) is orthogonal and seeded
+    gen = rq.RaBitQ.build(g["base_in"], g["centroids_in"], None, seed=7)
+    Pg = gen.orthogonal.astype(np.float64)
+    assert np.abs(Pg @ Pg.T - np.eye(gen.dim)).max() < 1e-5
+    gen2 = rq.RaBitQ.build(g["base_in"], g["centroids_in"], None, seed=7)
+    assert np.array_equal(gen.orthogonal, gen2.orthogonal)
+    for i in (oidx, gidx, back, fp, gen, gen2):
+        i.close()
