@@ -63,6 +63,20 @@ __device__ __forceinline__ uint64_t surv_key(const SurvRec &r) {
     return ((uint64_t)r.slot << 32) | r.pos;
 }
 
+// One wave-level append of the scan kernel: `cnt` (<= 64) survivors of 64 CONSECUTIVE list positions
+// starting at `pos`, stored at recs[base .. base+cnt) in ascending position order (ballot rank order
+// = lane order = position order).  Runs of different sub-tiles never interleave, so ordering a
+// query's survivors in the reference's visiting order only needs the run directory sorted.
+struct __attribute__((aligned(16))) RunRec {
+    uint32_t pos;   // first list position of the 64-wide sub-tile
+    uint32_t slot;  // probe slot
+    uint32_t base;  // index of the run's first record in the query's survivor buffer
+    uint32_t cnt;
+};
+__device__ __forceinline__ uint64_t surv_key(const RunRec &r) {
+    return ((uint64_t)r.slot << 32) | r.pos;
+}
+
 // Per-(query, probe slot) scalars written by the prep kernel, 32 bytes so a wave can fetch them
 // with one s_load_dwordx8.
 struct __attribute__((aligned(32))) PairScalars {

@@ -330,7 +330,8 @@ __global__ __launch_bounds__(1024) void list_sort_kernel(unsigned long long *__r
     }
 }
 
-// gather into cluster order: one wave per destination position
+// gather into cluster order: one wave per destination position, grid-stride (HIP silently wraps a
+// launch whose gridDim.x * blockDim.x reaches 2^32, so the grid is capped and the kernel loops)
 __global__ __launch_bounds__(256) void gather_kernel(const unsigned long long *__restrict__ keys, uint64_t n,
                                                      const float *__restrict__ base_in, uint32_t d,
                                                      uint32_t dim, const uint64_t *__restrict__ codes_in,
@@ -340,16 +341,16 @@ __global__ __launch_bounds__(256) void gather_kernel(const unsigned long long *_
                                                      float4 *__restrict__ factors_out,
                                                      uint32_t *__restrict__ map_ids) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint64_t p = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (p >= n) return;
-    const uint32_t id = (uint32_t)keys[p];
     const uint32_t W = dim >> 6;
-    for (uint32_t e = lane; e < dim; e += 64)
-        base_out[p * dim + e] = e < d ? base_in[(uint64_t)id * d + e] : 0.0f;
-    for (uint32_t w = lane; w < W; w += 64) codes_out[p * W + w] = codes_in[(uint64_t)id * W + w];
-    if (lane == 0) {
-        factors_out[p] = factors_in[id];
-        map_ids[p] = id;
+    for (uint64_t p = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < n; p += (uint64_t)gridDim.x * 4) {
+        const uint32_t id = (uint32_t)keys[p];
+        for (uint32_t e = lane; e < dim; e += 64)
+            base_out[p * dim + e] = e < d ? base_in[(uint64_t)id * d + e] : 0.0f;
+        for (uint32_t w = lane; w < W; w += 64) codes_out[p * W + w] = codes_in[(uint64_t)id * W + w];
+        if (lane == 0) {
+            factors_out[p] = factors_in[id];
+            map_ids[p] = id;
+        }
     }
 }
 

@@ -371,14 +371,15 @@ struct ScanPtrs {   // host-side bundle only
     const uint32_t *planes;       // per pair 8W dwords (4 planes x W u64)
     const float *thr;             // per query
     SurvRec *surv;                // per query `cap` records
-    uint32_t *surv_cnt;           // per query
+    RunRec *runs;                 // per query `cap` run descriptors
+    unsigned long long *surv_cnt; // per query: low 32 bits = records, high 32 bits = runs
 };
 #define SCAN_PARAMS                                                                                  \
     const uint32_t *__restrict__ codes, const float4 *__restrict__ factors,                          \
         const uint32_t *__restrict__ grp_start, const uint32_t *__restrict__ pair_list,              \
         const PairScalars *__restrict__ scal, const uint32_t *__restrict__ planes,                   \
-        const float *__restrict__ thr_of_query, SurvRec *__restrict__ surv, uint32_t *__restrict__ surv_cnt,  \
-        const ScanArgs a
+        const float *__restrict__ thr_of_query, SurvRec *__restrict__ surv, RunRec *__restrict__ runs, \
+        unsigned long long *__restrict__ surv_cnt, const ScanArgs a
 
 template <int W>
 __device__ __forceinline__ uint32_t asym_dot(const uint32_t (&code)[2 * W],
@@ -474,12 +475,17 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
             total += (uint32_t)__popcll(m[c]);
         }
         if (total) {  // wave-uniform
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(surv_cnt + b, total);
-            base = __builtin_amdgcn_readfirstlane(base);
+            uint32_t nruns = 0;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) nruns += m[c] ? 1u : 0u;
+            unsigned long long old = 0;
+            if (lane == 0) old = atomicAdd(surv_cnt + b, ((unsigned long long)nruns << 32) | total);
+            uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)old);
+            uint32_t rbase = __builtin_amdgcn_readfirstlane((uint32_t)(old >> 32));
             SurvRec *out = surv + (uint64_t)b * a.cap;
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
+                const uint32_t cntc = (uint32_t)__popcll(m[c]);
                 if (pass[c]) {
                     uint32_t at = base + (uint32_t)__popcll(m[c] & ((1ull << lane) - 1ull));
                     if (at < a.cap) {
@@ -491,7 +497,16 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
                         out[at] = r;
                     }
                 }
-                base += (uint32_t)__popcll(m[c]);
+                if (cntc && lane == 0 && rbase < a.cap) {
+                    RunRec rr;
+                    rr.pos = list_begin + first + c * 256 + (threadIdx.x & ~63u);
+                    rr.slot = slot;
+                    rr.base = base;
+                    rr.cnt = cntc;
+                    runs[(uint64_t)b * a.cap + rbase] = rr;
+                }
+                base += cntc;
+                rbase += cntc ? 1u : 0u;
             }
         }
     }
@@ -536,9 +551,11 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(SCAN_PARAMS, uint32_t
         bool pass = valid && rough < thr_of_query[b];
         uint64_t m = __ballot(pass);
         if (m) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(surv_cnt + b, (uint32_t)__popcll(m));
-            base = __builtin_amdgcn_readfirstlane(base);
+            const uint32_t cntc = (uint32_t)__popcll(m);
+            unsigned long long old = 0;
+            if (lane == 0) old = atomicAdd(surv_cnt + b, (1ull << 32) | cntc);
+            uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)old);
+            uint32_t rbase = __builtin_amdgcn_readfirstlane((uint32_t)(old >> 32));
             if (pass) {
                 uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                 if (at < a.cap) {
@@ -546,6 +563,12 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(SCAN_PARAMS, uint32_t
                     r.pos = pos, r.slot = slot, r.rough = rough, r.accurate = 0.0f;
                     surv[(uint64_t)b * a.cap + at] = r;
                 }
+            }
+            if (lane == 0 && rbase < a.cap) {
+                RunRec rr;
+                rr.pos = list_begin + lo + tile * 256 + (threadIdx.x & ~63u);
+                rr.slot = slot, rr.base = base, rr.cnt = cntc;
+                runs[(uint64_t)b * a.cap + rbase] = rr;
             }
         }
     }
@@ -579,12 +602,12 @@ __global__ __launch_bounds__(256) void scan_dense_kernel(const uint32_t *__restr
 // grid (gx, nq); block 256.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void accurate_kernel(SurvRec *__restrict__ surv,
-                                                       const uint32_t *__restrict__ surv_cnt,
+                                                       const unsigned long long *__restrict__ surv_cnt,
                                                        uint32_t cap, const float *__restrict__ base,
                                                        const float *__restrict__ qpad, uint32_t dim) {
     const uint32_t b = blockIdx.y;
-    uint32_t n = surv_cnt[b];
-    n = n < cap ? n : cap;
+    uint32_t n = (uint32_t)surv_cnt[b];
+    if (n > cap) return;  // overflowed: this query is re-run with a larger buffer
     const uint32_t l = threadIdx.x & 7, grp = threadIdx.x >> 3;
     const float *q = qpad + (uint64_t)b * dim;
     SurvRec *recs = surv + (uint64_t)b * cap;
@@ -623,16 +646,11 @@ __global__ __launch_bounds__(256) void accurate_flat_kernel(const uint32_t *__re
 // (src/rabitq.rs:304 outer loop, :348 inner loop).  One block per query; LDS when it fits.
 // ------------------------------------------------------------------------------------------------
 #define RQ_SORT_LDS_RECS 2048
-__global__ __launch_bounds__(256) void sort_survivors_kernel(SurvRec *__restrict__ surv,
-                                                             const uint32_t *__restrict__ surv_cnt,
-                                                             uint32_t cap) {
-    __shared__ SurvRec lds[RQ_SORT_LDS_RECS];
-    const uint32_t b = blockIdx.x;
-    uint32_t n = surv_cnt[b];
-    n = n < cap ? n : cap;
+template <typename T>
+__device__ __forceinline__ void sort_segment(T *__restrict__ recs, uint32_t n) {
+    __shared__ T lds[RQ_SORT_LDS_RECS];
     if (n < 2) return;
-    SurvRec *recs = surv + (uint64_t)b * cap;
-    auto key = [](const SurvRec &r) { return surv_key(r); };
+    auto key = [](const T &r) { return surv_key(r); };
     if (n <= RQ_SORT_LDS_RECS) {
         for (uint32_t i = threadIdx.x; i < n; i += 256) lds[i] = recs[i];
         __syncthreads();
@@ -642,6 +660,24 @@ __global__ __launch_bounds__(256) void sort_survivors_kernel(SurvRec *__restrict
         __syncthreads();
         bitonic_sort_block(recs, n, key);  // in global memory (L2), rare
     }
+}
+// run directory of a stage: high 32 bits of the per-query counter = number of runs
+__global__ __launch_bounds__(256) void sort_runs_kernel(RunRec *__restrict__ runs,
+                                                        const unsigned long long *__restrict__ surv_cnt,
+                                                        uint32_t cap) {
+    const uint32_t b = blockIdx.x;
+    const unsigned long long c = surv_cnt[b];
+    if ((uint32_t)c > cap) return;
+    sort_segment(runs + (uint64_t)b * cap, (uint32_t)(c >> 32));
+}
+// heuristic ranker's accepted array (src/rerank.rs:170-176): by (Ord32(accurate), arrival)
+__global__ __launch_bounds__(256) void sort_survivors_kernel(SurvRec *__restrict__ surv,
+                                                             const uint32_t *__restrict__ surv_cnt,
+                                                             uint32_t cap) {
+    const uint32_t b = blockIdx.x;
+    uint32_t n = surv_cnt[b];
+    n = n < cap ? n : cap;
+    sort_segment(surv + (uint64_t)b * cap, n);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -672,14 +708,18 @@ struct ReplayState {
 
 template <bool HEURISTIC>
 __global__ __launch_bounds__(64) void replay_kernel(const SurvRec *__restrict__ surv,
-                                                    uint32_t *__restrict__ surv_cnt, uint32_t cap,
+                                                    const RunRec *__restrict__ runs,
+                                                    unsigned long long *__restrict__ surv_cnt, uint32_t cap,
                                                     const uint32_t *__restrict__ map_ids, uint32_t topk,
                                                     ReplayState st) {
     __shared__ int32_t hkey[HEURISTIC ? 1 : RQ_MAX_TOPK];
     __shared__ uint32_t hid[HEURISTIC ? 1 : RQ_MAX_TOPK];
     const uint32_t b = blockIdx.x, lane = threadIdx.x;
-    const uint32_t cnt = surv_cnt[b];
-    const uint32_t n = cnt < cap ? cnt : cap;
+    const unsigned long long cnt64 = surv_cnt[b];
+    const uint32_t cnt = (uint32_t)cnt64;
+    const bool overflow = cnt > cap;   // records were dropped: the query is re-run with a larger buffer
+    const uint32_t n = overflow ? 0 : cnt;
+    const uint32_t nruns = overflow ? 0 : (uint32_t)(cnt64 >> 32);
     if (lane == 0) {
         if (cnt > st.need[b]) st.need[b] = cnt;
         st.nsurv[b] += n;
@@ -703,8 +743,10 @@ __global__ __launch_bounds__(64) void replay_kernel(const SurvRec *__restrict__ 
         alen = st.arr_len[b];
     }
     const SurvRec *recs = surv + (uint64_t)b * cap;
-    for (uint32_t base = 0; base < n; base += 64) {
-        const bool have = base + lane < n;
+    const RunRec *dir = runs + (uint64_t)b * cap;
+    for (uint32_t ri = 0; ri < nruns; ++ri) {
+        const uint32_t base = dir[ri].base, rc = dir[ri].cnt;
+        const bool have = lane < rc;
         SurvRec r;
         if (have) r = recs[base + lane];
         else r.pos = 0, r.slot = 0, r.rough = 0.0f, r.accurate = 0.0f;
@@ -841,7 +883,8 @@ __global__ void finalize_heuristic_kernel(const ReplayState st, uint32_t nq, uin
 }
 
 // per-batch totals for METRICS (src/metrics.rs:44-53): sums of the per-query counters.
-// out4 = {rough, precise (queries without overflow only), #overflowed queries, accurate distances computed}
+// out4[0..5) = {rough, precise (queries without overflow only), #overflowed queries, accurate distances
+// computed, max buffer need}
 __global__ __launch_bounds__(256) void metrics_sum_kernel(const unsigned long long *__restrict__ rough,
                                                           const uint32_t *__restrict__ precise,
                                                           const uint32_t *__restrict__ need,
@@ -849,21 +892,25 @@ __global__ __launch_bounds__(256) void metrics_sum_kernel(const unsigned long lo
                                                           const uint32_t *__restrict__ nsurv, uint32_t nq,
                                                           uint32_t cap, uint32_t hcap,
                                                           unsigned long long *__restrict__ out4) {
-    __shared__ unsigned long long s[4];
-    if (threadIdx.x < 4) s[threadIdx.x] = 0;
+    __shared__ unsigned long long s[5];
+    if (threadIdx.x < 5) s[threadIdx.x] = 0;
     __syncthreads();
-    unsigned long long r = 0, p = 0, o = 0, a = 0;
+    unsigned long long r = 0, p = 0, o = 0, a = 0, mx = 0;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) {
         const bool ok = need[i] <= cap && (!arr_len || arr_len[i] <= hcap);
         r += rough[i];
         p += ok ? precise[i] : 0;
         o += ok ? 0 : 1;
         a += nsurv[i];
+        unsigned long long nd = need[i] > (arr_len ? arr_len[i] : 0) ? need[i] : arr_len[i];
+        mx = nd > mx ? nd : mx;
     }
     atomicAdd(&s[0], r);
     atomicAdd(&s[1], p);
     atomicAdd(&s[2], o);
     atomicAdd(&s[3], a);
+    atomicMax(&s[4], mx);
     __syncthreads();
     if (threadIdx.x < 4) atomicAdd(&out4[threadIdx.x], s[threadIdx.x]);
+    if (threadIdx.x == 4) atomicMax(&out4[4], s[4]);
 }

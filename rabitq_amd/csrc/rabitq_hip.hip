@@ -155,14 +155,15 @@ struct Workspace {
     hipStream_t stream = nullptr;
     bool busy = false;
     DevBuf<float> qpad, y, dist, probe_dist, thr, recent;
-    DevBuf<uint32_t> probe_cluster, pair_list, grp_cnt, grp_start, surv_cnt, heap_len, heap_id, precise, need,
+    DevBuf<uint32_t> probe_cluster, pair_list, grp_cnt, grp_start, heap_len, heap_id, precise, need,
         nsurv, win_count, arr_len, row_map;
     DevBuf<int32_t> heap_key;
     DevBuf<PairScalars> scal;
     DevBuf<uint64_t> planes;
-    DevBuf<unsigned long long> rough_cnt, totals;
+    DevBuf<unsigned long long> rough_cnt, totals, surv_cnt;
     DevBuf<SurvRec> surv, arr;
-    unsigned long long *h_totals = nullptr;  // pinned, 4
+    DevBuf<RunRec> runs;
+    unsigned long long *h_totals = nullptr;  // pinned, 8
     Prof prof;
     ~Workspace() {
         if (h_totals) (void)hipHostFree(h_totals);
@@ -179,6 +180,7 @@ struct rq_index {
     DevBuf<float4> factors;
     std::mutex ws_mu;
     std::vector<std::unique_ptr<Workspace>> ws_pool;
+    std::atomic<uint32_t> cap_hint{0};  // survivor-buffer capacity learnt from earlier batches
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -199,24 +201,38 @@ __global__ void gather_rows_kernel(const float *__restrict__ in, const uint32_t 
 // ------------------------------------------------------------------------------------------------
 // rotation launcher (MFMA kernel for bulk, VALU kernel for a handful of rows; bit-identical)
 // ------------------------------------------------------------------------------------------------
+// HIP silently wraps a launch whose gridDim.x * blockDim.x reaches 2^32: every launcher keeps
+// blocks * threads below this bound (rows are chunked, big kernels are grid-stride).
+#define RQ_MAX_BLOCKS_256 ((1u << 23) - 1)  // blocks of 256 threads: < 2^31 threads per launch
+
 static void launch_rotate(const float *x, const float *P, float *out, uint64_t n, uint32_t dim, bool mfma,
                           hipStream_t st) {
-    if (n == 0) return;
-    if (mfma) {
-        uint64_t blocks = (uint64_t)ceil_div(n, ROT_BM) * (dim / ROT_BN);
-        rotate_mfma_kernel<<<dim3((uint32_t)blocks), dim3(256), 0, st>>>(x, P, out, n, dim);
-    } else {
-        rotate_valu_kernel<<<dim3(ceil_div(n, 4), dim / 64), dim3(64, 4), 0, st>>>(x, P, out, n, dim);
+    const uint64_t rows_per_launch = mfma ? (uint64_t)(RQ_MAX_BLOCKS_256 / (dim / ROT_BN)) * ROT_BM
+                                          : (uint64_t)RQ_MAX_BLOCKS_256 * 4;
+    for (uint64_t r0 = 0; r0 < n; r0 += rows_per_launch) {
+        const uint64_t m = std::min(rows_per_launch, n - r0);
+        const float *xs = x + r0 * dim;
+        float *os = out + r0 * dim;
+        if (mfma) {
+            uint64_t blocks = (uint64_t)ceil_div(m, ROT_BM) * (dim / ROT_BN);
+            rotate_mfma_kernel<<<dim3((uint32_t)blocks), dim3(256), 0, st>>>(xs, P, os, m, dim);
+        } else {
+            rotate_valu_kernel<<<dim3(ceil_div(m, 4), dim / 64), dim3(64, 4), 0, st>>>(xs, P, os, m, dim);
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // scan dispatch on W = dim / 64
 // ------------------------------------------------------------------------------------------------
-#define SCAN_ARGS p.codes, p.factors, p.grp_start, p.pair_list, p.scal, p.planes, p.thr, p.surv, p.surv_cnt, a
+#define SCAN_ARGS p.codes, p.factors, p.grp_start, p.pair_list, p.scal, p.planes, p.thr, p.surv, p.runs, p.surv_cnt, a
 static void launch_scan(const ScanPtrs &p, const ScanArgs &a, uint32_t W, hipStream_t st) {
     const uint64_t blocks = (uint64_t)a.ngroups * a.tiles_per_group;
     if (blocks == 0) return;
+    if (blocks > RQ_MAX_BLOCKS_256) {  // cannot happen for k <= 2^16 lists of < 2^32 vectors; never wrap silently
+        fprintf(stderr, "rabitq_hip: scan grid of %llu blocks exceeds the launch bound\n", (unsigned long long)blocks);
+        abort();
+    }
     dim3 g((uint32_t)blocks), b(256);
     switch (W) {
         case 1: scan_kernel<1, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
@@ -254,7 +270,7 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
     const uint32_t nprobe = std::min(qp.probe, idx->k);
     const uint64_t nq = qp.nq, npairs = nq * nprobe;
     if (!ws.stream) HIPC(hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking));
-    if (!ws.h_totals) HIPC(hipHostMalloc((void **)&ws.h_totals, 4 * sizeof(unsigned long long)));
+    if (!ws.h_totals) HIPC(hipHostMalloc((void **)&ws.h_totals, 8 * sizeof(unsigned long long)));
     RQC(ws.qpad.ensure(nq * idx->dim));
     RQC(ws.y.ensure(nq * idx->dim));
     RQC(ws.dist.ensure(nq * idx->k));
@@ -263,12 +279,13 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
     RQC(ws.scal.ensure(npairs));
     RQC(ws.planes.ensure(npairs * 4 * idx->W));
     RQC(ws.rough_cnt.ensure(nq));
-    RQC(ws.totals.ensure(4));
+    RQC(ws.totals.ensure(8));
     RQC(ws.pair_list.ensure(npairs));
     RQC(ws.grp_cnt.ensure(idx->k + 1));
     RQC(ws.grp_start.ensure(idx->k + 1));
     RQC(ws.thr.ensure(nq));
     RQC(ws.surv.ensure(nq * qp.cap));
+    RQC(ws.runs.ensure(nq * qp.cap));
     RQC(ws.surv_cnt.ensure(nq));
     RQC(ws.heap_len.ensure(nq));
     RQC(ws.heap_key.ensure(nq * qp.topk));
@@ -285,7 +302,7 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
 }
 
 struct PassResult {
-    uint64_t rough = 0, precise = 0, overflowed = 0;
+    uint64_t rough = 0, precise = 0, overflowed = 0, max_need = 0;
 };
 
 // Runs one pass over nq queries already resident at d_q (nq x len).  Results go to row
@@ -331,14 +348,14 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     // 4. ranker state (rerank.rs:70-77, :129-139)
     fill_f32_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(ws.thr.p, 3.402823466e+38f, nq);
     fill_f32_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(ws.recent.p, -3.402823466e+38f, nq);
-    HIPC(hipMemsetAsync(ws.surv_cnt.p, 0, nq * 4, st));
+    HIPC(hipMemsetAsync(ws.surv_cnt.p, 0, nq * 8, st));
     HIPC(hipMemsetAsync(ws.heap_len.p, 0, nq * 4, st));
     HIPC(hipMemsetAsync(ws.precise.p, 0, nq * 4, st));
     HIPC(hipMemsetAsync(ws.need.p, 0, nq * 4, st));
     HIPC(hipMemsetAsync(ws.nsurv.p, 0, nq * 4, st));
     HIPC(hipMemsetAsync(ws.win_count.p, 0, nq * 4, st));
     HIPC(hipMemsetAsync(ws.arr_len.p, 0, nq * 4, st));
-    HIPC(hipMemsetAsync(ws.totals.p, 0, 4 * sizeof(unsigned long long), st));
+    HIPC(hipMemsetAsync(ws.totals.p, 0, 8 * sizeof(unsigned long long), st));
     pf.end();
 
     ReplayState rs;
@@ -362,7 +379,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             stages.push_back({0, 1, (uint32_t)lo, last ? INF : (uint32_t)hi});
             if (last) break;
             lo = hi;
-            hi = std::min<uint64_t>(hi * 16, 0xFFFFFFF0ull);
+            hi = std::min<uint64_t>(hi * 4, 0xFFFFFFF0ull);
         }
         if (nprobe > 1) stages.push_back({1, nprobe, 0, INF});
     }
@@ -398,6 +415,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         sp.planes = reinterpret_cast<const uint32_t *>(ws.planes.p);
         sp.thr = ws.thr.p;
         sp.surv = ws.surv.p;
+        sp.runs = ws.runs.p;
         sp.surv_cnt = ws.surv_cnt.p;
         a.nprobe = nprobe, a.cap = qp.cap, a.pos_lo = sg.pos_lo, a.pos_hi = sg.pos_hi;
         a.tiles_per_group = ceil_div(phi - sg.pos_lo, tile);
@@ -410,13 +428,13 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         accurate_kernel<<<dim3(gx, nq), 256, 0, st>>>(ws.surv.p, ws.surv_cnt.p, qp.cap, idx->base.p, qpad, dim);
         pf.end();
         pf.begin(PF_SORT);
-        sort_survivors_kernel<<<nq, 256, 0, st>>>(ws.surv.p, ws.surv_cnt.p, qp.cap);
+        sort_runs_kernel<<<nq, 256, 0, st>>>(ws.runs.p, ws.surv_cnt.p, qp.cap);
         pf.end();
         pf.begin(PF_REPLAY);
         if (qp.heuristic)
-            replay_kernel<true><<<nq, 64, 0, st>>>(ws.surv.p, ws.surv_cnt.p, qp.cap, idx->map_ids.p, topk, rs);
+            replay_kernel<true><<<nq, 64, 0, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->map_ids.p, topk, rs);
         else
-            replay_kernel<false><<<nq, 64, 0, st>>>(ws.surv.p, ws.surv_cnt.p, qp.cap, idx->map_ids.p, topk, rs);
+            replay_kernel<false><<<nq, 64, 0, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->map_ids.p, topk, rs);
         pf.end();
     }
 
@@ -435,12 +453,13 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         ws.totals.p);
     pf.end();
     if (pf.on) (void)hipEventRecord(pf.spans[total_span].b, st);
-    HIPC(hipMemcpyAsync(ws.h_totals, ws.totals.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPC(hipMemcpyAsync(ws.h_totals, ws.totals.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIPC(hipStreamSynchronize(st));
     HIPC(hipGetLastError());
     res->rough = ws.h_totals[0];
     res->precise = ws.h_totals[1];
     res->overflowed = ws.h_totals[2];
+    res->max_need = ws.h_totals[4];
     if (pf.on && prof_acc) {
         float ms[PF_N] = {0};
         pf.collect(ms);
@@ -498,15 +517,25 @@ static rq_status query_device(rq_index *idx, const float *d_q, uint32_t nq, uint
     uint64_t tot_rough = 0, tot_precise = 0;
     bool any_empty = false;
     std::vector<uint32_t> h_need, h_alen, over_rows;
-    for (uint32_t q0 = 0; q0 < nq; q0 += RQ_MAX_NQ_PER_PASS) {
-        QueryParams qp{std::min(nq - q0, RQ_MAX_NQ_PER_PASS), len, probe, topk, heuristic, RQ_DEFAULT_CAP,
-                       RQ_DEFAULT_CAP};
+    for (uint32_t q0 = 0, step_nq = 0; q0 < nq; q0 += step_nq) {
+        // survivor / run buffers: 32 B per slot per query; keep one pass under ~24 GiB
+        const uint32_t cap0 = std::max(RQ_DEFAULT_CAP, idx->cap_hint.load());
+        step_nq = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nq - q0, RQ_MAX_NQ_PER_PASS),
+                                               std::max<uint64_t>(1, (24ull << 30) / ((uint64_t)cap0 * 32)));
+        // (query, list) pairs per pass <= 2^22: bounds the per-pair buffers and every launch size
+        step_nq = std::min<uint32_t>(step_nq, std::max<uint32_t>(1, (1u << 22) / std::min(probe, idx->k)));
+        QueryParams qp{step_nq, len, probe, topk, heuristic, cap0, cap0};
         RQC(ws_prepare(idx, *ws, qp));
         PassResult pr;
         RQC(run_pass(idx, *ws, d_q + (uint64_t)q0 * len, qp, nullptr, d_out_dist + (uint64_t)q0 * topk,
                      d_out_id + (uint64_t)q0 * topk, d_out_n + q0, &pr, &prof));
         tot_rough += pr.rough;
         tot_precise += pr.precise;
+        if (pr.max_need > cap0) {  // remember (with headroom) so that later batches do not overflow
+            uint32_t want = pow2_ceil((uint32_t)std::min<uint64_t>(pr.max_need + pr.max_need / 4, 1u << 22));
+            uint32_t cur = idx->cap_hint.load();
+            while (cur < want && !idx->cap_hint.compare_exchange_weak(cur, want)) {}
+        }
         // survivor-buffer overflow: re-run exactly those queries with the capacity they asked for
         uint32_t cap = qp.cap, hcap = qp.hcap;
         if (pr.overflowed) {
@@ -741,7 +770,7 @@ static rq_status build_device(const float *d_base, uint64_t n, uint32_t d, const
     RQC(idx->factors.alloc(n));
     RQC(idx->map_ids.alloc(n));
     if (n)
-        gather_kernel<<<ceil_div(n, 4), 256>>>(keys.p, n, d_base, d, dim, codes_tmp.p, factors_tmp.p, idx->base.p,
+        gather_kernel<<<std::min<uint32_t>(ceil_div(n, 4), 1u << 20), 256>>>(keys.p, n, d_base, d, dim, codes_tmp.p, factors_tmp.p, idx->base.p,
                                                idx->codes.p, idx->factors.p, idx->map_ids.p);
     HIPC(hipDeviceSynchronize());
     HIPC(hipGetLastError());
@@ -1116,8 +1145,12 @@ rq_status rq_quantize_pack(const float *x_rot, uint64_t n, uint32_t dim, const f
     HIPC(hipMemcpy(dx.p, x_rot, n * dim * 4, hipMemcpyHostToDevice));
     HIPC(hipMemcpy(tmp.centroids.p, centroids_rot, (size_t)k * dim * 4, hipMemcpyHostToDevice));
     transpose_kernel<<<dim3(ceil_div(dim, 32), ceil_div(k, 32)), dim3(32, 8)>>>(tmp.centroids.p, tmp.cent_t.p, k, dim);
-    launch_assign(dx.p, &tmp, n, dl.p, dd.p, nullptr);
-    if (n) quantize_kernel<<<ceil_div(n, 32), 256>>>(dx.p, tmp.centroids.p, dl.p, n, dim, dc.p, df.p);
+    for (uint64_t i0 = 0; i0 < n; i0 += (1ull << 20)) {  // chunked: launches stay far below 2^32 threads
+        const uint64_t m = std::min<uint64_t>(1ull << 20, n - i0);
+        launch_assign(dx.p + i0 * dim, &tmp, m, dl.p + i0, dd.p + i0, nullptr);
+        quantize_kernel<<<ceil_div(m, 32), 256>>>(dx.p + i0 * dim, tmp.centroids.p, dl.p + i0, m, dim,
+                                                  dc.p + i0 * tmp.W, df.p + i0);
+    }
     HIPC(hipDeviceSynchronize());
     HIPC(hipGetLastError());
     if (n) {

@@ -1,0 +1,51 @@
+"""Multi-GPU query fan-out: IVF lists (or, equivalently, the vectors under a shared centroid set)
+are sharded one shard per GPU / process; every rank answers the same query batch against its shard
+and the per-shard top-k are exchanged with ONE all-gather per batch and merged.
+
+The payload is nq * topk * 8 bytes per rank (80 B/query at topk = 10), i.e. latency-bound on xGMI,
+so a single fused all-gather per batch is the right collective -- not a ring all-reduce
+(SURVEY.md section 8e).  torch.distributed (backend "nccl" == RCCL on ROCm, "gloo" on CPU) is plumbing.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def pack_topk(dist_t: torch.Tensor, ids_t: torch.Tensor, counts: torch.Tensor, id_offset: int) -> torch.Tensor:
+    """(nq, topk) f32 distances + u32/i64 local ids + valid counts -> (nq, topk, 2) i64 payload of
+    (monotone distance key, global id); invalid entries get the maximum key."""
+    nq, topk = dist_t.shape
+    bits = dist_t.contiguous().view(torch.int32).to(torch.int64)
+    key = torch.where(bits < 0, bits ^ 0x7FFFFFFF, bits)          # Ord32 (src/ord32.rs:12-17)
+    valid = torch.arange(topk, device=dist_t.device)[None, :] < counts.to(torch.int64)[:, None]
+    key = torch.where(valid, key, torch.full_like(key, 2**31))
+    gid = ids_t.to(torch.int64) + id_offset
+    gid = torch.where(valid, gid, torch.full_like(gid, -1))
+    return torch.stack([key, gid], dim=-1)
+
+
+def merge_shard_topk(payload: torch.Tensor, topk: int, group=None):
+    """All-gather every rank's (nq, topk, 2) payload and keep the topk smallest per query.
+    Returns (dist f32 (nq, topk), ids i64 (nq, topk), counts i64 (nq,)), identical on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world > 1:
+        flat = payload.contiguous().reshape(-1)
+        gathered = torch.empty(world * flat.numel(), dtype=payload.dtype, device=payload.device)
+        dist.all_gather_into_tensor(gathered, flat, group=group)   # ONE collective per query batch
+        gathered = gathered.reshape((world,) + tuple(payload.shape))
+    else:
+        gathered = payload[None]
+    nq = payload.shape[0]
+    allp = gathered.permute(1, 0, 2, 3).reshape(nq, -1, 2)       # (nq, world*topk, 2)
+    # order by (key, global id): deterministic on every rank
+    by_id = torch.argsort(allp[..., 1], dim=1, stable=True)      # two stable passes = lexicographic
+    k1 = torch.gather(allp[..., 0], 1, by_id)
+    by_key = torch.argsort(k1, dim=1, stable=True)[:, :topk]
+    order = torch.gather(by_id, 1, by_key)
+    key = torch.gather(allp[..., 0], 1, order)
+    gid = torch.gather(allp[..., 1], 1, order)
+    counts = (key < 2**31).sum(dim=1)
+    k32 = key.clamp(max=2**31 - 1).to(torch.int32)
+    bits = torch.where(k32 < 0, k32 ^ 0x7FFFFFFF, k32)
+    return bits.view(torch.float32), gid, counts

@@ -228,11 +228,13 @@ def test_survivor_overflow_retry_is_exact(rq, oracle):
     oidx = oracle.OracleIndex.build(x, centres, P)
     gidx = rq.RaBitQ.build(x, centres, P)
     queries = rng.standard_normal((6, d)).astype(np.float32) * 0.2
-    rq.set_profiling = None
-    _compare_with_oracle(rq, oracle, oidx, gidx, queries, 1, 400, False)
-    _compare_with_oracle(rq, oracle, oidx, gidx, queries, 1, 400, True)
     from rabitq_amd import index as ix
-    assert ix.last_profile()["retries"] > 0
+    _compare_with_oracle(rq, oracle, oidx, gidx, queries, 1, 2000, False)
+    assert ix.last_profile()["retries"] > 0, "the test no longer exercises the overflow path"
+    _compare_with_oracle(rq, oracle, oidx, gidx, queries, 1, 2000, False)
+    assert ix.last_profile()["retries"] == 0, "the learnt capacity hint should prevent a second overflow"
+    _compare_with_oracle(rq, oracle, oidx, gidx, queries, 1, 1000, True)   # window-12 threshold: no overflow
+    _compare_with_oracle(rq, oracle, oidx, gidx, queries, 1, 400, False)
     gidx.close()
 
 

@@ -1,0 +1,77 @@
+"""world_size-2 gloo test of the multi-GPU fan-out (rabitq_amd/sharding.py): each rank indexes half
+of the vectors under the shared centroid set (here with the CPU oracle standing in for a GPU
+shard), the per-shard top-k are all-gathered once and merged; the merge must equal the top-k of
+the union, on every rank."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from rabitq_amd.sharding import merge_shard_topk, pack_topk
+    from tests import synth
+    n, d, k, topk, probe = 3000, 64, 12, 10, 12
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.8, seed=3)
+    P = synth.random_orthogonal(d, seed=4)
+    queries, _, _ = synth.mixture(16, d, k, sigma=0.8, seed=5)
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    idx = oracle.OracleIndex.build(x[lo:hi], centres, P)                 # this rank's shard
+    dd = np.full((len(queries), topk), np.nan, np.float32)
+    ii = np.zeros((len(queries), topk), np.int64)
+    cnt = np.zeros(len(queries), np.int64)
+    for qi, q in enumerate(queries):
+        a, b = idx.query(q, probe, topk)
+        cnt[qi] = len(b)
+        dd[qi, :len(b)], ii[qi, :len(b)] = a, b
+    if rank == 1:
+        cnt[3] = 4                                                       # a ragged shard result
+    payload = pack_topk(torch.from_numpy(dd), torch.from_numpy(ii), torch.from_numpy(cnt), id_offset=lo)
+    md, mi, mc = merge_shard_topk(payload, topk)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), d=md.numpy(), i=mi.numpy(), c=mc.numpy(), sd=dd, si=ii + lo, sc=cnt)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_allgather_merge(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"r{i}.npz") for i in range(world)]
+    assert np.array_equal(r[0]["d"].view(np.uint32), r[1]["d"].view(np.uint32)) and np.array_equal(r[0]["i"], r[1]["i"])
+    nq, topk = r[0]["d"].shape
+    for q in range(nq):
+        cand = []
+        for s in r:
+            cand += [(float(s["sd"][q, j]), int(s["si"][q, j])) for j in range(int(s["sc"][q]))]
+        cand.sort()
+        want = cand[:topk]
+        got = [(float(r[0]["d"][q, j]), int(r[0]["i"][q, j])) for j in range(int(r[0]["c"][q]))]
+        assert got == want, q
+        assert all(got[j][0] <= got[j + 1][0] for j in range(len(got) - 1))
+    # the merged answer is (nearly) the exact answer over the union of the shards
+    sys.path.insert(0, ROOT)
+    from tests import synth
+    x, _, _ = synth.mixture(3000, 64, 12, sigma=0.8, seed=3)
+    queries, _, _ = synth.mixture(16, 64, 12, sigma=0.8, seed=5)
+    gt = synth.brute_force_topk(x, queries, topk)
+    hits = sum(len(set(r[0]["i"][q, :int(r[0]["c"][q])].tolist()) & set(gt[q].tolist())) for q in range(nq) if q != 3)
+    assert hits / (10 * (nq - 1)) >= 0.95
