@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--gt-queries", type=int, default=1000)
     ap.add_argument("--cpu-queries", type=int, default=32, help="CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--small-batch", type=int, default=64, help="queries of the HBM-regime scan measurement")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo = single-GPU rehearsal)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     args = ap.parse_args()
 
     import torch
@@ -59,7 +62,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        dist.init_process_group(args.backend, rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+    if args.same_device:
+        local_rank = 0
     assert world == max(args.gpus, 1), f"--gpus {args.gpus} but WORLD_SIZE {world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
@@ -110,6 +115,8 @@ def main():
         del d2
     if world > 1:   # global ground truth = merge of the shards' exact top-k
         pay = sharding.pack_topk(best_d.float(), best_i - rank * n, torch.full((ngt,), topk, device=dev), rank * n)
+        if args.backend == "gloo":
+            pay = pay.cpu()
         _, best_i, _ = sharding.merge_shard_topk(pay, topk)
     gt = best_i.cpu().numpy()
     torch.cuda.synchronize()
@@ -120,6 +127,18 @@ def main():
     idx = rabitq_amd.RaBitQ.build_device(x.data_ptr(), n, d, centres.data_ptr(), k, orthogonal=P)
     torch.cuda.synchronize()
     build_s = time.time() - tb
+    # rotation (a5) on the matrix cores: X' = X P for a 4M-row slice of the base, HIP-event timed
+    rot_rows = min(n, 4_000_000)
+    rot_out = torch.empty((rot_rows, idx.dim), device=dev, dtype=torch.float32) if d == idx.dim else None
+    rotation = None
+    if rot_out is not None:
+        idx.rotate_device(x.data_ptr(), rot_rows, rot_out.data_ptr())          # warm-up
+        ms = min(idx.rotate_device(x.data_ptr(), rot_rows, rot_out.data_ptr()) for _ in range(3))
+        tf = 2.0 * rot_rows * idx.dim * idx.dim / (ms * 1e-3) / 1e12
+        rotation = {"bound": "mfma", "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s",
+                    "frac": round(tf / 157.3, 4), "kernel": "rotate_mfma_kernel (v_mfma_f32_32x32x2_f32, exact f32)",
+                    "rows": rot_rows, "ms": round(ms, 4), "GBps_in_plus_out": round(2 * rot_rows * idx.dim * 4 / (ms * 1e-3) / 1e9, 1)}
+        del rot_out
     del x
     torch.cuda.empty_cache()
     log(f"index built in {build_s:.1f}s: n={idx.n} dim={idx.dim} k={idx.k} max_list_len={idx.max_list_len}")
@@ -133,6 +152,8 @@ def main():
                                out_n.data_ptr())
         if world > 1:
             pay = sharding.pack_topk(out_d, out_i.to(torch.int64) & 0xFFFFFFFF, out_n, rank * n)
+            if args.backend == "gloo":
+                pay = pay.cpu()
             return sharding.merge_shard_topk(pay, topk)
         return out_d, out_i.to(torch.int64) & 0xFFFFFFFF, out_n
 
@@ -156,7 +177,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t1
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if args.backend == "gloo" else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     qps = B * args.steps / elapsed
@@ -187,6 +208,26 @@ def main():
                         "kernel time from HIP events; a list is read from HBM once per launch and scored against "
                         "every query probing it, so the algorithmic rate may exceed physical HBM traffic"}
 
+    # ---- the same scan kernel in its HBM-bound regime: a small batch, (almost) no list shared --------
+    small = None
+    sb = min(args.small_batch, B)
+    if sb > 0:
+        for _ in range(2):
+            idx.query_batch_device(queries.data_ptr(), sb, d, nprobe, topk, out_d.data_ptr(), out_i.data_ptr(),
+                                   out_n.data_ptr())
+        sp = {}
+        reps = 10
+        for _ in range(reps):
+            idx.query_batch_device(queries.data_ptr(), sb, d, nprobe, topk, out_d.data_ptr(), out_i.data_ptr(),
+                                   out_n.data_ptr())
+            for key, v in rqi.last_profile().items():
+                sp[key] = sp.get(key, 0) + v
+        gbs = sp["scan_bytes"] / (sp["ms_scan"] * 1e-3) / 1e9
+        small = {"batch": sb, "scan_ms_per_batch": round(sp["ms_scan"] / reps, 4),
+                 "total_ms_per_batch": round(sp["ms_total"] / reps, 4),
+                 "scan_algorithmic_GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / 8000.0, 4),
+                 "queries_per_s": round(sb * reps / (sp["ms_total"] * 1e-3), 1)}
+
     line = {"metric": "queries/sec at recall@10>=0.95, 100Mx128; HBM GB/s on popcount scan", "value": round(qps, 1),
             "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -199,7 +240,8 @@ def main():
             "rough_per_query": m["rough"] / max(m["query"], 1), "precise_per_query": m["precise"] / max(m["query"], 1),
             "kernel_ms_per_step": {key[3:]: round(prof[key] / args.steps, 3) for key in prof if key.startswith("ms_")},
             "rerank_candidates_per_query": prof["rerank_candidates"] / (B * args.steps),
-            "retries": int(prof["retries"]), "roofline": roofline}
+            "retries": int(prof["retries"]), "roofline": roofline, "roofline_rotation": rotation,
+            "scan_small_batch": small}
 
     # ---- CPU baseline: the oracle (port of the reference's AVX2 path) on this box's host cores ------
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_queries > 0:

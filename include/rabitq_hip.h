@@ -132,6 +132,11 @@ rq_status rq_metrics_reset(void);
  * 0 the VALU kernel. */
 rq_status rq_rotate(const float *x, uint64_t n, uint32_t dim, const float *orthogonal, int use_mfma,
                     float *out);
+/* Same rotation on device-resident rows with the index's own P (the build's rotate step,
+ * src/rabitq.rs:188): d_x and d_out are n x dim device arrays.  If out_ms is non-NULL it receives
+ * the MFMA kernel's duration measured with HIP events on the launch stream (bench.py's rotation
+ * roofline). */
+rq_status rq_rotate_device(const rq_index *idx, const float *d_x, uint64_t n, float *d_out, float *out_ms);
 /* Nearest rotated centroid + residual sign-pack + factors for already-rotated vectors
  * (src/utils.rs:261-277, :53-67; src/rabitq.rs:203-229): out_label n, out_dist n,
  * out_codes n x dim/64, out_factors n. */

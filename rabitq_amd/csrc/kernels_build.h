@@ -25,60 +25,114 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define ROT_BM 64
 #define ROT_BN 64
 #define ROT_BK 64
-__global__ __launch_bounds__(256) void rotate_mfma_kernel(const float *__restrict__ x,
-                                                          const float *__restrict__ P,
-                                                          float *__restrict__ out, uint64_t n,
-                                                          uint32_t dim) {
-    __shared__ float Xs[ROT_BM][ROT_BK + 1];
-    __shared__ __attribute__((aligned(16))) float Ps[ROT_BK][ROT_BN];
+
+struct RotStage {  // one pipeline item's global->register staging: 64x64 X slab + 64x64 P slab
+    float4 x[4], p[4];
+};
+
+__device__ __forceinline__ void rot_load(RotStage &st, const float *__restrict__ x, const float *__restrict__ P,
+                                         uint64_t n, uint32_t dim, uint64_t row0, uint32_t col0, uint32_t k0,
+                                         uint32_t tid) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        uint32_t idx = tid + 256 * it;  // 0..1023 float4 slots
+        uint32_t rr = idx >> 4, c4 = (idx & 15) * 4;
+        st.x[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + rr < n) st.x[it] = *reinterpret_cast<const float4 *>(x + (row0 + rr) * dim + k0 + c4);
+        st.p[it] = *reinterpret_cast<const float4 *>(P + (uint64_t)(k0 + rr) * dim + col0 + c4);
+    }
+}
+
+__device__ __forceinline__ void rot_store_lds(const RotStage &st, float (*Xs)[ROT_BK + 1], float (*Ps)[ROT_BN],
+                                              uint32_t tid) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        uint32_t idx = tid + 256 * it;
+        uint32_t rr = idx >> 4, c4 = (idx & 15) * 4;
+        Xs[rr][c4] = st.x[it].x, Xs[rr][c4 + 1] = st.x[it].y, Xs[rr][c4 + 2] = st.x[it].z, Xs[rr][c4 + 3] = st.x[it].w;
+        *reinterpret_cast<float4 *>(&Ps[rr][c4]) = st.p[it];
+    }
+}
+
+template <bool FIRST>
+__device__ __forceinline__ void rot_compute(f32x16 (&acc)[8], const float (*Xs)[ROT_BK + 1],
+                                            const float (*Ps)[ROT_BN], uint32_t wr, uint32_t wc, uint32_t li,
+                                            uint32_t kk) {
+#pragma unroll
+    for (int cp = 0; cp < ROT_BK / 16; ++cp) {
+        const uint32_t kbase = 8 * (2 * cp + kk);  // this half-wave's chunk inside the slab
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            float a = Xs[wr * 32 + li][kbase + l];
+            float b = Ps[kbase + l][wc * 32 + li];
+            if (FIRST && cp == 0) {
+                f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // C = inline constant 0
+                acc[l] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, zero, 0, 0, 0);
+            } else {
+                acc[l] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[l], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// Persistent: block (col tile c, group g) walks row tiles g, g+G, ... ; the (row tile, K slab) items
+// form one software-pipelined stream: while item i is on the matrix cores out of LDS buffer i&1, the
+// global loads of item i+1 are in flight into registers and are written to buffer (i+1)&1 after the
+// MFMAs; one barrier per item.
+__global__ __launch_bounds__(256, 2) void rotate_mfma_kernel(const float *__restrict__ x,
+                                                             const float *__restrict__ P,
+                                                             float *__restrict__ out, uint64_t n,
+                                                             uint32_t dim, uint32_t groups) {
+    __shared__ float Xs[2][ROT_BM][ROT_BK + 1];
+    __shared__ __attribute__((aligned(16))) float Ps[2][ROT_BK][ROT_BN];
     const uint32_t ncol_tiles = dim / ROT_BN;
-    const uint64_t row_tile = blockIdx.x / ncol_tiles;
-    const uint32_t col_tile = blockIdx.x - row_tile * ncol_tiles;
-    const uint64_t row0 = row_tile * ROT_BM;
+    const uint32_t col_tile = blockIdx.x % ncol_tiles, g = blockIdx.x / ncol_tiles;
     const uint32_t col0 = col_tile * ROT_BN;
+    const uint64_t nrow_tiles = (n + ROT_BM - 1) / ROT_BM;
+    if (g >= nrow_tiles) return;
+    const uint64_t my_tiles = (nrow_tiles - g + groups - 1) / groups;
+    const uint32_t nslab = dim / ROT_BK;
+    const uint64_t total = my_tiles * nslab;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t wr = wave >> 1, wc = wave & 1;
     const uint32_t li = lane & 31, kk = lane >> 5;
 
     f32x16 acc[8];
-#pragma unroll
-    for (int l = 0; l < 8; ++l)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[l][r] = 0.0f;
-
-    for (uint32_t k0 = 0; k0 < dim; k0 += ROT_BK) {
-        // stage X[row0..+64][k0..+64] and P[k0..+64][col0..+64]
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            uint32_t idx = tid + 256 * it;  // 0..1023 float4 slots
-            uint32_t rr = idx >> 4, c4 = (idx & 15) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row0 + rr < n) v = *reinterpret_cast<const float4 *>(x + (row0 + rr) * dim + k0 + c4);
-            Xs[rr][c4] = v.x, Xs[rr][c4 + 1] = v.y, Xs[rr][c4 + 2] = v.z, Xs[rr][c4 + 3] = v.w;
-            float4 p = *reinterpret_cast<const float4 *>(P + (uint64_t)(k0 + rr) * dim + col0 + c4);
-            *reinterpret_cast<float4 *>(&Ps[rr][c4]) = p;
+    RotStage st;
+    rot_load(st, x, P, n, dim, (uint64_t)g * ROT_BM, col0, 0, tid);
+    rot_store_lds(st, Xs[0], Ps[0], tid);
+    __syncthreads();
+    uint64_t tile = g;
+    uint32_t slab = 0;
+    for (uint64_t it = 0; it < total; ++it) {
+        // next item's coordinates
+        uint64_t ntile = tile;
+        uint32_t nsl = slab + 1;
+        if (nsl == nslab) {
+            nsl = 0;
+            ntile = tile + groups;
         }
-        __syncthreads();
+        const bool more = it + 1 < total;
+        if (more) rot_load(st, x, P, n, dim, ntile * ROT_BM, col0, nsl * ROT_BK, tid);
+        const uint32_t buf = (uint32_t)(it & 1);
+        if (slab == 0) rot_compute<true>(acc, Xs[buf], Ps[buf], wr, wc, li, kk);
+        else rot_compute<false>(acc, Xs[buf], Ps[buf], wr, wc, li, kk);
+        if (slab + 1 == nslab) {
+            // epilogue: AVX fold per element; C/D map: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+            const uint64_t row0 = tile * ROT_BM;
 #pragma unroll
-        for (int cp = 0; cp < ROT_BK / 16; ++cp) {
-            const uint32_t kbase = 8 * (2 * cp + kk);  // this half-wave's chunk inside the slab
-#pragma unroll
-            for (int l = 0; l < 8; ++l) {
-                float a = Xs[wr * 32 + li][kbase + l];
-                float b = Ps[kbase + l][wc * 32 + li];
-                acc[l] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[l], 0, 0, 0);
+            for (int r = 0; r < 16; ++r) {
+                float c0 = acc[0][r] + acc[4][r], c1 = acc[1][r] + acc[5][r];
+                float c2 = acc[2][r] + acc[6][r], c3 = acc[3][r] + acc[7][r];
+                float v = (c0 + c1) + (c2 + c3);
+                uint64_t row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (row < n) out[row * dim + col0 + wc * 32 + li] = v;
             }
         }
+        if (more) rot_store_lds(st, Xs[buf ^ 1], Ps[buf ^ 1], tid);
         __syncthreads();
-    }
-    // epilogue: AVX fold per element; C/D map: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float c0 = acc[0][r] + acc[4][r], c1 = acc[1][r] + acc[5][r];
-        float c2 = acc[2][r] + acc[6][r], c3 = acc[3][r] + acc[7][r];
-        float v = (c0 + c1) + (c2 + c3);
-        uint64_t row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-        if (row < n) out[row * dim + col0 + wc * 32 + li] = v;
+        tile = ntile;
+        slab = nsl;
     }
 }
 

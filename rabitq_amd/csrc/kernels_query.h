@@ -225,6 +225,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ y,
                                                    uint32_t pairs_per_row, uint32_t dim,
                                                    PairScalars *__restrict__ scal,
                                                    uint64_t *__restrict__ planes,
+                                                   uint32_t *__restrict__ qnib,
                                                    uint32_t *__restrict__ out_sum_u32,
                                                    unsigned long long *__restrict__ rough_count) {
     const uint32_t lane = threadIdx.x & 63;
@@ -259,6 +260,14 @@ __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ y,
         for (int bit = 0; bit < 4; ++bit) {
             uint64_t word = __ballot((q >> bit) & 1);
             if (lane == 0) pl[bit * W + w] = word;
+        }
+        if (qnib) {  // the same 4-bit codes packed 8 per dword (dword m <-> dims 8m..8m+7, nibble i <-> dim 8m+i):
+                     // the operand form of v_dot8_u32_u4 used by the fused scan kernel
+            uint32_t nib = ((uint32_t)q & 15u) << (4 * (lane & 7));
+            nib |= __shfl_xor(nib, 1, 8);
+            nib |= __shfl_xor(nib, 2, 8);
+            nib |= __shfl_xor(nib, 4, 8);
+            if ((lane & 7) == 0) qnib[(uint64_t)p * 8 * W + 8 * w + (lane >> 3)] = nib;
         }
     }
     for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
@@ -368,7 +377,8 @@ struct ScanPtrs {   // host-side bundle only
     const uint32_t *grp_start;    // cluster-major: k+1 offsets into pair_list
     const uint32_t *pair_list;    // flattened pair ids p = b * nprobe + slot
     const PairScalars *scal;      // per pair
-    const uint32_t *planes;       // per pair 8W dwords (4 planes x W u64)
+    const uint32_t *planes;       // per pair 8W dwords (4 planes x W u64)       [generic kernel]
+    const uint32_t *qnib;         // per pair 8W dwords (4-bit codes, 8 per dword) [fused kernel]
     const float *thr;             // per query
     SurvRec *surv;                // per query `cap` records
     RunRec *runs;                 // per query `cap` run descriptors
@@ -378,21 +388,17 @@ struct ScanPtrs {   // host-side bundle only
     const uint32_t *__restrict__ codes, const float4 *__restrict__ factors,                          \
         const uint32_t *__restrict__ grp_start, const uint32_t *__restrict__ pair_list,              \
         const PairScalars *__restrict__ scal, const uint32_t *__restrict__ planes,                   \
+        const uint32_t *__restrict__ qnib,                                                           \
         const float *__restrict__ thr_of_query, SurvRec *__restrict__ surv, RunRec *__restrict__ runs, \
         unsigned long long *__restrict__ surv_cnt, const ScanArgs a
 
-template <int W>
-__device__ __forceinline__ uint32_t asym_dot(const uint32_t (&code)[2 * W],
-                                             const uint32_t *__restrict__ pl) {
-    uint32_t s = 0;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        uint32_t t = 0;
-#pragma unroll
-        for (int i = 0; i < 2 * W; ++i) t += __popc(code[i] & pl[p * 2 * W + i]);
-        s += t << p;
-    }
-    return s;
+// 8 code bits -> 8 nibbles (bit i -> nibble i), so that sum_j bit_j * q_j becomes v_dot8_u32_u4
+__device__ __forceinline__ uint32_t spread8(uint32_t b) {
+    uint32_t x = b & 0xFFu;
+    x = (x | (x << 12)) & 0x000F000Fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    return x;
 }
 
 __device__ __forceinline__ float rough_distance(uint32_t s, const float4 &f, float lower, float delta,
@@ -405,6 +411,13 @@ __device__ __forceinline__ float rough_distance(uint32_t s, const float4 &f, flo
     return t - f.z * ycd_sqrt;              // - error_bound * dist_sqrt
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// The integer part: the asymmetric dot product sum_p popcount(code & plane_p) << p
+// (src/utils.rs:113-135, src/simd.rs:326-384) equals sum_j bit_j(code) * q_j exactly.  Each lane
+// expands its candidates' code bits to nibbles ONCE per block (amortised over every query of the
+// group) and the per-query work is 8W chained v_dot8_u32_u4 (8 dimensions each, u32 accumulate,
+// query operand in an SGPR) instead of 8W v_and + 8W v_bcnt + adds.
 template <int W, int CPL>
 __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
     const uint32_t g = blockIdx.x / a.tiles_per_group;
@@ -427,7 +440,7 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
     const uint32_t first = lo + tile * (256 * CPL);
     if (first >= hi) return;
 
-    uint32_t code[CPL][2 * W];
+    uint32_t xn[CPL][8 * W];  // nibble-expanded codes
     float4 fac[CPL];
     uint32_t pos[CPL];
     bool valid[CPL];
@@ -437,19 +450,24 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
         valid[c] = local < hi;
         pos[c] = list_begin + (valid[c] ? local : lo);
         const uint32_t *cp = codes + (uint64_t)pos[c] * (2 * W);
+        uint32_t code[2 * W];
         if constexpr ((2 * W) % 4 == 0) {
 #pragma unroll
             for (int i = 0; i < 2 * W; i += 4) {
                 uint4 v = *reinterpret_cast<const uint4 *>(cp + i);
-                code[c][i] = v.x, code[c][i + 1] = v.y, code[c][i + 2] = v.z, code[c][i + 3] = v.w;
+                code[i] = v.x, code[i + 1] = v.y, code[i + 2] = v.z, code[i + 3] = v.w;
             }
         } else {
 #pragma unroll
             for (int i = 0; i < 2 * W; i += 2) {
                 uint2 v = *reinterpret_cast<const uint2 *>(cp + i);
-                code[c][i] = v.x, code[c][i + 1] = v.y;
+                code[i] = v.x, code[i + 1] = v.y;
             }
         }
+#pragma unroll
+        for (int j = 0; j < 2 * W; ++j)
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) xn[c][4 * j + kq] = spread8(code[j] >> (8 * kq));
         fac[c] = factors[pos[c]];
     }
 
@@ -461,20 +479,42 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
         const float lower = sp->lower, delta = sp->delta, sumq = sp->sumq, ycd = sp->ycd,
                     ycd_sqrt = sp->ycd_sqrt;
         const float thr = thr_of_query[b];
-        const uint32_t *pl = planes + (uint64_t)p * (8 * W);
+        const uint32_t *qn = qnib + (uint64_t)p * (8 * W);
         bool pass[CPL];
         float rough[CPL];
+        uint32_t sdot[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int m = 0; m < 8 * W; ++m) acc = __builtin_amdgcn_udot8(xn[c][m], qn[m], acc, false);
+            sdot[c] = acc;
+        }
+        if constexpr (CPL == 2) {
+            // both candidates of a lane in packed f32 (v_pk_*): one rounding per op, same order
+            f32x2 sf = {(float)sdot[0], (float)sdot[1]};
+            f32x2 cds = {fac[0].w, fac[1].w}, ppc = {fac[0].y, fac[1].y}, fip = {fac[0].x, fac[1].x},
+                  eb = {fac[0].z, fac[1].z};
+            f32x2 t = cds + ycd;
+            t = t + lower * ppc;
+            f32x2 u = (2.0f * sf - sumq) * fip;
+            t = t + u * delta;
+            f32x2 r = t - eb * ycd_sqrt;
+            rough[0] = r.x, rough[1] = r.y;
+        } else {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c)
+                rough[c] = rough_distance(sdot[c], fac[c], lower, delta, sumq, ycd, ycd_sqrt);
+        }
         uint32_t total = 0;
         uint64_t m[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-            uint32_t s = asym_dot<W>(code[c], pl);
-            rough[c] = rough_distance(s, fac[c], lower, delta, sumq, ycd, ycd_sqrt);
             pass[c] = valid[c] && (rough[c] < thr);
             m[c] = __ballot(pass[c]);
             total += (uint32_t)__popcll(m[c]);
         }
-        if (total) {  // wave-uniform
+        if (total) {  // wave-uniform: one 64-bit atomic reserves the records and the run descriptors
             uint32_t nruns = 0;
 #pragma unroll
             for (int c = 0; c < CPL; ++c) nruns += m[c] ? 1u : 0u;

@@ -160,6 +160,7 @@ struct Workspace {
     DevBuf<int32_t> heap_key;
     DevBuf<PairScalars> scal;
     DevBuf<uint64_t> planes;
+    DevBuf<uint32_t> qnib;
     DevBuf<unsigned long long> rough_cnt, totals, surv_cnt;
     DevBuf<SurvRec> surv, arr;
     DevBuf<RunRec> runs;
@@ -207,15 +208,17 @@ __global__ void gather_rows_kernel(const float *__restrict__ in, const uint32_t 
 
 static void launch_rotate(const float *x, const float *P, float *out, uint64_t n, uint32_t dim, bool mfma,
                           hipStream_t st) {
-    const uint64_t rows_per_launch = mfma ? (uint64_t)(RQ_MAX_BLOCKS_256 / (dim / ROT_BN)) * ROT_BM
-                                          : (uint64_t)RQ_MAX_BLOCKS_256 * 4;
+    const uint64_t rows_per_launch = mfma ? (1ull << 40) : (uint64_t)RQ_MAX_BLOCKS_256 * 4;
     for (uint64_t r0 = 0; r0 < n; r0 += rows_per_launch) {
         const uint64_t m = std::min(rows_per_launch, n - r0);
         const float *xs = x + r0 * dim;
         float *os = out + r0 * dim;
         if (mfma) {
-            uint64_t blocks = (uint64_t)ceil_div(m, ROT_BM) * (dim / ROT_BN);
-            rotate_mfma_kernel<<<dim3((uint32_t)blocks), dim3(256), 0, st>>>(xs, P, os, m, dim);
+            // persistent: 2 blocks per CU x 256 CUs, split between the column tiles
+            const uint32_t ncol = dim / ROT_BN;
+            const uint64_t nrow_tiles = ceil_div(m, ROT_BM);
+            const uint32_t groups = (uint32_t)std::min<uint64_t>(nrow_tiles, std::max<uint32_t>(1, 512 / ncol));
+            rotate_mfma_kernel<<<dim3(groups * ncol), dim3(256), 0, st>>>(xs, P, os, m, dim, groups);
         } else {
             rotate_valu_kernel<<<dim3(ceil_div(m, 4), dim / 64), dim3(64, 4), 0, st>>>(xs, P, os, m, dim);
         }
@@ -225,7 +228,7 @@ static void launch_rotate(const float *x, const float *P, float *out, uint64_t n
 // ------------------------------------------------------------------------------------------------
 // scan dispatch on W = dim / 64
 // ------------------------------------------------------------------------------------------------
-#define SCAN_ARGS p.codes, p.factors, p.grp_start, p.pair_list, p.scal, p.planes, p.thr, p.surv, p.runs, p.surv_cnt, a
+#define SCAN_ARGS p.codes, p.factors, p.grp_start, p.pair_list, p.scal, p.planes, p.qnib, p.thr, p.surv, p.runs, p.surv_cnt, a
 static void launch_scan(const ScanPtrs &p, const ScanArgs &a, uint32_t W, hipStream_t st) {
     const uint64_t blocks = (uint64_t)a.ngroups * a.tiles_per_group;
     if (blocks == 0) return;
@@ -278,6 +281,7 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
     RQC(ws.probe_cluster.ensure(npairs));
     RQC(ws.scal.ensure(npairs));
     RQC(ws.planes.ensure(npairs * 4 * idx->W));
+    RQC(ws.qnib.ensure(npairs * 8 * idx->W));
     RQC(ws.rough_cnt.ensure(nq));
     RQC(ws.totals.ensure(8));
     RQC(ws.pair_list.ensure(npairs));
@@ -344,7 +348,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     HIPC(hipMemsetAsync(ws.rough_cnt.p, 0, nq * sizeof(unsigned long long), st));
     prep_kernel<<<ceil_div(npairs, 4), 256, 0, st>>>(ws.y.p, idx->centroids.p, idx->offsets.p, ws.probe_cluster.p,
                                                      ws.probe_dist.p, npairs, nprobe, dim, ws.scal.p, ws.planes.p,
-                                                     nullptr, ws.rough_cnt.p);
+                                                     ws.qnib.p, nullptr, ws.rough_cnt.p);
     // 4. ranker state (rerank.rs:70-77, :129-139)
     fill_f32_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(ws.thr.p, 3.402823466e+38f, nq);
     fill_f32_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(ws.recent.p, -3.402823466e+38f, nq);
@@ -413,6 +417,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         sp.pair_list = ws.pair_list.p;
         sp.scal = ws.scal.p;
         sp.planes = reinterpret_cast<const uint32_t *>(ws.planes.p);
+        sp.qnib = ws.qnib.p;
         sp.thr = ws.thr.p;
         sp.surv = ws.surv.p;
         sp.runs = ws.runs.p;
@@ -1123,6 +1128,25 @@ rq_status rq_rotate(const float *x, uint64_t n, uint32_t dim, const float *ortho
     return RQ_OK;
 }
 
+rq_status rq_rotate_device(const rq_index *idx, const float *d_x, uint64_t n, float *d_out, float *out_ms) {
+    RQC(ensure_device());
+    if (!idx || !d_x || !d_out) return fail(RQ_ERR_INVALID, "null argument");
+    hipEvent_t e0, e1;
+    HIPC(hipEventCreate(&e0));
+    HIPC(hipEventCreate(&e1));
+    HIPC(hipEventRecord(e0, nullptr));
+    launch_rotate(d_x, idx->P.p, d_out, n, idx->dim, true, nullptr);
+    HIPC(hipEventRecord(e1, nullptr));
+    HIPC(hipEventSynchronize(e1));
+    HIPC(hipGetLastError());
+    float ms = 0;
+    HIPC(hipEventElapsedTime(&ms, e0, e1));
+    if (out_ms) *out_ms = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return RQ_OK;
+}
+
 rq_status rq_quantize_pack(const float *x_rot, uint64_t n, uint32_t dim, const float *centroids_rot, uint32_t k,
                            uint32_t *out_label, float *out_dist, uint64_t *out_codes, rq_factor_t *out_factors) {
     RQC(ensure_device());
@@ -1214,7 +1238,7 @@ rq_status rq_query_prep(const rq_index *idx, const float *y, uint32_t nq, const 
     HIPC(hipMemcpy(dc.p, cluster, nq * 4, hipMemcpyHostToDevice));
     HIPC(hipMemset(ycd.p, 0, nq * 4));
     prep_kernel<<<ceil_div(nq, 4), 256>>>(dy.p, idx->centroids.p, idx->offsets.p, dc.p, ycd.p, nq, 1, dim, scal.p,
-                                          planes.p, dsum.p, nullptr);
+                                          planes.p, nullptr, dsum.p, nullptr);
     HIPC(hipDeviceSynchronize());
     HIPC(hipGetLastError());
     std::vector<PairScalars> hs(nq);

@@ -88,6 +88,12 @@ class RaBitQ:
                                    C.byref(h)))
         return cls(h)
 
+    def rotate_device(self, x_ptr: int, n: int, out_ptr: int) -> float:
+        """X' = X P on device-resident rows (MFMA kernel); returns the kernel time in ms (HIP events)."""
+        ms = C.c_float()
+        check(lib().rq_rotate_device(self._h, C.c_void_p(x_ptr), n, C.c_void_p(out_ptr), C.byref(ms)))
+        return float(ms.value)
+
     def close(self):
         if getattr(self, "_h", None):
             lib().rq_free(self._h)
