@@ -35,9 +35,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     # workload (defaults = BASELINE.json configs[2], the configuration the metric is quoted on)
-    ap.add_argument("--n", type=int, default=100_000_000, help="vectors per GPU")
+    ap.add_argument("--vectors", type=int, default=100_000_000, help="vectors per GPU")
     ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--k", type=int, default=4096, help="IVF lists per GPU")
+    ap.add_argument("--lists", type=int, default=4096, help="IVF lists per GPU")
     ap.add_argument("--nprobe", type=int, default=64)
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--batch", type=int, default=10000, help="queries per step")
@@ -72,7 +72,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     _lib.check(_lib.lib().rq_init(local_rank))
 
-    n, d, k_local, nprobe, topk, B = args.n, args.dim, args.k, args.nprobe, args.topk, args.batch
+    n, d, k_local, nprobe, topk, B = args.vectors, args.dim, args.lists, args.nprobe, args.topk, args.batch
     k = k_local * world                      # global list count; every rank knows all centroids
     t0 = time.time()
 

@@ -77,9 +77,8 @@ __device__ __forceinline__ uint64_t surv_key(const RunRec &r) {
     return ((uint64_t)r.slot << 32) | r.pos;
 }
 
-// Per-(query, probe slot) scalars written by the prep kernel, 32 bytes so a wave can fetch them
-// with one s_load_dwordx8.
-struct __attribute__((aligned(32))) PairScalars {
+// Per-(query, probe slot) scalars written by the prep kernel; 40 bytes = s_load_dwordx8 + x2.
+struct __attribute__((aligned(8))) PairScalars {
     float lower;      // lower_bound                      (src/rabitq.rs:305)
     float delta;      // (hi - lo) * SCALAR               (:307)
     float sumq;       // scalar_sum as f32                (:322)
@@ -88,4 +87,6 @@ struct __attribute__((aligned(32))) PairScalars {
     uint32_t row;         // query row b of this pair (pair id p = row * nprobe + slot)
     uint32_t list_begin;  // offsets[cluster]
     uint32_t list_len;
+    uint32_t stream_begin;  // candidates the reference visits before this list (sum of earlier slots' lengths)
+    uint32_t pad;
 };

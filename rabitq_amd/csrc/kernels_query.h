@@ -226,8 +226,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ y,
                                                    PairScalars *__restrict__ scal,
                                                    uint64_t *__restrict__ planes,
                                                    uint32_t *__restrict__ qnib,
-                                                   uint32_t *__restrict__ out_sum_u32,
-                                                   unsigned long long *__restrict__ rough_count) {
+                                                   uint32_t *__restrict__ out_sum_u32) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= npairs) return;
@@ -282,10 +281,27 @@ __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ y,
         s.row = row;
         s.list_begin = offsets[c];
         s.list_len = offsets[c + 1] - offsets[c];
+        s.stream_begin = 0;  // filled by pair_prefix_kernel
+        s.pad = 0;
         scal[p] = s;
         if (out_sum_u32) out_sum_u32[p] = sum;
-        if (rough_count) atomicAdd(rough_count + row, (unsigned long long)s.list_len);  // rerank.rs:105
     }
+}
+
+// Position of every probed list in the query's candidate stream (the order the reference visits
+// candidates: lists nearest-first, members in stored order) and the stream length, which is also
+// what the reference adds to METRICS.rough for this query (src/rerank.rs:105).
+__global__ void pair_prefix_kernel(PairScalars *__restrict__ scal, uint32_t nq, uint32_t nprobe,
+                                   unsigned long long *__restrict__ rough_count) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nq) return;
+    unsigned long long acc = 0;
+    for (uint32_t s = 0; s < nprobe; ++s) {
+        PairScalars *ps = scal + (uint64_t)b * nprobe + s;
+        ps->stream_begin = acc > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)acc;
+        acc += ps->list_len;
+    }
+    rough_count[b] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -293,20 +309,18 @@ __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ y,
 // pair-major: one group per pair.  cluster-major: pairs bucketed by list so that a list is read
 // from HBM once and scored against every query probing it.
 // ------------------------------------------------------------------------------------------------
-__global__ void enumerate_pairs_kernel(uint32_t nq, uint32_t nprobe, uint32_t slot_lo, uint32_t ns,
-                                       uint32_t *__restrict__ pair_list) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq * ns) return;
-    uint32_t b = i / ns, s = slot_lo + (i - b * ns);
-    pair_list[i] = b * nprobe + s;
+// does list [begin, begin+len) of the candidate stream intersect the stage [s_lo, s_hi) ?
+__device__ __forceinline__ bool pair_in_stage(const PairScalars &ps, uint32_t s_lo, uint32_t s_hi) {
+    const uint64_t b = ps.stream_begin, e = b + ps.list_len;
+    return ps.list_len != 0 && b < s_hi && e > s_lo;
 }
 
-__global__ void group_count_kernel(const uint32_t *__restrict__ probe_cluster, uint32_t nq, uint32_t nprobe,
-                                   uint32_t slot_lo, uint32_t ns, uint32_t *__restrict__ grp_cnt) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq * ns) return;
-    uint32_t b = i / ns, s = slot_lo + (i - b * ns);
-    atomicAdd(&grp_cnt[probe_cluster[b * nprobe + s]], 1u);
+__global__ void group_count_kernel(const PairScalars *__restrict__ scal,
+                                   const uint32_t *__restrict__ probe_cluster, uint32_t npairs, uint32_t s_lo,
+                                   uint32_t s_hi, uint32_t *__restrict__ grp_cnt) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npairs) return;
+    if (pair_in_stage(scal[p], s_lo, s_hi)) atomicAdd(&grp_cnt[probe_cluster[p]], 1u);
 }
 
 // exclusive scan of cnt[0..k) into start[0..k]; single block, any k.  Also zeroes cnt for the
@@ -341,16 +355,72 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(uint32_t *__restrict__
     if (tid == 0) start[k] = carry;
 }
 
-__global__ void group_fill_kernel(const uint32_t *__restrict__ probe_cluster, uint32_t nq, uint32_t nprobe,
-                                  uint32_t slot_lo, uint32_t ns, const uint32_t *__restrict__ grp_start,
-                                  uint32_t *__restrict__ grp_cursor, uint32_t *__restrict__ pair_list) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq * ns) return;
-    uint32_t b = i / ns, s = slot_lo + (i - b * ns);
-    uint32_t p = b * nprobe + s;
-    uint32_t c = probe_cluster[p];
-    uint32_t at = atomicAdd(&grp_cursor[c], 1u);
-    pair_list[grp_start[c] + at] = p;
+// Per-stage work records.  Everything the scan needs about one (query, list) pair, contiguous, so
+// that the scan's inner loop is one pointer bump plus immediate-offset scalar loads:
+//   dwords [0, 8W)      query operand: 4-bit codes 8 per dword (fused kernel) or the 4 bit planes
+//   dwords 8W + ...     RQ_REC_* below
+// Cluster-major: records of the pairs probing list c are stored at grp_start[c] ...; pair-major:
+// record i belongs to pair i (pairs outside the stage get an empty range).
+#define RQ_REC_LOWER 0
+#define RQ_REC_DELTA 1
+#define RQ_REC_SUMQ 2
+#define RQ_REC_YCD 3
+#define RQ_REC_YCD_SQRT 4
+#define RQ_REC_THR 5
+#define RQ_REC_LO 6          // first list position of this pair that belongs to the stage
+#define RQ_REC_HI 7          // one past the last
+#define RQ_REC_ROW 8
+#define RQ_REC_SLOT 9
+#define RQ_REC_LIST_BEGIN 10
+#define RQ_REC_LIST_LEN 11
+#define RQ_REC_TAIL 16
+
+__global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__restrict__ scal,
+                                                         const uint32_t *__restrict__ probe_cluster,
+                                                         const uint32_t *__restrict__ operand /* 8W dwords per pair */,
+                                                         const float *__restrict__ thr, uint32_t npairs,
+                                                         uint32_t nprobe, uint32_t W, uint32_t s_lo, uint32_t s_hi,
+                                                         uint32_t cluster_major,
+                                                         const uint32_t *__restrict__ grp_start,
+                                                         uint32_t *__restrict__ grp_cursor,
+                                                         uint32_t *__restrict__ recs) {
+    const uint32_t sub = threadIdx.x & 15;                       // 16 lanes per pair
+    const uint32_t p = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (p >= npairs) return;
+    const PairScalars ps = scal[p];
+    const bool in = pair_in_stage(ps, s_lo, s_hi);
+    if (cluster_major && !in) return;
+    uint32_t at = p;
+    if (cluster_major) {
+        const uint32_t c = probe_cluster[p];
+        uint32_t a = 0;
+        if (sub == 0) a = atomicAdd(&grp_cursor[c], 1u);
+        at = grp_start[c] + __shfl(a, 0, 16);
+    }
+    const uint32_t stride = 8 * W + RQ_REC_TAIL;
+    uint32_t *r = recs + (uint64_t)at * stride;
+    for (uint32_t i = sub; i < 8 * W; i += 16) r[i] = operand[(uint64_t)p * 8 * W + i];
+    if (sub == 0) {
+        uint32_t lo = 0, hi = 0;
+        if (in) {
+            lo = s_lo > ps.stream_begin ? s_lo - ps.stream_begin : 0u;
+            hi = s_hi - ps.stream_begin;  // in-stage => stream_begin < s_hi
+            hi = hi < ps.list_len ? hi : ps.list_len;
+        }
+        uint32_t *t = r + 8 * W;
+        t[RQ_REC_LOWER] = __builtin_bit_cast(uint32_t, ps.lower);
+        t[RQ_REC_DELTA] = __builtin_bit_cast(uint32_t, ps.delta);
+        t[RQ_REC_SUMQ] = __builtin_bit_cast(uint32_t, ps.sumq);
+        t[RQ_REC_YCD] = __builtin_bit_cast(uint32_t, ps.ycd);
+        t[RQ_REC_YCD_SQRT] = __builtin_bit_cast(uint32_t, ps.ycd_sqrt);
+        t[RQ_REC_THR] = __builtin_bit_cast(uint32_t, thr[ps.row]);
+        t[RQ_REC_LO] = lo;
+        t[RQ_REC_HI] = hi;
+        t[RQ_REC_ROW] = ps.row;
+        t[RQ_REC_SLOT] = p - ps.row * nprobe;
+        t[RQ_REC_LIST_BEGIN] = ps.list_begin;
+        t[RQ_REC_LIST_LEN] = ps.list_len;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -368,28 +438,22 @@ __global__ void group_fill_kernel(const uint32_t *__restrict__ probe_cluster, ui
 // HBM traffic is the list itself: D/8 + 16 bytes per candidate, 16 B/lane coalesced loads at D=128.
 // ------------------------------------------------------------------------------------------------
 struct ScanArgs {   // scalars only; pointers are explicit __restrict__ kernel parameters so the
-                    // compiler may keep the wave-uniform operand fetches on the scalar unit (s_load)
-    uint32_t nprobe, cap, pos_lo, pos_hi, tiles_per_group, ngroups, cluster_major;
+                    // compiler keeps the wave-uniform operand fetches on the scalar unit (s_load)
+    uint32_t cap, tiles_per_group, ngroups, cluster_major;
 };
 struct ScanPtrs {   // host-side bundle only
     const uint32_t *codes;        // n * 2W dwords (x_binary_vec, src/rabitq.rs:66)
     const float4 *factors;        // n (src/rabitq.rs:67): x=factor_ip y=factor_ppc z=error_bound w=cds
-    const uint32_t *grp_start;    // cluster-major: k+1 offsets into pair_list
-    const uint32_t *pair_list;    // flattened pair ids p = b * nprobe + slot
-    const PairScalars *scal;      // per pair
-    const uint32_t *planes;       // per pair 8W dwords (4 planes x W u64)       [generic kernel]
-    const uint32_t *qnib;         // per pair 8W dwords (4-bit codes, 8 per dword) [fused kernel]
-    const float *thr;             // per query
+    const uint32_t *grp_start;    // cluster-major: k+1 offsets into the record array
+    const uint32_t *recs;         // per-stage work records (stage_fill_kernel)
     SurvRec *surv;                // per query `cap` records
     RunRec *runs;                 // per query `cap` run descriptors
     unsigned long long *surv_cnt; // per query: low 32 bits = records, high 32 bits = runs
 };
 #define SCAN_PARAMS                                                                                  \
     const uint32_t *__restrict__ codes, const float4 *__restrict__ factors,                          \
-        const uint32_t *__restrict__ grp_start, const uint32_t *__restrict__ pair_list,              \
-        const PairScalars *__restrict__ scal, const uint32_t *__restrict__ planes,                   \
-        const uint32_t *__restrict__ qnib,                                                           \
-        const float *__restrict__ thr_of_query, SurvRec *__restrict__ surv, RunRec *__restrict__ runs, \
+        const uint32_t *__restrict__ grp_start, const uint32_t *__restrict__ recs,                   \
+        SurvRec *__restrict__ surv, RunRec *__restrict__ runs,                                       \
         unsigned long long *__restrict__ surv_cnt, const ScanArgs a
 
 // 8 code bits -> 8 nibbles (bit i -> nibble i), so that sum_j bit_j * q_j becomes v_dot8_u32_u4
@@ -420,6 +484,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // query operand in an SGPR) instead of 8W v_and + 8W v_bcnt + adds.
 template <int W, int CPL>
 __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
+    constexpr uint32_t STRIDE = 8 * W + RQ_REC_TAIL;
     const uint32_t g = blockIdx.x / a.tiles_per_group;
     const uint32_t tile = blockIdx.x - g * a.tiles_per_group;
     uint32_t pb, pe;
@@ -432,23 +497,21 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
     }
     if (pb >= pe) return;
     const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // the list of this group (all its pairs share it)
-    const uint32_t p0 = __builtin_amdgcn_readfirstlane(pair_list[pb]);
-    const uint32_t list_begin = scal[p0].list_begin, list_len = scal[p0].list_len;
-    const uint32_t lo = a.pos_lo < list_len ? a.pos_lo : list_len;
-    const uint32_t hi = a.pos_hi < list_len ? a.pos_hi : list_len;
-    const uint32_t first = lo + tile * (256 * CPL);
-    if (first >= hi) return;
+    const uint32_t *rec = recs + (uint64_t)pb * STRIDE;
+    const uint32_t list_begin = rec[8 * W + RQ_REC_LIST_BEGIN], list_len = rec[8 * W + RQ_REC_LIST_LEN];
+    const uint32_t first = tile * (256 * CPL);  // first list position of this tile
+    if (first >= list_len) return;
+    if (!a.cluster_major && rec[8 * W + RQ_REC_LO] >= rec[8 * W + RQ_REC_HI]) return;  // pair not in this stage
 
     uint32_t xn[CPL][8 * W];  // nibble-expanded codes
     float4 fac[CPL];
     uint32_t pos[CPL];
-    bool valid[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
         uint32_t local = first + c * 256 + threadIdx.x;
-        valid[c] = local < hi;
-        pos[c] = list_begin + (valid[c] ? local : lo);
+        pos[c] = list_begin + (local < list_len ? local : 0);
         const uint32_t *cp = codes + (uint64_t)pos[c] * (2 * W);
         uint32_t code[2 * W];
         if constexpr ((2 * W) % 4 == 0) {
@@ -471,16 +534,15 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
         fac[c] = factors[pos[c]];
     }
 
-    for (uint32_t i = pb; i < pe; ++i) {
-        const uint32_t p = __builtin_amdgcn_readfirstlane(pair_list[i]);
-        const PairScalars *sp = scal + p;
-        const uint32_t b = sp->row;
-        const uint32_t slot = p - b * a.nprobe;
-        const float lower = sp->lower, delta = sp->delta, sumq = sp->sumq, ycd = sp->ycd,
-                    ycd_sqrt = sp->ycd_sqrt;
-        const float thr = thr_of_query[b];
-        const uint32_t *qn = qnib + (uint64_t)p * (8 * W);
-        bool pass[CPL];
+    for (uint32_t i = pb; i < pe; ++i, rec += STRIDE) {
+        const uint32_t *qn = rec;
+        const uint32_t *t = rec + 8 * W;
+        // positions of this list that belong to the stage: [lo_p, hi_p) (wave-uniform)
+        const uint32_t lo_p = t[RQ_REC_LO], hi_p = t[RQ_REC_HI];
+        if (hi_p <= first || lo_p >= first + 256 * CPL) continue;
+        const float lower = __builtin_bit_cast(float, t[RQ_REC_LOWER]), delta = __builtin_bit_cast(float, t[RQ_REC_DELTA]),
+                    sumq = __builtin_bit_cast(float, t[RQ_REC_SUMQ]), ycd = __builtin_bit_cast(float, t[RQ_REC_YCD]),
+                    ycd_sqrt = __builtin_bit_cast(float, t[RQ_REC_YCD_SQRT]), thr = __builtin_bit_cast(float, t[RQ_REC_THR]);
         float rough[CPL];
         uint32_t sdot[CPL];
 #pragma unroll
@@ -495,11 +557,11 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
             f32x2 sf = {(float)sdot[0], (float)sdot[1]};
             f32x2 cds = {fac[0].w, fac[1].w}, ppc = {fac[0].y, fac[1].y}, fip = {fac[0].x, fac[1].x},
                   eb = {fac[0].z, fac[1].z};
-            f32x2 t = cds + ycd;
-            t = t + lower * ppc;
+            f32x2 tt = cds + ycd;
+            tt = tt + lower * ppc;
             f32x2 u = (2.0f * sf - sumq) * fip;
-            t = t + u * delta;
-            f32x2 r = t - eb * ycd_sqrt;
+            tt = tt + u * delta;
+            f32x2 r = tt - eb * ycd_sqrt;
             rough[0] = r.x, rough[1] = r.y;
         } else {
 #pragma unroll
@@ -508,13 +570,26 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
         }
         uint32_t total = 0;
         uint64_t m[CPL];
+        if (lo_p <= first && first + 256 * CPL <= hi_p) {  // whole tile inside the stage (the common case)
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            pass[c] = valid[c] && (rough[c] < thr);
-            m[c] = __ballot(pass[c]);
-            total += (uint32_t)__popcll(m[c]);
+            for (int c = 0; c < CPL; ++c) {
+                m[c] = __ballot(rough[c] < thr);  // src/rerank.rs:84 gate
+                total += (uint32_t)__popcll(m[c]);
+            }
+        } else {  // boundary tile: lanes of this wave hold positions P0 .. P0+63, the in-stage ones are a bit range
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const uint32_t P0 = first + c * 256 + wave * 64;
+                const uint32_t ra = lo_p > P0 ? (lo_p - P0 < 64 ? lo_p - P0 : 64) : 0;
+                const uint32_t rb = hi_p > P0 ? (hi_p - P0 < 64 ? hi_p - P0 : 64) : 0;
+                const uint64_t below_b = rb >= 64 ? ~0ull : ((1ull << rb) - 1ull);
+                const uint64_t below_a = ra >= 64 ? ~0ull : ((1ull << ra) - 1ull);
+                m[c] = __ballot(rough[c] < thr) & below_b & ~below_a;
+                total += (uint32_t)__popcll(m[c]);
+            }
         }
         if (total) {  // wave-uniform: one 64-bit atomic reserves the records and the run descriptors
+            const uint32_t b = t[RQ_REC_ROW], slot = t[RQ_REC_SLOT];
             uint32_t nruns = 0;
 #pragma unroll
             for (int c = 0; c < CPL; ++c) nruns += m[c] ? 1u : 0u;
@@ -526,7 +601,7 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
                 const uint32_t cntc = (uint32_t)__popcll(m[c]);
-                if (pass[c]) {
+                if ((m[c] >> lane) & 1ull) {
                     uint32_t at = base + (uint32_t)__popcll(m[c] & ((1ull << lane) - 1ull));
                     if (at < a.cap) {
                         SurvRec r;
@@ -554,6 +629,7 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
 
 // generic-W fallback (dim/64 not in the templated set): code words re-read per query (L1-resident)
 __global__ __launch_bounds__(256) void scan_generic_kernel(SCAN_PARAMS, uint32_t W) {
+    const uint32_t STRIDE = 8 * W + RQ_REC_TAIL;
     const uint32_t g = blockIdx.x / a.tiles_per_group;
     const uint32_t tile = blockIdx.x - g * a.tiles_per_group;
     uint32_t pb, pe;
@@ -566,31 +642,39 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(SCAN_PARAMS, uint32_t
     }
     if (pb >= pe) return;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t p0 = __builtin_amdgcn_readfirstlane(pair_list[pb]);
-    const uint32_t list_begin = scal[p0].list_begin, list_len = scal[p0].list_len;
-    const uint32_t lo = a.pos_lo < list_len ? a.pos_lo : list_len;
-    const uint32_t hi = a.pos_hi < list_len ? a.pos_hi : list_len;
-    const uint32_t local = lo + tile * 256 + threadIdx.x;
-    if (lo + tile * 256 >= hi) return;
-    const bool valid = local < hi;
-    const uint32_t pos = list_begin + (valid ? local : lo);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t *rec = recs + (uint64_t)pb * STRIDE;
+    const uint32_t list_begin = rec[8 * W + RQ_REC_LIST_BEGIN], list_len = rec[8 * W + RQ_REC_LIST_LEN];
+    const uint32_t first = tile * 256;
+    if (first >= list_len) return;
+    if (!a.cluster_major && rec[8 * W + RQ_REC_LO] >= rec[8 * W + RQ_REC_HI]) return;
+    const uint32_t local = first + threadIdx.x;
+    const uint32_t pos = list_begin + (local < list_len ? local : 0);
     const uint32_t *cp = codes + (uint64_t)pos * (2 * W);
     const float4 fac = factors[pos];
-    for (uint32_t i = pb; i < pe; ++i) {
-        const uint32_t p = __builtin_amdgcn_readfirstlane(pair_list[i]);
-        const PairScalars *sp = scal + p;
-        const uint32_t b = sp->row, slot = p - b * a.nprobe;
-        const uint32_t *pl = planes + (uint64_t)p * (8 * W);
+    for (uint32_t i = pb; i < pe; ++i, rec += STRIDE) {
+        const uint32_t *pl = rec;  // the 4 bit planes (AND-popcount form)
+        const uint32_t *t = rec + 8 * W;
+        const uint32_t lo_p = t[RQ_REC_LO], hi_p = t[RQ_REC_HI];
+        if (hi_p <= first || lo_p >= first + 256) continue;
         uint32_t s = 0;
         for (int pp = 0; pp < 4; ++pp) {
-            uint32_t t = 0;
-            for (uint32_t w = 0; w < 2 * W; ++w) t += __popc(cp[w] & pl[pp * 2 * W + w]);
-            s += t << pp;
+            uint32_t tt = 0;
+            for (uint32_t w = 0; w < 2 * W; ++w) tt += __popc(cp[w] & pl[pp * 2 * W + w]);
+            s += tt << pp;
         }
-        float rough = rough_distance(s, fac, sp->lower, sp->delta, sp->sumq, sp->ycd, sp->ycd_sqrt);
-        bool pass = valid && rough < thr_of_query[b];
-        uint64_t m = __ballot(pass);
+        float rough = rough_distance(s, fac, __builtin_bit_cast(float, t[RQ_REC_LOWER]),
+                                     __builtin_bit_cast(float, t[RQ_REC_DELTA]), __builtin_bit_cast(float, t[RQ_REC_SUMQ]),
+                                     __builtin_bit_cast(float, t[RQ_REC_YCD]), __builtin_bit_cast(float, t[RQ_REC_YCD_SQRT]));
+        const uint32_t P0 = first + wave * 64;
+        const uint32_t ra = lo_p > P0 ? (lo_p - P0 < 64 ? lo_p - P0 : 64) : 0;
+        const uint32_t rb = hi_p > P0 ? (hi_p - P0 < 64 ? hi_p - P0 : 64) : 0;
+        const uint64_t below_b = rb >= 64 ? ~0ull : ((1ull << rb) - 1ull);
+        const uint64_t below_a = ra >= 64 ? ~0ull : ((1ull << ra) - 1ull);
+        uint64_t m = __ballot(rough < __builtin_bit_cast(float, t[RQ_REC_THR])) & below_b & ~below_a;
         if (m) {
+            const uint32_t b = t[RQ_REC_ROW], slot = t[RQ_REC_SLOT];
+            const bool pass = (m >> lane) & 1ull;
             const uint32_t cntc = (uint32_t)__popcll(m);
             unsigned long long old = 0;
             if (lane == 0) old = atomicAdd(surv_cnt + b, (1ull << 32) | cntc);
@@ -606,7 +690,7 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(SCAN_PARAMS, uint32_t
             }
             if (lane == 0 && rbase < a.cap) {
                 RunRec rr;
-                rr.pos = list_begin + lo + tile * 256 + (threadIdx.x & ~63u);
+                rr.pos = list_begin + first + (threadIdx.x & ~63u);
                 rr.slot = slot, rr.base = base, rr.cnt = cntc;
                 runs[(uint64_t)b * a.cap + rbase] = rr;
             }

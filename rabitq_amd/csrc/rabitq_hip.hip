@@ -155,7 +155,7 @@ struct Workspace {
     hipStream_t stream = nullptr;
     bool busy = false;
     DevBuf<float> qpad, y, dist, probe_dist, thr, recent;
-    DevBuf<uint32_t> probe_cluster, pair_list, grp_cnt, grp_start, heap_len, heap_id, precise, need,
+    DevBuf<uint32_t> probe_cluster, recs, grp_cnt, grp_start, heap_len, heap_id, precise, need,
         nsurv, win_count, arr_len, row_map;
     DevBuf<int32_t> heap_key;
     DevBuf<PairScalars> scal;
@@ -228,7 +228,7 @@ static void launch_rotate(const float *x, const float *P, float *out, uint64_t n
 // ------------------------------------------------------------------------------------------------
 // scan dispatch on W = dim / 64
 // ------------------------------------------------------------------------------------------------
-#define SCAN_ARGS p.codes, p.factors, p.grp_start, p.pair_list, p.scal, p.planes, p.qnib, p.thr, p.surv, p.runs, p.surv_cnt, a
+#define SCAN_ARGS p.codes, p.factors, p.grp_start, p.recs, p.surv, p.runs, p.surv_cnt, a
 static void launch_scan(const ScanPtrs &p, const ScanArgs &a, uint32_t W, hipStream_t st) {
     const uint64_t blocks = (uint64_t)a.ngroups * a.tiles_per_group;
     if (blocks == 0) return;
@@ -247,6 +247,12 @@ static void launch_scan(const ScanPtrs &p, const ScanArgs &a, uint32_t W, hipStr
         case 12: scan_kernel<12, 1><<<g, b, 0, st>>>(SCAN_ARGS); break;
         case 16: scan_kernel<16, 1><<<g, b, 0, st>>>(SCAN_ARGS); break;
         default: scan_generic_kernel<<<g, b, 0, st>>>(SCAN_ARGS, W); break;
+    }
+}
+static bool scan_is_fused(uint32_t W) {
+    switch (W) {
+        case 1: case 2: case 3: case 4: case 6: case 8: case 12: case 16: return true;
+        default: return false;
     }
 }
 static uint32_t scan_tile(uint32_t W) {
@@ -284,7 +290,7 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
     RQC(ws.qnib.ensure(npairs * 8 * idx->W));
     RQC(ws.rough_cnt.ensure(nq));
     RQC(ws.totals.ensure(8));
-    RQC(ws.pair_list.ensure(npairs));
+    RQC(ws.recs.ensure(npairs * (8ull * idx->W + RQ_REC_TAIL)));
     RQC(ws.grp_cnt.ensure(idx->k + 1));
     RQC(ws.grp_start.ensure(idx->k + 1));
     RQC(ws.thr.ensure(nq));
@@ -348,7 +354,8 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     HIPC(hipMemsetAsync(ws.rough_cnt.p, 0, nq * sizeof(unsigned long long), st));
     prep_kernel<<<ceil_div(npairs, 4), 256, 0, st>>>(ws.y.p, idx->centroids.p, idx->offsets.p, ws.probe_cluster.p,
                                                      ws.probe_dist.p, npairs, nprobe, dim, ws.scal.p, ws.planes.p,
-                                                     ws.qnib.p, nullptr, ws.rough_cnt.p);
+                                                     ws.qnib.p, nullptr);
+    pair_prefix_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(ws.scal.p, nq, nprobe, ws.rough_cnt.p);
     // 4. ranker state (rerank.rs:70-77, :129-139)
     fill_f32_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(ws.thr.p, 3.402823466e+38f, nq);
     fill_f32_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(ws.recent.p, -3.402823466e+38f, nq);
@@ -367,63 +374,60 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     rs.precise = ws.precise.p, rs.need = ws.need.p, rs.nsurv = ws.nsurv.p, rs.recent_max = ws.recent.p, rs.win_count = ws.win_count.p;
     rs.arr_len = ws.arr_len.p, rs.arr = ws.arr.p, rs.hcap = qp.hcap;
 
-    // 5. stages.  A stage scans positions [pos_lo, pos_hi) of the lists at probe slots
-    // [slot_lo, slot_hi) with the threshold each query's ranker holds at the start of the stage
-    // (an upper bound of the reference's threshold everywhere in the stage, since it never rises),
-    // then replays the survivors in the reference's order.  Stage 0 has threshold f32::MAX.
+    // 5. stages.  The reference visits a query's candidates as ONE stream: probed lists nearest-first,
+    // members in stored order.  A stage covers stream positions [s_lo, s_hi) (of every query) and is
+    // scanned with the threshold each query's ranker holds at the start of the stage -- an upper
+    // bound of the reference's threshold everywhere in the stage, since it never rises -- then the
+    // survivors are replayed in the reference's order.  Stage 0 = the first topk candidates
+    // (threshold f32::MAX), later stages grow geometrically.
     struct Stage {
-        uint32_t slot_lo, slot_hi, pos_lo, pos_hi;
+        uint32_t s_lo, s_hi;
     };
     std::vector<Stage> stages;
     {
-        const uint32_t INF = 0xFFFFFFFFu;
+        const uint64_t total_max = std::min<uint64_t>((uint64_t)nprobe * idx->max_list_len, idx->n);
         uint64_t lo = 0, hi = std::max<uint32_t>(topk, 1);
-        while (true) {
-            bool last = hi >= idx->max_list_len;
-            stages.push_back({0, 1, (uint32_t)lo, last ? INF : (uint32_t)hi});
-            if (last) break;
+        while (lo < total_max) {
+            const bool last = hi >= total_max;
+            stages.push_back({(uint32_t)lo, last ? 0xFFFFFFFFu : (uint32_t)hi});
             lo = hi;
             hi = std::min<uint64_t>(hi * 4, 0xFFFFFFF0ull);
         }
-        if (nprobe > 1) stages.push_back({1, nprobe, 0, INF});
     }
     const uint32_t tile = scan_tile(W);
+    const uint64_t avg_len = std::max<uint64_t>(1, idx->n / std::max<uint32_t>(k, 1));
     for (const Stage &sg : stages) {
-        const uint32_t ns = std::min(sg.slot_hi, nprobe) - sg.slot_lo;
-        const uint32_t np = nq * ns;
-        const uint32_t phi = std::min(sg.pos_hi, idx->max_list_len);
-        if (np == 0 || phi <= sg.pos_lo) continue;
-        const bool cluster_major = np >= k / 2 && np > 64;
+        const uint64_t span = (uint64_t)std::min<uint64_t>(sg.s_hi, (uint64_t)nprobe * idx->max_list_len) - sg.s_lo;
+        const uint64_t est_pairs = (uint64_t)nq * std::min<uint64_t>(nprobe, span / avg_len + 2);
+        const bool cluster_major = est_pairs >= k / 2 && est_pairs > 64;
         pf.begin(PF_GROUP);
-        ScanArgs a;
-        ScanPtrs sp;
+        ScanArgs a{};
+        ScanPtrs sp{};
         a.cluster_major = cluster_major ? 1u : 0u;
         if (cluster_major) {
             HIPC(hipMemsetAsync(ws.grp_cnt.p, 0, (k + 1) * 4, st));
-            group_count_kernel<<<ceil_div(np, 256), 256, 0, st>>>(ws.probe_cluster.p, nq, nprobe, sg.slot_lo, ns,
-                                                                  ws.grp_cnt.p);
+            group_count_kernel<<<ceil_div(npairs, 256), 256, 0, st>>>(ws.scal.p, ws.probe_cluster.p, npairs, sg.s_lo,
+                                                                      sg.s_hi, ws.grp_cnt.p);
             group_scan_kernel<<<1, 1024, 0, st>>>(ws.grp_cnt.p, k, ws.grp_start.p);
-            group_fill_kernel<<<ceil_div(np, 256), 256, 0, st>>>(ws.probe_cluster.p, nq, nprobe, sg.slot_lo, ns,
-                                                                 ws.grp_start.p, ws.grp_cnt.p, ws.pair_list.p);
             a.ngroups = k;
         } else {
-            enumerate_pairs_kernel<<<ceil_div(np, 256), 256, 0, st>>>(nq, nprobe, sg.slot_lo, ns, ws.pair_list.p);
-            a.ngroups = np;
+            a.ngroups = npairs;
         }
+        // pack the stage's work records (query operand + scalars + current threshold + local range)
+        stage_fill_kernel<<<ceil_div(npairs, 16), 256, 0, st>>>(
+            ws.scal.p, ws.probe_cluster.p,
+            scan_is_fused(W) ? ws.qnib.p : reinterpret_cast<const uint32_t *>(ws.planes.p), ws.thr.p, npairs, nprobe, W,
+            sg.s_lo, sg.s_hi, a.cluster_major, ws.grp_start.p, ws.grp_cnt.p, ws.recs.p);
         pf.end();
         sp.codes = reinterpret_cast<const uint32_t *>(idx->codes.p);
         sp.factors = idx->factors.p;
         sp.grp_start = ws.grp_start.p;
-        sp.pair_list = ws.pair_list.p;
-        sp.scal = ws.scal.p;
-        sp.planes = reinterpret_cast<const uint32_t *>(ws.planes.p);
-        sp.qnib = ws.qnib.p;
-        sp.thr = ws.thr.p;
+        sp.recs = ws.recs.p;
         sp.surv = ws.surv.p;
         sp.runs = ws.runs.p;
         sp.surv_cnt = ws.surv_cnt.p;
-        a.nprobe = nprobe, a.cap = qp.cap, a.pos_lo = sg.pos_lo, a.pos_hi = sg.pos_hi;
-        a.tiles_per_group = ceil_div(phi - sg.pos_lo, tile);
+        a.cap = qp.cap;
+        a.tiles_per_group = ceil_div(std::min<uint64_t>(idx->max_list_len, sg.s_hi), tile);
         pf.begin(PF_SCAN);
         launch_scan(sp, a, W, st);
         pf.end();
@@ -1238,7 +1242,7 @@ rq_status rq_query_prep(const rq_index *idx, const float *y, uint32_t nq, const 
     HIPC(hipMemcpy(dc.p, cluster, nq * 4, hipMemcpyHostToDevice));
     HIPC(hipMemset(ycd.p, 0, nq * 4));
     prep_kernel<<<ceil_div(nq, 4), 256>>>(dy.p, idx->centroids.p, idx->offsets.p, dc.p, ycd.p, nq, 1, dim, scal.p,
-                                          planes.p, nullptr, dsum.p, nullptr);
+                                          planes.p, nullptr, dsum.p);
     HIPC(hipDeviceSynchronize());
     HIPC(hipGetLastError());
     std::vector<PairScalars> hs(nq);
