@@ -301,3 +301,102 @@ def test_dump_is_byte_identical_and_loads(rq, oracle, tmp_path):
     assert np.array_equal(gen.orthogonal, gen2.orthogonal)
     for i in (oidx, gidx, back, fp, gen, gen2):
         i.close()
+
+
+# ---- f1: the CLI harness (crates/cli/src/main.rs) -------------------------------------------------
+def test_cli_harness_build_then_load(rq, oracle, tmp_path, capsys):
+    from rabitq_amd import cli, vecs
+    n, d, k = 3000, 128, 12
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.7, seed=77, centre_scale=0.6)
+    queries, _, _ = synth.mixture(25, d, k, sigma=0.7, seed=78, centre_scale=0.6)
+    gt = synth.brute_force_topk(x, queries, 10)
+    vecs.write_vecs(tmp_path / "base.fvecs", x)
+    vecs.write_vecs(tmp_path / "cent.fvecs", centres)
+    vecs.write_vecs(tmp_path / "query.fvecs", queries)
+    vecs.write_vecs(tmp_path / "truth.ivecs", gt)
+    argv = ["-b", str(tmp_path / "base.fvecs"), "-c", str(tmp_path / "cent.fvecs"), "-q", str(tmp_path / "query.fvecs"),
+            "-t", str(tmp_path / "truth.ivecs"), "-s", str(tmp_path / "saved"), "-p", "12", "-k", "10", "--batch", "8"]
+    assert cli.main(argv) == 0                      # builds + dumps
+    out1 = capsys.readouterr().out
+    assert "training..." in out1 and os.path.isdir(tmp_path / "saved")
+    assert cli.main(argv) == 0                      # second run loads the dumped index
+    out2 = capsys.readouterr().out
+    assert "loading from" in out2
+
+    def parse(out):
+        line = [l for l in out.splitlines() if l.startswith("QPS:")][0]
+        met = [l for l in out.splitlines() if l.startswith("Metrics [")][0]
+        return float(line.split("recall:")[1]), met
+    r1, m1 = parse(out1)
+    r2, m2 = parse(out2)
+    assert r1 == r2 and m1 == m2 and r1 >= 0.95
+    # the dumped directory is the crate's format: the oracle loads it and gives the same counters
+    oidx = oracle.OracleIndex.load_from_dir(str(tmp_path / "saved"))
+    oracle.metrics_reset()
+    for q in queries:
+        oidx.query(q, 12, 10)
+    m = oracle.metrics()
+    assert f"query: {m['query']}, rough: {m['rough']}, precise: {m['precise']}" in m1
+
+
+# ---- properties at larger sizes (what the oracle cannot check in seconds) ---------------------------
+@pytest.mark.parametrize("n,d,k,probe", [(2_000_000, 128, 1024, 32), (200_000, 768, 256, 32)])
+def test_large_index_properties(rq, n, d, k, probe):
+    import torch
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    centres = torch.randn(k, d, generator=g, device=dev)
+    u = torch.randint(0, k, (n,), generator=g, device=dev)
+    x = centres[u] + 0.5 * torch.randn(n, d, generator=g, device=dev)
+    nq = 256
+    uq = torch.randint(0, k, (nq,), generator=g, device=dev)
+    q = (centres[uq] + 0.5 * torch.randn(nq, d, generator=g, device=dev)).contiguous()
+    P = synth.random_orthogonal(d, seed=1)
+    idx = rq.RaBitQ.build_device(x.data_ptr(), n, d, centres.data_ptr(), k, orthogonal=P)
+    off, ids = idx.offsets.astype(np.int64), idx.map_ids
+    assert off[0] == 0 and off[-1] == n and np.all(np.diff(off) >= 0)
+    assert np.array_equal(np.sort(ids), np.arange(n, dtype=np.uint32))              # a permutation
+    assert np.array_equal(np.diff(off), torch.bincount(u, minlength=k).cpu().numpy())  # well separated mixture
+    fac, codes = idx.factors, idx.codes
+    pop = np.zeros(n, np.int64)
+    for w in range(codes.shape[1]):
+        pop += np.array([bin(int(v)).count("1") for v in codes[:2000, w]] + [0] * (n - 2000))
+    np.testing.assert_array_equal(fac[:2000, 1], fac[:2000, 0] * (2 * pop[:2000] - idx.dim).astype(np.float32))
+    # rotation is orthogonal and codes are the signs of the rotated residual: check a sample
+    cent = idx.centroids
+    sample = np.arange(0, n, n // 500)[:500]
+    pos_of = np.empty(n, np.int64)
+    pos_of[ids] = np.arange(n)
+    xs = rq.ops.rotate(x[torch.from_numpy(sample).to(dev)].cpu().numpy(), P)
+    lab = np.searchsorted(off, pos_of[sample], side="right") - 1
+    r = xs - cent[lab]
+    bits_ = (r > 0)
+    want = np.zeros((len(sample), d // 64), np.uint64)
+    for j in range(d):
+        want[:, j // 64] |= bits_[:, j].astype(np.uint64) << np.uint64(j % 64)
+    assert np.array_equal(codes[pos_of[sample]], want)
+    np.testing.assert_allclose(fac[pos_of[sample], 3], (r.astype(np.float64) ** 2).sum(1), rtol=1e-5)
+    # queries: batch == one-at-a-time, recall against an exact f64 brute force
+    dist, got, cnt = idx.query_batch(q.cpu().numpy(), probe, 10)
+    for j in (0, 7, 100):
+        single = idx.query(q[j].cpu().numpy(), probe, 10)
+        assert [i for _, i in single] == got[j, :cnt[j]].tolist()
+    qd = q.double()
+    best = torch.full((nq, 10), float("inf"), device=dev, dtype=torch.float64)
+    besti = torch.full((nq, 10), -1, device=dev, dtype=torch.int64)
+    for i0 in range(0, n, 500_000):
+        xb = x[i0:i0 + 500_000].double()
+        d2 = (qd * qd).sum(1, keepdim=True) - 2 * qd @ xb.T + (xb * xb).sum(1)[None]
+        cd, ci = torch.topk(d2, 10, dim=1, largest=False)
+        alld, alli = torch.cat([best, cd], 1), torch.cat([besti, ci + i0], 1)
+        sel = torch.topk(alld, 10, dim=1, largest=False).indices
+        best, besti = torch.gather(alld, 1, sel), torch.gather(alli, 1, sel)
+    gt = besti.cpu().numpy()
+    recall = np.mean([len(set(got[j, :10].tolist()) & set(gt[j].tolist())) / 10 for j in range(nq)])
+    assert recall >= 0.95, recall
+    # returned distances are the exact squared L2 of the returned ids
+    xr = x[torch.from_numpy(got[:8, :10].astype(np.int64)).to(dev)].double()
+    exact = ((xr - qd[:8, None, :]) ** 2).sum(-1).cpu().numpy()
+    np.testing.assert_allclose(dist[:8, :10], exact, rtol=1e-5)
+    idx.close()
