@@ -82,6 +82,13 @@ rq_status rq_build_device(const float *d_base, uint64_t n, uint32_t d, const flo
 rq_status rq_build_from_path(const char *base_fvecs, const char *centroid_fvecs,
                              const float *orthogonal, uint64_t seed, rq_index **out);
 
+/* ---- centroid training (scripts/cluster.py:63-108 does this offline with faiss k-means) -------- */
+/* Lloyd k-means on a sample of min(n, points_per_centroid * k) vectors (points_per_centroid = 256
+ * in the reference script); d_base is n x d in device memory, d_centroids_out receives k x d.
+ * No parity target (faiss is not available; results depend on the seed): judged by recall. */
+rq_status rq_kmeans_device(const float *d_base, uint64_t n, uint32_t d, uint32_t k, uint32_t iters,
+                           uint32_t points_per_centroid, uint64_t seed, float *d_centroids_out);
+
 /* ---- persistence: load_from_dir / dump_to_dir, src/rabitq.rs:84-156 -------------------------- */
 /* Byte-compatible with the crate's five-file directory (vecs framing: src/utils.rs:280-364). */
 rq_status rq_load_dir(const char *dir, rq_index **out);

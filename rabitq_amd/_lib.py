@@ -20,7 +20,7 @@ STATUS_NAMES = {0: "RQ_OK", -1: "RQ_ERR_INVALID", -2: "RQ_ERR_DIM_MISMATCH", -3:
 
 # every symbol include/rabitq_hip.h declares (checked by tests/test_abi.py against the header)
 EXPORTS = [
-    "rq_version", "rq_last_error", "rq_init", "rq_build", "rq_build_device", "rq_build_from_path", "rq_load_dir",
+    "rq_version", "rq_last_error", "rq_init", "rq_build", "rq_build_device", "rq_build_from_path", "rq_kmeans_device", "rq_load_dir",
     "rq_dump_dir", "rq_free", "rq_from_arrays", "rq_info", "rq_get_array", "rq_get_device_ptr", "rq_query",
     "rq_query_batch", "rq_query_batch_device", "rq_metrics", "rq_metrics_reset", "rq_rotate", "rq_rotate_device",
     "rq_quantize_pack",
@@ -77,6 +77,7 @@ def lib():
         "rq_build": (i32, [f32p, u64, u32, f32p, u32, f32p, u64, pp]),
         "rq_build_device": (i32, [f32p, u64, u32, f32p, u32, f32p, u64, pp]),
         "rq_build_from_path": (i32, [C.c_char_p, C.c_char_p, f32p, u64, pp]),
+        "rq_kmeans_device": (i32, [f32p, u64, u32, u32, u32, u32, u64, f32p]),
         "rq_load_dir": (i32, [C.c_char_p, pp]),
         "rq_dump_dir": (i32, [vp, C.c_char_p]),
         "rq_free": (None, [vp]),

@@ -412,3 +412,57 @@ __global__ void max_list_len_kernel(const uint32_t *__restrict__ offsets, uint32
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < k) atomicMax(out, offsets[i + 1] - offsets[i]);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Centroid training (the crate takes centroids as an input; scripts/cluster.py:63-108 trains them
+// with faiss k-means on a 256-points-per-centroid sample).  Lloyd iterations on a sample, reusing
+// the nearest-centroid kernels above.  No parity target (faiss is absent, results are seed
+// dependent): judged by recall only.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t rq_mix64(uint64_t x) {  // splitmix64
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ void kmeans_sample_kernel(const float *__restrict__ x, uint64_t n, uint32_t d, uint32_t dim,
+                                     uint64_t seed, uint64_t ns, float *__restrict__ xs) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns * dim) return;
+    uint64_t r = i / dim;
+    uint32_t c = (uint32_t)(i - r * dim);
+    uint64_t src = rq_mix64(seed * 0x100000001B3ull + r) % n;
+    xs[i] = c < d ? x[src * d + c] : 0.0f;
+}
+
+__global__ void kmeans_accumulate_kernel(const float *__restrict__ xs, const uint32_t *__restrict__ label,
+                                         uint64_t ns, uint32_t dim, float *__restrict__ sums,
+                                         uint32_t *__restrict__ counts) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns * dim) return;
+    uint64_t r = i / dim;
+    uint32_t c = (uint32_t)(i - r * dim);
+    uint32_t l = label[r];
+    atomicAdd(&sums[(uint64_t)l * dim + c], xs[i]);
+    if (c == 0) atomicAdd(&counts[l], 1u);
+}
+
+__global__ void kmeans_update_kernel(const float *__restrict__ sums, const uint32_t *__restrict__ counts,
+                                     const float *__restrict__ xs, uint64_t ns, uint32_t k, uint32_t dim,
+                                     uint64_t seed, float *__restrict__ centroids) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)k * dim) return;
+    uint32_t j = (uint32_t)(i / dim), c = (uint32_t)(i - (uint64_t)j * dim);
+    uint32_t cnt = counts[j];
+    if (cnt) centroids[i] = sums[i] / (float)cnt;
+    else centroids[i] = xs[(rq_mix64(seed ^ (0xABCDull + j)) % ns) * dim + c];  // re-seed an empty cluster
+}
+
+__global__ void unpad_rows_kernel(const float *__restrict__ in, float *__restrict__ out, uint64_t n, uint32_t dim,
+                                  uint32_t d) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * d) return;
+    uint64_t r = i / d;
+    out[i] = in[r * dim + (i - r * d)];
+}

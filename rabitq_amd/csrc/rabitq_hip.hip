@@ -880,6 +880,46 @@ rq_status rq_init(int device) {
     return RQ_OK;
 }
 
+rq_status rq_kmeans_device(const float *d_base, uint64_t n, uint32_t d, uint32_t k, uint32_t iters,
+                           uint32_t points_per_centroid, uint64_t seed, float *d_centroids_out) {
+    RQC(ensure_device());
+    if (!d_base || !d_centroids_out || n == 0 || d == 0 || k == 0) return fail(RQ_ERR_INVALID, "bad k-means arguments");
+    const uint32_t dim = (d + 63) / 64 * 64;
+    if (dim > 4096) return fail(RQ_ERR_UNSUPPORTED, "dim > 4096 not supported");
+    const uint64_t ns = std::max<uint64_t>(k, std::min<uint64_t>(n, (uint64_t)std::max(points_per_centroid, 1u) * k));
+    if (ns * dim > (1ull << 31)) return fail(RQ_ERR_UNSUPPORTED, "k-means sample too large");
+    rq_index tmp;  // only its centroid buffers are used (launch_assign)
+    tmp.dim = dim, tmp.k = k, tmp.W = dim / 64;
+    DevBuf<float> xs, sums;
+    DevBuf<uint32_t> label, counts;
+    DevBuf<float> dist;
+    RQC(xs.alloc(ns * dim));
+    RQC(tmp.centroids.alloc((size_t)k * dim));
+    RQC(tmp.cent_t.alloc((size_t)k * dim));
+    RQC(sums.alloc((size_t)k * dim));
+    RQC(label.alloc(ns));
+    RQC(dist.alloc(ns));
+    RQC(counts.alloc(k));
+    kmeans_sample_kernel<<<ceil_div(ns * dim, 256), 256>>>(d_base, n, d, dim, seed, ns, xs.p);
+    HIPC(hipMemcpy(tmp.centroids.p, xs.p, (size_t)k * dim * 4, hipMemcpyDeviceToDevice));  // init: first k sample rows
+    for (uint32_t it = 0; it < iters; ++it) {
+        transpose_kernel<<<dim3(ceil_div(dim, 32), ceil_div(k, 32)), dim3(32, 8)>>>(tmp.centroids.p, tmp.cent_t.p, k, dim);
+        for (uint64_t i0 = 0; i0 < ns; i0 += (1ull << 20)) {
+            const uint64_t m = std::min<uint64_t>(1ull << 20, ns - i0);
+            launch_assign(xs.p + i0 * dim, &tmp, m, label.p + i0, dist.p + i0, nullptr);
+        }
+        HIPC(hipMemset(sums.p, 0, (size_t)k * dim * 4));
+        HIPC(hipMemset(counts.p, 0, (size_t)k * 4));
+        kmeans_accumulate_kernel<<<ceil_div(ns * dim, 256), 256>>>(xs.p, label.p, ns, dim, sums.p, counts.p);
+        kmeans_update_kernel<<<ceil_div((uint64_t)k * dim, 256), 256>>>(sums.p, counts.p, xs.p, ns, k, dim,
+                                                                        seed + it + 1, tmp.centroids.p);
+    }
+    unpad_rows_kernel<<<ceil_div((uint64_t)k * d, 256), 256>>>(tmp.centroids.p, d_centroids_out, k, dim, d);
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipGetLastError());
+    return RQ_OK;
+}
+
 rq_status rq_build_device(const float *d_base, uint64_t n, uint32_t d, const float *d_centroids, uint32_t k,
                           const float *orthogonal_host, uint64_t seed, rq_index **out) {
     return build_device(d_base, n, d, d_centroids, k, orthogonal_host, seed, out);

@@ -66,3 +66,9 @@ def rerank(index, query_padded, positions):
     out = np.empty(pos.size, np.float32)
     check(lib().rq_rerank(index._h, _addr(q), _addr(pos), pos.size, _addr(out)))
     return out
+
+
+def kmeans_device(base_ptr: int, n: int, d: int, k: int, out_ptr: int, iters: int = 20, points_per_centroid: int = 256,
+                  seed: int = 0) -> None:
+    """Train k centroids on device-resident vectors (scripts/cluster.py's job, done on the GPU)."""
+    check(lib().rq_kmeans_device(C.c_void_p(base_ptr), n, d, k, iters, points_per_centroid, seed, C.c_void_p(out_ptr)))

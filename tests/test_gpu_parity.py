@@ -400,3 +400,34 @@ def test_large_index_properties(rq, n, d, k, probe):
     exact = ((xr - qd[:8, None, :]) ** 2).sum(-1).cpu().numpy()
     np.testing.assert_allclose(dist[:8, :10], exact, rtol=1e-5)
     idx.close()
+
+
+# ---- f2: centroid training on the GPU (scripts/cluster.py's role) -----------------------------------
+def test_kmeans_centroids_give_recall(rq):
+    import torch
+    dev = torch.device("cuda", 0)
+    n, d, k = 300_000, 96, 64      # d = 96 pads to 128
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    centres = torch.randn(k, d, generator=g, device=dev)
+    u = torch.randint(0, k, (n,), generator=g, device=dev)
+    x = (centres[u] + 0.5 * torch.randn(n, d, generator=g, device=dev)).contiguous()
+    learnt = torch.zeros((k, d), device=dev)
+    rq.ops.kmeans_device(x.data_ptr(), n, d, k, learnt.data_ptr(), iters=15, seed=3)
+    assert torch.isfinite(learnt).all()
+
+    def qerr(c):  # mean squared distance to the nearest centroid
+        d2 = torch.cdist(x[:20000], c) ** 2
+        return float(d2.min(1).values.mean())
+    # Lloyd from a random start can merge/split a few of the well-separated generating clusters (faiss does
+    # too); what matters is that the error is of the same order and that the index built on it recalls
+    ratio = qerr(learnt) / qerr(centres)
+    assert ratio < 3.0, ratio
+    idx = rq.RaBitQ.build_device(x.data_ptr(), n, d, learnt.data_ptr(), k, orthogonal=synth.random_orthogonal(128, 2))
+    q = x[:200] + 0.05
+    _, ids, cnt = idx.query_batch(q.cpu().numpy(), 8, 10)
+    d2 = torch.cdist(q.double(), x.double()) ** 2
+    gt = torch.topk(d2, 10, dim=1, largest=False).indices.cpu().numpy()
+    recall = np.mean([len(set(ids[j, :10].tolist()) & set(gt[j].tolist())) / 10 for j in range(200)])
+    assert recall >= 0.95, recall
+    idx.close()
