@@ -1026,7 +1026,8 @@ __global__ __launch_bounds__(256) void metrics_sum_kernel(const unsigned long lo
         p += ok ? precise[i] : 0;
         o += ok ? 0 : 1;
         a += nsurv[i];
-        unsigned long long nd = need[i] > (arr_len ? arr_len[i] : 0) ? need[i] : arr_len[i];
+        const unsigned long long al = arr_len ? arr_len[i] : 0ull;
+        unsigned long long nd = need[i] > al ? (unsigned long long)need[i] : al;
         mx = nd > mx ? nd : mx;
     }
     atomicAdd(&s[0], r);

@@ -431,3 +431,84 @@ def test_kmeans_centroids_give_recall(rq):
     recall = np.mean([len(set(ids[j, :10].tolist()) & set(gt[j].tolist())) / 10 for j in range(200)])
     assert recall >= 0.95, recall
     idx.close()
+
+
+# ---- ties, degenerate sizes, concurrency -------------------------------------------------------------
+def test_duplicates_and_ties_match_oracle(rq, oracle):
+    # exact duplicate vectors => equal rough AND equal accurate distances: which of the tied candidates
+    # survives in the heap depends on Rust's BinaryHeap sift order and on strict `<` gates
+    rng = np.random.default_rng(12)
+    d, k = 64, 4
+    uniq = rng.standard_normal((60, d)).astype(np.float32)
+    x = np.concatenate([uniq, uniq[:40], uniq[:40], uniq[10:30]])            # many exact duplicates
+    x = x[rng.permutation(len(x))]
+    centres = np.concatenate([uniq[:2] * 0.5, uniq[:2] * 0.5])                # duplicate centroids: coarse ties
+    P = synth.random_orthogonal(d, seed=8)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    gidx = rq.RaBitQ.build(x, centres, P)
+    assert np.array_equal(gidx.map_ids, oidx.map_ids) and np.array_equal(gidx.offsets, oidx.offsets)
+    qs = np.concatenate([uniq[:6], uniq[:3] + 0.01]).astype(np.float32)
+    for probe, topk in ((4, 5), (2, 10), (4, 64), (1, 1)):
+        _compare_with_oracle(rq, oracle, oidx, gidx, qs, probe, topk, False)
+    _compare_with_oracle(rq, oracle, oidx, gidx, qs, 4, 7, True)
+    gidx.close()
+    oidx.close()
+
+
+def test_degenerate_sizes(rq, oracle):
+    d = 64
+    P = np.eye(d, dtype=np.float32)
+    centres = np.zeros((3, d), np.float32)
+    centres[1] += 1.0
+    centres[2] -= 1.0
+    # empty index: every list empty -> no results, no crash
+    empty = rq.RaBitQ.build(np.zeros((0, d), np.float32), centres, P)
+    assert empty.n == 0 and empty.max_list_len == 0 and empty.offsets.tolist() == [0, 0, 0, 0]
+    dd, ii, cnt = empty.query_batch(np.ones((3, d), np.float32), 3, 5)
+    assert cnt.tolist() == [0, 0, 0]
+    empty.close()
+    # one vector, one list, topk at the engine limit
+    one = rq.RaBitQ.build(np.ones((1, d), np.float32), centres[:1], P)
+    res = one.query(np.ones(d, np.float32), 1, 2048)
+    assert res == [(0.0, 0)]
+    with pytest.raises(rq.RabitqError) as e:
+        one.query(np.ones(d, np.float32), 1, 2049)
+    assert e.value.status == -6
+    one.close()
+    # zero queries is a no-op
+    x, c2, _ = synth.mixture(200, d, 3, seed=4)
+    g = rq.RaBitQ.build(x, c2, P)
+    dd, ii, cnt = g.query_batch(np.zeros((0, d), np.float32), 2, 5)
+    assert dd.shape[0] == 0
+    g.close()
+
+
+def test_concurrent_queries_one_handle(rq, oracle):
+    # `RaBitQ::query(&self)` is called from many tokio workers in the service (crates/service/src/main.rs:36-44)
+    import threading
+    n, d, k = 8000, 128, 16
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.8, seed=31, centre_scale=0.6)
+    P = synth.random_orthogonal(d, seed=32)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    gidx = rq.RaBitQ.build(x, centres, P)
+    queries, _, _ = synth.mixture(48, d, k, sigma=0.8, seed=33, centre_scale=0.6)
+    want = [oidx.query(q, 6, 10)[1].tolist() for q in queries]
+    got = [None] * len(queries)
+    errs = []
+
+    def worker(t):
+        try:
+            for j in range(t, len(queries), 6):
+                if j % 2:
+                    got[j] = [i for _, i in gidx.query(queries[j], 6, 10)]
+                else:
+                    _, ids, cnt = gidx.query_batch(queries[j:j + 1], 6, 10)
+                    got[j] = ids[0, :cnt[0]].tolist()
+        except Exception as ex:  # noqa: BLE001
+            errs.append(ex)
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    assert got == want
+    gidx.close()
