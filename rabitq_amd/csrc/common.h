@@ -13,6 +13,8 @@
 
 #define RQ_WAVE 64
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));  // operands of v_pk_*_f32 (each component rounds on its own)
+
 // ---- src/ord32.rs:12-26: monotone f32 <-> i32 key ----------------------------------------------
 __host__ __device__ __forceinline__ int32_t ord32_from_f32(float x) {
     int32_t bits = __builtin_bit_cast(int32_t, x);

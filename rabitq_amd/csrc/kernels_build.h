@@ -189,15 +189,20 @@ __global__ __launch_bounds__(256) void assign_regs_kernel(const float *__restric
         __syncthreads();
         const uint32_t lim = (k - j0) < ASSIGN_CT ? (k - j0) : ASSIGN_CT;
         for (uint32_t ct = 0; ct < lim; ++ct) {
-            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            // the 8 AVX-lane chains as 4 packed pairs: v_pk_add_f32 (diff) + v_pk_fma_f32, each component
+            // rounded exactly like the scalar sub / fma
+            f32x2 acc2[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
 #pragma unroll
             for (int c = 0; c < DIM; c += 8) {
 #pragma unroll
-                for (int l = 0; l < 8; ++l) {
-                    float d = cs[ct][c + l] - xv[c + l];
-                    acc[l] = fmaf(d, d, acc[l]);
+                for (int l = 0; l < 4; ++l) {
+                    f32x2 cv = {cs[ct][c + 2 * l], cs[ct][c + 2 * l + 1]};
+                    f32x2 xx = {xv[c + 2 * l], xv[c + 2 * l + 1]};
+                    f32x2 d = cv - xx;
+                    acc2[l] = __builtin_elementwise_fma(d, d, acc2[l]);
                 }
             }
+            float acc[8] = {acc2[0].x, acc2[0].y, acc2[1].x, acc2[1].y, acc2[2].x, acc2[2].y, acc2[3].x, acc2[3].y};
             float dd = reduce8_regs(acc);
             if (dd < best) {
                 best = dd;
@@ -232,25 +237,30 @@ __global__ __launch_bounds__(256) void assign_generic_kernel(const float *__rest
 #pragma unroll
     for (int v = 0; v < VT; ++v) bestkey[v] = ((unsigned long long)ord32_biased(3.402823466e+38f) << 32);
     for (uint32_t j = threadIdx.x; j < k; j += 256) {
-        float acc[VT][8];
+        f32x2 acc2[VT / 2][8];  // vector pairs in packed f32
 #pragma unroll
-        for (int v = 0; v < VT; ++v)
+        for (int v = 0; v < VT / 2; ++v)
 #pragma unroll
-            for (int l = 0; l < 8; ++l) acc[v][l] = 0.0f;
+            for (int l = 0; l < 8; ++l) acc2[v][l] = f32x2{0.0f, 0.0f};
         for (uint32_t c = 0; c < dim; c += 8) {
 #pragma unroll
             for (int l = 0; l < 8; ++l) {
                 float ce = cent_t[(uint64_t)(c + l) * k + j];
+                f32x2 ce2 = {ce, ce};
 #pragma unroll
-                for (int v = 0; v < VT; ++v) {
-                    float d = ce - xs[v * dim + c + l];
-                    acc[v][l] = fmaf(d, d, acc[v][l]);
+                for (int v = 0; v < VT / 2; ++v) {
+                    f32x2 xx = {xs[(2 * v) * dim + c + l], xs[(2 * v + 1) * dim + c + l]};
+                    f32x2 d = ce2 - xx;
+                    acc2[v][l] = __builtin_elementwise_fma(d, d, acc2[v][l]);
                 }
             }
         }
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
-            float dd = reduce8_regs(acc[v]);
+            float accv[8];
+#pragma unroll
+            for (int l = 0; l < 8; ++l) accv[l] = (v & 1) ? acc2[v / 2][l].y : acc2[v / 2][l].x;
+            float dd = reduce8_regs(accv);
             // strict `<` against f32::MAX start: NaN and >= MAX never win (utils.rs:271)
             if (dd < 3.402823466e+38f) {
                 unsigned long long key = ((unsigned long long)ord32_biased(dd) << 32) | j;

@@ -66,27 +66,35 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restric
         ys[i] = (q0 + v < nq) ? y[(uint64_t)(q0 + v) * dim + e] : 0.0f;
     }
     __syncthreads();
-    float acc[QT][8];
+    static_assert(QT % 2 == 0, "queries are processed in packed pairs");
+    f32x2 acc[QT / 2][8];  // [query pair][AVX lane]: v_pk_add_f32 + v_pk_fma_f32, per-component rounding
 #pragma unroll
-    for (int v = 0; v < QT; ++v)
+    for (int v = 0; v < QT / 2; ++v)
 #pragma unroll
-        for (int l = 0; l < 8; ++l) acc[v][l] = 0.0f;
+        for (int l = 0; l < 8; ++l) acc[v][l] = f32x2{0.0f, 0.0f};
     const bool live = j < k;
     for (uint32_t c = 0; c < dim; c += 8) {
 #pragma unroll
         for (int l = 0; l < 8; ++l) {
             float ce = live ? cent_t[(uint64_t)(c + l) * k + j] : 0.0f;
+            f32x2 ce2 = {ce, ce};
 #pragma unroll
-            for (int v = 0; v < QT; ++v) {
-                float d = ce - ys[v * dim + c + l];
-                acc[v][l] = fmaf(d, d, acc[v][l]);
+            for (int v = 0; v < QT / 2; ++v) {
+                f32x2 yy = {ys[(2 * v) * dim + c + l], ys[(2 * v + 1) * dim + c + l]};
+                f32x2 d = ce2 - yy;
+                acc[v][l] = __builtin_elementwise_fma(d, d, acc[v][l]);
             }
         }
     }
     if (live) {
 #pragma unroll
-        for (int v = 0; v < QT; ++v)
-            if (q0 + v < nq) dist[(uint64_t)(q0 + v) * k + j] = reduce8_regs(acc[v]);
+        for (int v = 0; v < QT / 2; ++v) {
+            float a0[8], a1[8];
+#pragma unroll
+            for (int l = 0; l < 8; ++l) a0[l] = acc[v][l].x, a1[l] = acc[v][l].y;
+            if (q0 + 2 * v < nq) dist[(uint64_t)(q0 + 2 * v) * k + j] = reduce8_regs(a0);
+            if (q0 + 2 * v + 1 < nq) dist[(uint64_t)(q0 + 2 * v + 1) * k + j] = reduce8_regs(a1);
+        }
     }
 }
 
@@ -475,7 +483,6 @@ __device__ __forceinline__ float rough_distance(uint32_t s, const float4 &f, flo
     return t - f.z * ycd_sqrt;              // - error_bound * dist_sqrt
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // The integer part: the asymmetric dot product sum_p popcount(code & plane_p) << p
 // (src/utils.rs:113-135, src/simd.rs:326-384) equals sum_j bit_j(code) * q_j exactly.  Each lane
