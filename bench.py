@@ -228,6 +228,22 @@ def main():
                  "scan_algorithmic_GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / 8000.0, 4),
                  "queries_per_s": round(sb * reps / (sp["ms_total"] * 1e-3), 1)}
 
+    # ---- one query at a time through the host-pointer API, as crates/cli/src/main.rs:69-75 does -------
+    single = None
+    if rank == 0:
+        qh = queries[:64].cpu().numpy()
+        for q1 in qh[:4]:
+            idx.query(q1, nprobe, topk)
+        lat = []
+        for q1 in qh:
+            t2 = time.perf_counter()
+            idx.query(q1, nprobe, topk)
+            lat.append(time.perf_counter() - t2)
+        lat = np.array(lat)
+        single = {"queries": len(lat), "mean_ms": round(float(lat.mean() * 1e3), 4),
+                  "p50_ms": round(float(np.median(lat) * 1e3), 4), "p99_ms": round(float(np.quantile(lat, 0.99) * 1e3), 4),
+                  "queries_per_s": round(len(lat) / float(lat.sum()), 1), "device_ms": round(rqi.last_profile()["ms_total"], 4)}
+
     line = {"metric": "queries/sec at recall@10>=0.95, 100Mx128; HBM GB/s on popcount scan", "value": round(qps, 1),
             "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -241,7 +257,7 @@ def main():
             "kernel_ms_per_step": {key[3:]: round(prof[key] / args.steps, 3) for key in prof if key.startswith("ms_")},
             "rerank_candidates_per_query": prof["rerank_candidates"] / (B * args.steps),
             "retries": int(prof["retries"]), "roofline": roofline, "roofline_rotation": rotation,
-            "scan_small_batch": small}
+            "scan_small_batch": small, "single_query": single}
 
     # ---- CPU baseline: the oracle (port of the reference's AVX2 path) on this box's host cores ------
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_queries > 0:

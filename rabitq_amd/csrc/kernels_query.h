@@ -729,31 +729,9 @@ __global__ __launch_bounds__(256) void scan_dense_kernel(const uint32_t *__restr
 // Rerank distances (src/rerank.rs:85-90 -> src/simd.rs:14-73): accurate = ||base[pos] - q||^2 in
 // the ORIGINAL space, exact AVX2 order.  8 GPU lanes play the 8 AVX lanes of one candidate (lane l
 // runs the fused chain over elements 8c + l), so a wave reranks 8 survivors at a time and each
-// 32-byte sector of the 4*dim-byte row is consumed by exactly one load.
-// grid (gx, nq); block 256.
+// 32-byte sector of the 4*dim-byte row is consumed by exactly one load.  In the query pipeline this
+// is phase (A) of stage_finish_kernel.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void accurate_kernel(SurvRec *__restrict__ surv,
-                                                       const unsigned long long *__restrict__ surv_cnt,
-                                                       uint32_t cap, const float *__restrict__ base,
-                                                       const float *__restrict__ qpad, uint32_t dim) {
-    const uint32_t b = blockIdx.y;
-    uint32_t n = (uint32_t)surv_cnt[b];
-    if (n > cap) return;  // overflowed: this query is re-run with a larger buffer
-    const uint32_t l = threadIdx.x & 7, grp = threadIdx.x >> 3;
-    const float *q = qpad + (uint64_t)b * dim;
-    SurvRec *recs = surv + (uint64_t)b * cap;
-    for (uint32_t i = blockIdx.x * 32 + grp; i < n; i += gridDim.x * 32) {
-        const float *x = base + (uint64_t)recs[i].pos * dim;
-        float acc = 0.0f;
-        for (uint32_t c = 0; c < dim; c += 8) {
-            float d = x[c + l] - q[c + l];
-            acc = fmaf(d, d, acc);
-        }
-        acc = reduce8_lanes(acc);
-        if (l == 0) recs[i].accurate = acc;
-    }
-}
-
 // flat variant for the per-stage test entry rq_rerank: positions given directly
 __global__ __launch_bounds__(256) void accurate_flat_kernel(const uint32_t *__restrict__ pos, uint32_t m,
                                                             const float *__restrict__ base,
@@ -792,15 +770,6 @@ __device__ __forceinline__ void sort_segment(T *__restrict__ recs, uint32_t n) {
         bitonic_sort_block(recs, n, key);  // in global memory (L2), rare
     }
 }
-// run directory of a stage: high 32 bits of the per-query counter = number of runs
-__global__ __launch_bounds__(256) void sort_runs_kernel(RunRec *__restrict__ runs,
-                                                        const unsigned long long *__restrict__ surv_cnt,
-                                                        uint32_t cap) {
-    const uint32_t b = blockIdx.x;
-    const unsigned long long c = surv_cnt[b];
-    if ((uint32_t)c > cap) return;
-    sort_segment(runs + (uint64_t)b * cap, (uint32_t)(c >> 32));
-}
 // heuristic ranker's accepted array (src/rerank.rs:170-176): by (Ord32(accurate), arrival)
 __global__ __launch_bounds__(256) void sort_survivors_kernel(SurvRec *__restrict__ surv,
                                                              const uint32_t *__restrict__ surv_cnt,
@@ -837,26 +806,12 @@ struct ReplayState {
 
 #define RQ_MAX_TOPK 2048
 
+// One wave replays a query's survivors (run directory `dir`, records `recs`) through the ranker.
 template <bool HEURISTIC>
-__global__ __launch_bounds__(64) void replay_kernel(const SurvRec *__restrict__ surv,
-                                                    const RunRec *__restrict__ runs,
-                                                    unsigned long long *__restrict__ surv_cnt, uint32_t cap,
-                                                    const uint32_t *__restrict__ map_ids, uint32_t topk,
-                                                    ReplayState st) {
-    __shared__ int32_t hkey[HEURISTIC ? 1 : RQ_MAX_TOPK];
-    __shared__ uint32_t hid[HEURISTIC ? 1 : RQ_MAX_TOPK];
-    const uint32_t b = blockIdx.x, lane = threadIdx.x;
-    const unsigned long long cnt64 = surv_cnt[b];
-    const uint32_t cnt = (uint32_t)cnt64;
-    const bool overflow = cnt > cap;   // records were dropped: the query is re-run with a larger buffer
-    const uint32_t n = overflow ? 0 : cnt;
-    const uint32_t nruns = overflow ? 0 : (uint32_t)(cnt64 >> 32);
-    if (lane == 0) {
-        if (cnt > st.need[b]) st.need[b] = cnt;
-        st.nsurv[b] += n;
-        surv_cnt[b] = 0;  // ready for the next stage
-    }
-    if (n == 0) return;
+__device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, const RunRec *__restrict__ dir,
+                                            uint32_t nruns, const uint32_t *__restrict__ map_ids, uint32_t topk,
+                                            uint32_t b, const ReplayState &st, int32_t *hkey, uint32_t *hid) {
+    const uint32_t lane = threadIdx.x & 63;
     float thr = st.thr[b];
     uint32_t precise = 0;
     uint32_t hlen = 0, wcount = 0, alen = 0;
@@ -867,14 +822,11 @@ __global__ __launch_bounds__(64) void replay_kernel(const SurvRec *__restrict__ 
             hkey[i] = st.heap_key[(uint64_t)b * topk + i];
             hid[i] = st.heap_id[(uint64_t)b * topk + i];
         }
-        __syncthreads();
     } else {
         recent = st.recent_max[b];
         wcount = st.win_count[b];
         alen = st.arr_len[b];
     }
-    const SurvRec *recs = surv + (uint64_t)b * cap;
-    const RunRec *dir = runs + (uint64_t)b * cap;
     for (uint32_t ri = 0; ri < nruns; ++ri) {
         const uint32_t base = dir[ri].base, rc = dir[ri].cnt;
         const bool have = lane < rc;
@@ -959,7 +911,6 @@ __global__ __launch_bounds__(64) void replay_kernel(const SurvRec *__restrict__ 
         }
     }
     if constexpr (!HEURISTIC) {
-        __syncthreads();
         for (uint32_t i = lane; i < hlen; i += 64) {
             st.heap_key[(uint64_t)b * topk + i] = hkey[i];
             st.heap_id[(uint64_t)b * topk + i] = hid[i];
@@ -974,6 +925,118 @@ __global__ __launch_bounds__(64) void replay_kernel(const SurvRec *__restrict__ 
         st.thr[b] = thr;
         st.precise[b] += precise;
     }
+}
+
+// One block per query finishes a stage: (A) exact rerank distances of the stage's survivors
+// (src/rerank.rs:85-90, 8 lanes = the 8 AVX lanes of src/simd.rs:14-73), (B) sort of the run
+// directory into the reference's visiting order, (C) wave 0 replays the ranker.
+template <bool HEURISTIC>
+__global__ __launch_bounds__(256) void stage_finish_kernel(SurvRec *__restrict__ surv, RunRec *__restrict__ runs,
+                                                           unsigned long long *__restrict__ surv_cnt, uint32_t cap,
+                                                           const float *__restrict__ base,
+                                                           const float *__restrict__ qpad, uint32_t dim,
+                                                           const uint32_t *__restrict__ map_ids, uint32_t topk,
+                                                           ReplayState st) {
+    __shared__ int32_t hkey[HEURISTIC ? 1 : RQ_MAX_TOPK];
+    __shared__ uint32_t hid[HEURISTIC ? 1 : RQ_MAX_TOPK];
+    const uint32_t b = blockIdx.x;
+    const unsigned long long cnt64 = surv_cnt[b];
+    const uint32_t cnt = (uint32_t)cnt64;
+    const bool overflow = cnt > cap;  // records were dropped: the query is re-run with a larger buffer
+    const uint32_t n = overflow ? 0 : cnt;
+    const uint32_t nruns = overflow ? 0 : (uint32_t)(cnt64 >> 32);
+    __syncthreads();  // every thread has read the counter before thread 0 resets it
+    if (threadIdx.x == 0) {
+        if (cnt > st.need[b]) st.need[b] = cnt;
+        st.nsurv[b] += n;
+        surv_cnt[b] = 0;  // ready for the next stage
+    }
+    if (n == 0) return;
+    SurvRec *recs = surv + (uint64_t)b * cap;
+    {  // (A)
+        const uint32_t l = threadIdx.x & 7, grp = threadIdx.x >> 3;
+        const float *q = qpad + (uint64_t)b * dim;
+        for (uint32_t i = grp; i < n; i += 32) {
+            const float *x = base + (uint64_t)recs[i].pos * dim;
+            float acc = 0.0f;
+            for (uint32_t c = 0; c < dim; c += 8) {
+                float d = x[c + l] - q[c + l];
+                acc = fmaf(d, d, acc);
+            }
+            acc = reduce8_lanes(acc);
+            if (l == 0) recs[i].accurate = acc;
+        }
+    }
+    sort_segment(runs + (uint64_t)b * cap, nruns);  // (B)
+    __syncthreads();                                  // (A)'s stores and (B)'s order visible to wave 0
+    if (threadIdx.x < 64)                             // (C)
+        replay_wave<HEURISTIC>(recs, runs + (uint64_t)b * cap, nruns, map_ids, topk, b, st, hkey, hid);
+}
+
+// ---- the same three phases as separate launches: better for large batches, where all queries'
+// survivors are reranked with full-chip parallelism before the (latency-bound) replay --------------
+// grid (gx, nq); block 256
+__global__ __launch_bounds__(256) void accurate_kernel(SurvRec *__restrict__ surv,
+                                                       const unsigned long long *__restrict__ surv_cnt,
+                                                       uint32_t cap, const float *__restrict__ base,
+                                                       const float *__restrict__ qpad, uint32_t dim) {
+    const uint32_t b = blockIdx.y;
+    const uint32_t n = (uint32_t)surv_cnt[b];
+    if (n > cap) return;  // overflowed: this query is re-run with a larger buffer
+    const uint32_t l = threadIdx.x & 7, grp = threadIdx.x >> 3;
+    const float *q = qpad + (uint64_t)b * dim;
+    SurvRec *recs = surv + (uint64_t)b * cap;
+    for (uint32_t i = blockIdx.x * 32 + grp; i < n; i += gridDim.x * 32) {
+        const float *x = base + (uint64_t)recs[i].pos * dim;
+        float acc = 0.0f;
+        for (uint32_t c = 0; c < dim; c += 8) {
+            float d = x[c + l] - q[c + l];
+            acc = fmaf(d, d, acc);
+        }
+        acc = reduce8_lanes(acc);
+        if (l == 0) recs[i].accurate = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void sort_runs_kernel(RunRec *__restrict__ runs,
+                                                        const unsigned long long *__restrict__ surv_cnt,
+                                                        uint32_t cap) {
+    const uint32_t b = blockIdx.x;
+    const unsigned long long c = surv_cnt[b];
+    if ((uint32_t)c > cap) return;
+    sort_segment(runs + (uint64_t)b * cap, (uint32_t)(c >> 32));
+}
+
+template <bool HEURISTIC>
+__global__ __launch_bounds__(64) void replay_kernel(const SurvRec *__restrict__ surv, const RunRec *__restrict__ runs,
+                                                    unsigned long long *__restrict__ surv_cnt, uint32_t cap,
+                                                    const uint32_t *__restrict__ map_ids, uint32_t topk,
+                                                    ReplayState st) {
+    __shared__ int32_t hkey[HEURISTIC ? 1 : RQ_MAX_TOPK];
+    __shared__ uint32_t hid[HEURISTIC ? 1 : RQ_MAX_TOPK];
+    const uint32_t b = blockIdx.x;
+    const unsigned long long cnt64 = surv_cnt[b];
+    const uint32_t cnt = (uint32_t)cnt64;
+    const bool overflow = cnt > cap;
+    const uint32_t n = overflow ? 0 : cnt;
+    const uint32_t nruns = overflow ? 0 : (uint32_t)(cnt64 >> 32);
+    if (threadIdx.x == 0) {
+        if (cnt > st.need[b]) st.need[b] = cnt;
+        st.nsurv[b] += n;
+        surv_cnt[b] = 0;  // ready for the next stage
+    }
+    if (n == 0) return;
+    replay_wave<HEURISTIC>(surv + (uint64_t)b * cap, runs + (uint64_t)b * cap, nruns, map_ids, topk, b, st, hkey, hid);
+}
+
+// ranker state of a fresh query (src/rerank.rs:70-77, :129-139) + per-query counters, one launch
+__global__ void init_state_kernel(ReplayState st, unsigned long long *__restrict__ surv_cnt, uint32_t nq) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nq) return;
+    st.thr[b] = 3.402823466e+38f;          // f32::MAX
+    st.recent_max[b] = -3.402823466e+38f;  // f32::MIN
+    st.heap_len[b] = 0, st.precise[b] = 0, st.need[b] = 0, st.nsurv[b] = 0, st.win_count[b] = 0, st.arr_len[b] = 0;
+    surv_cnt[b] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------

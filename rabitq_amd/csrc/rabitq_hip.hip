@@ -351,28 +351,18 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
 
     // 3. per-pair query quantisation (:304-317)
     pf.begin(PF_PREP);
-    HIPC(hipMemsetAsync(ws.rough_cnt.p, 0, nq * sizeof(unsigned long long), st));
     prep_kernel<<<ceil_div(npairs, 4), 256, 0, st>>>(ws.y.p, idx->centroids.p, idx->offsets.p, ws.probe_cluster.p,
                                                      ws.probe_dist.p, npairs, nprobe, dim, ws.scal.p, ws.planes.p,
                                                      ws.qnib.p, nullptr);
     pair_prefix_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(ws.scal.p, nq, nprobe, ws.rough_cnt.p);
-    // 4. ranker state (rerank.rs:70-77, :129-139)
-    fill_f32_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(ws.thr.p, 3.402823466e+38f, nq);
-    fill_f32_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(ws.recent.p, -3.402823466e+38f, nq);
-    HIPC(hipMemsetAsync(ws.surv_cnt.p, 0, nq * 8, st));
-    HIPC(hipMemsetAsync(ws.heap_len.p, 0, nq * 4, st));
-    HIPC(hipMemsetAsync(ws.precise.p, 0, nq * 4, st));
-    HIPC(hipMemsetAsync(ws.need.p, 0, nq * 4, st));
-    HIPC(hipMemsetAsync(ws.nsurv.p, 0, nq * 4, st));
-    HIPC(hipMemsetAsync(ws.win_count.p, 0, nq * 4, st));
-    HIPC(hipMemsetAsync(ws.arr_len.p, 0, nq * 4, st));
-    HIPC(hipMemsetAsync(ws.totals.p, 0, 8 * sizeof(unsigned long long), st));
-    pf.end();
-
     ReplayState rs;
     rs.thr = ws.thr.p, rs.heap_len = ws.heap_len.p, rs.heap_key = ws.heap_key.p, rs.heap_id = ws.heap_id.p;
     rs.precise = ws.precise.p, rs.need = ws.need.p, rs.nsurv = ws.nsurv.p, rs.recent_max = ws.recent.p, rs.win_count = ws.win_count.p;
     rs.arr_len = ws.arr_len.p, rs.arr = ws.arr.p, rs.hcap = qp.hcap;
+    // 4. ranker state (rerank.rs:70-77, :129-139) and per-query counters
+    init_state_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(rs, ws.surv_cnt.p, nq);
+    HIPC(hipMemsetAsync(ws.totals.p, 0, 8 * sizeof(unsigned long long), st));
+    pf.end();
 
     // 5. stages.  The reference visits a query's candidates as ONE stream: probed lists nearest-first,
     // members in stored order.  A stage covers stream positions [s_lo, s_hi) (of every query) and is
@@ -386,12 +376,14 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     std::vector<Stage> stages;
     {
         const uint64_t total_max = std::min<uint64_t>((uint64_t)nprobe * idx->max_list_len, idx->n);
+        // small batches are launch-bound (coarser stages), large ones rerank-bound (tighter thresholds)
+        const uint64_t growth = nq >= 256 ? 4 : 16;
         uint64_t lo = 0, hi = std::max<uint32_t>(topk, 1);
         while (lo < total_max) {
             const bool last = hi >= total_max;
             stages.push_back({(uint32_t)lo, last ? 0xFFFFFFFFu : (uint32_t)hi});
             lo = hi;
-            hi = std::min<uint64_t>(hi * 4, 0xFFFFFFF0ull);
+            hi = std::min<uint64_t>(hi * growth, 0xFFFFFFF0ull);
         }
     }
     const uint32_t tile = scan_tile(W);
@@ -432,19 +424,30 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         launch_scan(sp, a, W, st);
         pf.end();
         if (prof_acc) prof_acc->scan_launches++;
-        pf.begin(PF_RERANK);
-        const uint32_t gx = std::max(1u, std::min(64u, 8192u / std::max(nq, 1u)));
-        accurate_kernel<<<dim3(gx, nq), 256, 0, st>>>(ws.surv.p, ws.surv_cnt.p, qp.cap, idx->base.p, qpad, dim);
-        pf.end();
-        pf.begin(PF_SORT);
-        sort_runs_kernel<<<nq, 256, 0, st>>>(ws.runs.p, ws.surv_cnt.p, qp.cap);
-        pf.end();
-        pf.begin(PF_REPLAY);
-        if (qp.heuristic)
-            replay_kernel<true><<<nq, 64, 0, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->map_ids.p, topk, rs);
-        else
-            replay_kernel<false><<<nq, 64, 0, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->map_ids.p, topk, rs);
-        pf.end();
+        if (nq < 256) {  // small batch: one fused launch per stage (launch-bound regime)
+            pf.begin(PF_RERANK);
+            if (qp.heuristic)
+                stage_finish_kernel<true><<<nq, 256, 0, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->base.p,
+                                                              qpad, dim, idx->map_ids.p, topk, rs);
+            else
+                stage_finish_kernel<false><<<nq, 256, 0, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->base.p,
+                                                               qpad, dim, idx->map_ids.p, topk, rs);
+            pf.end();
+        } else {  // large batch: full-chip rerank, then run-directory sort, then one replay wave per query
+            pf.begin(PF_RERANK);
+            const uint32_t gx = std::max(1u, std::min(64u, 8192u / std::max(nq, 1u)));
+            accurate_kernel<<<dim3(gx, nq), 256, 0, st>>>(ws.surv.p, ws.surv_cnt.p, qp.cap, idx->base.p, qpad, dim);
+            pf.end();
+            pf.begin(PF_SORT);
+            sort_runs_kernel<<<nq, 256, 0, st>>>(ws.runs.p, ws.surv_cnt.p, qp.cap);
+            pf.end();
+            pf.begin(PF_REPLAY);
+            if (qp.heuristic)
+                replay_kernel<true><<<nq, 64, 0, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->map_ids.p, topk, rs);
+            else
+                replay_kernel<false><<<nq, 64, 0, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->map_ids.p, topk, rs);
+            pf.end();
+        }
     }
 
     // 6. results
@@ -1106,26 +1109,45 @@ rq_status rq_query_batch_device(const rq_index *idx, const float *d_queries, uin
                         d_out_id, d_out_n);
 }
 
+// Device staging of the host-pointer entry points: grown on demand, kept per host thread so a
+// per-vector `query()` loop does not pay hipMalloc/hipFree on every call (intentionally never freed).
+struct HostStaging {
+    void *p[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t cap[4] = {0, 0, 0, 0};
+    rq_status get(int i, size_t bytes, void **out) {
+        if (bytes > cap[i]) {
+            if (p[i]) (void)hipFree(p[i]);
+            p[i] = nullptr, cap[i] = 0;
+            size_t want = std::max<size_t>(bytes, 4096);
+            hipError_t e = hipMalloc(&p[i], want);
+            if (e != hipSuccess) return fail(RQ_ERR_OOM, std::string("staging hipMalloc failed: ") + hipGetErrorString(e));
+            cap[i] = want;
+        }
+        *out = p[i];
+        return RQ_OK;
+    }
+};
+static thread_local HostStaging g_staging;
+
 rq_status rq_query_batch(const rq_index *idx, const float *queries, uint32_t nq, uint32_t len, uint32_t probe,
                          uint32_t topk, int heuristic_rank, float *out_dist, uint32_t *out_id, uint32_t *out_n) {
     RQC(ensure_device());
     if (!idx || !queries || !out_dist || !out_id || !out_n) return fail(RQ_ERR_INVALID, "null argument");
     if (nq == 0) return RQ_OK;
     if (topk == 0) return fail(RQ_ERR_UNSUPPORTED, "topk must be in [1, 2048]");
-    DevBuf<float> dq, dd;
-    DevBuf<uint32_t> di, dn;
-    RQC(dq.alloc((uint64_t)nq * len));
-    RQC(dd.alloc((uint64_t)nq * topk));
-    RQC(di.alloc((uint64_t)nq * topk));
-    RQC(dn.alloc(nq));
-    HIPC(hipMemcpy(dq.p, queries, (uint64_t)nq * len * 4, hipMemcpyHostToDevice));
-    HIPC(hipMemset(dn.p, 0, nq * 4));
-    rq_status s = query_device(const_cast<rq_index *>(idx), dq.p, nq, len, probe, topk, heuristic_rank != 0, dd.p, di.p,
-                               dn.p);
+    void *dq, *dd, *di, *dn;
+    RQC(g_staging.get(0, (uint64_t)nq * len * 4, &dq));
+    RQC(g_staging.get(1, (uint64_t)nq * topk * 4, &dd));
+    RQC(g_staging.get(2, (uint64_t)nq * topk * 4, &di));
+    RQC(g_staging.get(3, (uint64_t)nq * 4, &dn));
+    HIPC(hipMemcpy(dq, queries, (uint64_t)nq * len * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemset(dn, 0, nq * 4));
+    rq_status s = query_device(const_cast<rq_index *>(idx), (const float *)dq, nq, len, probe, topk, heuristic_rank != 0,
+                               (float *)dd, (uint32_t *)di, (uint32_t *)dn);
     if (s != RQ_OK && s != RQ_ERR_EMPTY) return s;
-    HIPC(hipMemcpy(out_dist, dd.p, (uint64_t)nq * topk * 4, hipMemcpyDeviceToHost));
-    HIPC(hipMemcpy(out_id, di.p, (uint64_t)nq * topk * 4, hipMemcpyDeviceToHost));
-    HIPC(hipMemcpy(out_n, dn.p, nq * 4, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(out_dist, dd, (uint64_t)nq * topk * 4, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(out_id, di, (uint64_t)nq * topk * 4, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(out_n, dn, nq * 4, hipMemcpyDeviceToHost));
     return s;
 }
 
