@@ -184,6 +184,10 @@ typedef struct {
     uint32_t retries;          /* queries re-run because a survivor buffer overflowed   */
 } rq_profile_t;
 rq_status rq_set_profiling(int enabled);
+/* Engine options.  "scan_impl": 0 = auto (default: int8 matrix-core scan when many queries share each
+ * list, v_dot8 VALU scan otherwise), 1 = VALU only, 2 = matrix cores wherever available.  All
+ * settings return identical results; the option exists for tests and measurements. */
+rq_status rq_set_option(const char *name, int value);
 rq_status rq_last_profile(rq_profile_t *out);
 
 #ifdef __cplusplus

@@ -24,7 +24,7 @@ EXPORTS = [
     "rq_dump_dir", "rq_free", "rq_from_arrays", "rq_info", "rq_get_array", "rq_get_device_ptr", "rq_query",
     "rq_query_batch", "rq_query_batch_device", "rq_metrics", "rq_metrics_reset", "rq_rotate", "rq_rotate_device",
     "rq_quantize_pack",
-    "rq_coarse_rank", "rq_query_prep", "rq_scan", "rq_rerank", "rq_set_profiling", "rq_last_profile",
+    "rq_coarse_rank", "rq_query_prep", "rq_scan", "rq_rerank", "rq_set_profiling", "rq_set_option", "rq_last_profile",
 ]
 
 
@@ -98,6 +98,7 @@ def lib():
         "rq_scan": (i32, [vp, u32, flt, u64p, flt, flt, flt, f32p]),
         "rq_rerank": (i32, [vp, f32p, u32p, u32, f32p]),
         "rq_set_profiling": (i32, [C.c_int]),
+        "rq_set_option": (i32, [C.c_char_p, C.c_int]),
         "rq_last_profile": (i32, [C.POINTER(ProfileT)]),
     }
     for name, (res, args) in sig.items():

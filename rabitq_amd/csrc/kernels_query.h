@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ y,
                                                    PairScalars *__restrict__ scal,
                                                    uint64_t *__restrict__ planes,
                                                    uint32_t *__restrict__ qnib,
+                                                   uint8_t *__restrict__ qbytes,
                                                    uint32_t *__restrict__ out_sum_u32) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ y,
             uint64_t word = __ballot((q >> bit) & 1);
             if (lane == 0) pl[bit * W + w] = word;
         }
+        if (qbytes) qbytes[(uint64_t)p * dim + 64 * w + lane] = (uint8_t)((uint32_t)q & 15u);  // i8 MFMA operand
         if (qnib) {  // the same 4-bit codes packed 8 per dword (dword m <-> dims 8m..8m+7, nibble i <-> dim 8m+i):
                      // the operand form of v_dot8_u32_u4 used by the fused scan kernel
             uint32_t nib = ((uint32_t)q & 15u) << (4 * (lane & 7));
@@ -385,9 +387,9 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(uint32_t *__restrict__
 
 __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__restrict__ scal,
                                                          const uint32_t *__restrict__ probe_cluster,
-                                                         const uint32_t *__restrict__ operand /* 8W dwords per pair */,
+                                                         const uint32_t *__restrict__ operand /* opdw dwords per pair */,
                                                          const float *__restrict__ thr, uint32_t npairs,
-                                                         uint32_t nprobe, uint32_t W, uint32_t s_lo, uint32_t s_hi,
+                                                         uint32_t nprobe, uint32_t opdw, uint32_t s_lo, uint32_t s_hi,
                                                          uint32_t cluster_major,
                                                          const uint32_t *__restrict__ grp_start,
                                                          uint32_t *__restrict__ grp_cursor,
@@ -405,9 +407,9 @@ __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__re
         if (sub == 0) a = atomicAdd(&grp_cursor[c], 1u);
         at = grp_start[c] + __shfl(a, 0, 16);
     }
-    const uint32_t stride = 8 * W + RQ_REC_TAIL;
+    const uint32_t stride = opdw + RQ_REC_TAIL;
     uint32_t *r = recs + (uint64_t)at * stride;
-    for (uint32_t i = sub; i < 8 * W; i += 16) r[i] = operand[(uint64_t)p * 8 * W + i];
+    for (uint32_t i = sub; i < opdw; i += 16) r[i] = operand[(uint64_t)p * opdw + i];
     if (sub == 0) {
         uint32_t lo = 0, hi = 0;
         if (in) {
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__re
             hi = s_hi - ps.stream_begin;  // in-stage => stream_begin < s_hi
             hi = hi < ps.list_len ? hi : ps.list_len;
         }
-        uint32_t *t = r + 8 * W;
+        uint32_t *t = r + opdw;
         t[RQ_REC_LOWER] = __builtin_bit_cast(uint32_t, ps.lower);
         t[RQ_REC_DELTA] = __builtin_bit_cast(uint32_t, ps.delta);
         t[RQ_REC_SUMQ] = __builtin_bit_cast(uint32_t, ps.sumq);
@@ -631,6 +633,210 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
                 rbase += cntc ? 1u : 0u;
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same scan on the matrix cores, for stages where many queries share each list.
+//
+// sum_p popcount(code & plane_p) << p == sum_j bit_j(code) * q_j is an int8 inner product, exact in
+// i32.  In a batch the VALU form above is issue-bound (v_dot8_u32_u4 delivers ~1 dimension per
+// lane-cycle); v_mfma_i32_32x32x32_i8 delivers the 32 queries x 32 candidates x 32 dimensions
+// block in 32 cycles.  Roles: A = 32 queries x K (their 4-bit codes as bytes, from the stage
+// records through LDS), B = K x 32 candidates (code bits expanded to 0/1 bytes ONCE per block via a
+// 256-entry byte->8-bytes table in LDS), D lane map: column = candidate (lane & 31), the 16
+// registers x 2 half-waves = the 32 query rows.  So for one accumulator register a __ballot gives,
+// per half-wave, one query's gate over 32 CONSECUTIVE list positions: the same run protocol as the
+// VALU kernel.  The f32 epilogue is the reference's expression, evaluated for register pairs with
+// v_pk_*_f32 (rows 2p, 2p+1 are consecutive queries; per-query scalars are read from LDS as pairs).
+//
+// block = 4 waves; wave w owns NT sub-tiles of 32 positions: first + w*32*NT + t*32 + (lane&31).
+// LDS: byte table 2 KiB + 2 x (32 query operands, row stride KS*8+4 dwords: conflict-free
+// ds_read_b128) + 2 x 16 x 32 transposed record tails.
+// ------------------------------------------------------------------------------------------------
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+typedef int v16i32 __attribute__((ext_vector_type(16)));
+
+template <int W, int NT>
+__global__ __launch_bounds__(256) void scan_mfma_kernel(SCAN_PARAMS) {
+    constexpr int KS = 2 * W;                   // K slabs of 32 dimensions
+    constexpr uint32_t OPDW = 16 * W;           // operand dwords per record: dim bytes
+    constexpr uint32_t STRIDE = OPDW + RQ_REC_TAIL;
+    constexpr uint32_t OPLD = OPDW + 4;         // LDS row stride (dwords) of the operand image
+    constexpr uint32_t TILE = 128 * NT;
+    __shared__ __attribute__((aligned(16))) uint32_t lut[256][2];
+    __shared__ __attribute__((aligned(16))) uint32_t opbuf[2][32][OPLD];
+    __shared__ __attribute__((aligned(16))) uint32_t tailT[2][RQ_REC_TAIL][32];
+    __shared__ float scratch[4][16][64];  // a wave's 16 rough values per lane, only touched when something passed
+
+    const uint32_t g = blockIdx.x / a.tiles_per_group;
+    const uint32_t tile = blockIdx.x - g * a.tiles_per_group;
+    const uint32_t pb = grp_start[g], pe = grp_start[g + 1];  // cluster-major only
+    if (pb >= pe) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t *rec0 = recs + (uint64_t)pb * STRIDE;
+    const uint32_t list_begin = rec0[OPDW + RQ_REC_LIST_BEGIN], list_len = rec0[OPDW + RQ_REC_LIST_LEN];
+    const uint32_t first = tile * TILE;
+    if (first >= list_len) return;
+
+    {  // byte -> 8 bytes (bit e -> byte e) table
+        uint32_t b = tid;
+        uint32_t lo = (b & 1) | ((b & 2) << 7) | ((b & 4) << 14) | ((b & 8) << 21);
+        uint32_t hi = ((b >> 4) & 1) | (((b >> 4) & 2) << 7) | (((b >> 4) & 4) << 14) | (((b >> 4) & 8) << 21);
+        lut[b][0] = lo;
+        lut[b][1] = hi;
+    }
+    __syncthreads();
+
+    // B operands + factors of this lane's candidates (both half-waves hold the same candidate j of a
+    // sub-tile; half h supplies dimensions 16h..16h+15 of every 32-dimension slab)
+    v4i32 bop[NT][KS];
+    float4 fac[NT];
+    uint32_t lpos[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        lpos[t] = first + wave * (32 * NT) + t * 32 + j;
+        const uint32_t pos = list_begin + (lpos[t] < list_len ? lpos[t] : 0);
+        const uint32_t *cp = codes + (uint64_t)pos * (2 * W);
+        fac[t] = factors[pos];
+#pragma unroll
+        for (int sl = 0; sl < KS; ++sl) {
+            const uint32_t bits = (cp[sl] >> (16 * h)) & 0xFFFFu;  // dims 32*sl + 16h .. +15
+            const uint32_t b0 = bits & 0xFF, b1 = bits >> 8;
+            v4i32 v = {(int)lut[b0][0], (int)lut[b0][1], (int)lut[b1][0], (int)lut[b1][1]};
+            bop[t][sl] = v;
+        }
+    }
+
+    const uint32_t ntiles = (pe - pb + 31) / 32;
+    // stage query tile 0
+    auto stage_load = [&](uint32_t qt, uint4 (&regs)[(32 * STRIDE / 4 + 255) / 256]) {
+#pragma unroll
+        for (uint32_t it = 0; it < (32 * STRIDE / 4 + 255) / 256; ++it) {
+            const uint32_t q4 = tid + 256 * it;  // float4 slot inside the 32-record slab
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q4 < 32 * STRIDE / 4) {
+                const uint32_t qi = q4 / (STRIDE / 4);
+                if (pb + qt * 32 + qi < pe)
+                    v = *reinterpret_cast<const uint4 *>(recs + ((uint64_t)pb + qt * 32) * STRIDE + (uint64_t)q4 * 4);
+                else if (q4 - qi * (STRIDE / 4) == (OPDW + RQ_REC_THR) / 4)  // padding query: threshold -inf, empty range
+                    v = make_uint4(0, 0xFF800000u, 0, 0);                      // dwords 4..7 of the tail: ycd_sqrt, THR, LO, HI
+            }
+            regs[it] = v;
+        }
+    };
+    auto stage_store = [&](uint32_t buf, const uint4 (&regs)[(32 * STRIDE / 4 + 255) / 256]) {
+#pragma unroll
+        for (uint32_t it = 0; it < (32 * STRIDE / 4 + 255) / 256; ++it) {
+            const uint32_t q4 = tid + 256 * it;
+            if (q4 < 32 * STRIDE / 4) {
+                const uint32_t qi = q4 / (STRIDE / 4), d4 = (q4 - qi * (STRIDE / 4)) * 4;
+                const uint4 v = regs[it];
+                if (d4 < OPDW) {
+                    *reinterpret_cast<uint4 *>(&opbuf[buf][qi][d4]) = v;
+                } else {
+                    const uint32_t f = d4 - OPDW;
+                    tailT[buf][f][qi] = v.x, tailT[buf][f + 1][qi] = v.y, tailT[buf][f + 2][qi] = v.z, tailT[buf][f + 3][qi] = v.w;
+                }
+            }
+        }
+    };
+    uint4 sregs[(32 * STRIDE / 4 + 255) / 256];
+    stage_load(0, sregs);
+    stage_store(0, sregs);
+    __syncthreads();
+
+    for (uint32_t qt = 0; qt < ntiles; ++qt) {
+        const uint32_t buf = qt & 1;
+        const bool more = qt + 1 < ntiles;
+        if (more) stage_load(qt + 1, sregs);
+        // is every query's stage range a superset of this block's tile?  (then no per-lane range checks)
+        bool full_i = true;
+        if (lane < 32) full_i = tailT[buf][RQ_REC_LO][lane] <= first && first + TILE <= tailT[buf][RQ_REC_HI][lane];
+        // padding queries (empty range, threshold -inf) can never pass, so they need no range check either
+        if (lane < 32 && tailT[buf][RQ_REC_LO][lane] >= tailT[buf][RQ_REC_HI][lane]) full_i = true;
+        const bool all_full = __ballot(full_i) == ~0ull;
+
+        v4i32 aop[KS];  // A: query row j (= lane & 31), dims 32*sl + 16h .. +15
+#pragma unroll
+        for (int sl = 0; sl < KS; ++sl) aop[sl] = *reinterpret_cast<const v4i32 *>(&opbuf[buf][j][8 * sl + 4 * h]);
+
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            v16i32 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int sl = 0; sl < KS; ++sl) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop[sl], bop[t][sl], acc, 0, 0, 0);
+            const f32x2 cds = {fac[t].w, fac[t].w}, ppc = {fac[t].y, fac[t].y}, fip = {fac[t].x, fac[t].x},
+                        eb = {fac[t].z, fac[t].z};
+            float rough[16];
+            uint64_t anym = 0;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {  // hot path: the gate only
+                const int gr = 2 * p;
+                const uint32_t row0 = (gr & 3) + 8 * (gr >> 2) + 4 * h;  // even: rows row0, row0+1
+                const f32x2 lower = *reinterpret_cast<const f32x2 *>(&tailT[buf][RQ_REC_LOWER][row0]);
+                const f32x2 delta = *reinterpret_cast<const f32x2 *>(&tailT[buf][RQ_REC_DELTA][row0]);
+                const f32x2 sumq = *reinterpret_cast<const f32x2 *>(&tailT[buf][RQ_REC_SUMQ][row0]);
+                const f32x2 ycd = *reinterpret_cast<const f32x2 *>(&tailT[buf][RQ_REC_YCD][row0]);
+                const f32x2 ysq = *reinterpret_cast<const f32x2 *>(&tailT[buf][RQ_REC_YCD_SQRT][row0]);
+                const f32x2 thr = *reinterpret_cast<const f32x2 *>(&tailT[buf][RQ_REC_THR][row0]);
+                const f32x2 sf = {(float)acc[gr], (float)acc[gr + 1]};
+                f32x2 tt = cds + ycd;                 // center_distance_square + y_c_distance_square
+                tt = tt + lower * ppc;                // + lower_bound * factor_ppc
+                const f32x2 u = (2.0f * sf - sumq) * fip;
+                tt = tt + u * delta;
+                const f32x2 r = tt - eb * ysq;        // - error_bound * dist_sqrt
+                rough[gr] = r.x, rough[gr + 1] = r.y;
+                anym |= __ballot(r.x < thr.x) | __ballot(r.y < thr.y);  // src/rerank.rs:84 gate (range applied below)
+            }
+            if (anym) {  // wave-uniform and rare in the stages this kernel serves: ONE copy of the emit code
+#pragma unroll
+                for (int gq = 0; gq < 16; ++gq) scratch[wave][gq][lane] = rough[gq];
+#pragma nounroll
+                for (uint32_t gq = 0; gq < 16; ++gq) {
+                    const uint32_t row = (gq & 3) + 8 * (gq >> 2) + 4 * h;
+                    const float rg = scratch[wave][gq][lane];
+                    bool pass = rg < __builtin_bit_cast(float, tailT[buf][RQ_REC_THR][row]);
+                    if (!all_full) pass = pass && lpos[t] >= tailT[buf][RQ_REC_LO][row] && lpos[t] < tailT[buf][RQ_REC_HI][row];
+                    const uint64_t m = __ballot(pass);
+                    if (m == 0) continue;
+#pragma nounroll
+                    for (uint32_t hh = 0; hh < 2; ++hh) {
+                        const uint32_t mh = (uint32_t)(m >> (32 * hh));
+                        if (mh == 0) continue;
+                        const uint32_t qrow = (gq & 3) + 8 * (gq >> 2) + 4 * hh;
+                        const uint32_t b = tailT[buf][RQ_REC_ROW][qrow], slot = tailT[buf][RQ_REC_SLOT][qrow];
+                        const uint32_t cntc = (uint32_t)__popc(mh);
+                        unsigned long long old = 0;
+                        if (lane == 32 * hh) old = atomicAdd(surv_cnt + b, (1ull << 32) | cntc);
+                        const uint32_t base = __shfl((uint32_t)old, 32 * hh, 64);
+                        const uint32_t rbase = __shfl((uint32_t)(old >> 32), 32 * hh, 64);
+                        if (h == hh && ((mh >> j) & 1u)) {
+                            const uint32_t at = base + (uint32_t)__popc(mh & ((1u << j) - 1u));
+                            if (at < a.cap) {
+                                SurvRec sr;
+                                sr.pos = list_begin + lpos[t];
+                                sr.slot = slot;
+                                sr.rough = rg;
+                                sr.accurate = 0.0f;
+                                surv[(uint64_t)b * a.cap + at] = sr;
+                            }
+                        }
+                        if (lane == 32 * hh && rbase < a.cap) {
+                            RunRec rr;
+                            rr.pos = list_begin + first + wave * (32 * NT) + t * 32;
+                            rr.slot = slot;
+                            rr.base = base;
+                            rr.cnt = cntc;
+                            runs[(uint64_t)b * a.cap + rbase] = rr;
+                        }
+                    }
+                }
+            }
+        }
+        if (more) stage_store(buf ^ 1, sregs);
+        __syncthreads();
     }
 }
 

@@ -161,6 +161,7 @@ struct Workspace {
     DevBuf<PairScalars> scal;
     DevBuf<uint64_t> planes;
     DevBuf<uint32_t> qnib;
+    DevBuf<uint8_t> qbytes;
     DevBuf<unsigned long long> rough_cnt, totals, surv_cnt;
     DevBuf<SurvRec> surv, arr;
     DevBuf<RunRec> runs;
@@ -249,6 +250,28 @@ static void launch_scan(const ScanPtrs &p, const ScanArgs &a, uint32_t W, hipStr
         default: scan_generic_kernel<<<g, b, 0, st>>>(SCAN_ARGS, W); break;
     }
 }
+// scan implementation: 0 = auto (matrix cores when many queries share each list, VALU otherwise),
+// 1 = VALU (v_dot8_u32_u4) only, 2 = matrix cores wherever the kernel exists (test hook)
+static std::atomic<int> g_scan_impl{0};
+
+static bool scan_has_mfma(uint32_t W) { return W == 1 || W == 2 || W == 4; }
+static uint32_t scan_mfma_tile(uint32_t W) { return W == 4 ? 256 : 512; }
+static void launch_scan_mfma(const ScanPtrs &p, const ScanArgs &a, uint32_t W, hipStream_t st) {
+    const uint64_t blocks = (uint64_t)a.ngroups * a.tiles_per_group;
+    if (blocks == 0) return;
+    if (blocks > RQ_MAX_BLOCKS_256) {
+        fprintf(stderr, "rabitq_hip: scan grid of %llu blocks exceeds the launch bound\n", (unsigned long long)blocks);
+        abort();
+    }
+    dim3 g((uint32_t)blocks), b(256);
+    switch (W) {
+        case 1: scan_mfma_kernel<1, 4><<<g, b, 0, st>>>(SCAN_ARGS); break;
+        case 2: scan_mfma_kernel<2, 4><<<g, b, 0, st>>>(SCAN_ARGS); break;
+        case 4: scan_mfma_kernel<4, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
+        default: abort();
+    }
+}
+
 static bool scan_is_fused(uint32_t W) {
     switch (W) {
         case 1: case 2: case 3: case 4: case 6: case 8: case 12: case 16: return true;
@@ -288,9 +311,10 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
     RQC(ws.scal.ensure(npairs));
     RQC(ws.planes.ensure(npairs * 4 * idx->W));
     RQC(ws.qnib.ensure(npairs * 8 * idx->W));
+    RQC(ws.qbytes.ensure(npairs * idx->dim));
     RQC(ws.rough_cnt.ensure(nq));
     RQC(ws.totals.ensure(8));
-    RQC(ws.recs.ensure(npairs * (8ull * idx->W + RQ_REC_TAIL)));
+    RQC(ws.recs.ensure(npairs * (16ull * idx->W + RQ_REC_TAIL)));
     RQC(ws.grp_cnt.ensure(idx->k + 1));
     RQC(ws.grp_start.ensure(idx->k + 1));
     RQC(ws.thr.ensure(nq));
@@ -353,7 +377,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     pf.begin(PF_PREP);
     prep_kernel<<<ceil_div(npairs, 4), 256, 0, st>>>(ws.y.p, idx->centroids.p, idx->offsets.p, ws.probe_cluster.p,
                                                      ws.probe_dist.p, npairs, nprobe, dim, ws.scal.p, ws.planes.p,
-                                                     ws.qnib.p, nullptr);
+                                                     ws.qnib.p, ws.qbytes.p, nullptr);
     pair_prefix_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(ws.scal.p, nq, nprobe, ws.rough_cnt.p);
     ReplayState rs;
     rs.thr = ws.thr.p, rs.heap_len = ws.heap_len.p, rs.heap_key = ws.heap_key.p, rs.heap_id = ws.heap_id.p;
@@ -379,9 +403,13 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         // small batches are launch-bound (coarser stages), large ones rerank-bound (tighter thresholds)
         const uint64_t growth = nq >= 256 ? 4 : 16;
         uint64_t lo = 0, hi = std::max<uint32_t>(topk, 1);
+        const uint64_t avg = std::max<uint64_t>(1, idx->n / std::max<uint32_t>(k, 1));
         while (lo < total_max) {
-            const bool last = hi >= total_max;
+            // past the first two lists' worth of candidates the threshold is already tight: scan the rest of
+            // the stream as ONE stage (every list then meets all its queries at once: full 32-query tiles)
+            const bool last = hi >= total_max || lo >= 2 * avg;
             stages.push_back({(uint32_t)lo, last ? 0xFFFFFFFFu : (uint32_t)hi});
+            if (last) break;
             lo = hi;
             hi = std::min<uint64_t>(hi * growth, 0xFFFFFFF0ull);
         }
@@ -391,7 +419,10 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     for (const Stage &sg : stages) {
         const uint64_t span = (uint64_t)std::min<uint64_t>(sg.s_hi, (uint64_t)nprobe * idx->max_list_len) - sg.s_lo;
         const uint64_t est_pairs = (uint64_t)nq * std::min<uint64_t>(nprobe, span / avg_len + 2);
-        const bool cluster_major = est_pairs >= k / 2 && est_pairs > 64;
+        const int impl = g_scan_impl.load();
+        // matrix cores pay once a 32-query tile is reasonably full: >= 8 (query, list) pairs per list on average
+        const bool use_mfma = scan_has_mfma(W) && impl != 1 && (impl == 2 || est_pairs >= 8ull * k);
+        const bool cluster_major = use_mfma || (est_pairs >= k / 2 && est_pairs > 64);
         pf.begin(PF_GROUP);
         ScanArgs a{};
         ScanPtrs sp{};
@@ -406,10 +437,11 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             a.ngroups = npairs;
         }
         // pack the stage's work records (query operand + scalars + current threshold + local range)
-        stage_fill_kernel<<<ceil_div(npairs, 16), 256, 0, st>>>(
-            ws.scal.p, ws.probe_cluster.p,
-            scan_is_fused(W) ? ws.qnib.p : reinterpret_cast<const uint32_t *>(ws.planes.p), ws.thr.p, npairs, nprobe, W,
-            sg.s_lo, sg.s_hi, a.cluster_major, ws.grp_start.p, ws.grp_cnt.p, ws.recs.p);
+        const uint32_t *operand = use_mfma ? reinterpret_cast<const uint32_t *>(ws.qbytes.p)
+                                           : (scan_is_fused(W) ? ws.qnib.p : reinterpret_cast<const uint32_t *>(ws.planes.p));
+        stage_fill_kernel<<<ceil_div(npairs, 16), 256, 0, st>>>(ws.scal.p, ws.probe_cluster.p, operand, ws.thr.p, npairs,
+                                                                nprobe, use_mfma ? 16 * W : 8 * W, sg.s_lo, sg.s_hi,
+                                                                a.cluster_major, ws.grp_start.p, ws.grp_cnt.p, ws.recs.p);
         pf.end();
         sp.codes = reinterpret_cast<const uint32_t *>(idx->codes.p);
         sp.factors = idx->factors.p;
@@ -419,9 +451,10 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         sp.runs = ws.runs.p;
         sp.surv_cnt = ws.surv_cnt.p;
         a.cap = qp.cap;
-        a.tiles_per_group = ceil_div(std::min<uint64_t>(idx->max_list_len, sg.s_hi), tile);
+        a.tiles_per_group = ceil_div(std::min<uint64_t>(idx->max_list_len, sg.s_hi), use_mfma ? scan_mfma_tile(W) : tile);
         pf.begin(PF_SCAN);
-        launch_scan(sp, a, W, st);
+        if (use_mfma) launch_scan_mfma(sp, a, W, st);
+        else launch_scan(sp, a, W, st);
         pf.end();
         if (prof_acc) prof_acc->scan_launches++;
         if (nq < 256) {  // small batch: one fused launch per stage (launch-bound regime)
@@ -1166,6 +1199,16 @@ rq_status rq_metrics_reset(void) {
     return RQ_OK;
 }
 
+rq_status rq_set_option(const char *name, int value) {
+    if (!name) return fail(RQ_ERR_INVALID, "null option name");
+    if (std::string(name) == "scan_impl") {
+        if (value < 0 || value > 2) return fail(RQ_ERR_INVALID, "scan_impl must be 0 (auto), 1 (valu) or 2 (mfma)");
+        g_scan_impl = value;
+        return RQ_OK;
+    }
+    return fail(RQ_ERR_INVALID, std::string("unknown option ") + name);
+}
+
 rq_status rq_set_profiling(int enabled) {
     g_profiling = enabled;
     return RQ_OK;
@@ -1304,7 +1347,7 @@ rq_status rq_query_prep(const rq_index *idx, const float *y, uint32_t nq, const 
     HIPC(hipMemcpy(dc.p, cluster, nq * 4, hipMemcpyHostToDevice));
     HIPC(hipMemset(ycd.p, 0, nq * 4));
     prep_kernel<<<ceil_div(nq, 4), 256>>>(dy.p, idx->centroids.p, idx->offsets.p, dc.p, ycd.p, nq, 1, dim, scal.p,
-                                          planes.p, nullptr, dsum.p);
+                                          planes.p, nullptr, nullptr, dsum.p);
     HIPC(hipDeviceSynchronize());
     HIPC(hipGetLastError());
     std::vector<PairScalars> hs(nq);

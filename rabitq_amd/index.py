@@ -201,6 +201,11 @@ def set_profiling(enabled: bool) -> None:
     check(lib().rq_set_profiling(int(enabled)))
 
 
+def set_option(name: str, value: int) -> None:
+    """Engine options (include/rabitq_hip.h: rq_set_option), e.g. set_option("scan_impl", 1)."""
+    check(lib().rq_set_option(name.encode(), int(value)))
+
+
 def last_profile() -> dict:
     p = ProfileT()
     check(lib().rq_last_profile(C.byref(p)))

@@ -512,3 +512,27 @@ def test_concurrent_queries_one_handle(rq, oracle):
     assert not errs, errs
     assert got == want
     gidx.close()
+
+
+# ---- the two scan implementations (VALU v_dot8 / int8 matrix cores) must be indistinguishable ---------
+@pytest.mark.parametrize("impl", [1, 2])
+@pytest.mark.parametrize("n,d,k,nq", [(12000, 128, 24, 160), (5000, 64, 10, 70), (4000, 256, 6, 50), (3000, 100, 8, 40)])
+def test_scan_implementations_match_oracle(rq, oracle, impl, n, d, k, nq):
+    from rabitq_amd import index as ix
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.8, seed=n + impl, centre_scale=0.6)
+    P = synth.random_orthogonal((d + 63) // 64 * 64, seed=d + 3)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    gidx = rq.RaBitQ.build(x, centres, P)
+    queries, _, _ = synth.mixture(nq, d, k, sigma=0.8, seed=n + 7, centre_scale=0.6)
+    queries[2] = x[11]
+    ix.set_option("scan_impl", impl)
+    try:
+        for probe, topk, heur in ((k, 10, False), (3, 1, False), (k, 50, False), (4, 10, True)):
+            _compare_with_oracle(rq, oracle, oidx, gidx, queries, probe, topk, heur)
+        # ragged: a single query, and a batch that is not a multiple of the 32-query tile
+        _compare_with_oracle(rq, oracle, oidx, gidx, queries[:1], k, 10, False)
+        _compare_with_oracle(rq, oracle, oidx, gidx, queries[:33], k, 10, False)
+    finally:
+        ix.set_option("scan_impl", 0)
+    gidx.close()
+    oidx.close()
