@@ -1033,12 +1033,28 @@ __device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, co
         wcount = st.win_count[b];
         alen = st.arr_len[b];
     }
+    // the directory is read 64 descriptors at a time (one coalesced load, broadcast by shuffle) and the
+    // records of run k+1 are in flight while run k is replayed
+    SurvRec nxt;
+    nxt.pos = 0, nxt.slot = 0, nxt.rough = 0.0f, nxt.accurate = 0.0f;
+    uint32_t dbase = 0, dcnt = 0;
+    if (lane < nruns) dbase = dir[lane].base, dcnt = dir[lane].cnt;
+    {
+        const uint32_t b0 = __shfl(dbase, 0, 64), c0 = __shfl(dcnt, 0, 64);
+        if (lane < c0) nxt = recs[b0 + lane];
+    }
     for (uint32_t ri = 0; ri < nruns; ++ri) {
-        const uint32_t base = dir[ri].base, rc = dir[ri].cnt;
+        const uint32_t rc = __shfl(dcnt, ri & 63, 64);
         const bool have = lane < rc;
-        SurvRec r;
-        if (have) r = recs[base + lane];
-        else r.pos = 0, r.slot = 0, r.rough = 0.0f, r.accurate = 0.0f;
+        SurvRec r = nxt;
+        if (ri + 1 < nruns) {  // wave-uniform
+            if (((ri + 1) & 63) == 0) {
+                dbase = 0, dcnt = 0;
+                if (ri + 1 + lane < nruns) dbase = dir[ri + 1 + lane].base, dcnt = dir[ri + 1 + lane].cnt;
+            }
+            const uint32_t nb = __shfl(dbase, (ri + 1) & 63, 64), nc = __shfl(dcnt, (ri + 1) & 63, 64);
+            if (lane < nc) nxt = recs[nb + lane];
+        }
         uint64_t m = __ballot(have && r.rough < thr);  // rerank.rs:84 / :146
         while (m) {
             const int i = __builtin_ctzll(m);
@@ -1186,21 +1202,29 @@ __global__ __launch_bounds__(256) void accurate_kernel(SurvRec *__restrict__ sur
                                                        const unsigned long long *__restrict__ surv_cnt,
                                                        uint32_t cap, const float *__restrict__ base,
                                                        const float *__restrict__ qpad, uint32_t dim) {
+    // TWO lanes per candidate: lane half hf carries AVX lanes 4hf..4hf+3 (elements 8c + 4hf + 0..3, one
+    // 16-byte load per chunk), so a row is fetched with float4 loads; the fold
+    // ((a0+a4)+(a1+a5)) + ((a2+a6)+(a3+a7)) needs one exchange between the two lanes.
     const uint32_t b = blockIdx.y;
     const uint32_t n = (uint32_t)surv_cnt[b];
     if (n > cap) return;  // overflowed: this query is re-run with a larger buffer
-    const uint32_t l = threadIdx.x & 7, grp = threadIdx.x >> 3;
+    const uint32_t hf = threadIdx.x & 1, grp = threadIdx.x >> 1;
     const float *q = qpad + (uint64_t)b * dim;
     SurvRec *recs = surv + (uint64_t)b * cap;
-    for (uint32_t i = blockIdx.x * 32 + grp; i < n; i += gridDim.x * 32) {
+    for (uint32_t i = blockIdx.x * 128 + grp; i < n; i += gridDim.x * 128) {
         const float *x = base + (uint64_t)recs[i].pos * dim;
-        float acc = 0.0f;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
         for (uint32_t c = 0; c < dim; c += 8) {
-            float d = x[c + l] - q[c + l];
-            acc = fmaf(d, d, acc);
+            const float4 xv = *reinterpret_cast<const float4 *>(x + c + 4 * hf);
+            const float4 qv = *reinterpret_cast<const float4 *>(q + c + 4 * hf);
+            float d0 = xv.x - qv.x, d1 = xv.y - qv.y, d2 = xv.z - qv.z, d3 = xv.w - qv.w;
+            a0 = fmaf(d0, d0, a0), a1 = fmaf(d1, d1, a1), a2 = fmaf(d2, d2, a2), a3 = fmaf(d3, d3, a3);
         }
-        acc = reduce8_lanes(acc);
-        if (l == 0) recs[i].accurate = acc;
+        // c_i = a_i + a_{i+4}: the partner lane holds the other half (commutative, so both lanes agree)
+        const float c0 = a0 + __shfl_xor(a0, 1, 2), c1 = a1 + __shfl_xor(a1, 1, 2);
+        const float c2 = a2 + __shfl_xor(a2, 1, 2), c3 = a3 + __shfl_xor(a3, 1, 2);
+        const float r = (c0 + c1) + (c2 + c3);
+        if (hf == 0) recs[i].accurate = r;
     }
 }
 

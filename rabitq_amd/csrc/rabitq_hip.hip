@@ -407,7 +407,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         while (lo < total_max) {
             // past the first two lists' worth of candidates the threshold is already tight: scan the rest of
             // the stream as ONE stage (every list then meets all its queries at once: full 32-query tiles)
-            const bool last = hi >= total_max || lo >= 2 * avg;
+            const bool last = hi >= total_max || lo >= avg;
             stages.push_back({(uint32_t)lo, last ? 0xFFFFFFFFu : (uint32_t)hi});
             if (last) break;
             lo = hi;
@@ -468,7 +468,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             pf.end();
         } else {  // large batch: full-chip rerank, then run-directory sort, then one replay wave per query
             pf.begin(PF_RERANK);
-            const uint32_t gx = std::max(1u, std::min(64u, 8192u / std::max(nq, 1u)));
+            const uint32_t gx = std::max(1u, std::min(16u, 4096u / std::max(nq, 1u)));
             accurate_kernel<<<dim3(gx, nq), 256, 0, st>>>(ws.surv.p, ws.surv_cnt.p, qp.cap, idx->base.p, qpad, dim);
             pf.end();
             pf.begin(PF_SORT);
