@@ -1242,8 +1242,9 @@ __global__ __launch_bounds__(64) void replay_kernel(const SurvRec *__restrict__ 
                                                     unsigned long long *__restrict__ surv_cnt, uint32_t cap,
                                                     const uint32_t *__restrict__ map_ids, uint32_t topk,
                                                     ReplayState st) {
-    __shared__ int32_t hkey[HEURISTIC ? 1 : RQ_MAX_TOPK];
-    __shared__ uint32_t hid[HEURISTIC ? 1 : RQ_MAX_TOPK];
+    extern __shared__ __attribute__((aligned(16))) unsigned char replay_smem[];  // topk * 8 bytes (heap ranker)
+    int32_t *hkey = reinterpret_cast<int32_t *>(replay_smem);
+    uint32_t *hid = reinterpret_cast<uint32_t *>(replay_smem) + topk;
     const uint32_t b = blockIdx.x;
     const unsigned long long cnt64 = surv_cnt[b];
     const uint32_t cnt = (uint32_t)cnt64;

@@ -476,9 +476,9 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             pf.end();
             pf.begin(PF_REPLAY);
             if (qp.heuristic)
-                replay_kernel<true><<<nq, 64, 0, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->map_ids.p, topk, rs);
+                replay_kernel<true><<<nq, 64, 16, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->map_ids.p, topk, rs);
             else
-                replay_kernel<false><<<nq, 64, 0, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->map_ids.p, topk, rs);
+                replay_kernel<false><<<nq, 64, (size_t)topk * 8, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->map_ids.p, topk, rs);
             pf.end();
         }
     }
