@@ -961,16 +961,16 @@ __global__ __launch_bounds__(256) void accurate_flat_kernel(const uint32_t *__re
 // (src/rabitq.rs:304 outer loop, :348 inner loop).  One block per query; LDS when it fits.
 // ------------------------------------------------------------------------------------------------
 #define RQ_SORT_LDS_RECS 2048
-template <typename T>
+template <typename T, uint32_t LDS_RECS = RQ_SORT_LDS_RECS>
 __device__ __forceinline__ void sort_segment(T *__restrict__ recs, uint32_t n) {
-    __shared__ T lds[RQ_SORT_LDS_RECS];
+    __shared__ T lds[LDS_RECS];
     if (n < 2) return;
     auto key = [](const T &r) { return surv_key(r); };
-    if (n <= RQ_SORT_LDS_RECS) {
-        for (uint32_t i = threadIdx.x; i < n; i += 256) lds[i] = recs[i];
+    if (n <= LDS_RECS) {
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) lds[i] = recs[i];
         __syncthreads();
         bitonic_sort_block(lds, n, key);
-        for (uint32_t i = threadIdx.x; i < n; i += 256) recs[i] = lds[i];
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) recs[i] = lds[i];
     } else {
         __syncthreads();
         bitonic_sort_block(recs, n, key);  // in global memory (L2), rare
@@ -1228,13 +1228,14 @@ __global__ __launch_bounds__(256) void accurate_kernel(SurvRec *__restrict__ sur
     }
 }
 
-__global__ __launch_bounds__(256) void sort_runs_kernel(RunRec *__restrict__ runs,
+__global__ __launch_bounds__(64) void sort_runs_kernel(RunRec *__restrict__ runs,
                                                         const unsigned long long *__restrict__ surv_cnt,
                                                         uint32_t cap) {
     const uint32_t b = blockIdx.x;
     const unsigned long long c = surv_cnt[b];
     if ((uint32_t)c > cap) return;
-    sort_segment(runs + (uint64_t)b * cap, (uint32_t)(c >> 32));
+    // a stage rarely leaves more than a few dozen runs per query: a small LDS image keeps residency high
+    sort_segment<RunRec, 256>(runs + (uint64_t)b * cap, (uint32_t)(c >> 32));
 }
 
 template <bool HEURISTIC>

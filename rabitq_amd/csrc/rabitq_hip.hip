@@ -472,7 +472,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             accurate_kernel<<<dim3(gx, nq), 256, 0, st>>>(ws.surv.p, ws.surv_cnt.p, qp.cap, idx->base.p, qpad, dim);
             pf.end();
             pf.begin(PF_SORT);
-            sort_runs_kernel<<<nq, 256, 0, st>>>(ws.runs.p, ws.surv_cnt.p, qp.cap);
+            sort_runs_kernel<<<nq, 64, 0, st>>>(ws.runs.p, ws.surv_cnt.p, qp.cap);
             pf.end();
             pf.begin(PF_REPLAY);
             if (qp.heuristic)
