@@ -401,7 +401,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     {
         const uint64_t total_max = std::min<uint64_t>((uint64_t)nprobe * idx->max_list_len, idx->n);
         // small batches are launch-bound (coarser stages), large ones rerank-bound (tighter thresholds)
-        const uint64_t growth = nq >= 256 ? 4 : 16;
+        const uint64_t growth = nq >= 256 ? 8 : 16;
         uint64_t lo = 0, hi = std::max<uint32_t>(topk, 1);
         const uint64_t avg = std::max<uint64_t>(1, idx->n / std::max<uint32_t>(k, 1));
         while (lo < total_max) {
