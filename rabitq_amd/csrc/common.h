@@ -92,3 +92,9 @@ struct __attribute__((aligned(8))) PairScalars {
     uint32_t stream_begin;  // candidates the reference visits before this list (sum of earlier slots' lengths)
     uint32_t pad;
 };
+
+// Index-wide bounds of the Factor fields, used to decide when the integer-threshold form of the gate
+// (matrix-core scan) is numerically safe for a query.
+struct FactorStats {
+    float cds_max, ppc_absmax, eb_max, invfip_absmax;
+};

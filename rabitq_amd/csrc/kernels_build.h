@@ -5,7 +5,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef RQ_F32X16_DEFINED
+#define RQ_F32X16_DEFINED
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Rotation X' = X P on the matrix cores (src/rabitq.rs:188-189; query side src/utils.rs:237-258).
@@ -475,4 +478,29 @@ __global__ void unpad_rows_kernel(const float *__restrict__ in, float *__restric
     if (i >= n * d) return;
     uint64_t r = i / d;
     out[i] = in[r * dim + (i - r * d)];
+}
+
+// index-wide bounds of the Factor fields (see FactorStats); non-finite / irregular entries are skipped:
+// such candidates take the exact path in the matrix-core scan anyway
+__global__ __launch_bounds__(256) void factor_stats_kernel(const float4 *__restrict__ factors, uint64_t n,
+                                                           uint32_t *__restrict__ out4 /* float bits, >= 0 */) {
+    float cds = 0.0f, ppc = 0.0f, eb = 0.0f, inv = 0.0f;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const float4 f = factors[i];
+        const float r = 1.0f / f.x;
+        const float mag = fabsf(r) + fabsf(f.w) + fabsf(f.y) + fabsf(f.z);
+        if (f.x < 0.0f && mag < 3.0e38f) {
+            cds = fmaxf(cds, fabsf(f.w)), ppc = fmaxf(ppc, fabsf(f.y)), eb = fmaxf(eb, fabsf(f.z)), inv = fmaxf(inv, fabsf(r));
+        }
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        cds = fmaxf(cds, __shfl_xor(cds, o, 64)), ppc = fmaxf(ppc, __shfl_xor(ppc, o, 64));
+        eb = fmaxf(eb, __shfl_xor(eb, o, 64)), inv = fmaxf(inv, __shfl_xor(inv, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {  // non-negative floats order like their bit patterns
+        atomicMax(&out4[0], __builtin_bit_cast(uint32_t, cds));
+        atomicMax(&out4[1], __builtin_bit_cast(uint32_t, ppc));
+        atomicMax(&out4[2], __builtin_bit_cast(uint32_t, eb));
+        atomicMax(&out4[3], __builtin_bit_cast(uint32_t, inv));
+    }
 }

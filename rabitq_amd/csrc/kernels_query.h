@@ -383,7 +383,8 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(uint32_t *__restrict__
 #define RQ_REC_SLOT 9
 #define RQ_REC_LIST_BEGIN 10
 #define RQ_REC_LIST_LEN 11
-#define RQ_REC_TAIL 16
+#define RQ_REC_V0 12         // v'[0..4]: per-query side of the integer threshold S*(c,q) = sum_r u'_c[r] * v'_q[r]
+#define RQ_REC_TAIL 20
 
 __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__restrict__ scal,
                                                          const uint32_t *__restrict__ probe_cluster,
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__re
                                                          uint32_t cluster_major,
                                                          const uint32_t *__restrict__ grp_start,
                                                          uint32_t *__restrict__ grp_cursor,
-                                                         uint32_t *__restrict__ recs) {
+                                                         uint32_t *__restrict__ recs, const FactorStats fs) {
     const uint32_t sub = threadIdx.x & 15;                       // 16 lanes per pair
     const uint32_t p = blockIdx.x * 16 + (threadIdx.x >> 4);
     if (p >= npairs) return;
@@ -430,6 +431,25 @@ __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__re
         t[RQ_REC_SLOT] = p - ps.row * nprobe;
         t[RQ_REC_LIST_BEGIN] = ps.list_begin;
         t[RQ_REC_LIST_LEN] = ps.list_len;
+        // Integer form of the gate (used by the matrix-core scan).  With F = factor_ip * delta < 0,
+        //   rough < thr  <=>  s > S* = [ (thr - ycd) + (-1) cds + (-lower) ppc + ysq eb ] / (2 F) + sumq / 2
+        // (real arithmetic), a rank-5 bilinear form in u'_c = (1, cds, ppc, eb)/fip, 1  and the v' below.
+        // S* is lowered by 2 so that f32 rounding on either side can never hide a candidate the exact
+        // f32 expression would pass; where the scales make that bound unsafe (or delta <= 0) the query is
+        // marked "always flagged" (S* = -inf) and every candidate takes the exact path.
+        const float th = thr[ps.row];
+        const float inv2d = 0.5f / ps.delta;
+        float v0 = (th - ps.ycd) * inv2d, v1 = -inv2d, v2 = -ps.lower * inv2d, v3 = ps.ycd_sqrt * inv2d;
+        float v4 = 0.5f * ps.sumq - 2.0f;
+        const float q = (fabsf(th - ps.ycd) + fs.cds_max + fabsf(ps.lower) * fs.ppc_absmax + ps.ycd_sqrt * fs.eb_max) *
+                            fs.invfip_absmax * fabsf(inv2d) + ps.sumq;
+        const bool safe = ps.delta > 0.0f && q < 524288.0f;  // also false for NaN / inf
+        if (!safe) v0 = __builtin_inff(), v1 = 0.0f, v2 = 0.0f, v3 = 0.0f, v4 = 0.0f;  // u'[0] < 0  =>  S* = -inf
+        t[RQ_REC_V0 + 0] = __builtin_bit_cast(uint32_t, v0);
+        t[RQ_REC_V0 + 1] = __builtin_bit_cast(uint32_t, v1);
+        t[RQ_REC_V0 + 2] = __builtin_bit_cast(uint32_t, v2);
+        t[RQ_REC_V0 + 3] = __builtin_bit_cast(uint32_t, v3);
+        t[RQ_REC_V0 + 4] = __builtin_bit_cast(uint32_t, v4);
     }
 }
 
@@ -655,10 +675,14 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
 // ds_read_b128) + 2 x 16 x 32 transposed record tails.
 // ------------------------------------------------------------------------------------------------
 typedef int v4i32 __attribute__((ext_vector_type(4)));
+#ifndef RQ_F32X16_DEFINED
+#define RQ_F32X16_DEFINED
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#endif
 typedef int v16i32 __attribute__((ext_vector_type(16)));
 
 template <int W, int NT>
-__global__ __launch_bounds__(256) void scan_mfma_kernel(SCAN_PARAMS) {
+__global__ __launch_bounds__(256, 3) void scan_mfma_kernel(SCAN_PARAMS) {
     constexpr int KS = 2 * W;                   // K slabs of 32 dimensions
     constexpr uint32_t OPDW = 16 * W;           // operand dwords per record: dim bytes
     constexpr uint32_t STRIDE = OPDW + RQ_REC_TAIL;
@@ -680,6 +704,20 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(SCAN_PARAMS) {
     const uint32_t first = tile * TILE;
     if (first >= list_len) return;
 
+    // everything the block needs from memory is requested up front, so the start-up costs ONE round trip:
+    // this lane's candidates (raw code words + factors) here, the first query tile further down
+    uint32_t craw[NT][KS];  // both half-waves hold the same candidate j of a sub-tile
+    float4 fac0[NT];
+    uint32_t lpos[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        lpos[t] = first + wave * (32 * NT) + t * 32 + j;
+        const uint32_t pos = list_begin + (lpos[t] < list_len ? lpos[t] : 0);
+        const uint32_t *cp = codes + (uint64_t)pos * (2 * W);
+        fac0[t] = factors[pos];
+#pragma unroll
+        for (int sl = 0; sl < KS; ++sl) craw[t][sl] = cp[sl];
+    }
     {  // byte -> 8 bytes (bit e -> byte e) table
         uint32_t b = tid;
         uint32_t lo = (b & 1) | ((b & 2) << 7) | ((b & 4) << 14) | ((b & 8) << 21);
@@ -687,48 +725,46 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(SCAN_PARAMS) {
         lut[b][0] = lo;
         lut[b][1] = hi;
     }
-    __syncthreads();
 
-    // B operands + factors of this lane's candidates (both half-waves hold the same candidate j of a
-    // sub-tile; half h supplies dimensions 16h..16h+15 of every 32-dimension slab)
-    v4i32 bop[NT][KS];
-    float4 fac[NT];
-    uint32_t lpos[NT];
+    float ub[NT][3];      // B operand of the threshold MFMAs: u'[2m + h], m = 0..2 (u'[5] = 0)
+    bool forced = false;  // candidates whose factors do not admit the integer-threshold form
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        lpos[t] = first + wave * (32 * NT) + t * 32 + j;
-        const uint32_t pos = list_begin + (lpos[t] < list_len ? lpos[t] : 0);
-        const uint32_t *cp = codes + (uint64_t)pos * (2 * W);
-        fac[t] = factors[pos];
-#pragma unroll
-        for (int sl = 0; sl < KS; ++sl) {
-            const uint32_t bits = (cp[sl] >> (16 * h)) & 0xFFFFu;  // dims 32*sl + 16h .. +15
-            const uint32_t b0 = bits & 0xFF, b1 = bits >> 8;
-            v4i32 v = {(int)lut[b0][0], (int)lut[b0][1], (int)lut[b1][0], (int)lut[b1][1]};
-            bop[t][sl] = v;
-        }
+        // u'_c = (1, cds, ppc, eb) / factor_ip, 1   (factor_ip < 0 for every regular vector, rabitq.rs:227)
+        const float rf = 1.0f / fac0[t].x;
+        float u0 = rf, u1 = fac0[t].w * rf, u2 = fac0[t].y * rf, u3 = fac0[t].z * rf, u4 = 1.0f;
+        const float mag = fabsf(u0) + fabsf(u1) + fabsf(u2) + fabsf(u3);
+        const bool ok = fac0[t].x < 0.0f && mag < 3.0e38f;  // false for NaN / inf / factor_ip >= 0
+        if (!ok) u0 = 0.0f, u1 = 0.0f, u2 = 0.0f, u3 = 0.0f, u4 = 0.0f, forced = true;
+        ub[t][0] = h ? u1 : u0;
+        ub[t][1] = h ? u3 : u2;
+        ub[t][2] = h ? 0.0f : u4;
     }
+    const uint64_t forcemask = __ballot(forced);
 
     const uint32_t ntiles = (pe - pb + 31) / 32;
     // stage query tile 0
-    auto stage_load = [&](uint32_t qt, uint4 (&regs)[(32 * STRIDE / 4 + 255) / 256]) {
+    constexpr uint32_t NSTG = (32 * STRIDE / 4 + 255) / 256;
+    auto stage_load = [&](uint32_t qt, uint4 (&regs)[NSTG]) {
 #pragma unroll
-        for (uint32_t it = 0; it < (32 * STRIDE / 4 + 255) / 256; ++it) {
+        for (uint32_t it = 0; it < NSTG; ++it) {
             const uint32_t q4 = tid + 256 * it;  // float4 slot inside the 32-record slab
             uint4 v = make_uint4(0, 0, 0, 0);
             if (q4 < 32 * STRIDE / 4) {
-                const uint32_t qi = q4 / (STRIDE / 4);
+                const uint32_t qi = q4 / (STRIDE / 4), w4 = q4 - qi * (STRIDE / 4);
                 if (pb + qt * 32 + qi < pe)
                     v = *reinterpret_cast<const uint4 *>(recs + ((uint64_t)pb + qt * 32) * STRIDE + (uint64_t)q4 * 4);
-                else if (q4 - qi * (STRIDE / 4) == (OPDW + RQ_REC_THR) / 4)  // padding query: threshold -inf, empty range
-                    v = make_uint4(0, 0xFF800000u, 0, 0);                      // dwords 4..7 of the tail: ycd_sqrt, THR, LO, HI
+                else if (w4 == (OPDW + RQ_REC_THR) / 4)  // padding query: threshold -inf, empty range ...
+                    v = make_uint4(0, 0xFF800000u, 0, 0);  // dwords ycd_sqrt, THR, LO, HI
+                else if (w4 == (OPDW + RQ_REC_V0) / 4)   // ... and S* = +inf: never flagged
+                    v = make_uint4(0xFF800000u, 0, 0, 0);  // v'[0] = -inf (u'[0] < 0), v'[1..3] = 0
             }
             regs[it] = v;
         }
     };
-    auto stage_store = [&](uint32_t buf, const uint4 (&regs)[(32 * STRIDE / 4 + 255) / 256]) {
+    auto stage_store = [&](uint32_t buf, const uint4 (&regs)[NSTG]) {
 #pragma unroll
-        for (uint32_t it = 0; it < (32 * STRIDE / 4 + 255) / 256; ++it) {
+        for (uint32_t it = 0; it < NSTG; ++it) {
             const uint32_t q4 = tid + 256 * it;
             if (q4 < 32 * STRIDE / 4) {
                 const uint32_t qi = q4 / (STRIDE / 4), d4 = (q4 - qi * (STRIDE / 4)) * 4;
@@ -742,10 +778,10 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(SCAN_PARAMS) {
             }
         }
     };
-    uint4 sregs[(32 * STRIDE / 4 + 255) / 256];
+    uint4 sregs[NSTG];
     stage_load(0, sregs);
     stage_store(0, sregs);
-    __syncthreads();
+    __syncthreads();  // table + first query tile visible
 
     for (uint32_t qt = 0; qt < ntiles; ++qt) {
         const uint32_t buf = qt & 1;
@@ -761,43 +797,47 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(SCAN_PARAMS) {
         v4i32 aop[KS];  // A: query row j (= lane & 31), dims 32*sl + 16h .. +15
 #pragma unroll
         for (int sl = 0; sl < KS; ++sl) aop[sl] = *reinterpret_cast<const v4i32 *>(&opbuf[buf][j][8 * sl + 4 * h]);
+        float ua[3];    // A operand of the threshold MFMAs: v'_row[2m + h] (v'[5] = 0)
+        ua[0] = __builtin_bit_cast(float, tailT[buf][RQ_REC_V0 + h][j]);
+        ua[1] = __builtin_bit_cast(float, tailT[buf][RQ_REC_V0 + 2 + h][j]);
+        ua[2] = h ? 0.0f : __builtin_bit_cast(float, tailT[buf][RQ_REC_V0 + 4][j]);
 
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             v16i32 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int sl = 0; sl < KS; ++sl) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop[sl], bop[t][sl], acc, 0, 0, 0);
-            const f32x2 cds = {fac[t].w, fac[t].w}, ppc = {fac[t].y, fac[t].y}, fip = {fac[t].x, fac[t].x},
-                        eb = {fac[t].z, fac[t].z};
-            float rough[16];
-            uint64_t anym = 0;
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {  // hot path: the gate only
-                const int gr = 2 * p;
-                const uint32_t row0 = (gr & 3) + 8 * (gr >> 2) + 4 * h;  // even: rows row0, row0+1
-                const f32x2 lower = *reinterpret_cast<const f32x2 *>(&tailT[buf][RQ_REC_LOWER][row0]);
-                const f32x2 delta = *reinterpret_cast<const f32x2 *>(&tailT[buf][RQ_REC_DELTA][row0]);
-                const f32x2 sumq = *reinterpret_cast<const f32x2 *>(&tailT[buf][RQ_REC_SUMQ][row0]);
-                const f32x2 ycd = *reinterpret_cast<const f32x2 *>(&tailT[buf][RQ_REC_YCD][row0]);
-                const f32x2 ysq = *reinterpret_cast<const f32x2 *>(&tailT[buf][RQ_REC_YCD_SQRT][row0]);
-                const f32x2 thr = *reinterpret_cast<const f32x2 *>(&tailT[buf][RQ_REC_THR][row0]);
-                const f32x2 sf = {(float)acc[gr], (float)acc[gr + 1]};
-                f32x2 tt = cds + ycd;                 // center_distance_square + y_c_distance_square
-                tt = tt + lower * ppc;                // + lower_bound * factor_ppc
-                const f32x2 u = (2.0f * sf - sumq) * fip;
-                tt = tt + u * delta;
-                const f32x2 r = tt - eb * ysq;        // - error_bound * dist_sqrt
-                rough[gr] = r.x, rough[gr + 1] = r.y;
-                anym |= __ballot(r.x < thr.x) | __ballot(r.y < thr.y);  // src/rerank.rs:84 gate (range applied below)
+            for (int sl = 0; sl < KS; ++sl) {
+                // B: code bits of dims 32*sl + 16h .. +15 -> 16 bytes of 0/1 through the LDS table (expanded per
+                // use: keeping the expanded operand resident costs 64 VGPRs and a wave of occupancy)
+                const uint32_t bits = (craw[t][sl] >> (16 * h)) & 0xFFFFu;
+                const uint32_t b0 = bits & 0xFF, b1 = bits >> 8;
+                const v4i32 bv = {(int)lut[b0][0], (int)lut[b0][1], (int)lut[b1][0], (int)lut[b1][1]};
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop[sl], bv, acc, 0, 0, 0);
             }
-            if (anym) {  // wave-uniform and rare in the stages this kernel serves: ONE copy of the emit code
+            // S*(query row, candidate col) on the (otherwise idle) matrix pipe: exact-f32 k-ordered fma chain
+            f32x16 sth = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-                for (int gq = 0; gq < 16; ++gq) scratch[wave][gq][lane] = rough[gq];
-#pragma nounroll
-                for (uint32_t gq = 0; gq < 16; ++gq) {
+            for (int mm = 0; mm < 3; ++mm) sth = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[mm], ub[t][mm], sth, 0, 0, 0);
+            uint32_t gmask = forcemask ? 0xFFFFu : 0u;  // accumulator registers with at least one flagged lane
+#pragma unroll
+            for (int gq = 0; gq < 16; ++gq)
+                gmask |= (__ballot((float)acc[gq] > sth[gq]) != 0ull ? 1u : 0u) << gq;  // hot path: s > S*
+            if (gmask) {  // wave-uniform and rare in the stages this kernel serves: exact evaluation + emit
+#pragma unroll
+                for (int gq = 0; gq < 16; ++gq) scratch[wave][gq][lane] = (float)acc[gq];
+                const float4 fc = factors[list_begin + (lpos[t] < list_len ? lpos[t] : 0)];  // not kept in registers
+                while (gmask) {  // only the flagged registers
+                    const uint32_t gq = (uint32_t)__builtin_ctz(gmask);
+                    gmask &= gmask - 1;
                     const uint32_t row = (gq & 3) + 8 * (gq >> 2) + 4 * h;
-                    const float rg = scratch[wave][gq][lane];
-                    bool pass = rg < __builtin_bit_cast(float, tailT[buf][RQ_REC_THR][row]);
+                    const float sf = scratch[wave][gq][lane];
+                    // the reference's expression, left to right (src/rabitq.rs:352-363)
+                    float tt = fc.w + __builtin_bit_cast(float, tailT[buf][RQ_REC_YCD][row]);
+                    tt = tt + __builtin_bit_cast(float, tailT[buf][RQ_REC_LOWER][row]) * fc.y;
+                    const float u = (2.0f * sf - __builtin_bit_cast(float, tailT[buf][RQ_REC_SUMQ][row])) * fc.x;
+                    tt = tt + u * __builtin_bit_cast(float, tailT[buf][RQ_REC_DELTA][row]);
+                    const float rg = tt - fc.z * __builtin_bit_cast(float, tailT[buf][RQ_REC_YCD_SQRT][row]);
+                    bool pass = rg < __builtin_bit_cast(float, tailT[buf][RQ_REC_THR][row]);  // src/rerank.rs:84
                     if (!all_full) pass = pass && lpos[t] >= tailT[buf][RQ_REC_LO][row] && lpos[t] < tailT[buf][RQ_REC_HI][row];
                     const uint64_t m = __ballot(pass);
                     if (m == 0) continue;

@@ -182,6 +182,7 @@ struct rq_index {
     DevBuf<float4> factors;
     std::mutex ws_mu;
     std::vector<std::unique_ptr<Workspace>> ws_pool;
+    FactorStats fstats{0, 0, 0, 0};
     std::atomic<uint32_t> cap_hint{0};  // survivor-buffer capacity learnt from earlier batches
 };
 
@@ -441,7 +442,8 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                                            : (scan_is_fused(W) ? ws.qnib.p : reinterpret_cast<const uint32_t *>(ws.planes.p));
         stage_fill_kernel<<<ceil_div(npairs, 16), 256, 0, st>>>(ws.scal.p, ws.probe_cluster.p, operand, ws.thr.p, npairs,
                                                                 nprobe, use_mfma ? 16 * W : 8 * W, sg.s_lo, sg.s_hi,
-                                                                a.cluster_major, ws.grp_start.p, ws.grp_cnt.p, ws.recs.p);
+                                                                a.cluster_major, ws.grp_start.p, ws.grp_cnt.p, ws.recs.p,
+                                                                idx->fstats);
         pf.end();
         sp.codes = reinterpret_cast<const uint32_t *>(idx->codes.p);
         sp.factors = idx->factors.p;
@@ -675,6 +677,14 @@ static rq_status finish_index(rq_index *idx) {
     HIPC(hipMemset(mx.p, 0, 4));
     if (idx->k) max_list_len_kernel<<<ceil_div(idx->k, 256), 256>>>(idx->offsets.p, idx->k, mx.p);
     HIPC(hipMemcpy(&idx->max_list_len, mx.p, 4, hipMemcpyDeviceToHost));
+    {  // Factor bounds for the integer-threshold form of the gate
+        DevBuf<uint32_t> st4;
+        RQC(st4.alloc(4));
+        HIPC(hipMemset(st4.p, 0, 16));
+        if (idx->n)
+            factor_stats_kernel<<<(uint32_t)std::min<uint64_t>(ceil_div(idx->n, 256), 4096), 256>>>(idx->factors.p, idx->n, st4.p);
+        HIPC(hipMemcpy(&idx->fstats, st4.p, 16, hipMemcpyDeviceToHost));
+    }
     HIPC(hipDeviceSynchronize());
     HIPC(hipGetLastError());
     return RQ_OK;
