@@ -201,7 +201,7 @@ def main():
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                "kernel": "scan_kernel", "launches": int(launches),
+                "kernel": "scan_mfma_kernel<W,NT> (batched stages) + scan_kernel<W,CPL> (early / small stages)", "launches": int(launches),
                 "avg_launch_ms": round(prof["ms_scan"] / launches, 4),
                 "algorithmic_bytes_per_launch": int(prof["scan_bytes"] / launches),
                 "note": "achieved = algorithmic bytes (sum over probed lists of len*(dim/8+16) per query) / scan "
