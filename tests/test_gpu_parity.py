@@ -536,3 +536,29 @@ def test_scan_implementations_match_oracle(rq, oracle, impl, n, d, k, nq):
         ix.set_option("scan_impl", 0)
     gidx.close()
     oidx.close()
+
+
+@pytest.mark.parametrize("impl", [1, 2])
+def test_scan_degenerate_factors_both_implementations(rq, oracle, impl):
+    # vectors that coincide with their centroid (zero residual: norm not `is_normal` -> ip = 0.8, factor_ip = -0,
+    # rabitq.rs:211-215) and queries that coincide with a centroid (delta = 0 -> 1/delta = inf): the integer
+    # threshold form of the matrix-core scan is not applicable there and must fall back to the exact gate
+    from rabitq_amd import index as ix
+    d, k, n = 128, 6, 3000
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.6, seed=91, centre_scale=0.7)
+    x[:40] = centres[np.arange(40) % k]                  # exact copies of centroids
+    x[40:60] = x[60:80]                                  # duplicates
+    P = np.eye(d, dtype=np.float32)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    gidx = rq.RaBitQ.build(x, centres, P)
+    assert np.array_equal(bits(gidx.factors), bits(oidx.factors))
+    assert (oidx.factors[:, 0] == 0).sum() >= 40          # the -0.0 factor_ip rows are really there
+    queries = np.concatenate([centres[:4], x[:4], x[100:140] + np.float32(0.01)]).astype(np.float32)
+    ix.set_option("scan_impl", impl)
+    try:
+        for probe, topk, heur in ((k, 10, False), (2, 3, False), (k, 100, False), (k, 10, True)):
+            _compare_with_oracle(rq, oracle, oidx, gidx, queries, probe, topk, heur)
+    finally:
+        ix.set_option("scan_impl", 0)
+    gidx.close()
+    oidx.close()
