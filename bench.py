@@ -147,9 +147,22 @@ def main():
     out_i = torch.zeros((B, topk), device=dev, dtype=torch.int32)
     out_n = torch.zeros((B,), device=dev, dtype=torch.int32)
 
+    pc_local = torch.zeros((B, nprobe), device=dev, dtype=torch.int32)
+    pd_local = torch.zeros((B, nprobe), device=dev, dtype=torch.float32)
+
     def step():
-        idx.query_batch_device(queries.data_ptr(), B, d, nprobe, topk, out_d.data_ptr(), out_i.data_ptr(),
-                               out_n.data_ptr())
+        if world > 1:
+            # each rank ranks only the lists it owns; one all-gather merges the per-rank nearest lists
+            idx.coarse_topk_device(queries.data_ptr(), B, d, rank * k_local, (rank + 1) * k_local, nprobe,
+                                   pc_local.data_ptr(), pd_local.data_ptr())
+            pcl, pdl = (pc_local.cpu(), pd_local.cpu()) if args.backend == "gloo" else (pc_local, pd_local)
+            pc, pdist = sharding.merge_probe_lists(pcl, pdl, nprobe)
+            pc, pdist = pc.to(dev), pdist.to(dev)
+            idx.query_batch_device_probed(queries.data_ptr(), B, d, pc.data_ptr(), pdist.data_ptr(), nprobe, topk,
+                                          out_d.data_ptr(), out_i.data_ptr(), out_n.data_ptr())
+        else:
+            idx.query_batch_device(queries.data_ptr(), B, d, nprobe, topk, out_d.data_ptr(), out_i.data_ptr(),
+                                   out_n.data_ptr())
         if world > 1:
             pay = sharding.pack_topk(out_d, out_i.to(torch.int64) & 0xFFFFFFFF, out_n, rank * n)
             if args.backend == "gloo":

@@ -129,6 +129,21 @@ rq_status rq_query_batch_device(const rq_index *idx, const float *d_queries, uin
                                 uint32_t len, uint32_t probe, uint32_t topk, int heuristic_rank,
                                 float *d_out_dist, uint32_t *d_out_id, uint32_t *d_out_n);
 
+/* ---- sharded deployments (one index shard per GPU / process) ----------------------------------- */
+/* The coarse ranking of src/rabitq.rs:283-297 restricted to lists [list_lo, list_hi): the `probe`
+ * nearest of them per query, ascending, as (global list id, distance); rows are `probe` wide, padded
+ * with (0xFFFFFFFF, +inf) when the range holds fewer lists.  A shard ranks only the lists it owns;
+ * the per-shard rows are all-gathered and merged by the caller (rabitq_amd/sharding.py). */
+rq_status rq_coarse_topk_device(const rq_index *idx, const float *d_queries, uint32_t nq, uint32_t len,
+                                uint32_t list_lo, uint32_t list_hi, uint32_t probe, uint32_t *d_out_cluster,
+                                float *d_out_dist);
+/* rq_query_batch_device with the probe lists supplied by the caller (nq x probe, visiting order,
+ * 0xFFFFFFFF = no list; probe <= k) instead of ranked internally. */
+rq_status rq_query_batch_device_probed(const rq_index *idx, const float *d_queries, uint32_t nq, uint32_t len,
+                                       const uint32_t *d_probe_cluster, const float *d_probe_dist, uint32_t probe,
+                                       uint32_t topk, int heuristic_rank, float *d_out_dist, uint32_t *d_out_id,
+                                       uint32_t *d_out_n);
+
 /* ---- metrics: METRICS, src/metrics.rs:65 ------------------------------------------------------ */
 rq_status rq_metrics(rq_metrics_t *out);
 rq_status rq_metrics_reset(void);

@@ -57,7 +57,8 @@ template <int QT>
 __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restrict__ cent_t,
                                                           const float *__restrict__ y,
                                                           float *__restrict__ dist, uint32_t k,
-                                                          uint32_t dim, uint32_t nq) {
+                                                          uint32_t dim, uint32_t nq, uint32_t kstride) {
+    // cent_t points at the first list of the range; k = number of lists ranked, kstride = row stride
     extern __shared__ __attribute__((aligned(16))) float ys[];  // QT * dim
     const uint32_t q0 = blockIdx.x * QT;
     const uint32_t j = blockIdx.y * 256 + threadIdx.x;
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restric
     for (uint32_t c = 0; c < dim; c += 8) {
 #pragma unroll
         for (int l = 0; l < 8; ++l) {
-            float ce = live ? cent_t[(uint64_t)(c + l) * k + j] : 0.0f;
+            float ce = live ? cent_t[(uint64_t)(c + l) * kstride + j] : 0.0f;
             f32x2 ce2 = {ce, ce};
 #pragma unroll
             for (int v = 0; v < QT / 2; ++v) {
@@ -149,7 +150,8 @@ __device__ __forceinline__ void bitonic_sort_block(T *a, uint32_t n, KeyFn key) 
 __global__ __launch_bounds__(256) void select_probe_kernel(const float *__restrict__ dist, uint32_t k,
                                                            uint32_t nprobe,
                                                            uint32_t *__restrict__ out_cluster,
-                                                           float *__restrict__ out_dist) {
+                                                           float *__restrict__ out_dist, uint32_t id_offset,
+                                                           uint32_t out_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem_raw);  // nprobe entries
     __shared__ uint32_t hist[256];
@@ -212,8 +214,12 @@ __global__ __launch_bounds__(256) void select_probe_kernel(const float *__restri
     bitonic_sort_block(keys, nprobe, [](uint64_t v) { return v; });
     for (uint32_t i = tid; i < nprobe; i += 256) {
         uint64_t key = keys[i];
-        out_cluster[(uint64_t)b * nprobe + i] = (uint32_t)key;
-        out_dist[(uint64_t)b * nprobe + i] = ord32_unbias((uint32_t)(key >> 32));
+        out_cluster[(uint64_t)b * out_stride + i] = (uint32_t)key + id_offset;
+        out_dist[(uint64_t)b * out_stride + i] = ord32_unbias((uint32_t)(key >> 32));
+    }
+    for (uint32_t i = nprobe + tid; i < out_stride; i += 256) {  // fewer lists than requested: "no list"
+        out_cluster[(uint64_t)b * out_stride + i] = 0xFFFFFFFFu;
+        out_dist[(uint64_t)b * out_stride + i] = __builtin_inff();
     }
 }
 
@@ -235,12 +241,24 @@ __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ y,
                                                    uint64_t *__restrict__ planes,
                                                    uint32_t *__restrict__ qnib,
                                                    uint8_t *__restrict__ qbytes,
-                                                   uint32_t *__restrict__ out_sum_u32) {
+                                                   uint32_t *__restrict__ out_sum_u32, uint32_t nlists,
+                                                   uint32_t skip_empty) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= npairs) return;
     const uint32_t row = p / pairs_per_row;
     const uint32_t c = pair_cluster[p];
+    const uint32_t len_c = c < nlists ? offsets[c + 1] - offsets[c] : 0u;
+    if (len_c == 0 && skip_empty) {  // nothing to scan for this pair (e.g. a list another shard owns)
+        if (lane == 0) {
+            PairScalars s;
+            s.lower = 0.0f, s.delta = 0.0f, s.sumq = 0.0f, s.ycd = pair_ycd[p], s.ycd_sqrt = 0.0f;
+            s.row = row, s.list_begin = 0, s.list_len = 0, s.stream_begin = 0, s.pad = 0;
+            scal[p] = s;
+            if (out_sum_u32) out_sum_u32[p] = 0;
+        }
+        return;
+    }
     const float *yr = y + (uint64_t)row * dim;
     const float *cr = centroids + (uint64_t)c * dim;
     const uint32_t W = dim >> 6;

@@ -342,9 +342,12 @@ struct PassResult {
 
 // Runs one pass over nq queries already resident at d_q (nq x len).  Results go to row
 // row_map[b] (or b) of the output arrays.  On return the stream is synchronised.
+// ext_cluster / ext_dist (nq x min(probe,k), device): if given, the probe lists are taken from there
+// (visiting order as supplied; id 0xFFFFFFFF = no list) instead of being ranked here.
 static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, const QueryParams &qp,
                           const uint32_t *d_row_map, float *d_out_dist, uint32_t *d_out_id, uint32_t *d_out_n,
-                          PassResult *res, rq_profile_t *prof_acc) {
+                          PassResult *res, rq_profile_t *prof_acc, const uint32_t *ext_cluster = nullptr,
+                          const float *ext_dist = nullptr) {
     const uint32_t dim = idx->dim, k = idx->k, W = idx->W;
     const uint32_t nq = qp.nq, nprobe = std::min(qp.probe, k), topk = qp.topk;
     const uint32_t npairs = nq * nprobe;
@@ -365,20 +368,27 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     pf.end();
 
     // 2. coarse distances + probe selection (:283-297)
-    pf.begin(PF_COARSE);
-    coarse_dist_kernel<4><<<dim3(ceil_div(nq, 4), ceil_div(k, 256)), 256, 4 * dim * sizeof(float), st>>>(
-        idx->cent_t.p, ws.y.p, ws.dist.p, k, dim, nq);
-    pf.end();
-    pf.begin(PF_SELECT);
-    select_probe_kernel<<<nq, 256, (size_t)nprobe * 8, st>>>(ws.dist.p, k, nprobe, ws.probe_cluster.p,
-                                                              ws.probe_dist.p);
-    pf.end();
+    const uint32_t *probe_cluster = ws.probe_cluster.p;
+    const float *probe_dist = ws.probe_dist.p;
+    if (ext_cluster) {
+        probe_cluster = ext_cluster;
+        probe_dist = ext_dist;
+    } else {
+        pf.begin(PF_COARSE);
+        coarse_dist_kernel<4><<<dim3(ceil_div(nq, 4), ceil_div(k, 256)), 256, 4 * dim * sizeof(float), st>>>(
+            idx->cent_t.p, ws.y.p, ws.dist.p, k, dim, nq, k);
+        pf.end();
+        pf.begin(PF_SELECT);
+        select_probe_kernel<<<nq, 256, (size_t)nprobe * 8, st>>>(ws.dist.p, k, nprobe, ws.probe_cluster.p, ws.probe_dist.p, 0,
+                                                                  nprobe);
+        pf.end();
+    }
 
     // 3. per-pair query quantisation (:304-317)
     pf.begin(PF_PREP);
-    prep_kernel<<<ceil_div(npairs, 4), 256, 0, st>>>(ws.y.p, idx->centroids.p, idx->offsets.p, ws.probe_cluster.p,
-                                                     ws.probe_dist.p, npairs, nprobe, dim, ws.scal.p, ws.planes.p,
-                                                     ws.qnib.p, ws.qbytes.p, nullptr);
+    prep_kernel<<<ceil_div(npairs, 4), 256, 0, st>>>(ws.y.p, idx->centroids.p, idx->offsets.p, probe_cluster, probe_dist,
+                                                     npairs, nprobe, dim, ws.scal.p, ws.planes.p, ws.qnib.p, ws.qbytes.p,
+                                                     nullptr, k, 1u);
     pair_prefix_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(ws.scal.p, nq, nprobe, ws.rough_cnt.p);
     ReplayState rs;
     rs.thr = ws.thr.p, rs.heap_len = ws.heap_len.p, rs.heap_key = ws.heap_key.p, rs.heap_id = ws.heap_id.p;
@@ -430,7 +440,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         a.cluster_major = cluster_major ? 1u : 0u;
         if (cluster_major) {
             HIPC(hipMemsetAsync(ws.grp_cnt.p, 0, (k + 1) * 4, st));
-            group_count_kernel<<<ceil_div(npairs, 256), 256, 0, st>>>(ws.scal.p, ws.probe_cluster.p, npairs, sg.s_lo,
+            group_count_kernel<<<ceil_div(npairs, 256), 256, 0, st>>>(ws.scal.p, probe_cluster, npairs, sg.s_lo,
                                                                       sg.s_hi, ws.grp_cnt.p);
             group_scan_kernel<<<1, 1024, 0, st>>>(ws.grp_cnt.p, k, ws.grp_start.p);
             a.ngroups = k;
@@ -440,7 +450,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         // pack the stage's work records (query operand + scalars + current threshold + local range)
         const uint32_t *operand = use_mfma ? reinterpret_cast<const uint32_t *>(ws.qbytes.p)
                                            : (scan_is_fused(W) ? ws.qnib.p : reinterpret_cast<const uint32_t *>(ws.planes.p));
-        stage_fill_kernel<<<ceil_div(npairs, 16), 256, 0, st>>>(ws.scal.p, ws.probe_cluster.p, operand, ws.thr.p, npairs,
+        stage_fill_kernel<<<ceil_div(npairs, 16), 256, 0, st>>>(ws.scal.p, probe_cluster, operand, ws.thr.p, npairs,
                                                                 nprobe, use_mfma ? 16 * W : 8 * W, sg.s_lo, sg.s_hi,
                                                                 a.cluster_major, ws.grp_start.p, ws.grp_cnt.p, ws.recs.p,
                                                                 idx->fstats);
@@ -542,7 +552,8 @@ static void ws_release(rq_index *idx, Workspace *w) {
 // queries/outputs in device memory
 static rq_status query_device(rq_index *idx, const float *d_q, uint32_t nq, uint32_t len, uint32_t probe,
                               uint32_t topk, bool heuristic, float *d_out_dist, uint32_t *d_out_id,
-                              uint32_t *d_out_n) {
+                              uint32_t *d_out_n, const uint32_t *ext_cluster = nullptr,
+                              const float *ext_dist = nullptr) {
     RQC(ensure_device());
     if (!idx || !d_q || !d_out_dist || !d_out_id || !d_out_n) return fail(RQ_ERR_INVALID, "null argument");
     if (idx->dim != (len + 63) / 64 * 64)  // rabitq.rs:275
@@ -574,8 +585,11 @@ static rq_status query_device(rq_index *idx, const float *d_q, uint32_t nq, uint
         QueryParams qp{step_nq, len, probe, topk, heuristic, cap0, cap0};
         RQC(ws_prepare(idx, *ws, qp));
         PassResult pr;
+        const uint32_t npb = std::min(probe, idx->k);
         RQC(run_pass(idx, *ws, d_q + (uint64_t)q0 * len, qp, nullptr, d_out_dist + (uint64_t)q0 * topk,
-                     d_out_id + (uint64_t)q0 * topk, d_out_n + q0, &pr, &prof));
+                     d_out_id + (uint64_t)q0 * topk, d_out_n + q0, &pr, &prof,
+                     ext_cluster ? ext_cluster + (uint64_t)q0 * npb : nullptr,
+                     ext_dist ? ext_dist + (uint64_t)q0 * npb : nullptr));
         tot_rough += pr.rough;
         tot_precise += pr.precise;
         if (pr.max_need > cap0) {  // remember (with headroom) so that later batches do not overflow
@@ -619,8 +633,21 @@ static rq_status query_device(rq_index *idx, const float *d_q, uint32_t nq, uint
                     gather_rows_kernel<<<ceil_div((uint64_t)m * len, 256), 256, 0, rws.stream>>>(
                         d_q + (uint64_t)q0 * len, sub_rows.p, m, len, sub_q.p);
                     PassResult rr;
+                    const uint32_t *sub_pc = nullptr;
+                    const float *sub_pd = nullptr;
+                    DevBuf<float> sub_probe_d, sub_probe_c;
+                    if (ext_cluster) {  // the caller's probe lists, restricted to the re-run queries
+                        RQC(sub_probe_c.ensure((uint64_t)m * npb));
+                        RQC(sub_probe_d.ensure((uint64_t)m * npb));
+                        gather_rows_kernel<<<ceil_div((uint64_t)m * npb, 256), 256, 0, rws.stream>>>(
+                            reinterpret_cast<const float *>(ext_cluster + (uint64_t)q0 * npb), sub_rows.p, m, npb, sub_probe_c.p);
+                        gather_rows_kernel<<<ceil_div((uint64_t)m * npb, 256), 256, 0, rws.stream>>>(
+                            ext_dist + (uint64_t)q0 * npb, sub_rows.p, m, npb, sub_probe_d.p);
+                        sub_pc = reinterpret_cast<const uint32_t *>(sub_probe_c.p);
+                        sub_pd = sub_probe_d.p;
+                    }
                     RQC(run_pass(idx, rws, sub_q.p, rq, sub_rows.p, d_out_dist + (uint64_t)q0 * topk,
-                                 d_out_id + (uint64_t)q0 * topk, d_out_n + q0, &rr, nullptr));
+                                 d_out_id + (uint64_t)q0 * topk, d_out_n + q0, &rr, nullptr, sub_pc, sub_pd));
                     tot_precise += rr.precise;
                     if (rr.overflowed) {
                         std::vector<uint32_t> n2(m), a2(m);
@@ -1145,6 +1172,44 @@ rq_status rq_get_array(const rq_index *idx, int which, void *dst, uint64_t dst_b
     return RQ_OK;
 }
 
+rq_status rq_coarse_topk_device(const rq_index *idx, const float *d_queries, uint32_t nq, uint32_t len,
+                                uint32_t list_lo, uint32_t list_hi, uint32_t probe, uint32_t *d_out_cluster,
+                                float *d_out_dist) {
+    RQC(ensure_device());
+    if (!idx || !d_queries || !d_out_cluster || !d_out_dist) return fail(RQ_ERR_INVALID, "null argument");
+    if (idx->dim != (len + 63) / 64 * 64) return fail(RQ_ERR_DIM_MISMATCH, "query length does not pad to dim");
+    if (probe == 0 || list_lo >= list_hi || list_hi > idx->k) return fail(RQ_ERR_INVALID, "bad list range / probe");
+    if (probe > RQ_MAX_PROBE) return fail(RQ_ERR_UNSUPPORTED, "probe > 16384");
+    if (nq == 0) return RQ_OK;
+    const uint32_t dim = idx->dim, kc = list_hi - list_lo, np = std::min(probe, kc);
+    DevBuf<float> qpad, y, dist;
+    RQC(y.alloc((uint64_t)nq * dim));
+    RQC(dist.alloc((uint64_t)nq * kc));
+    const float *qp = d_queries;
+    if (len != dim) {
+        RQC(qpad.alloc((uint64_t)nq * dim));
+        pad_rows_kernel<<<ceil_div((uint64_t)nq * dim, 256), 256>>>(d_queries, qpad.p, nq, len, dim);
+        qp = qpad.p;
+    }
+    launch_rotate(qp, idx->P.p, y.p, nq, dim, nq >= 32, nullptr);
+    coarse_dist_kernel<4><<<dim3(ceil_div(nq, 4), ceil_div(kc, 256)), 256, 4 * dim * sizeof(float)>>>(
+        idx->cent_t.p + list_lo, y.p, dist.p, kc, dim, nq, idx->k);
+    select_probe_kernel<<<nq, 256, (size_t)np * 8>>>(dist.p, kc, np, d_out_cluster, d_out_dist, list_lo, probe);
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipGetLastError());
+    return RQ_OK;
+}
+
+rq_status rq_query_batch_device_probed(const rq_index *idx, const float *d_queries, uint32_t nq, uint32_t len,
+                                       const uint32_t *d_probe_cluster, const float *d_probe_dist, uint32_t probe,
+                                       uint32_t topk, int heuristic_rank, float *d_out_dist, uint32_t *d_out_id,
+                                       uint32_t *d_out_n) {
+    if (!d_probe_cluster || !d_probe_dist) return fail(RQ_ERR_INVALID, "null probe lists");
+    if (idx && probe > idx->k) return fail(RQ_ERR_INVALID, "probe lists must have min(probe, k) columns: pass probe <= k");
+    return query_device(const_cast<rq_index *>(idx), d_queries, nq, len, probe, topk, heuristic_rank != 0, d_out_dist,
+                        d_out_id, d_out_n, d_probe_cluster, d_probe_dist);
+}
+
 rq_status rq_query_batch_device(const rq_index *idx, const float *d_queries, uint32_t nq, uint32_t len,
                                 uint32_t probe, uint32_t topk, int heuristic_rank, float *d_out_dist,
                                 uint32_t *d_out_id, uint32_t *d_out_n) {
@@ -1325,8 +1390,8 @@ rq_status rq_coarse_rank(const rq_index *idx, const float *queries, uint32_t nq,
     pad_rows_kernel<<<ceil_div((uint64_t)nq * dim, 256), 256>>>(dq.p, qpad.p, nq, len, dim);
     launch_rotate(qpad.p, idx->P.p, y.p, nq, dim, nq >= 32, nullptr);
     coarse_dist_kernel<4><<<dim3(ceil_div(nq, 4), ceil_div(k, 256)), 256, 4 * dim * sizeof(float)>>>(
-        idx->cent_t.p, y.p, dist.p, k, dim, nq);
-    select_probe_kernel<<<nq, 256, (size_t)nprobe * 8>>>(dist.p, k, nprobe, pc.p, pd.p);
+        idx->cent_t.p, y.p, dist.p, k, dim, nq, k);
+    select_probe_kernel<<<nq, 256, (size_t)nprobe * 8>>>(dist.p, k, nprobe, pc.p, pd.p, 0, nprobe);
     HIPC(hipDeviceSynchronize());
     HIPC(hipGetLastError());
     if (out_y) HIPC(hipMemcpy(out_y, y.p, (uint64_t)nq * dim * 4, hipMemcpyDeviceToHost));
@@ -1357,7 +1422,7 @@ rq_status rq_query_prep(const rq_index *idx, const float *y, uint32_t nq, const 
     HIPC(hipMemcpy(dc.p, cluster, nq * 4, hipMemcpyHostToDevice));
     HIPC(hipMemset(ycd.p, 0, nq * 4));
     prep_kernel<<<ceil_div(nq, 4), 256>>>(dy.p, idx->centroids.p, idx->offsets.p, dc.p, ycd.p, nq, 1, dim, scal.p,
-                                          planes.p, nullptr, nullptr, dsum.p);
+                                          planes.p, nullptr, nullptr, dsum.p, idx->k, 0u);
     HIPC(hipDeviceSynchronize());
     HIPC(hipGetLastError());
     std::vector<PairScalars> hs(nq);

@@ -178,6 +178,22 @@ class RaBitQ:
                                           C.c_void_p(out_dist_ptr), C.c_void_p(out_id_ptr), C.c_void_p(out_n_ptr)))
 
 
+    # ---- sharded deployments ---------------------------------------------------------------------
+    def coarse_topk_device(self, q_ptr: int, nq: int, length: int, list_lo: int, list_hi: int, probe: int,
+                           out_cluster_ptr: int, out_dist_ptr: int) -> None:
+        """The `probe` nearest lists among [list_lo, list_hi) per query (device buffers nq x probe)."""
+        check(lib().rq_coarse_topk_device(self._h, C.c_void_p(q_ptr), nq, length, list_lo, list_hi, probe,
+                                          C.c_void_p(out_cluster_ptr), C.c_void_p(out_dist_ptr)))
+
+    def query_batch_device_probed(self, q_ptr: int, nq: int, length: int, probe_cluster_ptr: int, probe_dist_ptr: int,
+                                  probe: int, topk: int, out_dist_ptr: int, out_id_ptr: int, out_n_ptr: int,
+                                  heuristic_rank: bool = False) -> None:
+        """query_batch_device with caller-supplied probe lists (nq x probe, visiting order)."""
+        check(lib().rq_query_batch_device_probed(self._h, C.c_void_p(q_ptr), nq, length, C.c_void_p(probe_cluster_ptr),
+                                                 C.c_void_p(probe_dist_ptr), probe, topk, int(heuristic_rank),
+                                                 C.c_void_p(out_dist_ptr), C.c_void_p(out_id_ptr), C.c_void_p(out_n_ptr)))
+
+
 # ---- METRICS (src/metrics.rs) --------------------------------------------------------------------
 def metrics() -> dict:
     m = MetricsT()

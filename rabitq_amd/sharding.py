@@ -49,3 +49,24 @@ def merge_shard_topk(payload: torch.Tensor, topk: int, group=None):
     k32 = key.clamp(max=2**31 - 1).to(torch.int32)
     bits = torch.where(k32 < 0, k32 ^ 0x7FFFFFFF, k32)
     return bits.view(torch.float32), gid, counts
+
+
+def merge_probe_lists(cluster: torch.Tensor, dist_t: torch.Tensor, nprobe: int, group=None):
+    """Sharded coarse ranking (src/rabitq.rs:283-297 over lists owned by different ranks): every rank
+    passes its (nq, nprobe) nearest OWN lists (global ids as int32/uint32 bits, f32 distances, padded
+    with id 0xFFFFFFFF / +inf); one all-gather, then the nprobe nearest overall per query, ascending
+    by (distance, list id) -- the same order a single index would visit them in.
+    Returns (cluster int32 (nq, nprobe) with the u32 bit patterns, dist f32 (nq, nprobe))."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    bits = dist_t.contiguous().view(torch.int32).to(torch.int64)          # distances are >= 0: bits order like values
+    ids = cluster.to(torch.int64) & 0xFFFFFFFF
+    key = (bits << 32) | ids
+    if world > 1:
+        flat = key.contiguous().reshape(-1)
+        gathered = torch.empty(world * flat.numel(), dtype=key.dtype, device=key.device)
+        dist.all_gather_into_tensor(gathered, flat, group=group)
+        key = gathered.reshape(world, *key.shape).permute(1, 0, 2).reshape(key.shape[0], -1)
+    key = torch.sort(key, dim=1).values[:, :nprobe]
+    out_ids = (key & 0xFFFFFFFF).to(torch.int32)      # wraps to the u32 bit pattern
+    out_dist = (key >> 32).to(torch.int32).view(torch.float32)
+    return out_ids.contiguous(), out_dist.contiguous()

@@ -562,3 +562,42 @@ def test_scan_degenerate_factors_both_implementations(rq, oracle, impl):
         ix.set_option("scan_impl", 0)
     gidx.close()
     oidx.close()
+
+
+# ---- sharded coarse ranking + externally supplied probe lists -----------------------------------------
+def test_sharded_coarse_and_probed_query_equal_single(rq):
+    import torch
+    from rabitq_amd import sharding
+    dev = torch.device("cuda", 0)
+    n, d, k, nq, probe, topk = 6000, 128, 40, 50, 12, 10
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.8, seed=61, centre_scale=0.6)
+    centres[7] = centres[3]                                   # tied coarse distances across the two "shards"
+    idx = rq.RaBitQ.build(x, centres, synth.random_orthogonal(d, seed=62))
+    queries, _, _ = synth.mixture(nq, d, k, sigma=0.8, seed=63, centre_scale=0.6)
+    _, want_cl, want_cd = rq.ops.coarse_rank(idx, queries, probe)
+    q = torch.from_numpy(queries).to(dev)
+    parts = []
+    for lo, hi in ((0, 5), (5, 23), (23, 40)):                # first range holds fewer lists than `probe`: padding
+        pc = torch.zeros((nq, probe), device=dev, dtype=torch.int32)
+        pdd = torch.zeros((nq, probe), device=dev, dtype=torch.float32)
+        idx.coarse_topk_device(q.data_ptr(), nq, d, lo, hi, probe, pc.data_ptr(), pdd.data_ptr())
+        parts.append((pc, pdd))
+    assert (parts[0][0][:, 5:] == -1).all() and torch.isinf(parts[0][1][:, 5:]).all()
+    pc = torch.cat([p[0] for p in parts], 1)
+    pdd = torch.cat([p[1] for p in parts], 1)
+    mc, md = sharding.merge_probe_lists(pc, pdd, probe)      # world 1: the merge of the concatenated rows
+    assert np.array_equal(mc.cpu().numpy().view(np.uint32), want_cl)
+    assert np.array_equal(md.cpu().numpy().view(np.uint32), want_cd.view(np.uint32))
+    od = torch.empty((nq, topk), device=dev)
+    oi = torch.zeros((nq, topk), device=dev, dtype=torch.int32)
+    on = torch.zeros(nq, device=dev, dtype=torch.int32)
+    rq.metrics_reset()
+    idx.query_batch_device_probed(q.data_ptr(), nq, d, mc.data_ptr(), md.data_ptr(), probe, topk, od.data_ptr(),
+                                  oi.data_ptr(), on.data_ptr())
+    m1 = rq.metrics()
+    rq.metrics_reset()
+    wd, wi, wn = idx.query_batch(queries, probe, topk)
+    assert rq.metrics() == m1
+    assert np.array_equal(on.cpu().numpy().view(np.uint32), wn)
+    assert np.array_equal(oi.cpu().numpy().view(np.uint32), wi) and np.array_equal(od.cpu().numpy().view(np.uint32), wd.view(np.uint32))
+    idx.close()

@@ -47,6 +47,23 @@ def _worker(rank, world, port, out_dir):
         cnt[3] = 4                                                       # a ragged shard result
     payload = pack_topk(torch.from_numpy(dd), torch.from_numpy(ii), torch.from_numpy(cnt), id_offset=lo)
     md, mi, mc = merge_shard_topk(payload, topk)
+    # sharded coarse ranking: each rank owns half of the lists
+    from rabitq_amd.sharding import merge_probe_lists
+    klo, khi = rank * k // world, (rank + 1) * k // world
+    npq = 5
+    pcl = np.full((len(queries), npq), -1, np.int32)
+    pdl = np.full((len(queries), npq), np.inf, np.float32)
+    full_c, full_d = [], []
+    for qi, q in enumerate(queries):
+        y = idx.rotate_query(q)
+        cl, cd = idx.coarse_rank(y, k)
+        full_c.append(cl[:npq]), full_d.append(cd[:npq])
+        own = [(dv, cv) for cv, dv in zip(cl, cd) if klo <= cv < khi][:npq]
+        for t, (dv, cv) in enumerate(own):
+            pcl[qi, t], pdl[qi, t] = cv, dv
+    gc, gd = merge_probe_lists(torch.from_numpy(pcl), torch.from_numpy(pdl), npq)
+    assert np.array_equal(gc.numpy().view(np.uint32), np.array(full_c, np.uint32)), "merged probe lists differ from the single-index ranking"
+    assert np.array_equal(gd.numpy().view(np.uint32), np.array(full_d, np.float32).view(np.uint32))
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), d=md.numpy(), i=mi.numpy(), c=mc.numpy(), sd=dd, si=ii + lo, sc=cnt)
     dist.barrier()
     dist.destroy_process_group()
