@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ y,
                                                    PairScalars *__restrict__ scal,
                                                    uint64_t *__restrict__ planes,
                                                    uint32_t *__restrict__ qnib,
-                                                   uint8_t *__restrict__ qbytes,
+                                                   uint32_t *__restrict__ qf6,
                                                    uint32_t *__restrict__ out_sum_u32, uint32_t nlists,
                                                    uint32_t skip_empty) {
     const uint32_t lane = threadIdx.x & 63;
@@ -287,7 +287,26 @@ __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ y,
             uint64_t word = __ballot((q >> bit) & 1);
             if (lane == 0) pl[bit * W + w] = word;
         }
-        if (qbytes) qbytes[(uint64_t)p * dim + 64 * w + lane] = (uint8_t)((uint32_t)q & 15u);  // i8 MFMA operand
+        if (qf6) {  // matrix-core operand: q/2 as fp6 e2m3 (every integer 0..15 is exact), 6-bit fields packed as a
+                    // little-endian bit stream; lane half h = lane>>5 of word w <-> the 6 dwords [h][w][0..6)
+            const uint32_t v = (uint32_t)q & 15u;
+            const uint32_t c6 = v < 4 ? 4 * v : (v < 8 ? 8 + 2 * v : 16 + v);
+            const uint32_t i16 = lane & 15, bitpos = 6 * i16, d0 = bitpos >> 5, off = bitpos & 31;
+            const uint64_t wide = (uint64_t)c6 << off;
+            const uint32_t lo32 = (uint32_t)wide, hi32 = (uint32_t)(wide >> 32);
+            uint32_t w0 = d0 == 0 ? lo32 : 0u;
+            uint32_t w1 = d0 == 0 ? hi32 : (d0 == 1 ? lo32 : 0u);
+            uint32_t w2 = d0 == 1 ? hi32 : (d0 == 2 ? lo32 : 0u);
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                w0 |= __shfl_xor(w0, o, 16);
+                w1 |= __shfl_xor(w1, o, 16);
+                w2 |= __shfl_xor(w2, o, 16);
+            }
+            if (i16 < 3)
+                qf6[(uint64_t)p * 12 * W + (lane >> 5) * 6 * W + 6 * w + 3 * ((lane >> 4) & 1) + i16] =
+                    i16 == 0 ? w0 : (i16 == 1 ? w1 : w2);
+        }
         if (qnib) {  // the same 4-bit codes packed 8 per dword (dword m <-> dims 8m..8m+7, nibble i <-> dim 8m+i):
                      // the operand form of v_dot8_u32_u4 used by the fused scan kernel
             uint32_t nib = ((uint32_t)q & 15u) << (4 * (lane & 7));
@@ -385,8 +404,9 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(uint32_t *__restrict__
 
 // Per-stage work records.  Everything the scan needs about one (query, list) pair, contiguous, so
 // that the scan's inner loop is one pointer bump plus immediate-offset scalar loads:
-//   dwords [0, 8W)      query operand: 4-bit codes 8 per dword (fused kernel) or the 4 bit planes
-//   dwords 8W + ...     RQ_REC_* below
+//   dwords [0, opdw)    query operand: 4-bit codes 8 per dword (fused kernel, 8W), the 4 bit planes (8W), or
+//                       the fp6 image of the codes (matrix-core kernel, 12W)
+//   dwords opdw + ...   RQ_REC_* below
 // Cluster-major: records of the pairs probing list c are stored at grp_start[c] ...; pair-major:
 // record i belongs to pair i (pairs outside the stage get an empty range).
 #define RQ_REC_LOWER 0
@@ -401,8 +421,16 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(uint32_t *__restrict__
 #define RQ_REC_SLOT 9
 #define RQ_REC_LIST_BEGIN 10
 #define RQ_REC_LIST_LEN 11
-#define RQ_REC_V0 12         // v'[0..4]: per-query side of the integer threshold S*(c,q) = sum_r u'_c[r] * v'_q[r]
+#define RQ_REC_V0 12         // 8 dwords: per-query bf16 operand of the integer threshold S*(c,q) = sum_r u'_c[r] * v'_q[r]
 #define RQ_REC_TAIL 20
+
+// f32 -> bf16 bits (round to nearest even) and back; finite inputs well inside the f32 range
+__device__ __forceinline__ uint32_t bf16_rne(float x) {
+    uint32_t u = __builtin_bit_cast(uint32_t, x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float bf16_to_f32(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
 
 __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__restrict__ scal,
                                                          const uint32_t *__restrict__ probe_cluster,
@@ -451,23 +479,51 @@ __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__re
         t[RQ_REC_LIST_LEN] = ps.list_len;
         // Integer form of the gate (used by the matrix-core scan).  With F = factor_ip * delta < 0,
         //   rough < thr  <=>  s > S* = [ (thr - ycd) + (-1) cds + (-lower) ppc + ysq eb ] / (2 F) + sumq / 2
-        // (real arithmetic), a rank-5 bilinear form in u'_c = (1, cds, ppc, eb)/fip, 1  and the v' below.
-        // S* is lowered by 2 so that f32 rounding on either side can never hide a candidate the exact
-        // f32 expression would pass; where the scales make that bound unsafe (or delta <= 0) the query is
-        // marked "always flagged" (S* = -inf) and every candidate takes the exact path.
+        // (real arithmetic), a rank-5 bilinear form in u'_c = (1, cds, ppc, eb)/fip, 1  and v'_q.  The scan
+        // starts its accumulator tile at -S*/2 (its dot products come out as s/2) with ONE
+        // v_mfma_f32_32x32x16_bf16: every u', v' is split into bf16 hi + lo and the products
+        // hi*hi + hi*lo + lo*hi are summed (12 slots), the constant term is split three ways (exact), 1
+        // slot is unused; the gate is then "accumulator > 0".  S* is lowered by a margin that covers the
+        // f32 rounding of the exact expression (2, safe while the terms stay below 2^19), the dropped
+        // lo*lo products and split residues (< 2^-14 of the sum of |terms|) and the roundings of adding
+        // s/2 onto -S*/2 inside the matrix unit (< 2^-19 of the magnitudes), so the test can never hide a
+        // candidate the exact f32 expression would pass; where the scales make the bound unsafe (or
+        // delta <= 0) the query is marked "always flagged" (-S* = +inf) and every candidate takes the
+        // exact path.
         const float th = thr[ps.row];
         const float inv2d = 0.5f / ps.delta;
-        float v0 = (th - ps.ycd) * inv2d, v1 = -inv2d, v2 = -ps.lower * inv2d, v3 = ps.ycd_sqrt * inv2d;
-        float v4 = 0.5f * ps.sumq - 2.0f;
-        const float q = (fabsf(th - ps.ycd) + fs.cds_max + fabsf(ps.lower) * fs.ppc_absmax + ps.ycd_sqrt * fs.eb_max) *
-                            fs.invfip_absmax * fabsf(inv2d) + ps.sumq;
-        const bool safe = ps.delta > 0.0f && q < 524288.0f;  // also false for NaN / inf
-        if (!safe) v0 = __builtin_inff(), v1 = 0.0f, v2 = 0.0f, v3 = 0.0f, v4 = 0.0f;  // u'[0] < 0  =>  S* = -inf
-        t[RQ_REC_V0 + 0] = __builtin_bit_cast(uint32_t, v0);
-        t[RQ_REC_V0 + 1] = __builtin_bit_cast(uint32_t, v1);
-        t[RQ_REC_V0 + 2] = __builtin_bit_cast(uint32_t, v2);
-        t[RQ_REC_V0 + 3] = __builtin_bit_cast(uint32_t, v3);
-        t[RQ_REC_V0 + 4] = __builtin_bit_cast(uint32_t, v4);
+        float v[4] = {(th - ps.ycd) * inv2d, -inv2d, -ps.lower * inv2d, ps.ycd_sqrt * inv2d};
+        const float qb = (fabsf(th - ps.ycd) + fs.cds_max + fabsf(ps.lower) * fs.ppc_absmax + ps.ycd_sqrt * fs.eb_max) *
+                         fs.invfip_absmax * fabsf(inv2d);
+        const bool safe = ps.delta > 0.0f && qb + ps.sumq < 524288.0f;  // also false for NaN / inf
+        const float margin = 2.0f + qb * (1.0f / 8192.0f) + (qb + ps.sumq) * (1.0f / 262144.0f);
+        const float v4 = -0.5f * (0.5f * ps.sumq - margin);
+        uint32_t vh[4], vl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float x = -0.5f * v[i];
+            vh[i] = bf16_rne(x);
+            vl[i] = bf16_rne(x - bf16_to_f32(vh[i]));
+        }
+        uint32_t c0 = bf16_rne(v4);
+        const float r1 = v4 - bf16_to_f32(c0);
+        uint32_t c1 = bf16_rne(r1);
+        uint32_t c2 = bf16_rne(r1 - bf16_to_f32(c1));
+        if (!safe) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vh[i] = 0, vl[i] = 0;
+            c0 = 0x7F80u, c1 = 0, c2 = 0;  // +inf * 1: -S* = +inf
+        }
+        // A operand of the threshold MFMA, element e of lane half h = slot 8h + e (the candidate side holds
+        // uh0 ul0 uh0 uh1 ul1 uh1 uh2 ul2 | uh2 uh3 ul3 uh3 1 1 1 0)
+        t[RQ_REC_V0 + 0] = vh[0] | (vh[0] << 16);
+        t[RQ_REC_V0 + 1] = vl[0] | (vh[1] << 16);
+        t[RQ_REC_V0 + 2] = vh[1] | (vl[1] << 16);
+        t[RQ_REC_V0 + 3] = vh[2] | (vh[2] << 16);
+        t[RQ_REC_V0 + 4] = vl[2] | (vh[3] << 16);
+        t[RQ_REC_V0 + 5] = vh[3] | (vl[3] << 16);
+        t[RQ_REC_V0 + 6] = c0 | (c1 << 16);
+        t[RQ_REC_V0 + 7] = c2;
     }
 }
 
@@ -488,6 +544,7 @@ __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__re
 struct ScanArgs {   // scalars only; pointers are explicit __restrict__ kernel parameters so the
                     // compiler keeps the wave-uniform operand fetches on the scalar unit (s_load)
     uint32_t cap, tiles_per_group, ngroups, cluster_major;
+    uint32_t dbg;  // developer ablations (scripts/ablate_scan.py); 0 in production
 };
 struct ScanPtrs {   // host-side bundle only
     const uint32_t *codes;        // n * 2W dwords (x_binary_vec, src/rabitq.rs:66)
@@ -677,39 +734,51 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
 // ------------------------------------------------------------------------------------------------
 // The same scan on the matrix cores, for stages where many queries share each list.
 //
-// sum_p popcount(code & plane_p) << p == sum_j bit_j(code) * q_j is an int8 inner product, exact in
-// i32.  In a batch the VALU form above is issue-bound (v_dot8_u32_u4 delivers ~1 dimension per
-// lane-cycle); v_mfma_i32_32x32x32_i8 delivers the 32 queries x 32 candidates x 32 dimensions
-// block in 32 cycles.  Roles: A = 32 queries x K (their 4-bit codes as bytes, from the stage
-// records through LDS), B = K x 32 candidates (code bits expanded to 0/1 bytes ONCE per block via a
-// 256-entry byte->8-bytes table in LDS), D lane map: column = candidate (lane & 31), the 16
-// registers x 2 half-waves = the 32 query rows.  So for one accumulator register a __ballot gives,
-// per half-wave, one query's gate over 32 CONSECUTIVE list positions: the same run protocol as the
-// VALU kernel.  The f32 epilogue is the reference's expression, evaluated for register pairs with
-// v_pk_*_f32 (rows 2p, 2p+1 are consecutive queries; per-query scalars are read from LDS as pairs).
+// sum_p popcount(code & plane_p) << p == sum_j bit_j(code) * q_j.  In a batch the VALU form above is
+// issue-bound (v_dot8_u32_u4 delivers ~1 dimension per lane-cycle).  Every q_j in 0..15 is exactly
+// q_j/2 in fp6 e2m3 and a code bit is exactly 1.0, so v_mfma_f32_32x32x64_f8f6f4 (A = e2m3, B = e2m3)
+// gives s/2 EXACTLY in f32 for 32 queries x 32 candidates x 64 dimensions in 32 cycles: twice the
+// rate of the i8 form, four times bf16.  Roles: A = 32 queries (their fp6 images, from the stage
+// records through LDS), B = 32 candidates (code bits expanded to fp6 ONCE per block through a
+// 256-entry byte -> 48-bit table in LDS, then resident in VGPRs for every query tile of the list),
+// D lane map: column = candidate (lane & 31), the 16 registers x 2 half-waves = the 32 query rows.
+// So for one accumulator register a __ballot gives, per half-wave, one query's gate over 32
+// CONSECUTIVE list positions: the same run protocol as the VALU kernel.
+//
+// The gate itself is hoisted out of f32: rough < thr  <=>  s > S*(query, candidate), and the 32x32
+// tile of S*/2 is ONE v_mfma_f32_32x32x16_bf16 (stage_fill_kernel explains the split and the margin),
+// so the hot epilogue is 16 compares.  Only accumulator registers with a flagged lane evaluate the
+// reference's f32 expression (src/rabitq.rs:352-363), and only its verdict is used.
 //
 // block = 4 waves; wave w owns NT sub-tiles of 32 positions: first + w*32*NT + t*32 + (lane&31).
-// LDS: byte table 2 KiB + 2 x (32 query operands, row stride KS*8+4 dwords: conflict-free
-// ds_read_b128) + 2 x 16 x 32 transposed record tails.
+// LDS: table 2 KiB + 2 x (32 query operands, row stride 12W+2 dwords: conflict-free ds_read_b64)
+// + 2 x 20 x 32 transposed record tails.
 // ------------------------------------------------------------------------------------------------
+typedef int v8i32 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 #ifndef RQ_F32X16_DEFINED
 #define RQ_F32X16_DEFINED
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
-typedef int v16i32 __attribute__((ext_vector_type(16)));
 
 template <int W, int NT>
 __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(SCAN_PARAMS) {
-    constexpr int KS = 2 * W;                   // K slabs of 32 dimensions
-    constexpr uint32_t OPDW = 16 * W;           // operand dwords per record: dim bytes
+    constexpr uint32_t OPDW = 12 * W;           // operand dwords per record: dim fp6 fields
     constexpr uint32_t STRIDE = OPDW + RQ_REC_TAIL;
-    constexpr uint32_t OPLD = OPDW + 4;         // LDS row stride (dwords) of the operand image
+    constexpr uint32_t OPLD = OPDW + 2;         // LDS row stride (dwords) of the operand image
     constexpr uint32_t TILE = 128 * NT;
-    __shared__ __attribute__((aligned(16))) uint32_t lut[256][2];
+    __shared__ __attribute__((aligned(16))) uint2 lut[256];
     __shared__ __attribute__((aligned(16))) uint32_t opbuf[2][32][OPLD];
     __shared__ __attribute__((aligned(16))) uint32_t tailT[2][RQ_REC_TAIL][32];
-    __shared__ float scratch[4][16][64];  // a wave's 16 rough values per lane, only touched when something passed
+    __shared__ __attribute__((aligned(16))) float4 facL[TILE];  // the tile's factors, for the exact path
+    // per-wave emit queue: survivors are parked here and written out in bulk (one atomic round trip per
+    // flush instead of one per run: the round trips, not the arithmetic, were what the waves waited for)
+    constexpr uint32_t QE = 256, QR = 64;
+    __shared__ uint32_t q_pos[4][QE];
+    __shared__ float q_rough[4][QE];
+    __shared__ uint32_t q_run[4][QE];
+    __shared__ uint32_t r_b[4][QR], r_slot[4][QR], r_pos[4][QR], r_cnt[4][QR], r_off[4][QR], r_base[4][QR];
 
     const uint32_t g = blockIdx.x / a.tiles_per_group;
     const uint32_t tile = blockIdx.x - g * a.tiles_per_group;
@@ -723,8 +792,8 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(SCAN_PARAMS) {
     if (first >= list_len) return;
 
     // everything the block needs from memory is requested up front, so the start-up costs ONE round trip:
-    // this lane's candidates (raw code words + factors) here, the first query tile further down
-    uint32_t craw[NT][KS];  // both half-waves hold the same candidate j of a sub-tile
+    // this lane's candidates (its half of every code word + factors) here, the first query tile further down
+    uint32_t craw[NT][W];  // lane half h holds dims 64m + 32h .. +31 of candidate j of a sub-tile
     float4 fac0[NT];
     uint32_t lpos[NT];
 #pragma unroll
@@ -734,31 +803,80 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(SCAN_PARAMS) {
         const uint32_t *cp = codes + (uint64_t)pos * (2 * W);
         fac0[t] = factors[pos];
 #pragma unroll
-        for (int sl = 0; sl < KS; ++sl) craw[t][sl] = cp[sl];
+        for (int m = 0; m < W; ++m) craw[t][m] = cp[2 * m + h];
     }
-    {  // byte -> 8 bytes (bit e -> byte e) table
-        uint32_t b = tid;
-        uint32_t lo = (b & 1) | ((b & 2) << 7) | ((b & 4) << 14) | ((b & 8) << 21);
-        uint32_t hi = ((b >> 4) & 1) | (((b >> 4) & 2) << 7) | (((b >> 4) & 4) << 14) | (((b >> 4) & 8) << 21);
-        lut[b][0] = lo;
-        lut[b][1] = hi;
+    {  // byte -> 8 fp6 fields (bit e -> 1.0 = 0b001000 at bits 6e .. 6e+5)
+        const uint32_t b = tid;
+        uint64_t f = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f |= (uint64_t)((b >> e) & 1u) << (6 * e + 3);
+        lut[b] = make_uint2((uint32_t)f, (uint32_t)(f >> 32));
     }
 
-    float ub[NT][3];      // B operand of the threshold MFMAs: u'[2m + h], m = 0..2 (u'[5] = 0)
+    uint32_t ub[NT][4];   // B operand of the threshold MFMA: 8 bf16 per lane (slots 8h .. 8h+7)
     bool forced = false;  // candidates whose factors do not admit the integer-threshold form
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         // u'_c = (1, cds, ppc, eb) / factor_ip, 1   (factor_ip < 0 for every regular vector, rabitq.rs:227)
         const float rf = 1.0f / fac0[t].x;
-        float u0 = rf, u1 = fac0[t].w * rf, u2 = fac0[t].y * rf, u3 = fac0[t].z * rf, u4 = 1.0f;
-        const float mag = fabsf(u0) + fabsf(u1) + fabsf(u2) + fabsf(u3);
-        const bool ok = fac0[t].x < 0.0f && mag < 3.0e38f;  // false for NaN / inf / factor_ip >= 0
-        if (!ok) u0 = 0.0f, u1 = 0.0f, u2 = 0.0f, u3 = 0.0f, u4 = 0.0f, forced = true;
-        ub[t][0] = h ? u1 : u0;
-        ub[t][1] = h ? u3 : u2;
-        ub[t][2] = h ? 0.0f : u4;
+        const float u[4] = {rf, fac0[t].w * rf, fac0[t].y * rf, fac0[t].z * rf};
+        const float mag = fabsf(u[0]) + fabsf(u[1]) + fabsf(u[2]) + fabsf(u[3]);
+        const bool ok = fac0[t].x < 0.0f && mag < 1.0e37f;  // false for NaN / inf / factor_ip >= 0
+        uint32_t uh[4], ul[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uh[i] = bf16_rne(u[i]);
+            ul[i] = bf16_rne(u[i] - bf16_to_f32(uh[i]));
+            if (!ok) uh[i] = 0, ul[i] = 0;
+        }
+        const uint32_t one = ok ? 0x3F80u : 0u;
+        if (!ok) forced = true;
+        // slots: uh0 ul0 uh0 uh1 ul1 uh1 uh2 ul2 | uh2 uh3 ul3 uh3 1 1 1 0
+        ub[t][0] = h ? (uh[2] | (uh[3] << 16)) : (uh[0] | (ul[0] << 16));
+        ub[t][1] = h ? (ul[3] | (uh[3] << 16)) : (uh[0] | (uh[1] << 16));
+        ub[t][2] = h ? (one | (one << 16)) : (ul[1] | (uh[1] << 16));
+        ub[t][3] = h ? one : (uh[2] | (ul[2] << 16));
     }
     const uint64_t forcemask = __ballot(forced);
+    if (h == 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) facL[lpos[t] - first] = fac0[t];
+    }
+
+    // ---- the emit queue of this wave ----
+    uint32_t nE = 0, nR = 0;  // wave-uniform fill levels
+    auto flush = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // LDS is in-order per wave
+        if (lane < nR) {  // one lane per run: all reservations in flight together
+            const uint32_t rb = r_b[wave][lane], rc = r_cnt[wave][lane];
+            const unsigned long long old = atomicAdd(surv_cnt + rb, (1ull << 32) | rc);
+            const uint32_t base = (uint32_t)old, rbase = (uint32_t)(old >> 32);
+            r_base[wave][lane] = base;
+            if (rbase < a.cap) {
+                RunRec rr;
+                rr.pos = r_pos[wave][lane];
+                rr.slot = r_slot[wave][lane];
+                rr.base = base;
+                rr.cnt = rc;
+                runs[(uint64_t)rb * a.cap + rbase] = rr;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // LDS is in-order per wave
+        for (uint32_t e = lane; e < nE; e += 64) {
+            const uint32_t r = q_run[wave][e];
+            const uint32_t at = r_base[wave][r] + (e - r_off[wave][r]);
+            if (at < a.cap) {
+                SurvRec sr;
+                sr.pos = q_pos[wave][e];
+                sr.slot = r_slot[wave][r];
+                sr.rough = q_rough[wave][e];
+                sr.accurate = 0.0f;
+                surv[(uint64_t)r_b[wave][r] * a.cap + at] = sr;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // LDS is in-order per wave
+        nE = 0, nR = 0;
+    };
 
     const uint32_t ntiles = (pe - pb + 31) / 32;
     // stage query tile 0
@@ -774,8 +892,8 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(SCAN_PARAMS) {
                     v = *reinterpret_cast<const uint4 *>(recs + ((uint64_t)pb + qt * 32) * STRIDE + (uint64_t)q4 * 4);
                 else if (w4 == (OPDW + RQ_REC_THR) / 4)  // padding query: threshold -inf, empty range ...
                     v = make_uint4(0, 0xFF800000u, 0, 0);  // dwords ycd_sqrt, THR, LO, HI
-                else if (w4 == (OPDW + RQ_REC_V0) / 4)   // ... and S* = +inf: never flagged
-                    v = make_uint4(0xFF800000u, 0, 0, 0);  // v'[0] = -inf (u'[0] < 0), v'[1..3] = 0
+                else if (w4 == (OPDW + RQ_REC_V0 + 4) / 4)  // ... and -S* = -inf: never flagged
+                    v = make_uint4(0, 0, 0x0000FF80u, 0);   // constant term hi = -inf (x 1), everything else 0
             }
             regs[it] = v;
         }
@@ -788,7 +906,8 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(SCAN_PARAMS) {
                 const uint32_t qi = q4 / (STRIDE / 4), d4 = (q4 - qi * (STRIDE / 4)) * 4;
                 const uint4 v = regs[it];
                 if (d4 < OPDW) {
-                    *reinterpret_cast<uint4 *>(&opbuf[buf][qi][d4]) = v;
+                    *reinterpret_cast<uint2 *>(&opbuf[buf][qi][d4]) = make_uint2(v.x, v.y);
+                    *reinterpret_cast<uint2 *>(&opbuf[buf][qi][d4 + 2]) = make_uint2(v.z, v.w);
                 } else {
                     const uint32_t f = d4 - OPDW;
                     tailT[buf][f][qi] = v.x, tailT[buf][f + 1][qi] = v.y, tailT[buf][f + 2][qi] = v.z, tailT[buf][f + 3][qi] = v.w;
@@ -801,9 +920,25 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(SCAN_PARAMS) {
     stage_store(0, sregs);
     __syncthreads();  // table + first query tile visible
 
-    for (uint32_t qt = 0; qt < ntiles; ++qt) {
-        const uint32_t buf = qt & 1;
-        const bool more = qt + 1 < ntiles;
+    // B: this lane's code bits as fp6 fields, 6 dwords per 32 dimensions, resident for the whole block
+    uint32_t bexp[NT][W][6];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int m = 0; m < W; ++m) {
+            const uint32_t c = craw[t][m];
+            const uint2 p0 = lut[c & 0xFFu], p1 = lut[(c >> 8) & 0xFFu], p2 = lut[(c >> 16) & 0xFFu], p3 = lut[c >> 24];
+            bexp[t][m][0] = p0.x;
+            bexp[t][m][1] = p0.y | (p1.x << 16);
+            bexp[t][m][2] = (p1.x >> 16) | (p1.y << 16);
+            bexp[t][m][3] = p2.x;
+            bexp[t][m][4] = p2.y | (p3.x << 16);
+            bexp[t][m][5] = (p3.x >> 16) | (p3.y << 16);
+        }
+
+    for (uint32_t qt = 0; qt < ((a.dbg & 4u) ? 0u : ntiles); ++qt) {
+        const uint32_t buf = (a.dbg & 2u) ? 0u : (qt & 1);
+        const bool more = qt + 1 < ntiles && !(a.dbg & 2u);
         if (more) stage_load(qt + 1, sregs);
         // is every query's stage range a superset of this block's tile?  (then no per-lane range checks)
         bool full_i = true;
@@ -812,43 +947,59 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(SCAN_PARAMS) {
         if (lane < 32 && tailT[buf][RQ_REC_LO][lane] >= tailT[buf][RQ_REC_HI][lane]) full_i = true;
         const bool all_full = __ballot(full_i) == ~0ull;
 
-        v4i32 aop[KS];  // A: query row j (= lane & 31), dims 32*sl + 16h .. +15
+        uint32_t aop[W][6];  // A: query row j (= lane & 31), dims 64m + 32h .. +31 as fp6
 #pragma unroll
-        for (int sl = 0; sl < KS; ++sl) aop[sl] = *reinterpret_cast<const v4i32 *>(&opbuf[buf][j][8 * sl + 4 * h]);
-        float ua[3];    // A operand of the threshold MFMAs: v'_row[2m + h] (v'[5] = 0)
-        ua[0] = __builtin_bit_cast(float, tailT[buf][RQ_REC_V0 + h][j]);
-        ua[1] = __builtin_bit_cast(float, tailT[buf][RQ_REC_V0 + 2 + h][j]);
-        ua[2] = h ? 0.0f : __builtin_bit_cast(float, tailT[buf][RQ_REC_V0 + 4][j]);
+        for (int m = 0; m < W; ++m)
+#pragma unroll
+            for (int e = 0; e < 6; e += 2) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(&opbuf[buf][j][6 * W * h + 6 * m + e]);
+                aop[m][e] = v.x, aop[m][e + 1] = v.y;
+            }
+        v4i32 ua;  // A operand of the threshold MFMA: slots 8h .. 8h+7 of query row j
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ua[e] = (int)tailT[buf][RQ_REC_V0 + 4 * h + e][j];
 
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            v16i32 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            // accumulator tile = -S*/2 (query row, candidate col) + s/2, all on the matrix pipe
+            const v4i32 ubv = {(int)ub[t][0], (int)ub[t][1], (int)ub[t][2], (int)ub[t][3]};
+            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ua), __builtin_bit_cast(bf16x8, ubv), acc, 0, 0, 0);
 #pragma unroll
-            for (int sl = 0; sl < KS; ++sl) {
-                // B: code bits of dims 32*sl + 16h .. +15 -> 16 bytes of 0/1 through the LDS table (expanded per
-                // use: keeping the expanded operand resident costs 64 VGPRs and a wave of occupancy)
-                const uint32_t bits = (craw[t][sl] >> (16 * h)) & 0xFFFFu;
-                const uint32_t b0 = bits & 0xFF, b1 = bits >> 8;
-                const v4i32 bv = {(int)lut[b0][0], (int)lut[b0][1], (int)lut[b1][0], (int)lut[b1][1]};
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop[sl], bv, acc, 0, 0, 0);
+            for (int m = 0; m < W; ++m) {
+                const v8i32 av = {(int)aop[m][0], (int)aop[m][1], (int)aop[m][2], (int)aop[m][3], (int)aop[m][4], (int)aop[m][5], 0, 0};
+                const v8i32 bv = {(int)bexp[t][m][0], (int)bexp[t][m][1], (int)bexp[t][m][2], (int)bexp[t][m][3],
+                                  (int)bexp[t][m][4], (int)bexp[t][m][5], 0, 0};
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 2 /*A e2m3*/, 2 /*B e2m3*/, 0, 0, 0, 0);
             }
-            // S*(query row, candidate col) on the (otherwise idle) matrix pipe: exact-f32 k-ordered fma chain
-            f32x16 sth = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            // hot path: is any of the 1024 (query, candidate) cells positive?  8 v_max3 + 1 compare
+            float mx = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);
 #pragma unroll
-            for (int mm = 0; mm < 3; ++mm) sth = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[mm], ub[t][mm], sth, 0, 0, 0);
-            uint32_t gmask = forcemask ? 0xFFFFu : 0u;  // accumulator registers with at least one flagged lane
+            for (int gq = 3; gq < 15; gq += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, acc[gq]), acc[gq + 1]);
+            mx = __builtin_fmaxf(mx, acc[15]);
+            uint32_t gmask = 0;
+            f32x16 sc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (forcemask != 0ull || __ballot(mx > 0.0f) != 0ull) {  // wave-uniform
+                gmask = forcemask ? 0xFFFFu : 0u;  // accumulator registers with at least one flagged lane
 #pragma unroll
-            for (int gq = 0; gq < 16; ++gq)
-                gmask |= (__ballot((float)acc[gq] > sth[gq]) != 0ull ? 1u : 0u) << gq;  // hot path: s > S*
-            if (gmask) {  // wave-uniform and rare in the stages this kernel serves: exact evaluation + emit
+                for (int gq = 0; gq < 16; ++gq) gmask |= (__ballot(acc[gq] > 0.0f) != 0ull ? 1u : 0u) << gq;
+                // the flagged cells need s itself: the same products again on a clean accumulator (exact)
 #pragma unroll
-                for (int gq = 0; gq < 16; ++gq) scratch[wave][gq][lane] = (float)acc[gq];
-                const float4 fc = factors[list_begin + (lpos[t] < list_len ? lpos[t] : 0)];  // not kept in registers
-                while (gmask) {  // only the flagged registers
+                for (int m = 0; m < W; ++m) {
+                    const v8i32 av = {(int)aop[m][0], (int)aop[m][1], (int)aop[m][2], (int)aop[m][3], (int)aop[m][4], (int)aop[m][5], 0, 0};
+                    const v8i32 bv = {(int)bexp[t][m][0], (int)bexp[t][m][1], (int)bexp[t][m][2], (int)bexp[t][m][3],
+                                      (int)bexp[t][m][4], (int)bexp[t][m][5], 0, 0};
+                    sc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, sc, 2, 2, 0, 0, 0, 0);
+                }
+            }
+            if (a.dbg & 1u) gmask = 0;
+            if (gmask) {  // wave-uniform: exact evaluation + emit, for the flagged registers only
+                const float4 fc = facL[lpos[t] - first];
+                while (gmask) {
                     const uint32_t gq = (uint32_t)__builtin_ctz(gmask);
                     gmask &= gmask - 1;
                     const uint32_t row = (gq & 3) + 8 * (gq >> 2) + 4 * h;
-                    const float sf = scratch[wave][gq][lane];
+                    const float sf = 2.0f * sc[gq];  // wave-uniform register index
                     // the reference's expression, left to right (src/rabitq.rs:352-363)
                     float tt = fc.w + __builtin_bit_cast(float, tailT[buf][RQ_REC_YCD][row]);
                     tt = tt + __builtin_bit_cast(float, tailT[buf][RQ_REC_LOWER][row]) * fc.y;
@@ -856,46 +1007,37 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(SCAN_PARAMS) {
                     tt = tt + u * __builtin_bit_cast(float, tailT[buf][RQ_REC_DELTA][row]);
                     const float rg = tt - fc.z * __builtin_bit_cast(float, tailT[buf][RQ_REC_YCD_SQRT][row]);
                     bool pass = rg < __builtin_bit_cast(float, tailT[buf][RQ_REC_THR][row]);  // src/rerank.rs:84
+                    pass = pass && lpos[t] < list_len;
                     if (!all_full) pass = pass && lpos[t] >= tailT[buf][RQ_REC_LO][row] && lpos[t] < tailT[buf][RQ_REC_HI][row];
                     const uint64_t m = __ballot(pass);
                     if (m == 0) continue;
-#pragma nounroll
-                    for (uint32_t hh = 0; hh < 2; ++hh) {
-                        const uint32_t mh = (uint32_t)(m >> (32 * hh));
-                        if (mh == 0) continue;
-                        const uint32_t qrow = (gq & 3) + 8 * (gq >> 2) + 4 * hh;
-                        const uint32_t b = tailT[buf][RQ_REC_ROW][qrow], slot = tailT[buf][RQ_REC_SLOT][qrow];
-                        const uint32_t cntc = (uint32_t)__popc(mh);
-                        unsigned long long old = 0;
-                        if (lane == 32 * hh) old = atomicAdd(surv_cnt + b, (1ull << 32) | cntc);
-                        const uint32_t base = __shfl((uint32_t)old, 32 * hh, 64);
-                        const uint32_t rbase = __shfl((uint32_t)(old >> 32), 32 * hh, 64);
-                        if (h == hh && ((mh >> j) & 1u)) {
-                            const uint32_t at = base + (uint32_t)__popc(mh & ((1u << j) - 1u));
-                            if (at < a.cap) {
-                                SurvRec sr;
-                                sr.pos = list_begin + lpos[t];
-                                sr.slot = slot;
-                                sr.rough = rg;
-                                sr.accurate = 0.0f;
-                                surv[(uint64_t)b * a.cap + at] = sr;
-                            }
-                        }
-                        if (lane == 32 * hh && rbase < a.cap) {
-                            RunRec rr;
-                            rr.pos = list_begin + first + wave * (32 * NT) + t * 32;
-                            rr.slot = slot;
-                            rr.base = base;
-                            rr.cnt = cntc;
-                            runs[(uint64_t)b * a.cap + rbase] = rr;
-                        }
+                    if (nE + 64 > QE || nR + 2 > QR) flush();
+                    // each half-wave is one run (one query x 32 consecutive positions); half 0 first
+                    const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
+                    const uint32_t c0 = (uint32_t)__popc(m0), c1 = (uint32_t)__popc(m1);
+                    const uint32_t myrun = nR + ((h && c0) ? 1u : 0u), myoff = nE + (h ? c0 : 0u);
+                    if (pass) {
+                        const uint32_t e = myoff + (uint32_t)__popc((h ? m1 : m0) & ((1u << j) - 1u));
+                        q_pos[wave][e] = list_begin + lpos[t];
+                        q_rough[wave][e] = rg;
+                        q_run[wave][e] = myrun;
                     }
+                    if (j == 0 && (h ? c1 : c0)) {
+                        r_b[wave][myrun] = tailT[buf][RQ_REC_ROW][row];
+                        r_slot[wave][myrun] = tailT[buf][RQ_REC_SLOT][row];
+                        r_pos[wave][myrun] = list_begin + first + wave * (32 * NT) + t * 32;
+                        r_cnt[wave][myrun] = h ? c1 : c0;
+                        r_off[wave][myrun] = myoff;
+                    }
+                    nE += c0 + c1;
+                    nR += (c0 ? 1u : 0u) + (c1 ? 1u : 0u);
                 }
             }
         }
         if (more) stage_store(buf ^ 1, sregs);
         __syncthreads();
     }
+    if (nE) flush();
 }
 
 // generic-W fallback (dim/64 not in the templated set): code words re-read per query (L1-resident)

@@ -161,7 +161,7 @@ struct Workspace {
     DevBuf<PairScalars> scal;
     DevBuf<uint64_t> planes;
     DevBuf<uint32_t> qnib;
-    DevBuf<uint8_t> qbytes;
+    DevBuf<uint32_t> qf6;
     DevBuf<unsigned long long> rough_cnt, totals, surv_cnt;
     DevBuf<SurvRec> surv, arr;
     DevBuf<RunRec> runs;
@@ -254,6 +254,7 @@ static void launch_scan(const ScanPtrs &p, const ScanArgs &a, uint32_t W, hipStr
 // scan implementation: 0 = auto (matrix cores when many queries share each list, VALU otherwise),
 // 1 = VALU (v_dot8_u32_u4) only, 2 = matrix cores wherever the kernel exists (test hook)
 static std::atomic<int> g_scan_impl{0};
+static std::atomic<int> g_scan_dbg{0};
 
 static bool scan_has_mfma(uint32_t W) { return W == 1 || W == 2 || W == 4; }
 static uint32_t scan_mfma_tile(uint32_t W) { return W == 4 ? 256 : 512; }
@@ -312,10 +313,10 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
     RQC(ws.scal.ensure(npairs));
     RQC(ws.planes.ensure(npairs * 4 * idx->W));
     RQC(ws.qnib.ensure(npairs * 8 * idx->W));
-    RQC(ws.qbytes.ensure(npairs * idx->dim));
+    RQC(ws.qf6.ensure(npairs * 12 * idx->W));
     RQC(ws.rough_cnt.ensure(nq));
     RQC(ws.totals.ensure(8));
-    RQC(ws.recs.ensure(npairs * (16ull * idx->W + RQ_REC_TAIL)));
+    RQC(ws.recs.ensure(npairs * (12ull * idx->W + RQ_REC_TAIL)));
     RQC(ws.grp_cnt.ensure(idx->k + 1));
     RQC(ws.grp_start.ensure(idx->k + 1));
     RQC(ws.thr.ensure(nq));
@@ -387,7 +388,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     // 3. per-pair query quantisation (:304-317)
     pf.begin(PF_PREP);
     prep_kernel<<<ceil_div(npairs, 4), 256, 0, st>>>(ws.y.p, idx->centroids.p, idx->offsets.p, probe_cluster, probe_dist,
-                                                     npairs, nprobe, dim, ws.scal.p, ws.planes.p, ws.qnib.p, ws.qbytes.p,
+                                                     npairs, nprobe, dim, ws.scal.p, ws.planes.p, ws.qnib.p, ws.qf6.p,
                                                      nullptr, k, 1u);
     pair_prefix_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(ws.scal.p, nq, nprobe, ws.rough_cnt.p);
     ReplayState rs;
@@ -448,10 +449,10 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             a.ngroups = npairs;
         }
         // pack the stage's work records (query operand + scalars + current threshold + local range)
-        const uint32_t *operand = use_mfma ? reinterpret_cast<const uint32_t *>(ws.qbytes.p)
+        const uint32_t *operand = use_mfma ? ws.qf6.p
                                            : (scan_is_fused(W) ? ws.qnib.p : reinterpret_cast<const uint32_t *>(ws.planes.p));
         stage_fill_kernel<<<ceil_div(npairs, 16), 256, 0, st>>>(ws.scal.p, probe_cluster, operand, ws.thr.p, npairs,
-                                                                nprobe, use_mfma ? 16 * W : 8 * W, sg.s_lo, sg.s_hi,
+                                                                nprobe, use_mfma ? 12 * W : 8 * W, sg.s_lo, sg.s_hi,
                                                                 a.cluster_major, ws.grp_start.p, ws.grp_cnt.p, ws.recs.p,
                                                                 idx->fstats);
         pf.end();
@@ -463,6 +464,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         sp.runs = ws.runs.p;
         sp.surv_cnt = ws.surv_cnt.p;
         a.cap = qp.cap;
+        a.dbg = (uint32_t)g_scan_dbg.load();
         a.tiles_per_group = ceil_div(std::min<uint64_t>(idx->max_list_len, sg.s_hi), use_mfma ? scan_mfma_tile(W) : tile);
         pf.begin(PF_SCAN);
         if (use_mfma) launch_scan_mfma(sp, a, W, st);
@@ -1279,6 +1281,10 @@ rq_status rq_set_option(const char *name, int value) {
     if (std::string(name) == "scan_impl") {
         if (value < 0 || value > 2) return fail(RQ_ERR_INVALID, "scan_impl must be 0 (auto), 1 (valu) or 2 (mfma)");
         g_scan_impl = value;
+        return RQ_OK;
+    }
+    if (std::string(name) == "scan_debug") {  // developer ablations of the matrix-core scan (results are WRONG when != 0)
+        g_scan_dbg = value;
         return RQ_OK;
     }
     return fail(RQ_ERR_INVALID, std::string("unknown option ") + name);

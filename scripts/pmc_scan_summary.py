@@ -1,0 +1,32 @@
+"""Summarise gpurun_out/pmc_mfma*/ (scripts/pmc_scan.sh): per-launch SQ counters of scan_mfma_kernel."""
+import collections
+import csv
+import glob
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+csv.field_size_limit(10**9)
+tot = {}
+for d in ("pmc_mfma", "pmc_mfma2"):
+    fs = glob.glob(os.path.join(ROOT, "gpurun_out", d, "*", "*counter_collection.csv"))
+    if not fs:
+        print(d, "missing")
+        continue
+    rows = [r for r in csv.DictReader(open(fs[0])) if "scan_mfma_kernel" in r["Kernel_Name"]]
+    byd = collections.defaultdict(dict)
+    for r in rows:
+        byd[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+    # the dominant launch = the one with the most waves / busy cycles
+    best = max(byd.values(), key=lambda c: c.get("SQ_WAVES", c.get("GRBM_GUI_ACTIVE", 0)))
+    tot.update(best)
+for k, v in sorted(tot.items()):
+    print(f"{k:28s} {v:16.0f}")
+if "SQ_BUSY_CYCLES" in tot and "GRBM_GUI_ACTIVE" in tot:
+    gui = tot["GRBM_GUI_ACTIVE"]
+    simd_cycles = gui * 256 * 4  # one count per SIMD-cycle if every SIMD were busy the whole launch
+    print("launch cycles (GRBM_GUI_ACTIVE):", gui)
+    for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_ANY"):
+        if k in tot:
+            print(f"  {k} / (launch cycles x 1024 SIMDs) = {tot[k] / simd_cycles:.3f}")
+    if "SQ_WAVE_CYCLES" in tot:
+        print(f"  mean waves per SIMD = {tot['SQ_WAVE_CYCLES'] / simd_cycles:.2f}")
