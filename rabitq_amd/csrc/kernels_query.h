@@ -371,9 +371,10 @@ __global__ void group_count_kernel(const PairScalars *__restrict__ scal,
 }
 
 // exclusive scan of cnt[0..k) into start[0..k]; single block, any k.  Also zeroes cnt for the
-// fill pass (cnt is reused as the per-list cursor).
+// fill pass (cnt is reused as the per-list cursor, so it holds the counts again afterwards).
+// pad32: every group starts at a multiple of 32 records (the matrix-core scan's query tiles).
 __global__ __launch_bounds__(1024) void group_scan_kernel(uint32_t *__restrict__ cnt, uint32_t k,
-                                                          uint32_t *__restrict__ start) {
+                                                          uint32_t *__restrict__ start, uint32_t pad32) {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -381,7 +382,9 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(uint32_t *__restrict__
     __syncthreads();
     for (uint32_t base = 0; base < k; base += 1024) {
         uint32_t i = base + tid;
-        uint32_t v = i < k ? cnt[i] : 0, incl = v;
+        uint32_t v = i < k ? cnt[i] : 0;
+        if (pad32) v = (v + 31u) & ~31u;
+        uint32_t incl = v;
         for (int o = 1; o < 64; o <<= 1) {
             uint32_t up = __shfl_up(incl, o, 64);
             if ((int)lane >= o) incl += up;
@@ -440,7 +443,8 @@ __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__re
                                                          uint32_t cluster_major,
                                                          const uint32_t *__restrict__ grp_start,
                                                          uint32_t *__restrict__ grp_cursor,
-                                                         uint32_t *__restrict__ recs, const FactorStats fs) {
+                                                         uint32_t *__restrict__ recs, const FactorStats fs,
+                                                         uint32_t tile_images) {
     const uint32_t sub = threadIdx.x & 15;                       // 16 lanes per pair
     const uint32_t p = blockIdx.x * 16 + (threadIdx.x >> 4);
     if (p >= npairs) return;
@@ -454,8 +458,20 @@ __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__re
         if (sub == 0) a = atomicAdd(&grp_cursor[c], 1u);
         at = grp_start[c] + __shfl(a, 0, 16);
     }
+    // record-major: record `at` = opdw operand dwords + RQ_REC_TAIL tail dwords.  tile images (matrix-core
+    // scan): records in tiles of 32, each tile stored as the exact LDS image the kernel copies in with
+    // LDS-DMA: 32 operand rows of opdw+2 dwords, then the tail transposed [RQ_REC_TAIL][32].
     const uint32_t stride = opdw + RQ_REC_TAIL;
     uint32_t *r = recs + (uint64_t)at * stride;
+    uint32_t tstride = 1;
+    uint32_t *t = r + opdw;
+    if (tile_images) {
+        const uint32_t opld = opdw + 2, img = 32 * opld + RQ_REC_TAIL * 32;
+        uint32_t *base = recs + (uint64_t)(at >> 5) * img;
+        r = base + (at & 31u) * opld;
+        t = base + 32 * opld + (at & 31u);
+        tstride = 32;
+    }
     for (uint32_t i = sub; i < opdw; i += 16) r[i] = operand[(uint64_t)p * opdw + i];
     if (sub == 0) {
         uint32_t lo = 0, hi = 0;
@@ -464,19 +480,18 @@ __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__re
             hi = s_hi - ps.stream_begin;  // in-stage => stream_begin < s_hi
             hi = hi < ps.list_len ? hi : ps.list_len;
         }
-        uint32_t *t = r + opdw;
-        t[RQ_REC_LOWER] = __builtin_bit_cast(uint32_t, ps.lower);
-        t[RQ_REC_DELTA] = __builtin_bit_cast(uint32_t, ps.delta);
-        t[RQ_REC_SUMQ] = __builtin_bit_cast(uint32_t, ps.sumq);
-        t[RQ_REC_YCD] = __builtin_bit_cast(uint32_t, ps.ycd);
-        t[RQ_REC_YCD_SQRT] = __builtin_bit_cast(uint32_t, ps.ycd_sqrt);
-        t[RQ_REC_THR] = __builtin_bit_cast(uint32_t, thr[ps.row]);
-        t[RQ_REC_LO] = lo;
-        t[RQ_REC_HI] = hi;
-        t[RQ_REC_ROW] = ps.row;
-        t[RQ_REC_SLOT] = p - ps.row * nprobe;
-        t[RQ_REC_LIST_BEGIN] = ps.list_begin;
-        t[RQ_REC_LIST_LEN] = ps.list_len;
+        t[(RQ_REC_LOWER) * tstride] = __builtin_bit_cast(uint32_t, ps.lower);
+        t[(RQ_REC_DELTA) * tstride] = __builtin_bit_cast(uint32_t, ps.delta);
+        t[(RQ_REC_SUMQ) * tstride] = __builtin_bit_cast(uint32_t, ps.sumq);
+        t[(RQ_REC_YCD) * tstride] = __builtin_bit_cast(uint32_t, ps.ycd);
+        t[(RQ_REC_YCD_SQRT) * tstride] = __builtin_bit_cast(uint32_t, ps.ycd_sqrt);
+        t[(RQ_REC_THR) * tstride] = __builtin_bit_cast(uint32_t, thr[ps.row]);
+        t[(RQ_REC_LO) * tstride] = lo;
+        t[(RQ_REC_HI) * tstride] = hi;
+        t[(RQ_REC_ROW) * tstride] = ps.row;
+        t[(RQ_REC_SLOT) * tstride] = p - ps.row * nprobe;
+        t[(RQ_REC_LIST_BEGIN) * tstride] = ps.list_begin;
+        t[(RQ_REC_LIST_LEN) * tstride] = ps.list_len;
         // Integer form of the gate (used by the matrix-core scan).  With F = factor_ip * delta < 0,
         //   rough < thr  <=>  s > S* = [ (thr - ycd) + (-1) cds + (-lower) ppc + ysq eb ] / (2 F) + sumq / 2
         // (real arithmetic), a rank-5 bilinear form in u'_c = (1, cds, ppc, eb)/fip, 1  and v'_q.  The scan
@@ -516,14 +531,14 @@ __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__re
         }
         // A operand of the threshold MFMA, element e of lane half h = slot 8h + e (the candidate side holds
         // uh0 ul0 uh0 uh1 ul1 uh1 uh2 ul2 | uh2 uh3 ul3 uh3 1 1 1 0)
-        t[RQ_REC_V0 + 0] = vh[0] | (vh[0] << 16);
-        t[RQ_REC_V0 + 1] = vl[0] | (vh[1] << 16);
-        t[RQ_REC_V0 + 2] = vh[1] | (vl[1] << 16);
-        t[RQ_REC_V0 + 3] = vh[2] | (vh[2] << 16);
-        t[RQ_REC_V0 + 4] = vl[2] | (vh[3] << 16);
-        t[RQ_REC_V0 + 5] = vh[3] | (vl[3] << 16);
-        t[RQ_REC_V0 + 6] = c0 | (c1 << 16);
-        t[RQ_REC_V0 + 7] = c2;
+        t[(RQ_REC_V0 + 0) * tstride] = vh[0] | (vh[0] << 16);
+        t[(RQ_REC_V0 + 1) * tstride] = vl[0] | (vh[1] << 16);
+        t[(RQ_REC_V0 + 2) * tstride] = vh[1] | (vl[1] << 16);
+        t[(RQ_REC_V0 + 3) * tstride] = vh[2] | (vh[2] << 16);
+        t[(RQ_REC_V0 + 4) * tstride] = vl[2] | (vh[3] << 16);
+        t[(RQ_REC_V0 + 5) * tstride] = vh[3] | (vl[3] << 16);
+        t[(RQ_REC_V0 + 6) * tstride] = c0 | (c1 << 16);
+        t[(RQ_REC_V0 + 7) * tstride] = c2;
     }
 }
 
@@ -550,6 +565,8 @@ struct ScanPtrs {   // host-side bundle only
     const uint32_t *codes;        // n * 2W dwords (x_binary_vec, src/rabitq.rs:66)
     const float4 *factors;        // n (src/rabitq.rs:67): x=factor_ip y=factor_ppc z=error_bound w=cds
     const uint32_t *grp_start;    // cluster-major: k+1 offsets into the record array
+    const uint32_t *grp_cnt;      // cluster-major: records per list
+    const uint32_t *offsets;      // k+1 list offsets of the index
     const uint32_t *recs;         // per-stage work records (stage_fill_kernel)
     SurvRec *surv;                // per query `cap` records
     RunRec *runs;                 // per query `cap` run descriptors
@@ -762,18 +779,43 @@ typedef int v4i32 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 
+// One 16-byte-per-lane LDS-DMA copy: lane l's 16 bytes at gsrc land at LDS byte address lds_dst + 16 l
+// (lds_dst wave-uniform).  Issued from an asm statement so that the compiler's own s_waitcnt bookkeeping
+// does not drain it early; completion is counted by hand (s_waitcnt vmcnt(N)) before the barrier that
+// precedes the first read.
+__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+
 template <int W, int NT>
-__global__ __launch_bounds__(256, 3) void scan_mfma_kernel(SCAN_PARAMS) {
-    constexpr uint32_t OPDW = 12 * W;           // operand dwords per record: dim fp6 fields
-    constexpr uint32_t STRIDE = OPDW + RQ_REC_TAIL;
-    constexpr uint32_t OPLD = OPDW + 2;         // LDS row stride (dwords) of the operand image
+__global__ __launch_bounds__(256, 3) void scan_mfma_kernel(const uint32_t *__restrict__ codes,
+                                                           const float4 *__restrict__ factors,
+                                                           const uint32_t *__restrict__ offsets,
+                                                           const uint32_t *__restrict__ grp_start,
+                                                           const uint32_t *__restrict__ grp_cnt,
+                                                           const uint32_t *__restrict__ recs,
+                                                           SurvRec *__restrict__ surv, RunRec *__restrict__ runs,
+                                                           unsigned long long *__restrict__ surv_cnt,
+                                                           const ScanArgs a) {
+    constexpr uint32_t OPDW = 12 * W;            // operand dwords per record: dim fp6 fields
+    constexpr uint32_t OPLD = OPDW + 2;          // row stride (dwords) of the operand image: conflict-free ds_read_b64
+    constexpr uint32_t IMG_OP = 32 * OPLD;       // a query tile image: 32 operand rows ...
+    constexpr uint32_t IMG = IMG_OP + RQ_REC_TAIL * 32;  // ... + the record tails, transposed [field][query]
+    constexpr uint32_t WQ4 = IMG / 16;           // 16-byte pieces each wave copies (a quarter of the image)
+    constexpr uint32_t NI = (WQ4 + 63) / 64;     // LDS-DMA instructions per wave per tile
+    static_assert(IMG % 16 == 0, "tile image must split into four 16-byte-aligned quarters");
     constexpr uint32_t TILE = 128 * NT;
     __shared__ __attribute__((aligned(16))) uint2 lut[256];
-    __shared__ __attribute__((aligned(16))) uint32_t opbuf[2][32][OPLD];
-    __shared__ __attribute__((aligned(16))) uint32_t tailT[2][RQ_REC_TAIL][32];
-    __shared__ __attribute__((aligned(16))) float4 facL[TILE];  // the tile's factors, for the exact path
-    // per-wave emit queue: survivors are parked here and written out in bulk (one atomic round trip per
-    // flush instead of one per run: the round trips, not the arithmetic, were what the waves waited for)
+    __shared__ __attribute__((aligned(16))) uint32_t ring[3][IMG];  // query tiles in flight (LDS-DMA targets)
+    __shared__ __attribute__((aligned(16))) float4 facL[TILE];      // the tile's factors, for the exact path
+    // per-wave emit queue: survivors are parked here and written out in bulk (one atomic round trip per flush)
     constexpr uint32_t QE = 256, QR = 64;
     __shared__ uint32_t q_pos[4][QE];
     __shared__ float q_rough[4][QE];
@@ -782,17 +824,18 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(SCAN_PARAMS) {
 
     const uint32_t g = blockIdx.x / a.tiles_per_group;
     const uint32_t tile = blockIdx.x - g * a.tiles_per_group;
-    const uint32_t pb = grp_start[g], pe = grp_start[g + 1];  // cluster-major only
-    if (pb >= pe) return;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t *rec0 = recs + (uint64_t)pb * STRIDE;
-    const uint32_t list_begin = rec0[OPDW + RQ_REC_LIST_BEGIN], list_len = rec0[OPDW + RQ_REC_LIST_LEN];
+    // one round trip: the group's records (cluster-major only) and its list
+    const uint32_t pb = grp_start[g], cnt = grp_cnt[g];
+    const uint32_t list_begin = offsets[g], list_len = offsets[g + 1] - list_begin;
+    if (cnt == 0) return;
     const uint32_t first = tile * TILE;
     if (first >= list_len) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t ntiles = (cnt + 31) / 32;
 
-    // everything the block needs from memory is requested up front, so the start-up costs ONE round trip:
-    // this lane's candidates (its half of every code word + factors) here, the first query tile further down
+    // everything the block needs from memory is requested up front: this lane's candidates (its half of
+    // every code word + factors) and the first two query tiles
     uint32_t craw[NT][W];  // lane half h holds dims 64m + 32h .. +31 of candidate j of a sub-tile
     float4 fac0[NT];
     uint32_t lpos[NT];
@@ -805,6 +848,18 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(SCAN_PARAMS) {
 #pragma unroll
         for (int m = 0; m < W; ++m) craw[t][m] = cp[2 * m + h];
     }
+    const uint32_t ring0 = lds_addr(&ring[0][0]);
+    auto dma_tile = [&](uint32_t qt, uint32_t slot) {  // this wave's quarter of query tile qt -> ring[slot]
+        const uint32_t *src = recs + ((uint64_t)(pb >> 5) + qt) * IMG + wave * (IMG / 4);
+        const uint32_t dst = ring0 + (slot * IMG + wave * (IMG / 4)) * 4;
+#pragma unroll
+        for (uint32_t i = 0; i < NI; ++i) {
+            const uint32_t q4 = i * 64 + lane;
+            if (q4 < WQ4) glds16(src + q4 * 4, dst + i * 1024);  // same active lanes in every wave: NI issues each
+        }
+    };
+    dma_tile(0, 0);
+    if (ntiles > 1) dma_tile(1, 1);
     {  // byte -> 8 fp6 fields (bit e -> 1.0 = 0b001000 at bits 6e .. 6e+5)
         const uint32_t b = tid;
         uint64_t f = 0;
@@ -861,7 +916,7 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(SCAN_PARAMS) {
                 runs[(uint64_t)rb * a.cap + rbase] = rr;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // LDS is in-order per wave
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         for (uint32_t e = lane; e < nE; e += 64) {
             const uint32_t r = q_run[wave][e];
             const uint32_t at = r_base[wave][r] + (e - r_off[wave][r]);
@@ -874,51 +929,13 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(SCAN_PARAMS) {
                 surv[(uint64_t)r_b[wave][r] * a.cap + at] = sr;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // LDS is in-order per wave
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        // nothing of the flush may stay outstanding: the counted waits below assume only LDS-DMA is in flight
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         nE = 0, nR = 0;
     };
 
-    const uint32_t ntiles = (pe - pb + 31) / 32;
-    // stage query tile 0
-    constexpr uint32_t NSTG = (32 * STRIDE / 4 + 255) / 256;
-    auto stage_load = [&](uint32_t qt, uint4 (&regs)[NSTG]) {
-#pragma unroll
-        for (uint32_t it = 0; it < NSTG; ++it) {
-            const uint32_t q4 = tid + 256 * it;  // float4 slot inside the 32-record slab
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (q4 < 32 * STRIDE / 4) {
-                const uint32_t qi = q4 / (STRIDE / 4), w4 = q4 - qi * (STRIDE / 4);
-                if (pb + qt * 32 + qi < pe)
-                    v = *reinterpret_cast<const uint4 *>(recs + ((uint64_t)pb + qt * 32) * STRIDE + (uint64_t)q4 * 4);
-                else if (w4 == (OPDW + RQ_REC_THR) / 4)  // padding query: threshold -inf, empty range ...
-                    v = make_uint4(0, 0xFF800000u, 0, 0);  // dwords ycd_sqrt, THR, LO, HI
-                else if (w4 == (OPDW + RQ_REC_V0 + 4) / 4)  // ... and -S* = -inf: never flagged
-                    v = make_uint4(0, 0, 0x0000FF80u, 0);   // constant term hi = -inf (x 1), everything else 0
-            }
-            regs[it] = v;
-        }
-    };
-    auto stage_store = [&](uint32_t buf, const uint4 (&regs)[NSTG]) {
-#pragma unroll
-        for (uint32_t it = 0; it < NSTG; ++it) {
-            const uint32_t q4 = tid + 256 * it;
-            if (q4 < 32 * STRIDE / 4) {
-                const uint32_t qi = q4 / (STRIDE / 4), d4 = (q4 - qi * (STRIDE / 4)) * 4;
-                const uint4 v = regs[it];
-                if (d4 < OPDW) {
-                    *reinterpret_cast<uint2 *>(&opbuf[buf][qi][d4]) = make_uint2(v.x, v.y);
-                    *reinterpret_cast<uint2 *>(&opbuf[buf][qi][d4 + 2]) = make_uint2(v.z, v.w);
-                } else {
-                    const uint32_t f = d4 - OPDW;
-                    tailT[buf][f][qi] = v.x, tailT[buf][f + 1][qi] = v.y, tailT[buf][f + 2][qi] = v.z, tailT[buf][f + 3][qi] = v.w;
-                }
-            }
-        }
-    };
-    uint4 sregs[NSTG];
-    stage_load(0, sregs);
-    stage_store(0, sregs);
-    __syncthreads();  // table + first query tile visible
+    __syncthreads();  // table visible (the LDS-DMA is invisible to this barrier's fence)
 
     // B: this lane's code bits as fp6 fields, 6 dwords per 32 dimensions, resident for the whole block
     uint32_t bexp[NT][W][6];
@@ -936,28 +953,34 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(SCAN_PARAMS) {
             bexp[t][m][5] = (p3.x >> 16) | (p3.y << 16);
         }
 
+    uint32_t slot = 0;  // ring slot of query tile qt
     for (uint32_t qt = 0; qt < ((a.dbg & 4u) ? 0u : ntiles); ++qt) {
-        const uint32_t buf = (a.dbg & 2u) ? 0u : (qt & 1);
-        const bool more = qt + 1 < ntiles && !(a.dbg & 2u);
-        if (more) stage_load(qt + 1, sregs);
-        // is every query's stage range a superset of this block's tile?  (then no per-lane range checks)
-        bool full_i = true;
-        if (lane < 32) full_i = tailT[buf][RQ_REC_LO][lane] <= first && first + TILE <= tailT[buf][RQ_REC_HI][lane];
-        // padding queries (empty range, threshold -inf) can never pass, so they need no range check either
-        if (lane < 32 && tailT[buf][RQ_REC_LO][lane] >= tailT[buf][RQ_REC_HI][lane]) full_i = true;
-        const bool all_full = __ballot(full_i) == ~0ull;
+        // tile qt has landed once at most the NI copies of tile qt+1 are still in flight (in-order counter)
+        if (qt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave's quarter of tile qt is in; everyone is done with tile qt-1
+        if (qt + 2 < ntiles) dma_tile(qt + 2, slot == 0 ? 2 : slot - 1);  // into the slot tile qt-1 occupied
+        const uint32_t *img = ring[slot];
+        const uint32_t nvalid = cnt - 32 * qt;  // rows >= nvalid of the last tile are stale memory: masked here
+        const bool valid = j < nvalid;
 
         uint32_t aop[W][6];  // A: query row j (= lane & 31), dims 64m + 32h .. +31 as fp6
 #pragma unroll
         for (int m = 0; m < W; ++m)
 #pragma unroll
             for (int e = 0; e < 6; e += 2) {
-                const uint2 v = *reinterpret_cast<const uint2 *>(&opbuf[buf][j][6 * W * h + 6 * m + e]);
-                aop[m][e] = v.x, aop[m][e + 1] = v.y;
+                const uint2 v = *reinterpret_cast<const uint2 *>(&img[j * OPLD + 6 * W * h + 6 * m + e]);
+                aop[m][e] = valid ? v.x : 0u, aop[m][e + 1] = valid ? v.y : 0u;
             }
         v4i32 ua;  // A operand of the threshold MFMA: slots 8h .. 8h+7 of query row j
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ua[e] = (int)tailT[buf][RQ_REC_V0 + 4 * h + e][j];
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t v = img[IMG_OP + (RQ_REC_V0 + 4 * h + e) * 32 + j];
+            // a missing query: -S* = -inf (constant term hi = -inf, times 1), never flagged
+            ua[e] = (int)(valid ? v : ((h == 1 && e == 2) ? 0x0000FF80u : 0u));
+        }
+        auto tail = [&](uint32_t f, uint32_t row) { return img[IMG_OP + f * 32 + row]; };
 
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -1001,14 +1024,14 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(SCAN_PARAMS) {
                     const uint32_t row = (gq & 3) + 8 * (gq >> 2) + 4 * h;
                     const float sf = 2.0f * sc[gq];  // wave-uniform register index
                     // the reference's expression, left to right (src/rabitq.rs:352-363)
-                    float tt = fc.w + __builtin_bit_cast(float, tailT[buf][RQ_REC_YCD][row]);
-                    tt = tt + __builtin_bit_cast(float, tailT[buf][RQ_REC_LOWER][row]) * fc.y;
-                    const float u = (2.0f * sf - __builtin_bit_cast(float, tailT[buf][RQ_REC_SUMQ][row])) * fc.x;
-                    tt = tt + u * __builtin_bit_cast(float, tailT[buf][RQ_REC_DELTA][row]);
-                    const float rg = tt - fc.z * __builtin_bit_cast(float, tailT[buf][RQ_REC_YCD_SQRT][row]);
-                    bool pass = rg < __builtin_bit_cast(float, tailT[buf][RQ_REC_THR][row]);  // src/rerank.rs:84
-                    pass = pass && lpos[t] < list_len;
-                    if (!all_full) pass = pass && lpos[t] >= tailT[buf][RQ_REC_LO][row] && lpos[t] < tailT[buf][RQ_REC_HI][row];
+                    float tt = fc.w + __builtin_bit_cast(float, tail(RQ_REC_YCD, row));
+                    tt = tt + __builtin_bit_cast(float, tail(RQ_REC_LOWER, row)) * fc.y;
+                    const float u = (2.0f * sf - __builtin_bit_cast(float, tail(RQ_REC_SUMQ, row))) * fc.x;
+                    tt = tt + u * __builtin_bit_cast(float, tail(RQ_REC_DELTA, row));
+                    const float rg = tt - fc.z * __builtin_bit_cast(float, tail(RQ_REC_YCD_SQRT, row));
+                    bool pass = rg < __builtin_bit_cast(float, tail(RQ_REC_THR, row));  // src/rerank.rs:84
+                    // a real query, and a list position inside its stage range
+                    pass = pass && row < nvalid && lpos[t] >= tail(RQ_REC_LO, row) && lpos[t] < tail(RQ_REC_HI, row);
                     const uint64_t m = __ballot(pass);
                     if (m == 0) continue;
                     if (nE + 64 > QE || nR + 2 > QR) flush();
@@ -1023,8 +1046,8 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(SCAN_PARAMS) {
                         q_run[wave][e] = myrun;
                     }
                     if (j == 0 && (h ? c1 : c0)) {
-                        r_b[wave][myrun] = tailT[buf][RQ_REC_ROW][row];
-                        r_slot[wave][myrun] = tailT[buf][RQ_REC_SLOT][row];
+                        r_b[wave][myrun] = tail(RQ_REC_ROW, row);
+                        r_slot[wave][myrun] = tail(RQ_REC_SLOT, row);
                         r_pos[wave][myrun] = list_begin + first + wave * (32 * NT) + t * 32;
                         r_cnt[wave][myrun] = h ? c1 : c0;
                         r_off[wave][myrun] = myoff;
@@ -1034,8 +1057,7 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(SCAN_PARAMS) {
                 }
             }
         }
-        if (more) stage_store(buf ^ 1, sregs);
-        __syncthreads();
+        slot = slot == 2 ? 0 : slot + 1;
     }
     if (nE) flush();
 }

@@ -266,12 +266,14 @@ static void launch_scan_mfma(const ScanPtrs &p, const ScanArgs &a, uint32_t W, h
         abort();
     }
     dim3 g((uint32_t)blocks), b(256);
+#define SCAN_MFMA_ARGS p.codes, p.factors, p.offsets, p.grp_start, p.grp_cnt, p.recs, p.surv, p.runs, p.surv_cnt, a
     switch (W) {
-        case 1: scan_mfma_kernel<1, 4><<<g, b, 0, st>>>(SCAN_ARGS); break;
-        case 2: scan_mfma_kernel<2, 4><<<g, b, 0, st>>>(SCAN_ARGS); break;
-        case 4: scan_mfma_kernel<4, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
+        case 1: scan_mfma_kernel<1, 4><<<g, b, 0, st>>>(SCAN_MFMA_ARGS); break;
+        case 2: scan_mfma_kernel<2, 4><<<g, b, 0, st>>>(SCAN_MFMA_ARGS); break;
+        case 4: scan_mfma_kernel<4, 2><<<g, b, 0, st>>>(SCAN_MFMA_ARGS); break;
         default: abort();
     }
+#undef SCAN_MFMA_ARGS
 }
 
 static bool scan_is_fused(uint32_t W) {
@@ -316,7 +318,8 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
     RQC(ws.qf6.ensure(npairs * 12 * idx->W));
     RQC(ws.rough_cnt.ensure(nq));
     RQC(ws.totals.ensure(8));
-    RQC(ws.recs.ensure(npairs * (12ull * idx->W + RQ_REC_TAIL)));
+    // record-major (8W + tail per pair) or tile images (pairs padded to 32 per list, 12W + 2 + tail per slot)
+    RQC(ws.recs.ensure((npairs + 32ull * idx->k + 32) * (12ull * idx->W + 2 + RQ_REC_TAIL)));
     RQC(ws.grp_cnt.ensure(idx->k + 1));
     RQC(ws.grp_start.ensure(idx->k + 1));
     RQC(ws.thr.ensure(nq));
@@ -443,7 +446,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             HIPC(hipMemsetAsync(ws.grp_cnt.p, 0, (k + 1) * 4, st));
             group_count_kernel<<<ceil_div(npairs, 256), 256, 0, st>>>(ws.scal.p, probe_cluster, npairs, sg.s_lo,
                                                                       sg.s_hi, ws.grp_cnt.p);
-            group_scan_kernel<<<1, 1024, 0, st>>>(ws.grp_cnt.p, k, ws.grp_start.p);
+            group_scan_kernel<<<1, 1024, 0, st>>>(ws.grp_cnt.p, k, ws.grp_start.p, use_mfma ? 1u : 0u);
             a.ngroups = k;
         } else {
             a.ngroups = npairs;
@@ -454,11 +457,13 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         stage_fill_kernel<<<ceil_div(npairs, 16), 256, 0, st>>>(ws.scal.p, probe_cluster, operand, ws.thr.p, npairs,
                                                                 nprobe, use_mfma ? 12 * W : 8 * W, sg.s_lo, sg.s_hi,
                                                                 a.cluster_major, ws.grp_start.p, ws.grp_cnt.p, ws.recs.p,
-                                                                idx->fstats);
+                                                                idx->fstats, use_mfma ? 1u : 0u);
         pf.end();
         sp.codes = reinterpret_cast<const uint32_t *>(idx->codes.p);
         sp.factors = idx->factors.p;
         sp.grp_start = ws.grp_start.p;
+        sp.grp_cnt = ws.grp_cnt.p;
+        sp.offsets = idx->offsets.p;
         sp.recs = ws.recs.p;
         sp.surv = ws.surv.p;
         sp.runs = ws.runs.p;
@@ -846,7 +851,7 @@ static rq_status build_device(const float *d_base, uint64_t n, uint32_t d, const
     RQC(keys.alloc(n));
     HIPC(hipMemset(cnt.p, 0, ((size_t)k + 1) * 4));
     if (n) label_hist_kernel<<<ceil_div(n, 256), 256>>>(label.p, n, cnt.p);
-    group_scan_kernel<<<1, 1024>>>(cnt.p, k, idx->offsets.p);  // also zeroes cnt -> cursor
+    group_scan_kernel<<<1, 1024>>>(cnt.p, k, idx->offsets.p, 0u);  // also zeroes cnt -> cursor
     if (n) label_scatter_kernel<<<ceil_div(n, 256), 256>>>(label.p, mind.p, n, 0, idx->offsets.p, cnt.p, keys.p);
     list_sort_kernel<<<k, 1024>>>(keys.p, idx->offsets.p);
     RQC(idx->base.alloc(n * dim));
