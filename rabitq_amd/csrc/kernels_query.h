@@ -1427,20 +1427,31 @@ __global__ __launch_bounds__(256) void accurate_kernel(SurvRec *__restrict__ sur
     // TWO lanes per candidate: lane half hf carries AVX lanes 4hf..4hf+3 (elements 8c + 4hf + 0..3, one
     // 16-byte load per chunk), so a row is fetched with float4 loads; the fold
     // ((a0+a4)+(a1+a5)) + ((a2+a6)+(a3+a7)) needs one exchange between the two lanes.
+    // The row of a candidate is fetched 8 chunks (64 dimensions, 8 x 16 bytes per lane) at a time so that
+    // every lane keeps 8 loads in flight (the kernel is a random 512-byte-row gather: latency-bound unless
+    // enough bytes are outstanding); the query sits in LDS.  dynamic LDS: dim floats.
+    extern __shared__ __attribute__((aligned(16))) float acc_q[];
     const uint32_t b = blockIdx.y;
     const uint32_t n = (uint32_t)surv_cnt[b];
-    if (n > cap) return;  // overflowed: this query is re-run with a larger buffer
+    if (n > cap || n == 0) return;  // overflowed: this query is re-run with a larger buffer
     const uint32_t hf = threadIdx.x & 1, grp = threadIdx.x >> 1;
-    const float *q = qpad + (uint64_t)b * dim;
+    for (uint32_t c = threadIdx.x * 4; c < dim; c += 1024)
+        *reinterpret_cast<float4 *>(acc_q + c) = *reinterpret_cast<const float4 *>(qpad + (uint64_t)b * dim + c);
+    __syncthreads();
     SurvRec *recs = surv + (uint64_t)b * cap;
     for (uint32_t i = blockIdx.x * 128 + grp; i < n; i += gridDim.x * 128) {
-        const float *x = base + (uint64_t)recs[i].pos * dim;
+        const float *x = base + (uint64_t)recs[i].pos * dim + 4 * hf;
         float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-        for (uint32_t c = 0; c < dim; c += 8) {
-            const float4 xv = *reinterpret_cast<const float4 *>(x + c + 4 * hf);
-            const float4 qv = *reinterpret_cast<const float4 *>(q + c + 4 * hf);
-            float d0 = xv.x - qv.x, d1 = xv.y - qv.y, d2 = xv.z - qv.z, d3 = xv.w - qv.w;
-            a0 = fmaf(d0, d0, a0), a1 = fmaf(d1, d1, a1), a2 = fmaf(d2, d2, a2), a3 = fmaf(d3, d3, a3);
+        for (uint32_t c = 0; c < dim; c += 64) {  // dim is a multiple of 64
+            float4 xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = *reinterpret_cast<const float4 *>(x + c + 8 * u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4 qv = *reinterpret_cast<const float4 *>(acc_q + c + 8 * u + 4 * hf);
+                const float d0 = xv[u].x - qv.x, d1 = xv[u].y - qv.y, d2 = xv[u].z - qv.z, d3 = xv[u].w - qv.w;
+                a0 = fmaf(d0, d0, a0), a1 = fmaf(d1, d1, a1), a2 = fmaf(d2, d2, a2), a3 = fmaf(d3, d3, a3);
+            }
         }
         // c_i = a_i + a_{i+4}: the partner lane holds the other half (commutative, so both lanes agree)
         const float c0 = a0 + __shfl_xor(a0, 1, 2), c1 = a1 + __shfl_xor(a1, 1, 2);

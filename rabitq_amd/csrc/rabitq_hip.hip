@@ -488,7 +488,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         } else {  // large batch: full-chip rerank, then run-directory sort, then one replay wave per query
             pf.begin(PF_RERANK);
             const uint32_t gx = std::max(1u, std::min(16u, 4096u / std::max(nq, 1u)));
-            accurate_kernel<<<dim3(gx, nq), 256, 0, st>>>(ws.surv.p, ws.surv_cnt.p, qp.cap, idx->base.p, qpad, dim);
+            accurate_kernel<<<dim3(gx, nq), 256, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.surv_cnt.p, qp.cap, idx->base.p, qpad, dim);
             pf.end();
             pf.begin(PF_SORT);
             sort_runs_kernel<<<nq, 64, 0, st>>>(ws.runs.p, ws.surv_cnt.p, qp.cap);

@@ -12,7 +12,8 @@ for d in ("pmc_mfma", "pmc_mfma2"):
     if not fs:
         print(d, "missing")
         continue
-    rows = [r for r in csv.DictReader(open(fs[0])) if "scan_mfma_kernel" in r["Kernel_Name"]]
+    fs.sort(key=os.path.getmtime)
+    rows = [r for r in csv.DictReader(open(fs[-1])) if "scan_mfma_kernel" in r["Kernel_Name"]]
     byd = collections.defaultdict(dict)
     for r in rows:
         byd[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
@@ -22,11 +23,20 @@ for d in ("pmc_mfma", "pmc_mfma2"):
 for k, v in sorted(tot.items()):
     print(f"{k:28s} {v:16.0f}")
 if "SQ_BUSY_CYCLES" in tot and "GRBM_GUI_ACTIVE" in tot:
-    gui = tot["GRBM_GUI_ACTIVE"]
+    gui = tot["GRBM_GUI_ACTIVE"] / 8  # the counter is summed over the 8 XCDs
     simd_cycles = gui * 256 * 4  # one count per SIMD-cycle if every SIMD were busy the whole launch
     print("launch cycles (GRBM_GUI_ACTIVE):", gui)
-    for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_ANY"):
+    # SQ_*_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count in units of 4 cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles
+    print(f"  matrix pipe busy          = {tot.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / simd_cycles:.3f}")
+    for k in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"):
         if k in tot:
-            print(f"  {k} / (launch cycles x 1024 SIMDs) = {tot[k] / simd_cycles:.3f}")
+            print(f"  {k:26s}= {4 * tot[k] / simd_cycles:.3f} of SIMD-cycles")
+    for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"):
+        if k in tot:
+            print(f"  {k:26s}= {4 * tot[k] / simd_cycles:.3f} of the 1-per-4-cycles issue rate")
     if "SQ_WAVE_CYCLES" in tot:
-        print(f"  mean waves per SIMD = {tot['SQ_WAVE_CYCLES'] / simd_cycles:.2f}")
+        wc = 4 * tot["SQ_WAVE_CYCLES"]
+        print(f"  mean waves per SIMD       = {wc / simd_cycles:.2f}")
+        print(f"  wave lifetime             = {wc / tot['SQ_WAVES']:.0f} cycles")
+        for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"):
+            print(f"  {k:26s}= {4 * tot[k] / wc:.3f} of wave-cycles")
