@@ -198,8 +198,10 @@ typedef struct {
     uint32_t scan_launches;
     uint32_t retries;          /* queries re-run because a survivor buffer overflowed   */
 } rq_profile_t;
-rq_status rq_set_profiling(int enabled);
-/* Engine options.  "scan_impl": 0 = auto (default: int8 matrix-core scan when many queries share each
+/* level: 0 = off; 1 = every kernel group bracketed (each event costs a few microseconds of stream
+ * time); 2 = only the scan launches and the whole pass (ms_scan, ms_total; the other fields stay 0). */
+rq_status rq_set_profiling(int level);
+/* Engine options.  "scan_impl": 0 = auto (default: fp6 matrix-core scan when many queries share each
  * list, v_dot8 VALU scan otherwise), 1 = VALU only, 2 = matrix cores wherever available.  All
  * settings return identical results; the option exists for tests and measurements. */
 rq_status rq_set_option(const char *name, int value);

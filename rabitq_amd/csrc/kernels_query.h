@@ -460,38 +460,37 @@ __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__re
     }
     // record-major: record `at` = opdw operand dwords + RQ_REC_TAIL tail dwords.  tile images (matrix-core
     // scan): records in tiles of 32, each tile stored as the exact LDS image the kernel copies in with
-    // LDS-DMA: 32 operand rows of opdw+2 dwords, then the tail transposed [RQ_REC_TAIL][32].
+    // LDS-DMA: 32 operand rows of opdw+2 dwords, then the 32 tails.
     const uint32_t stride = opdw + RQ_REC_TAIL;
     uint32_t *r = recs + (uint64_t)at * stride;
-    uint32_t tstride = 1;
-    uint32_t *t = r + opdw;
+    uint32_t *tdst = r + opdw;
     if (tile_images) {
         const uint32_t opld = opdw + 2, img = 32 * opld + RQ_REC_TAIL * 32;
         uint32_t *base = recs + (uint64_t)(at >> 5) * img;
         r = base + (at & 31u) * opld;
-        t = base + 32 * opld + (at & 31u);
-        tstride = 32;
+        tdst = base + 32 * opld + (at & 31u) * RQ_REC_TAIL;
     }
     for (uint32_t i = sub; i < opdw; i += 16) r[i] = operand[(uint64_t)p * opdw + i];
     if (sub == 0) {
+        uint32_t t[RQ_REC_TAIL];
         uint32_t lo = 0, hi = 0;
         if (in) {
             lo = s_lo > ps.stream_begin ? s_lo - ps.stream_begin : 0u;
             hi = s_hi - ps.stream_begin;  // in-stage => stream_begin < s_hi
             hi = hi < ps.list_len ? hi : ps.list_len;
         }
-        t[(RQ_REC_LOWER) * tstride] = __builtin_bit_cast(uint32_t, ps.lower);
-        t[(RQ_REC_DELTA) * tstride] = __builtin_bit_cast(uint32_t, ps.delta);
-        t[(RQ_REC_SUMQ) * tstride] = __builtin_bit_cast(uint32_t, ps.sumq);
-        t[(RQ_REC_YCD) * tstride] = __builtin_bit_cast(uint32_t, ps.ycd);
-        t[(RQ_REC_YCD_SQRT) * tstride] = __builtin_bit_cast(uint32_t, ps.ycd_sqrt);
-        t[(RQ_REC_THR) * tstride] = __builtin_bit_cast(uint32_t, thr[ps.row]);
-        t[(RQ_REC_LO) * tstride] = lo;
-        t[(RQ_REC_HI) * tstride] = hi;
-        t[(RQ_REC_ROW) * tstride] = ps.row;
-        t[(RQ_REC_SLOT) * tstride] = p - ps.row * nprobe;
-        t[(RQ_REC_LIST_BEGIN) * tstride] = ps.list_begin;
-        t[(RQ_REC_LIST_LEN) * tstride] = ps.list_len;
+        t[RQ_REC_LOWER] = __builtin_bit_cast(uint32_t, ps.lower);
+        t[RQ_REC_DELTA] = __builtin_bit_cast(uint32_t, ps.delta);
+        t[RQ_REC_SUMQ] = __builtin_bit_cast(uint32_t, ps.sumq);
+        t[RQ_REC_YCD] = __builtin_bit_cast(uint32_t, ps.ycd);
+        t[RQ_REC_YCD_SQRT] = __builtin_bit_cast(uint32_t, ps.ycd_sqrt);
+        t[RQ_REC_THR] = __builtin_bit_cast(uint32_t, thr[ps.row]);
+        t[RQ_REC_LO] = lo;
+        t[RQ_REC_HI] = hi;
+        t[RQ_REC_ROW] = ps.row;
+        t[RQ_REC_SLOT] = p - ps.row * nprobe;
+        t[RQ_REC_LIST_BEGIN] = ps.list_begin;
+        t[RQ_REC_LIST_LEN] = ps.list_len;
         // Integer form of the gate (used by the matrix-core scan).  With F = factor_ip * delta < 0,
         //   rough < thr  <=>  s > S* = [ (thr - ycd) + (-1) cds + (-lower) ppc + ysq eb ] / (2 F) + sumq / 2
         // (real arithmetic), a rank-5 bilinear form in u'_c = (1, cds, ppc, eb)/fip, 1  and v'_q.  The scan
@@ -529,16 +528,20 @@ __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__re
             for (int i = 0; i < 4; ++i) vh[i] = 0, vl[i] = 0;
             c0 = 0x7F80u, c1 = 0, c2 = 0;  // +inf * 1: -S* = +inf
         }
-        // A operand of the threshold MFMA, element e of lane half h = slot 8h + e (the candidate side holds
-        // uh0 ul0 uh0 uh1 ul1 uh1 uh2 ul2 | uh2 uh3 ul3 uh3 1 1 1 0)
-        t[(RQ_REC_V0 + 0) * tstride] = vh[0] | (vh[0] << 16);
-        t[(RQ_REC_V0 + 1) * tstride] = vl[0] | (vh[1] << 16);
-        t[(RQ_REC_V0 + 2) * tstride] = vh[1] | (vl[1] << 16);
-        t[(RQ_REC_V0 + 3) * tstride] = vh[2] | (vh[2] << 16);
-        t[(RQ_REC_V0 + 4) * tstride] = vl[2] | (vh[3] << 16);
-        t[(RQ_REC_V0 + 5) * tstride] = vh[3] | (vl[3] << 16);
-        t[(RQ_REC_V0 + 6) * tstride] = c0 | (c1 << 16);
-        t[(RQ_REC_V0 + 7) * tstride] = c2;
+        // A operand of the threshold MFMA, element e of lane half h = slot 8h + e:
+        //   vh0 vh0 vl0 vh1 vh1 vl1 c0 c1 | vh2 vh2 vl2 vh3 vh3 vl3 c2 0     against the candidate side's
+        //   uh0 ul0 uh0 uh1 ul1 uh1  1  1 | uh2 ul2 uh2 uh3 ul3 uh3  1 0
+        t[RQ_REC_V0 + 0] = vh[0] | (vh[0] << 16);
+        t[RQ_REC_V0 + 1] = vl[0] | (vh[1] << 16);
+        t[RQ_REC_V0 + 2] = vh[1] | (vl[1] << 16);
+        t[RQ_REC_V0 + 3] = c0 | (c1 << 16);
+        t[RQ_REC_V0 + 4] = vh[2] | (vh[2] << 16);
+        t[RQ_REC_V0 + 5] = vl[2] | (vh[3] << 16);
+        t[RQ_REC_V0 + 6] = vh[3] | (vl[3] << 16);
+        t[RQ_REC_V0 + 7] = c2;
+#pragma unroll
+        for (int i = 0; i < RQ_REC_TAIL; i += 4)  // 16-byte aligned in both layouts
+            *reinterpret_cast<uint4 *>(tdst + i) = make_uint4(t[i], t[i + 1], t[i + 2], t[i + 3]);
     }
 }
 
@@ -773,6 +776,7 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
 // ------------------------------------------------------------------------------------------------
 typedef int v8i32 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 #ifndef RQ_F32X16_DEFINED
 #define RQ_F32X16_DEFINED
@@ -807,7 +811,7 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(const uint32_t *__res
     constexpr uint32_t OPDW = 12 * W;            // operand dwords per record: dim fp6 fields
     constexpr uint32_t OPLD = OPDW + 2;          // row stride (dwords) of the operand image: conflict-free ds_read_b64
     constexpr uint32_t IMG_OP = 32 * OPLD;       // a query tile image: 32 operand rows ...
-    constexpr uint32_t IMG = IMG_OP + RQ_REC_TAIL * 32;  // ... + the record tails, transposed [field][query]
+    constexpr uint32_t IMG = IMG_OP + RQ_REC_TAIL * 32;  // ... + the 32 record tails
     constexpr uint32_t WQ4 = IMG / 16;           // 16-byte pieces each wave copies (a quarter of the image)
     constexpr uint32_t NI = (WQ4 + 63) / 64;     // LDS-DMA instructions per wave per tile
     static_assert(IMG % 16 == 0, "tile image must split into four 16-byte-aligned quarters");
@@ -872,25 +876,24 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(const uint32_t *__res
     bool forced = false;  // candidates whose factors do not admit the integer-threshold form
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        // u'_c = (1, cds, ppc, eb) / factor_ip, 1   (factor_ip < 0 for every regular vector, rabitq.rs:227)
-        const float rf = 1.0f / fac0[t].x;
-        const float u[4] = {rf, fac0[t].w * rf, fac0[t].y * rf, fac0[t].z * rf};
-        const float mag = fabsf(u[0]) + fabsf(u[1]) + fabsf(u[2]) + fabsf(u[3]);
+        // u'_c = (1, cds, ppc, eb) / factor_ip, 1   (factor_ip < 0 for every regular vector, rabitq.rs:227).
+        // Lane half 0 carries u'[0], u'[1], half 1 carries u'[2], u'[3]; an approximate reciprocal is enough
+        // (its 1 ulp is far inside the margin the bf16 split already needs).
+        const float rf = __builtin_amdgcn_rcpf(fac0[t].x);
+        const float mag = (1.0f + fabsf(fac0[t].w) + fabsf(fac0[t].y) + fabsf(fac0[t].z)) * fabsf(rf);
         const bool ok = fac0[t].x < 0.0f && mag < 1.0e37f;  // false for NaN / inf / factor_ip >= 0
-        uint32_t uh[4], ul[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uh[i] = bf16_rne(u[i]);
-            ul[i] = bf16_rne(u[i] - bf16_to_f32(uh[i]));
-            if (!ok) uh[i] = 0, ul[i] = 0;
-        }
-        const uint32_t one = ok ? 0x3F80u : 0u;
+        const float x0 = (h ? fac0[t].y : 1.0f) * rf, x1 = (h ? fac0[t].z : fac0[t].w) * rf;
+        f32x2 xs = {x0, x1};
+        const uint32_t hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(xs, bf16x2));  // xh0 | xh1 << 16 (RNE)
+        f32x2 res = {x0 - __builtin_bit_cast(float, hi << 16), x1 - __builtin_bit_cast(float, hi & 0xFFFF0000u)};
+        const uint32_t lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(res, bf16x2));  // xl0 | xl1 << 16
+        const uint32_t one = 0x3F80u;
+        // slots of this half: xh0 xl0 xh0 xh1 xl1 xh1 1 (1 | 0)
+        ub[t][0] = ok ? ((hi & 0xFFFFu) | (lo << 16)) : 0u;
+        ub[t][1] = ok ? hi : 0u;
+        ub[t][2] = ok ? ((lo >> 16) | (hi & 0xFFFF0000u)) : 0u;
+        ub[t][3] = ok ? (h ? one : (one | (one << 16))) : 0u;
         if (!ok) forced = true;
-        // slots: uh0 ul0 uh0 uh1 ul1 uh1 uh2 ul2 | uh2 uh3 ul3 uh3 1 1 1 0
-        ub[t][0] = h ? (uh[2] | (uh[3] << 16)) : (uh[0] | (ul[0] << 16));
-        ub[t][1] = h ? (ul[3] | (uh[3] << 16)) : (uh[0] | (uh[1] << 16));
-        ub[t][2] = h ? (one | (one << 16)) : (ul[1] | (uh[1] << 16));
-        ub[t][3] = h ? one : (uh[2] | (ul[2] << 16));
     }
     const uint64_t forcemask = __ballot(forced);
     if (h == 0) {
@@ -973,14 +976,12 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(const uint32_t *__res
                 const uint2 v = *reinterpret_cast<const uint2 *>(&img[j * OPLD + 6 * W * h + 6 * m + e]);
                 aop[m][e] = valid ? v.x : 0u, aop[m][e + 1] = valid ? v.y : 0u;
             }
-        v4i32 ua;  // A operand of the threshold MFMA: slots 8h .. 8h+7 of query row j
+        // A operand of the threshold MFMA: slots 8h .. 8h+7 of query row j
+        v4i32 ua = *reinterpret_cast<const v4i32 *>(&img[IMG_OP + j * RQ_REC_TAIL + RQ_REC_V0 + 4 * h]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const uint32_t v = img[IMG_OP + (RQ_REC_V0 + 4 * h + e) * 32 + j];
-            // a missing query: -S* = -inf (constant term hi = -inf, times 1), never flagged
-            ua[e] = (int)(valid ? v : ((h == 1 && e == 2) ? 0x0000FF80u : 0u));
-        }
-        auto tail = [&](uint32_t f, uint32_t row) { return img[IMG_OP + f * 32 + row]; };
+        for (int e = 0; e < 4; ++e)  // a missing query: -S* = -inf (constant term hi = -inf, times 1), never flagged
+            ua[e] = valid ? ua[e] : ((h == 0 && e == 3) ? 0x0000FF80 : 0);
+        auto tail = [&](uint32_t f, uint32_t row) { return img[IMG_OP + row * RQ_REC_TAIL + f]; };
 
 #pragma unroll
         for (int t = 0; t < NT; ++t) {

@@ -104,6 +104,7 @@ static thread_local rq_profile_t g_profile;
 
 struct Prof {
     bool on = false;
+    bool light = false;  // level 2: only the scan launches and the whole pass are bracketed
     hipStream_t stream = nullptr;
     struct Span {
         hipEvent_t a, b;
@@ -112,6 +113,8 @@ struct Prof {
     std::vector<Span> spans;
     std::vector<hipEvent_t> pool;
     size_t used = 0;
+    bool open = false;          // the last begin() was recorded (not filtered out)
+    hipEvent_t last_b = nullptr;  // end event of the previous span, reusable as the next begin while nothing ran since
     hipEvent_t get() {
         if (used == pool.size()) {
             hipEvent_t e;
@@ -120,21 +123,35 @@ struct Prof {
         }
         return pool[used++];
     }
+    // An event record costs ~5 us of stream time: adjacent spans share their boundary event.
     void begin(int cat) {
-        if (!on) return;
-        Span s{get(), get(), cat};
-        (void)hipEventRecord(s.a, stream);
+        open = on && !(light && cat != PF_SCAN && cat != PF_TOTAL);
+        if (!open) {
+            last_b = nullptr;
+            return;
+        }
+        Span s{last_b, get(), cat};
+        if (!s.a) {
+            s.a = get();
+            (void)hipEventRecord(s.a, stream);
+        }
+        last_b = nullptr;
         spans.push_back(s);
     }
     void end() {
-        if (!on) return;
+        if (!open) return;
         (void)hipEventRecord(spans.back().b, stream);
+        last_b = spans.back().b;
+        open = false;
     }
-    void reset(bool enable, hipStream_t st) {
-        on = enable;
+    void reset(int level, hipStream_t st) {
+        on = level != 0;
+        light = level == 2;
         stream = st;
         spans.clear();
         used = 0;
+        open = false;
+        last_b = nullptr;
     }
     void collect(float *ms /*PF_N*/) {
         for (auto &s : spans) {
@@ -357,7 +374,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     const uint32_t npairs = nq * nprobe;
     hipStream_t st = ws.stream;
     Prof &pf = ws.prof;
-    pf.reset(g_profiling.load() != 0, st);
+    pf.reset(g_profiling.load(), st);
     pf.begin(PF_TOTAL);
     size_t total_span = pf.spans.size() ? pf.spans.size() - 1 : 0;
 
@@ -1295,8 +1312,9 @@ rq_status rq_set_option(const char *name, int value) {
     return fail(RQ_ERR_INVALID, std::string("unknown option ") + name);
 }
 
-rq_status rq_set_profiling(int enabled) {
-    g_profiling = enabled;
+rq_status rq_set_profiling(int level) {
+    if (level < 0 || level > 2) return fail(RQ_ERR_INVALID, "profiling level must be 0, 1 or 2");
+    g_profiling = level;
     return RQ_OK;
 }
 rq_status rq_last_profile(rq_profile_t *out) {

@@ -213,8 +213,9 @@ def metrics_str() -> str:
             f"cache miss: {m['miss']}")
 
 
-def set_profiling(enabled: bool) -> None:
-    check(lib().rq_set_profiling(int(enabled)))
+def set_profiling(level) -> None:
+    """0/False = off, 1/True = HIP events around every kernel group, 2 = around the scan launches only."""
+    check(lib().rq_set_profiling(int(level)))
 
 
 def set_option(name: str, value: int) -> None:
