@@ -282,10 +282,12 @@ __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ y,
         float r = yr[64 * w + lane] - cr[64 * w + lane];
         int32_t q = cvtps_epi32((r - mn) * one_over_delta);
         sum += (uint32_t)q;
+        if (planes) {
 #pragma unroll
-        for (int bit = 0; bit < 4; ++bit) {
-            uint64_t word = __ballot((q >> bit) & 1);
-            if (lane == 0) pl[bit * W + w] = word;
+            for (int bit = 0; bit < 4; ++bit) {
+                uint64_t word = __ballot((q >> bit) & 1);
+                if (lane == 0) pl[bit * W + w] = word;
+            }
         }
         if (qf6) {  // matrix-core operand: q/2 as fp6 e2m3 (every integer 0..15 is exact), 6-bit fields packed as a
                     // little-endian bit stream; lane half h = lane>>5 of word w <-> the 6 dwords [h][w][0..6)
@@ -577,8 +579,8 @@ struct ScanPtrs {   // host-side bundle only
 };
 #define SCAN_PARAMS                                                                                  \
     const uint32_t *__restrict__ codes, const float4 *__restrict__ factors,                          \
-        const uint32_t *__restrict__ grp_start, const uint32_t *__restrict__ recs,                   \
-        SurvRec *__restrict__ surv, RunRec *__restrict__ runs,                                       \
+        const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ grp_start,                \
+        const uint32_t *__restrict__ recs, SurvRec *__restrict__ surv, RunRec *__restrict__ runs,    \
         unsigned long long *__restrict__ surv_cnt, const ScanArgs a
 
 // 8 code bits -> 8 nibbles (bit i -> nibble i), so that sum_j bit_j * q_j becomes v_dot8_u32_u4
@@ -619,12 +621,18 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
         pb = g;
         pe = g + 1;
     }
+    // the list of this group (all its pairs share it); cluster-major: straight from the index, in the same
+    // round trip as the group bounds
+    uint32_t list_begin = 0, list_len = 0;
+    if (a.cluster_major) {
+        list_begin = offsets[g];
+        list_len = offsets[g + 1] - list_begin;
+    }
     if (pb >= pe) return;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // the list of this group (all its pairs share it)
     const uint32_t *rec = recs + (uint64_t)pb * STRIDE;
-    const uint32_t list_begin = rec[8 * W + RQ_REC_LIST_BEGIN], list_len = rec[8 * W + RQ_REC_LIST_LEN];
+    if (!a.cluster_major) list_begin = rec[8 * W + RQ_REC_LIST_BEGIN], list_len = rec[8 * W + RQ_REC_LIST_LEN];
     const uint32_t first = tile * (256 * CPL);  // first list position of this tile
     if (first >= list_len) return;
     if (!a.cluster_major && rec[8 * W + RQ_REC_LO] >= rec[8 * W + RQ_REC_HI]) return;  // pair not in this stage
@@ -1256,37 +1264,56 @@ __device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, co
         wcount = st.win_count[b];
         alen = st.arr_len[b];
     }
-    // the directory is read 64 descriptors at a time (one coalesced load, broadcast by shuffle) and the
-    // records of run k+1 are in flight while run k is replayed
-    SurvRec nxt;
-    nxt.pos = 0, nxt.slot = 0, nxt.rough = 0.0f, nxt.accurate = 0.0f;
-    uint32_t dbase = 0, dcnt = 0;
-    if (lane < nruns) dbase = dir[lane].base, dcnt = dir[lane].cnt;
-    {
-        const uint32_t b0 = __shfl(dbase, 0, 64), c0 = __shfl(dcnt, 0, 64);
-        if (lane < c0) nxt = recs[b0 + lane];
-    }
-    for (uint32_t ri = 0; ri < nruns; ++ri) {
-        const uint32_t rc = __shfl(dcnt, ri & 63, 64);
-        const bool have = lane < rc;
-        SurvRec r = nxt;
-        if (ri + 1 < nruns) {  // wave-uniform
-            if (((ri + 1) & 63) == 0) {
-                dbase = 0, dcnt = 0;
-                if (ri + 1 + lane < nruns) dbase = dir[ri + 1 + lane].base, dcnt = dir[ri + 1 + lane].cnt;
-            }
-            const uint32_t nb = __shfl(dbase, (ri + 1) & 63, 64), nc = __shfl(dcnt, (ri + 1) & 63, 64);
-            if (lane < nc) nxt = recs[nb + lane];
+    // The survivors are replayed in stream order = directory order, then record order inside a run.  The
+    // directory is read 64 descriptors at a time; within such a chunk the stream is cut into batches of 64
+    // survivors (whatever runs they belong to): lane i finds its (run, offset) by a binary search over
+    // the chunk's prefix sums in LDS, so a batch costs two round trips (records, then their ids) however
+    // many short runs it spans, and batch k+1 is in flight while batch k is replayed.
+    __shared__ uint32_t s_pref[65], s_base[64];
+    for (uint32_t c0 = 0; c0 < nruns; c0 += 64) {
+        uint32_t dbase = 0, dcnt = 0;
+        if (c0 + lane < nruns) dbase = dir[c0 + lane].base, dcnt = dir[c0 + lane].cnt;
+        uint32_t incl = dcnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o, 64);
+            if ((int)lane >= o) incl += up;
         }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // previous chunk's readers are done (one wave)
+        s_pref[lane + 1] = incl;
+        s_base[lane] = dbase;
+        if (lane == 0) s_pref[0] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const uint32_t total = __shfl(incl, 63, 64);
+        auto fetch = [&](uint32_t off, SurvRec &rec, uint32_t &id) {
+            const uint32_t t = off + lane;
+            rec.pos = 0, rec.slot = 0, rec.rough = 0.0f, rec.accurate = 0.0f;
+            id = 0;
+            if (t < total) {
+                uint32_t lo = 0;  // largest r with s_pref[r] <= t
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1)
+                    if (lo + step < 64 && s_pref[lo + step] <= t) lo += step;
+                rec = recs[s_base[lo] + (t - s_pref[lo])];
+                id = map_ids[rec.pos];
+            }
+        };
+        SurvRec nxt;
+        uint32_t nxt_id;
+        fetch(0, nxt, nxt_id);
+        for (uint32_t off = 0; off < total; off += 64) {
+            const bool have = off + lane < total;
+            const SurvRec r = nxt;
+            const uint32_t r_id = nxt_id;
+            if (off + 64 < total) fetch(off + 64, nxt, nxt_id);  // wave-uniform
         uint64_t m = __ballot(have && r.rough < thr);  // rerank.rs:84 / :146
         while (m) {
             const int i = __builtin_ctzll(m);
             m &= m - 1;
             const float acc = __shfl(r.accurate, i, 64);
-            const uint32_t pos = __shfl(r.pos, i, 64);
             ++precise;
             if (!(acc < thr)) continue;  // rerank.rs:92 / :154
-            const uint32_t id = map_ids[pos];
+            const uint32_t id = __shfl(r_id, i, 64);
             if constexpr (!HEURISTIC) {
                 // push: append + sift_up(0, old_len)
                 int32_t key = ord32_from_f32(acc);
@@ -1353,6 +1380,7 @@ __device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, co
                 }
             }
             m &= __ballot(have && r.rough < thr);
+        }
         }
     }
     if constexpr (!HEURISTIC) {

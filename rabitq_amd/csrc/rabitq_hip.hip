@@ -247,7 +247,7 @@ static void launch_rotate(const float *x, const float *P, float *out, uint64_t n
 // ------------------------------------------------------------------------------------------------
 // scan dispatch on W = dim / 64
 // ------------------------------------------------------------------------------------------------
-#define SCAN_ARGS p.codes, p.factors, p.grp_start, p.recs, p.surv, p.runs, p.surv_cnt, a
+#define SCAN_ARGS p.codes, p.factors, p.offsets, p.grp_start, p.recs, p.surv, p.runs, p.surv_cnt, a
 static void launch_scan(const ScanPtrs &p, const ScanArgs &a, uint32_t W, hipStream_t st) {
     const uint64_t blocks = (uint64_t)a.ngroups * a.tiles_per_group;
     if (blocks == 0) return;
@@ -405,10 +405,14 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         pf.end();
     }
 
+    const int impl = g_scan_impl.load();  // one consistent choice for the whole pass
     // 3. per-pair query quantisation (:304-317)
     pf.begin(PF_PREP);
     prep_kernel<<<ceil_div(npairs, 4), 256, 0, st>>>(ws.y.p, idx->centroids.p, idx->offsets.p, probe_cluster, probe_dist,
-                                                     npairs, nprobe, dim, ws.scal.p, ws.planes.p, ws.qnib.p, ws.qf6.p,
+                                                     npairs, nprobe, dim, ws.scal.p,
+                                                     scan_is_fused(W) ? nullptr : ws.planes.p,   // only the generic-W scan reads bit planes
+                                                     scan_is_fused(W) ? ws.qnib.p : nullptr,
+                                                     scan_has_mfma(W) && impl != 1 ? ws.qf6.p : nullptr,
                                                      nullptr, k, 1u);
     pair_prefix_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(ws.scal.p, nq, nprobe, ws.rough_cnt.p);
     ReplayState rs;
@@ -451,7 +455,6 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     for (const Stage &sg : stages) {
         const uint64_t span = (uint64_t)std::min<uint64_t>(sg.s_hi, (uint64_t)nprobe * idx->max_list_len) - sg.s_lo;
         const uint64_t est_pairs = (uint64_t)nq * std::min<uint64_t>(nprobe, span / avg_len + 2);
-        const int impl = g_scan_impl.load();
         // matrix cores pay once a 32-query tile is reasonably full: >= 8 (query, list) pairs per list on average
         const bool use_mfma = scan_has_mfma(W) && impl != 1 && (impl == 2 || est_pairs >= 8ull * k);
         const bool cluster_major = use_mfma || (est_pairs >= k / 2 && est_pairs > 64);

@@ -50,4 +50,5 @@ for mode in modes:
                 acc[key] = acc.get(key, 0) + v / 3
     print(f"scan_debug={mode}: scan {acc['ms_scan']:.3f} ms  rerank {acc['ms_rerank']:.3f}  total {acc['ms_total']:.3f}  "
           f"rerank candidates/query {acc['rerank_candidates'] / B:.1f}", flush=True)
+    print("   ", {k[3:]: round(v, 3) for k, v in acc.items() if k.startswith("ms_")}, flush=True)
 rqi.set_option("scan_debug", 0)
