@@ -340,17 +340,28 @@ __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ y,
 // Position of every probed list in the query's candidate stream (the order the reference visits
 // candidates: lists nearest-first, members in stored order) and the stream length, which is also
 // what the reference adds to METRICS.rough for this query (src/rerank.rs:105).
-__global__ void pair_prefix_kernel(PairScalars *__restrict__ scal, uint32_t nq, uint32_t nprobe,
-                                   unsigned long long *__restrict__ rough_count) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void pair_prefix_kernel(PairScalars *__restrict__ scal, uint32_t nq, uint32_t nprobe,
+                                                          unsigned long long *__restrict__ rough_count) {
+    // one wave per query: 64 slots per step, exclusive scan by shuffles, carry across steps
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= nq) return;
-    unsigned long long acc = 0;
-    for (uint32_t s = 0; s < nprobe; ++s) {
+    unsigned long long carry = 0;
+    for (uint32_t s0 = 0; s0 < nprobe; s0 += 64) {
+        const uint32_t s = s0 + lane;
         PairScalars *ps = scal + (uint64_t)b * nprobe + s;
-        ps->stream_begin = acc > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)acc;
-        acc += ps->list_len;
+        const unsigned long long len = s < nprobe ? ps->list_len : 0;
+        unsigned long long incl = len;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long up = __shfl_up(incl, o, 64);
+            if ((int)lane >= o) incl += up;
+        }
+        const unsigned long long begin = carry + incl - len;
+        if (s < nprobe) ps->stream_begin = begin > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)begin;
+        carry += __shfl(incl, 63, 64);
     }
-    rough_count[b] = acc;
+    if (lane == 0) rough_count[b] = carry;
 }
 
 // ------------------------------------------------------------------------------------------------

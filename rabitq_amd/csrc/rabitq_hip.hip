@@ -337,7 +337,7 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
     RQC(ws.totals.ensure(8));
     // record-major (8W + tail per pair) or tile images (pairs padded to 32 per list, 12W + 2 + tail per slot)
     RQC(ws.recs.ensure((npairs + 32ull * idx->k + 32) * (12ull * idx->W + 2 + RQ_REC_TAIL)));
-    RQC(ws.grp_cnt.ensure(idx->k + 1));
+    RQC(ws.grp_cnt.ensure(idx->k + 4));
     RQC(ws.grp_start.ensure(idx->k + 1));
     RQC(ws.thr.ensure(nq));
     RQC(ws.surv.ensure(nq * qp.cap));
@@ -414,7 +414,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                                                      scan_is_fused(W) ? ws.qnib.p : nullptr,
                                                      scan_has_mfma(W) && impl != 1 ? ws.qf6.p : nullptr,
                                                      nullptr, k, 1u);
-    pair_prefix_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(ws.scal.p, nq, nprobe, ws.rough_cnt.p);
+    pair_prefix_kernel<<<ceil_div(nq, 4), 256, 0, st>>>(ws.scal.p, nq, nprobe, ws.rough_cnt.p);
     ReplayState rs;
     rs.thr = ws.thr.p, rs.heap_len = ws.heap_len.p, rs.heap_key = ws.heap_key.p, rs.heap_id = ws.heap_id.p;
     rs.precise = ws.precise.p, rs.need = ws.need.p, rs.nsurv = ws.nsurv.p, rs.recent_max = ws.recent.p, rs.win_count = ws.win_count.p;
@@ -455,7 +455,8 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     for (const Stage &sg : stages) {
         const uint64_t span = (uint64_t)std::min<uint64_t>(sg.s_hi, (uint64_t)nprobe * idx->max_list_len) - sg.s_lo;
         const uint64_t est_pairs = (uint64_t)nq * std::min<uint64_t>(nprobe, span / avg_len + 2);
-        // matrix cores pay once a 32-query tile is reasonably full: >= 8 (query, list) pairs per list on average
+        // matrix cores pay once many queries share each list AND survivors are rare (late stages): with ~7 pairs
+        // per list and hundreds of survivors per query the exact path dominates and the VALU kernel wins (measured)
         const bool use_mfma = scan_has_mfma(W) && impl != 1 && (impl == 2 || est_pairs >= 8ull * k);
         const bool cluster_major = use_mfma || (est_pairs >= k / 2 && est_pairs > 64);
         pf.begin(PF_GROUP);
@@ -463,7 +464,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         ScanPtrs sp{};
         a.cluster_major = cluster_major ? 1u : 0u;
         if (cluster_major) {
-            HIPC(hipMemsetAsync(ws.grp_cnt.p, 0, (k + 1) * 4, st));
+            HIPC(hipMemsetAsync(ws.grp_cnt.p, 0, (size_t)((k + 4) & ~3u) * 4, st));  // 16-byte multiple: one fill kernel
             group_count_kernel<<<ceil_div(npairs, 256), 256, 0, st>>>(ws.scal.p, probe_cluster, npairs, sg.s_lo,
                                                                       sg.s_hi, ws.grp_cnt.p);
             group_scan_kernel<<<1, 1024, 0, st>>>(ws.grp_cnt.p, k, ws.grp_start.p, use_mfma ? 1u : 0u);
