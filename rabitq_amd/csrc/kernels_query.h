@@ -59,31 +59,36 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restric
                                                           float *__restrict__ dist, uint32_t k,
                                                           uint32_t dim, uint32_t nq, uint32_t kstride) {
     // cent_t points at the first list of the range; k = number of lists ranked, kstride = row stride
-    extern __shared__ __attribute__((aligned(16))) float ys[];  // QT * dim
+    extern __shared__ __attribute__((aligned(16))) float ys[];  // [dim][QT]: one ds_read_b128 = 4 queries at one dimension
     const uint32_t q0 = blockIdx.x * QT;
     const uint32_t j = blockIdx.y * 256 + threadIdx.x;
     for (uint32_t i = threadIdx.x; i < QT * dim; i += 256) {
-        uint32_t v = i / dim, e = i - v * dim;
-        ys[i] = (q0 + v < nq) ? y[(uint64_t)(q0 + v) * dim + e] : 0.0f;
+        uint32_t v = i / dim, e = i - v * dim;  // coalesced reads of y, transposed into LDS
+        ys[e * QT + v] = (q0 + v < nq) ? y[(uint64_t)(q0 + v) * dim + e] : 0.0f;
     }
     __syncthreads();
-    static_assert(QT % 2 == 0, "queries are processed in packed pairs");
+    static_assert(QT % 4 == 0, "queries are processed in packed pairs, read four at a time");
     f32x2 acc[QT / 2][8];  // [query pair][AVX lane]: v_pk_add_f32 + v_pk_fma_f32, per-component rounding
 #pragma unroll
     for (int v = 0; v < QT / 2; ++v)
 #pragma unroll
         for (int l = 0; l < 8; ++l) acc[v][l] = f32x2{0.0f, 0.0f};
     const bool live = j < k;
+    const float *cp = cent_t + (live ? j : 0);
     for (uint32_t c = 0; c < dim; c += 8) {
+        float ce[8];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) ce[l] = cp[(uint64_t)(c + l) * kstride];  // 8 loads in flight
 #pragma unroll
         for (int l = 0; l < 8; ++l) {
-            float ce = live ? cent_t[(uint64_t)(c + l) * kstride + j] : 0.0f;
-            f32x2 ce2 = {ce, ce};
+            const f32x2 ce2 = {ce[l], ce[l]};
 #pragma unroll
-            for (int v = 0; v < QT / 2; ++v) {
-                f32x2 yy = {ys[(2 * v) * dim + c + l], ys[(2 * v + 1) * dim + c + l]};
-                f32x2 d = ce2 - yy;
-                acc[v][l] = __builtin_elementwise_fma(d, d, acc[v][l]);
+            for (int v4 = 0; v4 < QT / 4; ++v4) {
+                const float4 yq = *reinterpret_cast<const float4 *>(&ys[(c + l) * QT + 4 * v4]);
+                const f32x2 y01 = {yq.x, yq.y}, y23 = {yq.z, yq.w};
+                const f32x2 d01 = ce2 - y01, d23 = ce2 - y23;
+                acc[2 * v4][l] = __builtin_elementwise_fma(d01, d01, acc[2 * v4][l]);
+                acc[2 * v4 + 1][l] = __builtin_elementwise_fma(d23, d23, acc[2 * v4 + 1][l]);
             }
         }
     }

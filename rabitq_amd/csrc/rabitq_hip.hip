@@ -396,8 +396,12 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         probe_dist = ext_dist;
     } else {
         pf.begin(PF_COARSE);
-        coarse_dist_kernel<4><<<dim3(ceil_div(nq, 4), ceil_div(k, 256)), 256, 4 * dim * sizeof(float), st>>>(
-            idx->cent_t.p, ws.y.p, ws.dist.p, k, dim, nq, k);
+        if (nq >= 64 && dim <= 2048)  // 8 queries per thread: 8 packed VALU ops per centroid element loaded
+            coarse_dist_kernel<8><<<dim3(ceil_div(nq, 8), ceil_div(k, 256)), 256, 8 * dim * sizeof(float), st>>>(
+                idx->cent_t.p, ws.y.p, ws.dist.p, k, dim, nq, k);
+        else
+            coarse_dist_kernel<4><<<dim3(ceil_div(nq, 4), ceil_div(k, 256)), 256, 4 * dim * sizeof(float), st>>>(
+                idx->cent_t.p, ws.y.p, ws.dist.p, k, dim, nq, k);
         pf.end();
         pf.begin(PF_SELECT);
         select_probe_kernel<<<nq, 256, (size_t)nprobe * 8, st>>>(ws.dist.p, k, nprobe, ws.probe_cluster.p, ws.probe_dist.p, 0,
@@ -720,6 +724,8 @@ static rq_status finish_index(rq_index *idx) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(select_probe_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(coarse_dist_kernel<4>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(coarse_dist_kernel<8>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(assign_generic_kernel<8>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
