@@ -1416,6 +1416,37 @@ __device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, co
     }
 }
 
+// Exact f32 L2 of survivors recs[first], recs[first + step], ... against the query held in LDS
+// (src/rerank.rs:85-90; lane order of src/simd.rs:14-73).  TWO lanes per candidate: lane half hf carries
+// AVX lanes 4hf..4hf+3 (elements 8c + 4hf + 0..3, one 16-byte load per chunk); the fold
+// ((a0+a4)+(a1+a5)) + ((a2+a6)+(a3+a7)) needs one exchange between the two lanes.  A row is fetched 8
+// chunks (64 dimensions, 8 x 16 bytes per lane) at a time so that every lane keeps 8 loads in flight
+// (this is a random 512-byte-row gather: latency-bound unless enough bytes are outstanding).
+__device__ __forceinline__ void accurate_rows(SurvRec *__restrict__ recs, uint32_t n, const float *__restrict__ base,
+                                              const float *q_lds, uint32_t dim, uint32_t first, uint32_t step) {
+    const uint32_t hf = threadIdx.x & 1;
+    for (uint32_t i = first; i < n; i += step) {
+        const float *x = base + (uint64_t)recs[i].pos * dim + 4 * hf;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        for (uint32_t c = 0; c < dim; c += 64) {  // dim is a multiple of 64
+            float4 xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = *reinterpret_cast<const float4 *>(x + c + 8 * u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4 qv = *reinterpret_cast<const float4 *>(q_lds + c + 8 * u + 4 * hf);
+                const float d0 = xv[u].x - qv.x, d1 = xv[u].y - qv.y, d2 = xv[u].z - qv.z, d3 = xv[u].w - qv.w;
+                a0 = fmaf(d0, d0, a0), a1 = fmaf(d1, d1, a1), a2 = fmaf(d2, d2, a2), a3 = fmaf(d3, d3, a3);
+            }
+        }
+        // c_i = a_i + a_{i+4}: the partner lane holds the other half (commutative, so both lanes agree)
+        const float c0 = a0 + __shfl_xor(a0, 1, 2), c1 = a1 + __shfl_xor(a1, 1, 2);
+        const float c2 = a2 + __shfl_xor(a2, 1, 2), c3 = a3 + __shfl_xor(a3, 1, 2);
+        const float r = (c0 + c1) + (c2 + c3);
+        if (hf == 0) recs[i].accurate = r;
+    }
+}
+
 // One block per query finishes a stage: (A) exact rerank distances of the stage's survivors
 // (src/rerank.rs:85-90, 8 lanes = the 8 AVX lanes of src/simd.rs:14-73), (B) sort of the run
 // directory into the reference's visiting order, (C) wave 0 replays the ranker.
@@ -1428,6 +1459,7 @@ __global__ __launch_bounds__(256) void stage_finish_kernel(SurvRec *__restrict__
                                                            ReplayState st) {
     __shared__ int32_t hkey[HEURISTIC ? 1 : RQ_MAX_TOPK];
     __shared__ uint32_t hid[HEURISTIC ? 1 : RQ_MAX_TOPK];
+    extern __shared__ __attribute__((aligned(16))) float fin_q[];  // dim floats: the padded query
     const uint32_t b = blockIdx.x;
     const unsigned long long cnt64 = surv_cnt[b];
     const uint32_t cnt = (uint32_t)cnt64;
@@ -1443,18 +1475,10 @@ __global__ __launch_bounds__(256) void stage_finish_kernel(SurvRec *__restrict__
     if (n == 0) return;
     SurvRec *recs = surv + (uint64_t)b * cap;
     {  // (A)
-        const uint32_t l = threadIdx.x & 7, grp = threadIdx.x >> 3;
-        const float *q = qpad + (uint64_t)b * dim;
-        for (uint32_t i = grp; i < n; i += 32) {
-            const float *x = base + (uint64_t)recs[i].pos * dim;
-            float acc = 0.0f;
-            for (uint32_t c = 0; c < dim; c += 8) {
-                float d = x[c + l] - q[c + l];
-                acc = fmaf(d, d, acc);
-            }
-            acc = reduce8_lanes(acc);
-            if (l == 0) recs[i].accurate = acc;
-        }
+        for (uint32_t c = threadIdx.x * 4; c < dim; c += 1024)
+            *reinterpret_cast<float4 *>(fin_q + c) = *reinterpret_cast<const float4 *>(qpad + (uint64_t)b * dim + c);
+        __syncthreads();
+        accurate_rows(recs, n, base, fin_q, dim, threadIdx.x >> 1, 128);
     }
     sort_segment(runs + (uint64_t)b * cap, nruns);  // (B)
     __syncthreads();                                  // (A)'s stores and (B)'s order visible to wave 0
@@ -1472,38 +1496,14 @@ __global__ __launch_bounds__(256) void accurate_kernel(SurvRec *__restrict__ sur
     // TWO lanes per candidate: lane half hf carries AVX lanes 4hf..4hf+3 (elements 8c + 4hf + 0..3, one
     // 16-byte load per chunk), so a row is fetched with float4 loads; the fold
     // ((a0+a4)+(a1+a5)) + ((a2+a6)+(a3+a7)) needs one exchange between the two lanes.
-    // The row of a candidate is fetched 8 chunks (64 dimensions, 8 x 16 bytes per lane) at a time so that
-    // every lane keeps 8 loads in flight (the kernel is a random 512-byte-row gather: latency-bound unless
-    // enough bytes are outstanding); the query sits in LDS.  dynamic LDS: dim floats.
-    extern __shared__ __attribute__((aligned(16))) float acc_q[];
+    extern __shared__ __attribute__((aligned(16))) float acc_q[];  // dynamic LDS: dim floats (the padded query)
     const uint32_t b = blockIdx.y;
     const uint32_t n = (uint32_t)surv_cnt[b];
     if (n > cap || n == 0) return;  // overflowed: this query is re-run with a larger buffer
-    const uint32_t hf = threadIdx.x & 1, grp = threadIdx.x >> 1;
     for (uint32_t c = threadIdx.x * 4; c < dim; c += 1024)
         *reinterpret_cast<float4 *>(acc_q + c) = *reinterpret_cast<const float4 *>(qpad + (uint64_t)b * dim + c);
     __syncthreads();
-    SurvRec *recs = surv + (uint64_t)b * cap;
-    for (uint32_t i = blockIdx.x * 128 + grp; i < n; i += gridDim.x * 128) {
-        const float *x = base + (uint64_t)recs[i].pos * dim + 4 * hf;
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-        for (uint32_t c = 0; c < dim; c += 64) {  // dim is a multiple of 64
-            float4 xv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) xv[u] = *reinterpret_cast<const float4 *>(x + c + 8 * u);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float4 qv = *reinterpret_cast<const float4 *>(acc_q + c + 8 * u + 4 * hf);
-                const float d0 = xv[u].x - qv.x, d1 = xv[u].y - qv.y, d2 = xv[u].z - qv.z, d3 = xv[u].w - qv.w;
-                a0 = fmaf(d0, d0, a0), a1 = fmaf(d1, d1, a1), a2 = fmaf(d2, d2, a2), a3 = fmaf(d3, d3, a3);
-            }
-        }
-        // c_i = a_i + a_{i+4}: the partner lane holds the other half (commutative, so both lanes agree)
-        const float c0 = a0 + __shfl_xor(a0, 1, 2), c1 = a1 + __shfl_xor(a1, 1, 2);
-        const float c2 = a2 + __shfl_xor(a2, 1, 2), c3 = a3 + __shfl_xor(a3, 1, 2);
-        const float r = (c0 + c1) + (c2 + c3);
-        if (hf == 0) recs[i].accurate = r;
-    }
+    accurate_rows(surv + (uint64_t)b * cap, n, base, acc_q, dim, blockIdx.x * 128 + (threadIdx.x >> 1), gridDim.x * 128);
 }
 
 __global__ __launch_bounds__(64) void sort_runs_kernel(RunRec *__restrict__ runs,

@@ -504,10 +504,10 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         if (nq < 256) {  // small batch: one fused launch per stage (launch-bound regime)
             pf.begin(PF_RERANK);
             if (qp.heuristic)
-                stage_finish_kernel<true><<<nq, 256, 0, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->base.p,
+                stage_finish_kernel<true><<<nq, 256, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->base.p,
                                                               qpad, dim, idx->map_ids.p, topk, rs);
             else
-                stage_finish_kernel<false><<<nq, 256, 0, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->base.p,
+                stage_finish_kernel<false><<<nq, 256, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->base.p,
                                                                qpad, dim, idx->map_ids.p, topk, rs);
             pf.end();
         } else {  // large batch: full-chip rerank, then run-directory sort, then one replay wave per query
