@@ -197,6 +197,10 @@ typedef struct {
     uint64_t rerank_candidates;/* accurate distances computed (superset of `precise`)   */
     uint32_t scan_launches;
     uint32_t retries;          /* queries re-run because a survivor buffer overflowed   */
+    /* the matrix-core launches alone (a subset of the scan figures above) */
+    float ms_scan_matrix;      /* device time of the scan_mfma_kernel launches           */
+    uint32_t matrix_launches;
+    uint64_t matrix_pairs;     /* (query, candidate) pairs they scored                   */
 } rq_profile_t;
 /* level: 0 = off; 1 = every kernel group bracketed (each event costs a few microseconds of stream
  * time); 2 = only the scan launches and the whole pass (ms_scan, ms_total; the other fields stay 0). */

@@ -98,7 +98,7 @@ static std::atomic<uint64_t> g_rough{0}, g_precise{0}, g_query{0}, g_miss{0};
 // ------------------------------------------------------------------------------------------------
 // profiling
 // ------------------------------------------------------------------------------------------------
-enum { PF_ROTATE = 0, PF_COARSE, PF_SELECT, PF_PREP, PF_GROUP, PF_SCAN, PF_RERANK, PF_SORT, PF_REPLAY, PF_TOTAL, PF_N };
+enum { PF_ROTATE = 0, PF_COARSE, PF_SELECT, PF_PREP, PF_GROUP, PF_SCAN, PF_SCAN_MATRIX, PF_RERANK, PF_SORT, PF_REPLAY, PF_TOTAL, PF_N };
 static std::atomic<int> g_profiling{0};
 static thread_local rq_profile_t g_profile;
 
@@ -125,7 +125,7 @@ struct Prof {
     }
     // An event record costs ~5 us of stream time: adjacent spans share their boundary event.
     void begin(int cat) {
-        open = on && !(light && cat != PF_SCAN && cat != PF_TOTAL);
+        open = on && !(light && cat != PF_SCAN && cat != PF_SCAN_MATRIX && cat != PF_TOTAL);
         if (!open) {
             last_b = nullptr;
             return;
@@ -454,6 +454,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             hi = std::min<uint64_t>(hi * growth, 0xFFFFFFF0ull);
         }
     }
+    std::vector<Stage> matrix_ranges;  // stream ranges scanned on the matrix cores (profiling only)
     const uint32_t tile = scan_tile(W);
     const uint64_t avg_len = std::max<uint64_t>(1, idx->n / std::max<uint32_t>(k, 1));
     for (const Stage &sg : stages) {
@@ -496,11 +497,15 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         a.cap = qp.cap;
         a.dbg = (uint32_t)g_scan_dbg.load();
         a.tiles_per_group = ceil_div(std::min<uint64_t>(idx->max_list_len, sg.s_hi), use_mfma ? scan_mfma_tile(W) : tile);
-        pf.begin(PF_SCAN);
+        pf.begin(use_mfma ? PF_SCAN_MATRIX : PF_SCAN);
         if (use_mfma) launch_scan_mfma(sp, a, W, st);
         else launch_scan(sp, a, W, st);
         pf.end();
         if (prof_acc) prof_acc->scan_launches++;
+        if (prof_acc && use_mfma) {
+            prof_acc->matrix_launches++;
+            matrix_ranges.push_back({sg.s_lo, sg.s_hi});
+        }
         if (nq < 256) {  // small batch: one fused launch per stage (launch-bound regime)
             pf.begin(PF_RERANK);
             if (qp.heuristic)
@@ -554,7 +559,15 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         pf.collect(ms);
         prof_acc->ms_rotate += ms[PF_ROTATE], prof_acc->ms_coarse += ms[PF_COARSE];
         prof_acc->ms_select += ms[PF_SELECT], prof_acc->ms_prep += ms[PF_PREP], prof_acc->ms_group += ms[PF_GROUP];
-        prof_acc->ms_scan += ms[PF_SCAN], prof_acc->ms_rerank += ms[PF_RERANK], prof_acc->ms_sort += ms[PF_SORT];
+        prof_acc->ms_scan += ms[PF_SCAN] + ms[PF_SCAN_MATRIX], prof_acc->ms_scan_matrix += ms[PF_SCAN_MATRIX];
+        prof_acc->ms_rerank += ms[PF_RERANK], prof_acc->ms_sort += ms[PF_SORT];
+        if (!matrix_ranges.empty()) {  // pairs scored by those launches: per query, its stream length clipped to the range
+            std::vector<unsigned long long> len(nq);
+            HIPC(hipMemcpy(len.data(), ws.rough_cnt.p, (size_t)nq * 8, hipMemcpyDeviceToHost));
+            for (const Stage &r : matrix_ranges)
+                for (uint32_t b = 0; b < nq; ++b)
+                    prof_acc->matrix_pairs += std::min<unsigned long long>(len[b], r.s_hi) - std::min<unsigned long long>(len[b], r.s_lo);
+        }
         prof_acc->ms_replay += ms[PF_REPLAY], prof_acc->ms_total += ms[PF_TOTAL];
     }
     if (prof_acc) {
