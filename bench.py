@@ -49,6 +49,10 @@ def main():
     ap.add_argument("--small-batch", type=int, default=64, help="queries of the HBM-regime scan measurement")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo = single-GPU rehearsal)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="batches kept in flight in the timed loop (rq_query_batch_device_begin/_end); 1 = one blocking "
+                         "call per step (default: per-kernel times are then clean); the 2-in-flight rate is always "
+                         "measured as well and reported as `two_batches_in_flight`")
     args = ap.parse_args()
 
     import torch
@@ -143,9 +147,10 @@ def main():
     torch.cuda.empty_cache()
     log(f"index built in {build_s:.1f}s: n={idx.n} dim={idx.dim} k={idx.k} max_list_len={idx.max_list_len}")
 
-    out_d = torch.empty((B, topk), device=dev, dtype=torch.float32)
-    out_i = torch.zeros((B, topk), device=dev, dtype=torch.int32)
-    out_n = torch.zeros((B,), device=dev, dtype=torch.int32)
+    depth = max(1, args.pipeline) if world == 1 else 1
+    outs = [(torch.empty((B, topk), device=dev, dtype=torch.float32), torch.zeros((B, topk), device=dev, dtype=torch.int32),
+             torch.zeros((B,), device=dev, dtype=torch.int32)) for _ in range(max(depth, 2))]
+    out_d, out_i, out_n = outs[0]
 
     pc_local = torch.zeros((B, nprobe), device=dev, dtype=torch.int32)
     pd_local = torch.zeros((B, nprobe), device=dev, dtype=torch.float32)
@@ -175,20 +180,56 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    prof = {}
+
+    def run_steps(count, record, depth=depth):
+        """`count` steps; with depth > 1 a step's batch is begun before the previous one is ended, so consecutive
+        batches overlap on the device (each owns a workspace, a stream and an output slot)."""
+        res = None
+        if depth == 1:
+            for _ in range(count):
+                res = step()
+                if record:
+                    for key, v in rqi.last_profile().items():
+                        prof[key] = prof.get(key, 0) + v
+            return res
+        pending = []
+        for i in range(count + depth - 1):
+            if i < count:
+                od, oi, on = outs[i % depth]
+                pending.append((idx.query_batch_device_begin(queries.data_ptr(), B, d, nprobe, topk, od.data_ptr(),
+                                                             oi.data_ptr(), on.data_ptr()), i % depth))
+            if i >= depth - 1:
+                tk, slot = pending.pop(0)
+                idx.query_batch_device_end(tk)
+                if record:
+                    for key, v in rqi.last_profile().items():
+                        prof[key] = prof.get(key, 0) + v
+                od, oi, on = outs[slot]
+                res = (od, oi.to(torch.int64) & 0xFFFFFFFF, on)
+        return res
+
     rqi.set_profiling(2)         # HIP events on the engine's own stream around the scan launches (the roofline kernel)
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup, False)
     fence()
     rabitq_amd.metrics_reset()
-    prof = {}
     t1 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-        p = rqi.last_profile()
-        for key, v in p.items():
-            prof[key] = prof.get(key, 0) + v
+    res = run_steps(args.steps, True)
     fence()
     elapsed = time.perf_counter() - t1
+    # the same loop with two batches in flight: one batch's HBM-bound stages overlap the other's compute-bound scan
+    overlap = None
+    if world == 1:
+        run_steps(2, False, 2)
+        fence()
+        t2 = time.perf_counter()
+        run_steps(args.steps, False, 2)
+        fence()
+        e2 = time.perf_counter() - t2
+        overlap = {"batches_in_flight": 2, "value": round(B * args.steps / e2, 1), "unit": "queries/s",
+                   "ms_per_step": round(e2 / args.steps * 1e3, 3),
+                   "note": "rq_query_batch_device_begin/_end; per-kernel times are not clean in this mode, so the headline "
+                           "`value` and the roofline figures are taken with one batch at a time"}
     # per-kernel-group breakdown from ONE extra, untimed step (an event pair per group costs ~10 us of stream time each)
     rqi.set_profiling(1)
     step()
@@ -292,6 +333,7 @@ def main():
             "vs_baseline": None, "dtype": "u64 popcount + f32", "data": "synthetic",
             "config": {"workload": f"{n // 1_000_000}Mx{d} synthetic mixture per GPU, {k_local} lists per GPU, "
                                    f"nprobe={nprobe}, topk={topk}, batch={B} (BASELINE.json configs[2])",
+                       "batches_in_flight": depth,
                        "n_per_gpu": n, "dim": d, "lists_total": k, "nprobe": nprobe, "topk": topk, "batch": B,
                        "sigma": args.sigma, "centre_scale": args.centre_scale, "sharding": f"vectors x{world}"},
             "recall_at_10": round(recall, 4), "recall_queries": ngt, "build_seconds": round(build_s, 2),
@@ -300,7 +342,7 @@ def main():
             "rerank_candidates_per_query": prof["rerank_candidates"] / (B * args.steps),
             "retries": int(prof["retries"]), "roofline": roofline, "roofline_scan_all_launches": scan_all,
             "roofline_rotation": rotation,
-            "scan_small_batch": small, "single_query": single}
+            "scan_small_batch": small, "single_query": single, "two_batches_in_flight": overlap}
 
     # ---- CPU baseline: the oracle (port of the reference's AVX2 path) on this box's host cores ------
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_queries > 0:

@@ -128,6 +128,18 @@ rq_status rq_query_batch(const rq_index *idx, const float *queries, uint32_t nq,
 rq_status rq_query_batch_device(const rq_index *idx, const float *d_queries, uint32_t nq,
                                 uint32_t len, uint32_t probe, uint32_t topk, int heuristic_rank,
                                 float *d_out_dist, uint32_t *d_out_id, uint32_t *d_out_n);
+/* The same call in two halves, for callers that keep several batches in flight (a serving loop):
+ * _begin enqueues the whole batch on a workspace / HIP stream of its own and returns a ticket; _end
+ * waits for it, performs the (rare) survivor-buffer re-runs and the counter updates, reports the
+ * call's status and frees the ticket.  Queries and outputs must stay valid and untouched in between.
+ * Batches begun back to back overlap on the device: one batch's HBM-bound stages (exact rerank) run
+ * beside another's compute-bound scan.  Every begun ticket must be ended exactly once. */
+typedef struct rq_ticket rq_ticket;
+rq_status rq_query_batch_device_begin(const rq_index *idx, const float *d_queries, uint32_t nq,
+                                      uint32_t len, uint32_t probe, uint32_t topk, int heuristic_rank,
+                                      float *d_out_dist, uint32_t *d_out_id, uint32_t *d_out_n,
+                                      rq_ticket **out_ticket);
+rq_status rq_query_batch_device_end(rq_ticket *ticket);
 
 /* ---- sharded deployments (one index shard per GPU / process) ----------------------------------- */
 /* The coarse ranking of src/rabitq.rs:283-297 restricted to lists [list_lo, list_hi): the `probe`

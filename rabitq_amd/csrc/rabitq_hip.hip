@@ -168,9 +168,16 @@ struct Prof {
 // ------------------------------------------------------------------------------------------------
 // query workspace
 // ------------------------------------------------------------------------------------------------
+struct StreamRange {
+    uint32_t s_lo, s_hi;
+};
 struct Workspace {
     hipStream_t stream = nullptr;
     bool busy = false;
+    // context of a pass that has been enqueued but not yet finished (finish_pass)
+    size_t pend_total_span = 0;
+    uint32_t pend_nq = 0;
+    std::vector<StreamRange> pend_matrix_ranges;  // stream ranges scanned on the matrix cores (profiling only)
     DevBuf<float> qpad, y, dist, probe_dist, thr, recent;
     DevBuf<uint32_t> probe_cluster, recs, grp_cnt, grp_start, heap_len, heap_id, precise, need,
         nsurv, win_count, arr_len, row_map;
@@ -361,6 +368,40 @@ struct PassResult {
     uint64_t rough = 0, precise = 0, overflowed = 0, max_need = 0;
 };
 
+// Second half of a pass: wait for the stream, read the totals, collect the profile.
+static rq_status finish_pass(const rq_index *idx, Workspace &ws, PassResult *res, rq_profile_t *prof_acc) {
+    Prof &pf = ws.prof;
+    const uint32_t nq = ws.pend_nq, dim = idx->dim;
+    HIPC(hipStreamSynchronize(ws.stream));
+    HIPC(hipGetLastError());
+    res->rough = ws.h_totals[0];
+    res->precise = ws.h_totals[1];
+    res->overflowed = ws.h_totals[2];
+    res->max_need = ws.h_totals[4];
+    if (pf.on && prof_acc) {
+        float ms[PF_N] = {0};
+        pf.collect(ms);
+        prof_acc->ms_rotate += ms[PF_ROTATE], prof_acc->ms_coarse += ms[PF_COARSE];
+        prof_acc->ms_select += ms[PF_SELECT], prof_acc->ms_prep += ms[PF_PREP], prof_acc->ms_group += ms[PF_GROUP];
+        prof_acc->ms_scan += ms[PF_SCAN] + ms[PF_SCAN_MATRIX], prof_acc->ms_scan_matrix += ms[PF_SCAN_MATRIX];
+        prof_acc->ms_rerank += ms[PF_RERANK], prof_acc->ms_sort += ms[PF_SORT];
+        if (!ws.pend_matrix_ranges.empty()) {  // pairs scored by those launches: per query, its stream length clipped to the range
+            std::vector<unsigned long long> len(nq);
+            HIPC(hipMemcpy(len.data(), ws.rough_cnt.p, (size_t)nq * 8, hipMemcpyDeviceToHost));
+            for (const StreamRange &r : ws.pend_matrix_ranges)
+                for (uint32_t b = 0; b < nq; ++b)
+                    prof_acc->matrix_pairs += std::min<unsigned long long>(len[b], r.s_hi) - std::min<unsigned long long>(len[b], r.s_lo);
+        }
+        prof_acc->ms_replay += ms[PF_REPLAY], prof_acc->ms_total += ms[PF_TOTAL];
+    }
+    if (prof_acc) {
+        prof_acc->scan_candidates += res->rough;
+        prof_acc->scan_bytes += res->rough * (uint64_t)(dim / 8 + 16);
+        prof_acc->rerank_candidates += ws.h_totals[3];
+    }
+    return RQ_OK;
+}
+
 // Runs one pass over nq queries already resident at d_q (nq x len).  Results go to row
 // row_map[b] (or b) of the output arrays.  On return the stream is synchronised.
 // ext_cluster / ext_dist (nq x min(probe,k), device): if given, the probe lists are taken from there
@@ -368,7 +409,7 @@ struct PassResult {
 static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, const QueryParams &qp,
                           const uint32_t *d_row_map, float *d_out_dist, uint32_t *d_out_id, uint32_t *d_out_n,
                           PassResult *res, rq_profile_t *prof_acc, const uint32_t *ext_cluster = nullptr,
-                          const float *ext_dist = nullptr) {
+                          const float *ext_dist = nullptr, bool defer = false) {
     const uint32_t dim = idx->dim, k = idx->k, W = idx->W;
     const uint32_t nq = qp.nq, nprobe = std::min(qp.probe, k), topk = qp.topk;
     const uint32_t npairs = nq * nprobe;
@@ -454,7 +495,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             hi = std::min<uint64_t>(hi * growth, 0xFFFFFFF0ull);
         }
     }
-    std::vector<Stage> matrix_ranges;  // stream ranges scanned on the matrix cores (profiling only)
+    ws.pend_matrix_ranges.clear();
     const uint32_t tile = scan_tile(W);
     const uint64_t avg_len = std::max<uint64_t>(1, idx->n / std::max<uint32_t>(k, 1));
     for (const Stage &sg : stages) {
@@ -504,7 +545,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         if (prof_acc) prof_acc->scan_launches++;
         if (prof_acc && use_mfma) {
             prof_acc->matrix_launches++;
-            matrix_ranges.push_back({sg.s_lo, sg.s_hi});
+            ws.pend_matrix_ranges.push_back({sg.s_lo, sg.s_hi});
         }
         if (nq < 256) {  // small batch: one fused launch per stage (launch-bound regime)
             pf.begin(PF_RERANK);
@@ -548,34 +589,10 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     pf.end();
     if (pf.on) (void)hipEventRecord(pf.spans[total_span].b, st);
     HIPC(hipMemcpyAsync(ws.h_totals, ws.totals.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    HIPC(hipStreamSynchronize(st));
-    HIPC(hipGetLastError());
-    res->rough = ws.h_totals[0];
-    res->precise = ws.h_totals[1];
-    res->overflowed = ws.h_totals[2];
-    res->max_need = ws.h_totals[4];
-    if (pf.on && prof_acc) {
-        float ms[PF_N] = {0};
-        pf.collect(ms);
-        prof_acc->ms_rotate += ms[PF_ROTATE], prof_acc->ms_coarse += ms[PF_COARSE];
-        prof_acc->ms_select += ms[PF_SELECT], prof_acc->ms_prep += ms[PF_PREP], prof_acc->ms_group += ms[PF_GROUP];
-        prof_acc->ms_scan += ms[PF_SCAN] + ms[PF_SCAN_MATRIX], prof_acc->ms_scan_matrix += ms[PF_SCAN_MATRIX];
-        prof_acc->ms_rerank += ms[PF_RERANK], prof_acc->ms_sort += ms[PF_SORT];
-        if (!matrix_ranges.empty()) {  // pairs scored by those launches: per query, its stream length clipped to the range
-            std::vector<unsigned long long> len(nq);
-            HIPC(hipMemcpy(len.data(), ws.rough_cnt.p, (size_t)nq * 8, hipMemcpyDeviceToHost));
-            for (const Stage &r : matrix_ranges)
-                for (uint32_t b = 0; b < nq; ++b)
-                    prof_acc->matrix_pairs += std::min<unsigned long long>(len[b], r.s_hi) - std::min<unsigned long long>(len[b], r.s_lo);
-        }
-        prof_acc->ms_replay += ms[PF_REPLAY], prof_acc->ms_total += ms[PF_TOTAL];
-    }
-    if (prof_acc) {
-        prof_acc->scan_candidates += res->rough;
-        prof_acc->scan_bytes += res->rough * (uint64_t)(dim / 8 + 16);
-        prof_acc->rerank_candidates += ws.h_totals[3];
-    }
-    return RQ_OK;
+    ws.pend_total_span = total_span;
+    ws.pend_nq = nq;
+    if (defer) return RQ_OK;  // the caller finishes the pass later (rq_query_batch_device_end)
+    return finish_pass(idx, ws, res, prof_acc);
 }
 
 static Workspace *ws_acquire(rq_index *idx) {
@@ -594,11 +611,8 @@ static void ws_release(rq_index *idx, Workspace *w) {
     w->busy = false;
 }
 
-// queries/outputs in device memory
-static rq_status query_device(rq_index *idx, const float *d_q, uint32_t nq, uint32_t len, uint32_t probe,
-                              uint32_t topk, bool heuristic, float *d_out_dist, uint32_t *d_out_id,
-                              uint32_t *d_out_n, const uint32_t *ext_cluster = nullptr,
-                              const float *ext_dist = nullptr) {
+static rq_status validate_query(const rq_index *idx, const float *d_q, uint32_t len, uint32_t probe, uint32_t topk,
+                                const float *d_out_dist, const uint32_t *d_out_id, const uint32_t *d_out_n) {
     RQC(ensure_device());
     if (!idx || !d_q || !d_out_dist || !d_out_id || !d_out_n) return fail(RQ_ERR_INVALID, "null argument");
     if (idx->dim != (len + 63) / 64 * 64)  // rabitq.rs:275
@@ -608,110 +622,100 @@ static rq_status query_device(rq_index *idx, const float *d_q, uint32_t nq, uint
     if (topk == 0 || topk > RQ_MAX_TOPK) return fail(RQ_ERR_UNSUPPORTED, "topk must be in [1, 2048]");
     if (std::min(probe, idx->k) > RQ_MAX_PROBE) return fail(RQ_ERR_UNSUPPORTED, "probe > 16384 not supported");
     if (idx->dim > 4096) return fail(RQ_ERR_UNSUPPORTED, "dim > 4096 not supported");
-    if (nq == 0) return RQ_OK;
-    rq_profile_t prof;
-    memset(&prof, 0, sizeof prof);
-    Workspace *ws = ws_acquire(idx);
-    struct Rel {
-        rq_index *i;
-        Workspace *w;
-        ~Rel() { ws_release(i, w); }
-    } rel{idx, ws};
-    uint64_t tot_rough = 0, tot_precise = 0;
-    bool any_empty = false;
-    std::vector<uint32_t> h_need, h_alen, over_rows;
-    for (uint32_t q0 = 0, step_nq = 0; q0 < nq; q0 += step_nq) {
-        // survivor / run buffers: 32 B per slot per query; keep one pass under ~24 GiB
-        const uint32_t cap0 = std::max(RQ_DEFAULT_CAP, idx->cap_hint.load());
-        step_nq = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nq - q0, RQ_MAX_NQ_PER_PASS),
-                                               std::max<uint64_t>(1, (24ull << 30) / ((uint64_t)cap0 * 32)));
-        // (query, list) pairs per pass <= 2^22: bounds the per-pair buffers and every launch size
-        step_nq = std::min<uint32_t>(step_nq, std::max<uint32_t>(1, (1u << 22) / std::min(probe, idx->k)));
-        QueryParams qp{step_nq, len, probe, topk, heuristic, cap0, cap0};
-        RQC(ws_prepare(idx, *ws, qp));
-        PassResult pr;
-        const uint32_t npb = std::min(probe, idx->k);
-        RQC(run_pass(idx, *ws, d_q + (uint64_t)q0 * len, qp, nullptr, d_out_dist + (uint64_t)q0 * topk,
-                     d_out_id + (uint64_t)q0 * topk, d_out_n + q0, &pr, &prof,
-                     ext_cluster ? ext_cluster + (uint64_t)q0 * npb : nullptr,
-                     ext_dist ? ext_dist + (uint64_t)q0 * npb : nullptr));
-        tot_rough += pr.rough;
-        tot_precise += pr.precise;
-        if (pr.max_need > cap0) {  // remember (with headroom) so that later batches do not overflow
-            uint32_t want = pow2_ceil((uint32_t)std::min<uint64_t>(pr.max_need + pr.max_need / 4, 1u << 22));
-            uint32_t cur = idx->cap_hint.load();
-            while (cur < want && !idx->cap_hint.compare_exchange_weak(cur, want)) {}
-        }
-        // survivor-buffer overflow: re-run exactly those queries with the capacity they asked for
-        uint32_t cap = qp.cap, hcap = qp.hcap;
-        if (pr.overflowed) {
-            h_need.resize(qp.nq);
-            h_alen.resize(qp.nq);
-            HIPC(hipMemcpy(h_need.data(), ws->need.p, qp.nq * 4, hipMemcpyDeviceToHost));
-            HIPC(hipMemcpy(h_alen.data(), ws->arr_len.p, qp.nq * 4, hipMemcpyDeviceToHost));
-            over_rows.clear();
-            uint32_t max_need = 0, max_alen = 0;
-            for (uint32_t b = 0; b < qp.nq; ++b)
-                if (h_need[b] > cap || (heuristic && h_alen[b] > hcap)) {
-                    over_rows.push_back(b);
-                    max_need = std::max(max_need, h_need[b]);
-                    max_alen = std::max(max_alen, h_alen[b]);
-                }
-            int guard = 0;
-            while (!over_rows.empty() && guard++ < 8) {
-                prof.retries += (uint32_t)over_rows.size();
-                uint32_t ncap = std::max(cap * 2, pow2_ceil(max_need));
-                uint32_t nhcap = heuristic ? std::max(hcap * 2, pow2_ceil(std::max(max_alen, max_need))) : hcap;
-                // bound the retry workspace to ~4 GiB of survivor records
-                uint32_t chunk = (uint32_t)std::max<uint64_t>(1, (4ull << 30) / ((uint64_t)(ncap + nhcap) * sizeof(SurvRec)));
-                std::vector<uint32_t> still;
-                Workspace rws;
-                DevBuf<float> sub_q;
-                DevBuf<uint32_t> sub_rows;
-                for (size_t o = 0; o < over_rows.size(); o += chunk) {
-                    uint32_t m = (uint32_t)std::min<size_t>(chunk, over_rows.size() - o);
-                    QueryParams rq{m, len, probe, topk, heuristic, ncap, nhcap};
-                    RQC(ws_prepare(idx, rws, rq));
-                    RQC(sub_q.ensure((uint64_t)m * len));
-                    RQC(sub_rows.ensure(m));
-                    HIPC(hipMemcpy(sub_rows.p, over_rows.data() + o, m * 4, hipMemcpyHostToDevice));
-                    gather_rows_kernel<<<ceil_div((uint64_t)m * len, 256), 256, 0, rws.stream>>>(
-                        d_q + (uint64_t)q0 * len, sub_rows.p, m, len, sub_q.p);
-                    PassResult rr;
-                    const uint32_t *sub_pc = nullptr;
-                    const float *sub_pd = nullptr;
-                    DevBuf<float> sub_probe_d, sub_probe_c;
-                    if (ext_cluster) {  // the caller's probe lists, restricted to the re-run queries
-                        RQC(sub_probe_c.ensure((uint64_t)m * npb));
-                        RQC(sub_probe_d.ensure((uint64_t)m * npb));
-                        gather_rows_kernel<<<ceil_div((uint64_t)m * npb, 256), 256, 0, rws.stream>>>(
-                            reinterpret_cast<const float *>(ext_cluster + (uint64_t)q0 * npb), sub_rows.p, m, npb, sub_probe_c.p);
-                        gather_rows_kernel<<<ceil_div((uint64_t)m * npb, 256), 256, 0, rws.stream>>>(
-                            ext_dist + (uint64_t)q0 * npb, sub_rows.p, m, npb, sub_probe_d.p);
-                        sub_pc = reinterpret_cast<const uint32_t *>(sub_probe_c.p);
-                        sub_pd = sub_probe_d.p;
-                    }
-                    RQC(run_pass(idx, rws, sub_q.p, rq, sub_rows.p, d_out_dist + (uint64_t)q0 * topk,
-                                 d_out_id + (uint64_t)q0 * topk, d_out_n + q0, &rr, nullptr, sub_pc, sub_pd));
-                    tot_precise += rr.precise;
-                    if (rr.overflowed) {
-                        std::vector<uint32_t> n2(m), a2(m);
-                        HIPC(hipMemcpy(n2.data(), rws.need.p, m * 4, hipMemcpyDeviceToHost));
-                        HIPC(hipMemcpy(a2.data(), rws.arr_len.p, m * 4, hipMemcpyDeviceToHost));
-                        for (uint32_t b = 0; b < m; ++b)
-                            if (n2[b] > ncap || (heuristic && a2[b] > nhcap)) {
-                                still.push_back(over_rows[o + b]);
-                                max_need = std::max(max_need, n2[b]);
-                                max_alen = std::max(max_alen, a2[b]);
-                            }
-                    }
-                }
-                cap = ncap, hcap = nhcap;
-                over_rows.swap(still);
-            }
-            if (!over_rows.empty()) return fail(RQ_ERR_OOM, "survivor buffers kept overflowing");
-        }
+    return RQ_OK;
+}
+
+// queries per pass: survivor / run buffers are 32 B per slot per query (keep one pass under ~24 GiB) and
+// (query, list) pairs per pass <= 2^22 (bounds the per-pair buffers and every launch size)
+static uint32_t pass_queries(const rq_index *idx, uint32_t remaining, uint32_t probe, uint32_t cap0) {
+    uint32_t step_nq = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(remaining, RQ_MAX_NQ_PER_PASS),
+                                                    std::max<uint64_t>(1, (24ull << 30) / ((uint64_t)cap0 * 32)));
+    return std::min<uint32_t>(step_nq, std::max<uint32_t>(1, (1u << 22) / std::min(probe, idx->k)));
+}
+
+// After a finished pass: remember the capacity it needed and re-run exactly the queries whose survivor
+// buffers overflowed, with the capacity they asked for.  All pointers are those of the pass (already offset).
+static rq_status after_pass(rq_index *idx, Workspace *ws, const QueryParams &qp, const float *d_q, float *d_out_dist,
+                            uint32_t *d_out_id, uint32_t *d_out_n, const uint32_t *ext_cluster, const float *ext_dist,
+                            const PassResult &pr, rq_profile_t &prof, uint64_t &tot_precise) {
+    const uint32_t len = qp.len, probe = qp.probe, topk = qp.topk;
+    const bool heuristic = qp.heuristic;
+    const uint32_t npb = std::min(probe, idx->k);
+    if (pr.max_need > qp.cap) {  // remember (with headroom) so that later batches do not overflow
+        uint32_t want = pow2_ceil((uint32_t)std::min<uint64_t>(pr.max_need + pr.max_need / 4, 1u << 22));
+        uint32_t cur = idx->cap_hint.load();
+        while (cur < want && !idx->cap_hint.compare_exchange_weak(cur, want)) {}
     }
+    if (!pr.overflowed) return RQ_OK;
+    uint32_t cap = qp.cap, hcap = qp.hcap;
+    std::vector<uint32_t> h_need(qp.nq), h_alen(qp.nq), over_rows;
+    HIPC(hipMemcpy(h_need.data(), ws->need.p, qp.nq * 4, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(h_alen.data(), ws->arr_len.p, qp.nq * 4, hipMemcpyDeviceToHost));
+    uint32_t max_need = 0, max_alen = 0;
+    for (uint32_t b = 0; b < qp.nq; ++b)
+        if (h_need[b] > cap || (heuristic && h_alen[b] > hcap)) {
+            over_rows.push_back(b);
+            max_need = std::max(max_need, h_need[b]);
+            max_alen = std::max(max_alen, h_alen[b]);
+        }
+    int guard = 0;
+    while (!over_rows.empty() && guard++ < 8) {
+        prof.retries += (uint32_t)over_rows.size();
+        uint32_t ncap = std::max(cap * 2, pow2_ceil(max_need));
+        uint32_t nhcap = heuristic ? std::max(hcap * 2, pow2_ceil(std::max(max_alen, max_need))) : hcap;
+        // bound the retry workspace to ~4 GiB of survivor records
+        uint32_t chunk = (uint32_t)std::max<uint64_t>(1, (4ull << 30) / ((uint64_t)(ncap + nhcap) * sizeof(SurvRec)));
+        std::vector<uint32_t> still;
+        Workspace rws;
+        DevBuf<float> sub_q;
+        DevBuf<uint32_t> sub_rows;
+        for (size_t o = 0; o < over_rows.size(); o += chunk) {
+            uint32_t m = (uint32_t)std::min<size_t>(chunk, over_rows.size() - o);
+            QueryParams rq{m, len, probe, topk, heuristic, ncap, nhcap};
+            RQC(ws_prepare(idx, rws, rq));
+            RQC(sub_q.ensure((uint64_t)m * len));
+            RQC(sub_rows.ensure(m));
+            HIPC(hipMemcpy(sub_rows.p, over_rows.data() + o, m * 4, hipMemcpyHostToDevice));
+            gather_rows_kernel<<<ceil_div((uint64_t)m * len, 256), 256, 0, rws.stream>>>(d_q, sub_rows.p, m, len, sub_q.p);
+            PassResult rr;
+            const uint32_t *sub_pc = nullptr;
+            const float *sub_pd = nullptr;
+            DevBuf<float> sub_probe_d, sub_probe_c;
+            if (ext_cluster) {  // the caller's probe lists, restricted to the re-run queries
+                RQC(sub_probe_c.ensure((uint64_t)m * npb));
+                RQC(sub_probe_d.ensure((uint64_t)m * npb));
+                gather_rows_kernel<<<ceil_div((uint64_t)m * npb, 256), 256, 0, rws.stream>>>(
+                    reinterpret_cast<const float *>(ext_cluster), sub_rows.p, m, npb, sub_probe_c.p);
+                gather_rows_kernel<<<ceil_div((uint64_t)m * npb, 256), 256, 0, rws.stream>>>(ext_dist, sub_rows.p, m, npb,
+                                                                                              sub_probe_d.p);
+                sub_pc = reinterpret_cast<const uint32_t *>(sub_probe_c.p);
+                sub_pd = sub_probe_d.p;
+            }
+            RQC(run_pass(idx, rws, sub_q.p, rq, sub_rows.p, d_out_dist, d_out_id, d_out_n, &rr, nullptr, sub_pc, sub_pd));
+            tot_precise += rr.precise;
+            if (rr.overflowed) {
+                std::vector<uint32_t> n2(m), a2(m);
+                HIPC(hipMemcpy(n2.data(), rws.need.p, m * 4, hipMemcpyDeviceToHost));
+                HIPC(hipMemcpy(a2.data(), rws.arr_len.p, m * 4, hipMemcpyDeviceToHost));
+                for (uint32_t b = 0; b < m; ++b)
+                    if (n2[b] > ncap || (heuristic && a2[b] > nhcap)) {
+                        still.push_back(over_rows[o + b]);
+                        max_need = std::max(max_need, n2[b]);
+                        max_alen = std::max(max_alen, a2[b]);
+                    }
+            }
+        }
+        cap = ncap, hcap = nhcap;
+        over_rows.swap(still);
+    }
+    if (!over_rows.empty()) return fail(RQ_ERR_OOM, "survivor buffers kept overflowing");
+    return RQ_OK;
+}
+
+// tail of every query call: the reference's panics and counters
+static rq_status conclude_query(uint32_t nq, bool heuristic, const uint32_t *d_out_n, uint64_t tot_rough,
+                                uint64_t tot_precise, const rq_profile_t &prof) {
+    bool any_empty = false;
     if (heuristic) {  // rerank.rs:171-173: an empty array panics in the reference
         std::vector<uint32_t> h_n(nq);
         HIPC(hipMemcpy(h_n.data(), d_out_n, nq * 4, hipMemcpyDeviceToHost));
@@ -723,6 +727,108 @@ static rq_status query_device(rq_index *idx, const float *d_q, uint32_t nq, uint
     g_profile = prof;
     if (any_empty) return fail(RQ_ERR_EMPTY, "heuristic ranker accepted no candidate for at least one query");
     return RQ_OK;
+}
+
+// queries/outputs in device memory
+static rq_status query_device(rq_index *idx, const float *d_q, uint32_t nq, uint32_t len, uint32_t probe,
+                              uint32_t topk, bool heuristic, float *d_out_dist, uint32_t *d_out_id,
+                              uint32_t *d_out_n, const uint32_t *ext_cluster = nullptr,
+                              const float *ext_dist = nullptr) {
+    RQC(validate_query(idx, d_q, len, probe, topk, d_out_dist, d_out_id, d_out_n));
+    if (nq == 0) return RQ_OK;
+    rq_profile_t prof;
+    memset(&prof, 0, sizeof prof);
+    Workspace *ws = ws_acquire(idx);
+    struct Rel {
+        rq_index *i;
+        Workspace *w;
+        ~Rel() { ws_release(i, w); }
+    } rel{idx, ws};
+    uint64_t tot_rough = 0, tot_precise = 0;
+    const uint32_t npb = std::min(probe, idx->k);
+    for (uint32_t q0 = 0, step_nq = 0; q0 < nq; q0 += step_nq) {
+        const uint32_t cap0 = std::max(RQ_DEFAULT_CAP, idx->cap_hint.load());
+        step_nq = pass_queries(idx, nq - q0, probe, cap0);
+        QueryParams qp{step_nq, len, probe, topk, heuristic, cap0, cap0};
+        RQC(ws_prepare(idx, *ws, qp));
+        PassResult pr;
+        const float *q_at = d_q + (uint64_t)q0 * len;
+        float *od = d_out_dist + (uint64_t)q0 * topk;
+        uint32_t *oi = d_out_id + (uint64_t)q0 * topk, *on = d_out_n + q0;
+        const uint32_t *ec = ext_cluster ? ext_cluster + (uint64_t)q0 * npb : nullptr;
+        const float *ed = ext_dist ? ext_dist + (uint64_t)q0 * npb : nullptr;
+        RQC(run_pass(idx, *ws, q_at, qp, nullptr, od, oi, on, &pr, &prof, ec, ed));
+        tot_rough += pr.rough;
+        tot_precise += pr.precise;
+        RQC(after_pass(idx, ws, qp, q_at, od, oi, on, ec, ed, pr, prof, tot_precise));
+    }
+    return conclude_query(nq, heuristic, d_out_n, tot_rough, tot_precise, prof);
+}
+
+// The same call split in two, so that a caller can keep several batches in flight (each on its own
+// workspace and HIP stream): begin enqueues the whole pass and returns, end waits for it and does the
+// (rare) overflow re-runs.  Calls that need more than one pass run synchronously inside begin.
+struct rq_ticket {
+    rq_index *idx = nullptr;
+    Workspace *ws = nullptr;
+    QueryParams qp{};
+    const float *d_q = nullptr;
+    float *d_out_dist = nullptr;
+    uint32_t *d_out_id = nullptr, *d_out_n = nullptr;
+    const uint32_t *ext_cluster = nullptr;
+    const float *ext_dist = nullptr;
+    rq_profile_t prof;
+    bool done = false;
+    rq_status status = RQ_OK;
+};
+
+static rq_status query_device_begin(rq_index *idx, const float *d_q, uint32_t nq, uint32_t len, uint32_t probe,
+                                    uint32_t topk, bool heuristic, float *d_out_dist, uint32_t *d_out_id,
+                                    uint32_t *d_out_n, rq_ticket **out) {
+    if (!out) return fail(RQ_ERR_INVALID, "null argument");
+    *out = nullptr;
+    RQC(validate_query(idx, d_q, len, probe, topk, d_out_dist, d_out_id, d_out_n));
+    std::unique_ptr<rq_ticket> t(new rq_ticket());
+    t->idx = idx;
+    memset(&t->prof, 0, sizeof t->prof);
+    const uint32_t cap0 = std::max(RQ_DEFAULT_CAP, idx->cap_hint.load());
+    if (nq == 0 || pass_queries(idx, nq, probe, cap0) < nq) {  // nothing to overlap / several passes: synchronous
+        t->status = query_device(idx, d_q, nq, len, probe, topk, heuristic, d_out_dist, d_out_id, d_out_n);
+        t->done = true;
+        *out = t.release();
+        return RQ_OK;
+    }
+    t->qp = QueryParams{nq, len, probe, topk, heuristic, cap0, cap0};
+    t->d_q = d_q, t->d_out_dist = d_out_dist, t->d_out_id = d_out_id, t->d_out_n = d_out_n;
+    t->ws = ws_acquire(idx);
+    rq_status st = ws_prepare(idx, *t->ws, t->qp);
+    PassResult pr;
+    if (st == RQ_OK)
+        st = run_pass(idx, *t->ws, d_q, t->qp, nullptr, d_out_dist, d_out_id, d_out_n, &pr, &t->prof, nullptr, nullptr, true);
+    if (st != RQ_OK) {
+        (void)hipStreamSynchronize(t->ws->stream);
+        ws_release(idx, t->ws);
+        return st;
+    }
+    *out = t.release();
+    return RQ_OK;
+}
+
+static rq_status query_device_end(rq_ticket *tk) {
+    if (!tk) return fail(RQ_ERR_INVALID, "null ticket");
+    std::unique_ptr<rq_ticket> t(tk);
+    if (t->done) return t->status;
+    struct Rel {
+        rq_index *i;
+        Workspace *w;
+        ~Rel() { ws_release(i, w); }
+    } rel{t->idx, t->ws};
+    PassResult pr;
+    RQC(finish_pass(t->idx, *t->ws, &pr, &t->prof));
+    uint64_t tot_precise = pr.precise;
+    RQC(after_pass(t->idx, t->ws, t->qp, t->d_q, t->d_out_dist, t->d_out_id, t->d_out_n, nullptr, nullptr, pr, t->prof,
+                   tot_precise));
+    return conclude_query(t->qp.nq, t->qp.heuristic, t->d_out_n, pr.rough, tot_precise, t->prof);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1263,6 +1369,14 @@ rq_status rq_query_batch_device(const rq_index *idx, const float *d_queries, uin
     return query_device(const_cast<rq_index *>(idx), d_queries, nq, len, probe, topk, heuristic_rank != 0, d_out_dist,
                         d_out_id, d_out_n);
 }
+
+rq_status rq_query_batch_device_begin(const rq_index *idx, const float *d_queries, uint32_t nq, uint32_t len,
+                                      uint32_t probe, uint32_t topk, int heuristic_rank, float *d_out_dist,
+                                      uint32_t *d_out_id, uint32_t *d_out_n, rq_ticket **out_ticket) {
+    return query_device_begin(const_cast<rq_index *>(idx), d_queries, nq, len, probe, topk, heuristic_rank != 0,
+                              d_out_dist, d_out_id, d_out_n, out_ticket);
+}
+rq_status rq_query_batch_device_end(rq_ticket *ticket) { return query_device_end(ticket); }
 
 // Device staging of the host-pointer entry points: grown on demand, kept per host thread so a
 // per-vector `query()` loop does not pay hipMalloc/hipFree on every call (intentionally never freed).

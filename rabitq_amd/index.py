@@ -177,6 +177,20 @@ class RaBitQ:
         check(lib().rq_query_batch_device(self._h, C.c_void_p(q_ptr), nq, length, probe, topk, int(heuristic_rank),
                                           C.c_void_p(out_dist_ptr), C.c_void_p(out_id_ptr), C.c_void_p(out_n_ptr)))
 
+    def query_batch_device_begin(self, q_ptr: int, nq: int, length: int, probe: int, topk: int, out_dist_ptr: int,
+                                 out_id_ptr: int, out_n_ptr: int, heuristic_rank: bool = False):
+        """Enqueue a device-resident batch and return a ticket; finish it with query_batch_device_end(ticket).
+        Batches begun back to back overlap on the device (each has its own workspace and stream)."""
+        t = C.c_void_p()
+        check(lib().rq_query_batch_device_begin(self._h, C.c_void_p(q_ptr), nq, length, probe, topk, int(heuristic_rank),
+                                                C.c_void_p(out_dist_ptr), C.c_void_p(out_id_ptr), C.c_void_p(out_n_ptr),
+                                                C.byref(t)))
+        return t
+
+    @staticmethod
+    def query_batch_device_end(ticket) -> None:
+        check(lib().rq_query_batch_device_end(ticket))
+
 
     # ---- sharded deployments ---------------------------------------------------------------------
     def coarse_topk_device(self, q_ptr: int, nq: int, length: int, list_lo: int, list_hi: int, probe: int,

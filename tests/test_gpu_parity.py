@@ -602,3 +602,39 @@ def test_sharded_coarse_and_probed_query_equal_single(rq):
     assert np.array_equal(on.cpu().numpy().view(np.uint32), wn)
     assert np.array_equal(oi.cpu().numpy().view(np.uint32), wi) and np.array_equal(od.cpu().numpy().view(np.uint32), wd.view(np.uint32))
     idx.close()
+
+
+# ---- batches in flight: begin / end halves of the device batch call -----------------------------------
+def test_begin_end_batches_overlap_and_match_sync(rq):
+    import torch
+    n, d, k, nq = 20000, 128, 16, 300
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.7, seed=5, centre_scale=0.8)
+    gidx = rq.RaBitQ.build(x, centres, synth.random_orthogonal(d, seed=8))
+    dev = torch.device("cuda", 0)
+    qs = [torch.from_numpy(synth.mixture(nq, d, k, sigma=0.7, seed=100 + i, centre_scale=0.8)[0]).to(dev) for i in range(3)]
+    want = []
+    for q in qs:
+        od = torch.zeros((nq, 10), device=dev)
+        oi = torch.zeros((nq, 10), device=dev, dtype=torch.int32)
+        on = torch.zeros((nq,), device=dev, dtype=torch.int32)
+        gidx.query_batch_device(q.data_ptr(), nq, d, 6, 10, od.data_ptr(), oi.data_ptr(), on.data_ptr())
+        want.append((od.cpu().numpy().copy(), oi.cpu().numpy().copy(), on.cpu().numpy().copy()))
+    m0 = rq.metrics()
+    outs, tickets = [], []
+    for q in qs:   # three batches in flight at once
+        od = torch.zeros((nq, 10), device=dev)
+        oi = torch.zeros((nq, 10), device=dev, dtype=torch.int32)
+        on = torch.zeros((nq,), device=dev, dtype=torch.int32)
+        tickets.append(gidx.query_batch_device_begin(q.data_ptr(), nq, d, 6, 10, od.data_ptr(), oi.data_ptr(), on.data_ptr()))
+        outs.append((od, oi, on))
+    for t in tickets:
+        gidx.query_batch_device_end(t)
+    m1 = rq.metrics()
+    for (od, oi, on), (wd, wi, wn) in zip(outs, want):
+        cnt = on.cpu().numpy()
+        assert np.array_equal(cnt, wn)
+        valid = np.arange(10)[None, :] < cnt[:, None]
+        assert np.array_equal(oi.cpu().numpy()[valid], wi[valid])
+        assert np.array_equal(od.cpu().numpy().view(np.uint32)[valid], wd.view(np.uint32)[valid])
+    assert m1["query"] - m0["query"] == 3 * nq
+    gidx.close()
