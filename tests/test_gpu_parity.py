@@ -638,3 +638,34 @@ def test_begin_end_batches_overlap_and_match_sync(rq):
         assert np.array_equal(od.cpu().numpy().view(np.uint32)[valid], wd.view(np.uint32)[valid])
     assert m1["query"] - m0["query"] == 3 * nq
     gidx.close()
+
+
+def test_begin_end_overflow_retry_matches_sync(rq):
+    # the survivor-buffer overflow re-run must also work from the _end half (fresh index: no learnt capacity yet)
+    import torch
+    from rabitq_amd import index as ix
+    n, d = 24000, 64
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    centres = np.zeros((1, d), np.float32)
+    P = synth.random_orthogonal(d, seed=3)
+    queries = rng.standard_normal((6, d)).astype(np.float32) * 0.2
+    dev = torch.device("cuda", 0)
+    q = torch.from_numpy(queries).to(dev)
+    res = []
+    for mode in ("split", "sync"):
+        gidx = rq.RaBitQ.build(x, centres, P)
+        od = torch.zeros((6, 2000), device=dev)
+        oi = torch.zeros((6, 2000), device=dev, dtype=torch.int32)
+        on = torch.zeros((6,), device=dev, dtype=torch.int32)
+        if mode == "split":
+            t = gidx.query_batch_device_begin(q.data_ptr(), 6, d, 1, 2000, od.data_ptr(), oi.data_ptr(), on.data_ptr())
+            gidx.query_batch_device_end(t)
+        else:
+            gidx.query_batch_device(q.data_ptr(), 6, d, 1, 2000, od.data_ptr(), oi.data_ptr(), on.data_ptr())
+        assert ix.last_profile()["retries"] > 0, "the test no longer exercises the overflow path"
+        res.append((od.cpu().numpy().view(np.uint32), oi.cpu().numpy(), on.cpu().numpy()))
+        gidx.close()
+    assert np.array_equal(res[0][2], res[1][2]) and (res[0][2] == 2000).all()
+    assert np.array_equal(res[0][1], res[1][1])
+    assert np.array_equal(res[0][0], res[1][0])
