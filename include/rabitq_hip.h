@@ -219,7 +219,10 @@ typedef struct {
 rq_status rq_set_profiling(int level);
 /* Engine options.  "scan_impl": 0 = auto (default: fp6 matrix-core scan when many queries share each
  * list, v_dot8 VALU scan otherwise), 1 = VALU only, 2 = matrix cores wherever available.  All
- * settings return identical results; the option exists for tests and measurements. */
+ * settings return identical results; the option exists for tests and measurements.
+ * Developer knobs: "stage_growth" (geometric growth of the early stages, 0 = default; results are
+ * identical for every value), "scan_debug" (timing ablations of the matrix-core scan: results are
+ * WRONG while it is non-zero). */
 rq_status rq_set_option(const char *name, int value);
 rq_status rq_last_profile(rq_profile_t *out);
 

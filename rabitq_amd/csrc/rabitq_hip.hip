@@ -279,6 +279,7 @@ static void launch_scan(const ScanPtrs &p, const ScanArgs &a, uint32_t W, hipStr
 // 1 = VALU (v_dot8_u32_u4) only, 2 = matrix cores wherever the kernel exists (test hook)
 static std::atomic<int> g_scan_impl{0};
 static std::atomic<int> g_scan_dbg{0};
+static std::atomic<int> g_stage_growth{0};  // 0 = default schedule
 
 static bool scan_has_mfma(uint32_t W) { return W == 1 || W == 2 || W == 4; }
 static uint32_t scan_mfma_tile(uint32_t W) { return W == 4 ? 256 : 512; }
@@ -482,7 +483,8 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     {
         const uint64_t total_max = std::min<uint64_t>((uint64_t)nprobe * idx->max_list_len, idx->n);
         // small batches are launch-bound (coarser stages), large ones rerank-bound (tighter thresholds)
-        const uint64_t growth = nq >= 256 ? 8 : 16;
+        const int gopt = g_stage_growth.load();
+        const uint64_t growth = gopt >= 2 ? (uint64_t)gopt : (nq >= 256 ? 8 : 16);
         uint64_t lo = 0, hi = std::max<uint32_t>(topk, 1);
         const uint64_t avg = std::max<uint64_t>(1, idx->n / std::max<uint32_t>(k, 1));
         while (lo < total_max) {
@@ -1440,6 +1442,11 @@ rq_status rq_set_option(const char *name, int value) {
     if (std::string(name) == "scan_impl") {
         if (value < 0 || value > 2) return fail(RQ_ERR_INVALID, "scan_impl must be 0 (auto), 1 (valu) or 2 (mfma)");
         g_scan_impl = value;
+        return RQ_OK;
+    }
+    if (std::string(name) == "stage_growth") {  // geometric growth of the early stages (0 = default: 8, or 16 for small batches)
+        if (value != 0 && (value < 2 || value > 64)) return fail(RQ_ERR_INVALID, "stage_growth must be 0 or in [2, 64]");
+        g_stage_growth = value;
         return RQ_OK;
     }
     if (std::string(name) == "scan_debug") {  // developer ablations of the matrix-core scan (results are WRONG when != 0)

@@ -39,7 +39,18 @@ out_d = torch.empty((B, topk), device=dev)
 out_i = torch.zeros((B, topk), device=dev, dtype=torch.int32)
 out_n = torch.zeros((B,), device=dev, dtype=torch.int32)
 rqi.set_profiling(True)
-modes = [int(v) for v in os.environ.get("MODES", "0,1,2,3,0").split(",")]
+for gopt in [int(v) for v in os.environ.get("GROWTH", "").split(",") if v]:
+    rqi.set_option("stage_growth", gopt)
+    acc = {}
+    for it in range(4):
+        idx.query_batch_device(queries.data_ptr(), B, d, nprobe, topk, out_d.data_ptr(), out_i.data_ptr(), out_n.data_ptr())
+        if it:
+            for key, v in rqi.last_profile().items():
+                acc[key] = acc.get(key, 0) + v / 3
+    print(f"stage_growth={gopt}: total {acc['ms_total']:.3f} ms  scan {acc['ms_scan']:.3f} rerank {acc['ms_rerank']:.3f} replay {acc['ms_replay']:.3f} "
+          f"group {acc['ms_group']:.3f} sort {acc['ms_sort']:.3f} launches {acc['scan_launches']:.0f} cand/query {acc['rerank_candidates'] / B:.1f}", flush=True)
+rqi.set_option("stage_growth", 0)
+modes = [int(v) for v in os.environ.get("MODES", "0,1,2,3,0").split(",") if v]
 for mode in modes:
     rqi.set_option("scan_debug", mode)
     acc = {}
