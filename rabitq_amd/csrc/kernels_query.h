@@ -822,8 +822,13 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
 }
 
+// blocks per CU the register budget is cut for: the resident operands grow with W (6*W*NT dwords for the
+// candidates, 6*W for the query tile), so wide vectors run one block per CU with the full 512-register file
+template <int W>
+constexpr int scan_mfma_blocks_per_cu() { return W <= 2 ? 3 : (W <= 4 ? 2 : 1); }
+
 template <int W, int NT>
-__global__ __launch_bounds__(256, 3) void scan_mfma_kernel(const uint32_t *__restrict__ codes,
+__global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_kernel(const uint32_t *__restrict__ codes,
                                                            const float4 *__restrict__ factors,
                                                            const uint32_t *__restrict__ offsets,
                                                            const uint32_t *__restrict__ grp_start,
@@ -841,7 +846,7 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(const uint32_t *__res
     static_assert(IMG % 16 == 0, "tile image must split into four 16-byte-aligned quarters");
     constexpr uint32_t TILE = 128 * NT;
     __shared__ __attribute__((aligned(16))) uint2 lut[256];
-    __shared__ __attribute__((aligned(16))) uint32_t ring[3][IMG];  // query tiles in flight (LDS-DMA targets)
+    extern __shared__ __attribute__((aligned(16))) uint32_t ring[];  // 3 x IMG dwords: query tiles in flight (LDS-DMA targets)
     __shared__ __attribute__((aligned(16))) float4 facL[TILE];      // the tile's factors, for the exact path
     // per-wave emit queue: survivors are parked here and written out in bulk (one atomic round trip per flush)
     constexpr uint32_t QE = 256, QR = 64;
@@ -876,7 +881,7 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(const uint32_t *__res
 #pragma unroll
         for (int m = 0; m < W; ++m) craw[t][m] = cp[2 * m + h];
     }
-    const uint32_t ring0 = lds_addr(&ring[0][0]);
+    const uint32_t ring0 = lds_addr(&ring[0]);
     auto dma_tile = [&](uint32_t qt, uint32_t slot) {  // this wave's quarter of query tile qt -> ring[slot]
         const uint32_t *src = recs + ((uint64_t)(pb >> 5) + qt) * IMG + wave * (IMG / 4);
         const uint32_t dst = ring0 + (slot * IMG + wave * (IMG / 4)) * 4;
@@ -988,17 +993,19 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(const uint32_t *__res
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // every wave's quarter of tile qt is in; everyone is done with tile qt-1
         if (qt + 2 < ntiles) dma_tile(qt + 2, slot == 0 ? 2 : slot - 1);  // into the slot tile qt-1 occupied
-        const uint32_t *img = ring[slot];
+        const uint32_t *img = ring + slot * IMG;
         const uint32_t nvalid = cnt - 32 * qt;  // rows >= nvalid of the last tile are stale memory: masked here
         const bool valid = j < nvalid;
 
-        uint32_t aop[W][6];  // A: query row j (= lane & 31), dims 64m + 32h .. +31 as fp6
+        // A: query row j (= lane & 31), dims 64m + 32h .. +31 as fp6.  Rows >= nvalid hold stale bytes: harmless,
+        // every fp6 pattern is a finite number and such a row's accumulator starts at -inf (below)
+        uint32_t aop[W][6];
 #pragma unroll
         for (int m = 0; m < W; ++m)
 #pragma unroll
             for (int e = 0; e < 6; e += 2) {
                 const uint2 v = *reinterpret_cast<const uint2 *>(&img[j * OPLD + 6 * W * h + 6 * m + e]);
-                aop[m][e] = valid ? v.x : 0u, aop[m][e + 1] = valid ? v.y : 0u;
+                aop[m][e] = v.x, aop[m][e + 1] = v.y;
             }
         // A operand of the threshold MFMA: slots 8h .. 8h+7 of query row j
         v4i32 ua = *reinterpret_cast<const v4i32 *>(&img[IMG_OP + j * RQ_REC_TAIL + RQ_REC_V0 + 4 * h]);

@@ -281,8 +281,27 @@ static std::atomic<int> g_scan_impl{0};
 static std::atomic<int> g_scan_dbg{0};
 static std::atomic<int> g_stage_growth{0};  // 0 = default schedule
 
-static bool scan_has_mfma(uint32_t W) { return W == 1 || W == 2 || W == 4; }
-static uint32_t scan_mfma_tile(uint32_t W) { return W == 4 ? 256 : 512; }
+// matrix-core scan instantiations: W = dim/64, NT = 32-candidate sub-tiles per wave (resident operand registers
+// 6*W*NT), blocks per CU per scan_mfma_blocks_per_cu<W>()
+static bool scan_has_mfma(uint32_t W) {
+    switch (W) {
+        case 1: case 2: case 3: case 4: case 6: case 8: case 12: case 16: return true;
+        default: return false;
+    }
+}
+static uint32_t scan_mfma_nt(uint32_t W) { return W == 4 || W == 16 ? 2 : 4; }
+static uint32_t scan_mfma_tile(uint32_t W) { return 128 * scan_mfma_nt(W); }
+static size_t scan_mfma_ring_bytes(uint32_t W) { return 3ull * (32 * (12 * W + 2) + RQ_REC_TAIL * 32) * 4; }
+template <int W, int NT>
+static void launch_scan_mfma_t(const ScanPtrs &p, const ScanArgs &a, dim3 g, hipStream_t st) {
+    static std::once_flag once;  // the ring (dynamic LDS) of wide vectors exceeds the 64 KiB default
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(scan_mfma_kernel<W, NT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_mfma_ring_bytes(W));
+    });
+    scan_mfma_kernel<W, NT><<<g, dim3(256), scan_mfma_ring_bytes(W), st>>>(p.codes, p.factors, p.offsets, p.grp_start, p.grp_cnt,
+                                                                             p.recs, p.surv, p.runs, p.surv_cnt, a);
+}
 static void launch_scan_mfma(const ScanPtrs &p, const ScanArgs &a, uint32_t W, hipStream_t st) {
     const uint64_t blocks = (uint64_t)a.ngroups * a.tiles_per_group;
     if (blocks == 0) return;
@@ -290,15 +309,18 @@ static void launch_scan_mfma(const ScanPtrs &p, const ScanArgs &a, uint32_t W, h
         fprintf(stderr, "rabitq_hip: scan grid of %llu blocks exceeds the launch bound\n", (unsigned long long)blocks);
         abort();
     }
-    dim3 g((uint32_t)blocks), b(256);
-#define SCAN_MFMA_ARGS p.codes, p.factors, p.offsets, p.grp_start, p.grp_cnt, p.recs, p.surv, p.runs, p.surv_cnt, a
+    dim3 g((uint32_t)blocks);
     switch (W) {
-        case 1: scan_mfma_kernel<1, 4><<<g, b, 0, st>>>(SCAN_MFMA_ARGS); break;
-        case 2: scan_mfma_kernel<2, 4><<<g, b, 0, st>>>(SCAN_MFMA_ARGS); break;
-        case 4: scan_mfma_kernel<4, 2><<<g, b, 0, st>>>(SCAN_MFMA_ARGS); break;
+        case 1: launch_scan_mfma_t<1, 4>(p, a, g, st); break;
+        case 2: launch_scan_mfma_t<2, 4>(p, a, g, st); break;
+        case 3: launch_scan_mfma_t<3, 4>(p, a, g, st); break;
+        case 4: launch_scan_mfma_t<4, 2>(p, a, g, st); break;
+        case 6: launch_scan_mfma_t<6, 4>(p, a, g, st); break;
+        case 8: launch_scan_mfma_t<8, 4>(p, a, g, st); break;
+        case 12: launch_scan_mfma_t<12, 4>(p, a, g, st); break;
+        case 16: launch_scan_mfma_t<16, 2>(p, a, g, st); break;
         default: abort();
     }
-#undef SCAN_MFMA_ARGS
 }
 
 static bool scan_is_fused(uint32_t W) {

@@ -517,7 +517,9 @@ def test_concurrent_queries_one_handle(rq, oracle):
 # ---- the two scan implementations (VALU v_dot8 / fp6 matrix cores) must be indistinguishable ----------
 @pytest.mark.parametrize("impl", [1, 2])
 @pytest.mark.parametrize("n,d,k,nq", [(12000, 128, 24, 160), (5000, 64, 10, 70), (4000, 256, 6, 50), (3000, 100, 8, 40),
-                                      (6000, 128, 4, 420)])   # 420 pairs per list: 14 query tiles through the 3-slot ring
+                                      (6000, 128, 4, 420),    # 420 pairs per list: 14 query tiles through the 3-slot ring
+                                      (3000, 192, 6, 70), (2500, 384, 5, 70), (2000, 512, 4, 66), (2500, 768, 4, 80),
+                                      (1500, 1024, 3, 40)])   # the wide-vector instantiations (W = 3, 6, 8, 12, 16)
 def test_scan_implementations_match_oracle(rq, oracle, impl, n, d, k, nq):
     from rabitq_amd import index as ix
     x, centres, _ = synth.mixture(n, d, k, sigma=0.8, seed=n + impl, centre_scale=0.6)
