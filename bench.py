@@ -261,8 +261,9 @@ def main():
     if os.path.exists(tr_path):
         try:
             tj = json.load(open(tr_path))
-            traffic = tj.get("hbm_bytes_per_launch")
-            dom_traffic = tj.get("dominant_launch", {}).get("hbm_read_bytes")
+            if tj.get("config", {}) == {"vectors": n, "dim": d, "lists": k_local, "nprobe": nprobe, "batch": B}:  # same workload only
+                traffic = tj.get("hbm_bytes_per_launch")
+                dom_traffic = tj.get("dominant_launch", {}).get("hbm_read_bytes")
         except Exception:
             traffic = None
     scan_all = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
