@@ -742,7 +742,7 @@ static rq_status conclude_query(uint32_t nq, bool heuristic, const uint32_t *d_o
     bool any_empty = false;
     if (heuristic) {  // rerank.rs:171-173: an empty array panics in the reference
         std::vector<uint32_t> h_n(nq);
-        HIPC(hipMemcpy(h_n.data(), d_out_n, nq * 4, hipMemcpyDeviceToHost));
+        HIPC(hipMemcpy(h_n.data(), d_out_n, nq * 4, hipMemcpyDefault));  // d_out_n may be device or mapped host memory
         for (uint32_t v : h_n) any_empty |= (v == 0);
     }
     g_rough.fetch_add(tot_rough, std::memory_order_relaxed);      // rerank.rs:105
@@ -1407,6 +1407,8 @@ rq_status rq_query_batch_device_end(rq_ticket *ticket) { return query_device_end
 struct HostStaging {
     void *p[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t cap[4] = {0, 0, 0, 0};
+    void *pin = nullptr;  // pinned, device-mapped host buffer for small calls (zero-copy in both directions)
+    size_t pin_cap = 0;
     rq_status get(int i, size_t bytes, void **out) {
         if (bytes > cap[i]) {
             if (p[i]) (void)hipFree(p[i]);
@@ -1419,8 +1421,21 @@ struct HostStaging {
         *out = p[i];
         return RQ_OK;
     }
+    rq_status get_pinned(size_t bytes, void **out) {
+        if (bytes > pin_cap) {
+            if (pin) (void)hipHostFree(pin);
+            pin = nullptr, pin_cap = 0;
+            size_t want = std::max<size_t>(bytes, 65536);
+            hipError_t e = hipHostMalloc(&pin, want, hipHostMallocMapped | hipHostMallocCoherent);
+            if (e != hipSuccess) return fail(RQ_ERR_OOM, std::string("pinned staging allocation failed: ") + hipGetErrorString(e));
+            pin_cap = want;
+        }
+        *out = pin;
+        return RQ_OK;
+    }
 };
 static thread_local HostStaging g_staging;
+#define RQ_ZERO_COPY_BYTES (1u << 20)
 
 rq_status rq_query_batch(const rq_index *idx, const float *queries, uint32_t nq, uint32_t len, uint32_t probe,
                          uint32_t topk, int heuristic_rank, float *out_dist, uint32_t *out_id, uint32_t *out_n) {
@@ -1428,13 +1443,30 @@ rq_status rq_query_batch(const rq_index *idx, const float *queries, uint32_t nq,
     if (!idx || !queries || !out_dist || !out_id || !out_n) return fail(RQ_ERR_INVALID, "null argument");
     if (nq == 0) return RQ_OK;
     if (topk == 0) return fail(RQ_ERR_UNSUPPORTED, "topk must be in [1, 2048]");
+    const size_t qb = ((size_t)nq * len * 4 + 255) & ~(size_t)255, ob = ((size_t)nq * topk * 4 + 255) & ~(size_t)255;
+    if (qb + 2 * ob + (size_t)nq * 4 <= RQ_ZERO_COPY_BYTES) {
+        // small call (the reference's one-query-per-call loop): queries and results live in pinned host memory
+        // the kernels address directly, which replaces five blocking copies by two host memcpys
+        void *pin;
+        RQC(g_staging.get_pinned(qb + 2 * ob + (size_t)nq * 4, &pin));
+        void *dev = nullptr;
+        HIPC(hipHostGetDevicePointer(&dev, pin, 0));
+        char *h = static_cast<char *>(pin), *d = static_cast<char *>(dev);
+        memcpy(h, queries, (size_t)nq * len * 4);
+        rq_status s = query_device(const_cast<rq_index *>(idx), (const float *)d, nq, len, probe, topk, heuristic_rank != 0,
+                                   (float *)(d + qb), (uint32_t *)(d + qb + ob), (uint32_t *)(d + qb + 2 * ob));
+        if (s != RQ_OK && s != RQ_ERR_EMPTY) return s;
+        memcpy(out_dist, h + qb, (size_t)nq * topk * 4);
+        memcpy(out_id, h + qb + ob, (size_t)nq * topk * 4);
+        memcpy(out_n, h + qb + 2 * ob, (size_t)nq * 4);
+        return s;
+    }
     void *dq, *dd, *di, *dn;
     RQC(g_staging.get(0, (uint64_t)nq * len * 4, &dq));
     RQC(g_staging.get(1, (uint64_t)nq * topk * 4, &dd));
     RQC(g_staging.get(2, (uint64_t)nq * topk * 4, &di));
     RQC(g_staging.get(3, (uint64_t)nq * 4, &dn));
     HIPC(hipMemcpy(dq, queries, (uint64_t)nq * len * 4, hipMemcpyHostToDevice));
-    HIPC(hipMemset(dn, 0, nq * 4));
     rq_status s = query_device(const_cast<rq_index *>(idx), (const float *)dq, nq, len, probe, topk, heuristic_rank != 0,
                                (float *)dd, (uint32_t *)di, (uint32_t *)dn);
     if (s != RQ_OK && s != RQ_ERR_EMPTY) return s;
