@@ -1290,8 +1290,8 @@ __device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, co
     // The survivors are replayed in stream order = directory order, then record order inside a run.  The
     // directory is read 64 descriptors at a time; within such a chunk the stream is cut into batches of 64
     // survivors (whatever runs they belong to): lane i finds its (run, offset) by a binary search over
-    // the chunk's prefix sums in LDS, so a batch costs two round trips (records, then their ids) however
-    // many short runs it spans, and batch k+1 is in flight while batch k is replayed.
+    // the chunk's prefix sums in LDS, so a batch costs one round trip however many short runs it spans,
+    // and batch k+1 is in flight while batch k is replayed.
     __shared__ uint32_t s_pref[65], s_base[64];
     for (uint32_t c0 = 0; c0 < nruns; c0 += 64) {
         uint32_t dbase = 0, dcnt = 0;
@@ -1308,27 +1308,23 @@ __device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, co
         if (lane == 0) s_pref[0] = 0;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         const uint32_t total = __shfl(incl, 63, 64);
-        auto fetch = [&](uint32_t off, SurvRec &rec, uint32_t &id) {
+        auto fetch = [&](uint32_t off, SurvRec &rec) {
             const uint32_t t = off + lane;
             rec.pos = 0, rec.slot = 0, rec.rough = 0.0f, rec.accurate = 0.0f;
-            id = 0;
             if (t < total) {
                 uint32_t lo = 0;  // largest r with s_pref[r] <= t
 #pragma unroll
                 for (int step = 32; step >= 1; step >>= 1)
                     if (lo + step < 64 && s_pref[lo + step] <= t) lo += step;
                 rec = recs[s_base[lo] + (t - s_pref[lo])];
-                id = map_ids[rec.pos];
             }
         };
         SurvRec nxt;
-        uint32_t nxt_id;
-        fetch(0, nxt, nxt_id);
+        fetch(0, nxt);
         for (uint32_t off = 0; off < total; off += 64) {
             const bool have = off + lane < total;
             const SurvRec r = nxt;
-            const uint32_t r_id = nxt_id;
-            if (off + 64 < total) fetch(off + 64, nxt, nxt_id);  // wave-uniform
+            if (off + 64 < total) fetch(off + 64, nxt);  // wave-uniform
         uint64_t m = __ballot(have && r.rough < thr);  // rerank.rs:84 / :146
         while (m) {
             const int i = __builtin_ctzll(m);
@@ -1336,7 +1332,8 @@ __device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, co
             const float acc = __shfl(r.accurate, i, 64);
             ++precise;
             if (!(acc < thr)) continue;  // rerank.rs:92 / :154
-            const uint32_t id = __shfl(r_id, i, 64);
+            // the rankers carry the cluster-order POSITION; finalize_* maps it to the original id (rabitq.rs:324)
+            const uint32_t id = __shfl(r.pos, i, 64);
             if constexpr (!HEURISTIC) {
                 // push: append + sift_up(0, old_len)
                 int32_t key = ord32_from_f32(acc);
@@ -1560,8 +1557,9 @@ __global__ void init_state_kernel(ReplayState st, unsigned long long *__restrict
 // Results (src/rerank.rs:108-113 heap Vec order; :170-176 the topk smallest, here sorted).
 // ------------------------------------------------------------------------------------------------
 __global__ void finalize_heap_kernel(const ReplayState st, uint32_t nq, uint32_t topk,
-                                     const uint32_t *__restrict__ row_map, float *__restrict__ out_dist,
-                                     uint32_t *__restrict__ out_id, uint32_t *__restrict__ out_n) {
+                                     const uint32_t *__restrict__ row_map, const uint32_t *__restrict__ map_ids,
+                                     float *__restrict__ out_dist, uint32_t *__restrict__ out_id,
+                                     uint32_t *__restrict__ out_n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq * topk) return;
     uint32_t b = i / topk, e = i - b * topk;
@@ -1569,13 +1567,13 @@ __global__ void finalize_heap_kernel(const ReplayState st, uint32_t nq, uint32_t
     uint32_t len = st.heap_len[b];
     if (e < len) {
         out_dist[(uint64_t)ob * topk + e] = ord32_to_f32(st.heap_key[(uint64_t)b * topk + e]);
-        out_id[(uint64_t)ob * topk + e] = st.heap_id[(uint64_t)b * topk + e];
+        out_id[(uint64_t)ob * topk + e] = map_ids[st.heap_id[(uint64_t)b * topk + e]];  // position -> original id
     }
     if (e == 0) out_n[ob] = len;
 }
 
 __global__ void finalize_heuristic_kernel(const ReplayState st, uint32_t nq, uint32_t topk,
-                                          const uint32_t *__restrict__ row_map,
+                                          const uint32_t *__restrict__ row_map, const uint32_t *__restrict__ map_ids,
                                           float *__restrict__ out_dist, uint32_t *__restrict__ out_id,
                                           uint32_t *__restrict__ out_n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1588,7 +1586,7 @@ __global__ void finalize_heuristic_kernel(const ReplayState st, uint32_t nq, uin
     if (e < take) {
         const SurvRec &r = st.arr[(uint64_t)b * st.hcap + e];
         out_dist[(uint64_t)ob * topk + e] = r.rough;
-        out_id[(uint64_t)ob * topk + e] = __builtin_bit_cast(uint32_t, r.accurate);
+        out_id[(uint64_t)ob * topk + e] = map_ids[__builtin_bit_cast(uint32_t, r.accurate)];  // position -> original id
     }
     if (e == 0) out_n[ob] = take;
 }

@@ -601,10 +601,10 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     pf.begin(PF_REPLAY);
     if (qp.heuristic) {
         sort_survivors_kernel<<<nq, 256, 0, st>>>(ws.arr.p, ws.arr_len.p, qp.hcap);
-        finalize_heuristic_kernel<<<ceil_div((uint64_t)nq * topk, 256), 256, 0, st>>>(rs, nq, topk, d_row_map,
+        finalize_heuristic_kernel<<<ceil_div((uint64_t)nq * topk, 256), 256, 0, st>>>(rs, nq, topk, d_row_map, idx->map_ids.p,
                                                                                        d_out_dist, d_out_id, d_out_n);
     } else {
-        finalize_heap_kernel<<<ceil_div((uint64_t)nq * topk, 256), 256, 0, st>>>(rs, nq, topk, d_row_map, d_out_dist,
+        finalize_heap_kernel<<<ceil_div((uint64_t)nq * topk, 256), 256, 0, st>>>(rs, nq, topk, d_row_map, idx->map_ids.p, d_out_dist,
                                                                                   d_out_id, d_out_n);
     }
     metrics_sum_kernel<<<std::min(256u, ceil_div(nq, 256)), 256, 0, st>>>(
