@@ -1325,13 +1325,20 @@ __device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, co
             const bool have = off + lane < total;
             const SurvRec r = nxt;
             if (off + 64 < total) fetch(off + 64, nxt);  // wave-uniform
-        uint64_t m = __ballot(have && r.rough < thr);  // rerank.rs:84 / :146
+        uint64_t m = __ballot(have && r.rough < thr);  // rerank.rs:84 / :146: candidates the reference reranks
         while (m) {
-            const int i = __builtin_ctzll(m);
-            m &= m - 1;
+            // the threshold only moves when a candidate is accepted (rerank.rs:92 / :154), so everything before
+            // the next acceptance is counted in one step instead of visited one by one
+            const uint64_t acc_m = __ballot(have && r.rough < thr && r.accurate < thr) & m;
+            if (acc_m == 0) {
+                precise += (uint32_t)__popcll(m);
+                break;
+            }
+            const int i = __builtin_ctzll(acc_m);
+            const uint64_t upto = (2ull << i) - 1ull;  // lanes 0..i (i = 63 wraps to all ones)
+            precise += (uint32_t)__popcll(m & upto);
+            m &= ~upto;
             const float acc = __shfl(r.accurate, i, 64);
-            ++precise;
-            if (!(acc < thr)) continue;  // rerank.rs:92 / :154
             // the rankers carry the cluster-order POSITION; finalize_* maps it to the original id (rabitq.rs:324)
             const uint32_t id = __shfl(r.pos, i, 64);
             if constexpr (!HEURISTIC) {
