@@ -801,6 +801,11 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
 typedef int v8i32 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef int v16i32 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ int imax3(int a, int b, int c) {
+    const int m = a > b ? a : b;
+    return m > c ? m : c;
+}
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 #ifndef RQ_F32X16_DEFINED
 #define RQ_F32X16_DEFINED
@@ -1009,9 +1014,11 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
             }
         // A operand of the threshold MFMA: slots 8h .. 8h+7 of query row j
         v4i32 ua = *reinterpret_cast<const v4i32 *>(&img[IMG_OP + j * RQ_REC_TAIL + RQ_REC_V0 + 4 * h]);
+        if (nvalid < 32) {  // wave-uniform, last tile of a list only
 #pragma unroll
-        for (int e = 0; e < 4; ++e)  // a missing query: -S* = -inf (constant term hi = -inf, times 1), never flagged
-            ua[e] = valid ? ua[e] : ((h == 0 && e == 3) ? 0x0000FF80 : 0);
+            for (int e = 0; e < 4; ++e)  // a missing query: -S* = -inf (constant term hi = -inf, times 1), never flagged
+                ua[e] = valid ? ua[e] : ((h == 0 && e == 3) ? 0x0000FF80 : 0);
+        }
         auto tail = [&](uint32_t f, uint32_t row) { return img[IMG_OP + row * RQ_REC_TAIL + f]; };
 
 #pragma unroll
@@ -1027,15 +1034,18 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
                                   (int)bexp[t][m][4], (int)bexp[t][m][5], 0, 0};
                 acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 2 /*A e2m3*/, 2 /*B e2m3*/, 0, 0, 0, 0);
             }
-            // hot path: is any of the 1024 (query, candidate) cells positive?  8 v_max3 + 1 compare
-            float mx = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);
+            // hot path: is any of the 1024 (query, candidate) cells positive?  A float is positive iff its bit
+            // pattern is a positive int32 (a NaN with a clear sign bit counts as positive: conservative), so the
+            // reduction is 7 v_max3_i32 + 1 v_max_i32 + 1 compare, with no canonicalisation
+            const v16i32 ai = __builtin_bit_cast(v16i32, acc);
+            int mxi = imax3(ai[0], ai[1], ai[2]);
 #pragma unroll
-            for (int gq = 3; gq < 15; gq += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, acc[gq]), acc[gq + 1]);
-            mx = __builtin_fmaxf(mx, acc[15]);
-            uint32_t gmask = 0;
-            f32x16 sc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            if (forcemask != 0ull || __ballot(mx > 0.0f) != 0ull) {  // wave-uniform
-                gmask = forcemask ? 0xFFFFu : 0u;  // accumulator registers with at least one flagged lane
+            for (int gq = 3; gq < 15; gq += 2) mxi = imax3(mxi, ai[gq], ai[gq + 1]);
+            mxi = mxi > ai[15] ? mxi : ai[15];
+            if ((forcemask != 0ull || __ballot(mxi > 0) != 0ull) && !(a.dbg & 64u)) {  // wave-uniform; everything below
+                // lives inside this branch so that the common path carries no state of it (not even a zeroed tile)
+                uint32_t gmask = forcemask ? 0xFFFFu : 0u;  // accumulator registers with at least one flagged lane
+                f32x16 sc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                 for (int gq = 0; gq < 16; ++gq) gmask |= (__ballot(acc[gq] > 0.0f) != 0ull ? 1u : 0u) << gq;
                 // the flagged cells need s itself: the same products again on a clean accumulator (exact)
@@ -1046,9 +1056,8 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
                                       (int)bexp[t][m][4], (int)bexp[t][m][5], 0, 0};
                     sc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, sc, 2, 2, 0, 0, 0, 0);
                 }
-            }
-            if (a.dbg & 1u) gmask = 0;
-            if (gmask) {  // wave-uniform: exact evaluation + emit, for the flagged registers only
+                if (a.dbg & 1u) gmask = 0;
+                // exact evaluation + emit, for the flagged registers only
                 const float4 fc = facL[lpos[t] - first];
                 while (gmask) {
                     const uint32_t gq = (uint32_t)__builtin_ctz(gmask);
