@@ -228,6 +228,119 @@ __global__ __launch_bounds__(256) void select_probe_kernel(const float *__restri
     }
 }
 
+// The same selection with ONE WAVE per query, for nprobe <= 64 and k <= 64*KPL: the row of distances lives
+// in registers (lane l holds lists l, l+64, ...), the nprobe-th smallest key is found by bisection on
+// the monotone u32 image of the distance (count = per-lane compares + one wave reduction, typically
+// ~20 steps, stopping as soon as a threshold selects exactly nprobe), ties at the threshold are broken
+// by list id (a second bisection, rare), the winners are compacted by ballot and sorted across the 64
+// lanes with a shuffle bitonic network.  No LDS atomics, no block barriers.
+template <int KPL>
+__global__ __launch_bounds__(256) void select_probe_wave_kernel(const float *__restrict__ dist, uint32_t k,
+                                                                uint32_t nprobe, uint32_t *__restrict__ out_cluster,
+                                                                float *__restrict__ out_dist, uint32_t id_offset,
+                                                                uint32_t out_stride, uint32_t nq) {
+    __shared__ unsigned long long win[4][64];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t b = blockIdx.x * 4 + wave;
+    if (b >= nq) return;
+    const float *d = dist + (uint64_t)b * k;
+    uint32_t key[KPL];
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        const uint32_t j = lane + 64 * i;
+        key[i] = 0xFFFFFFFFu;  // "no list": above every real key (a NaN distance with all-ones payload is not supported)
+        if (j < k) {
+            key[i] = ord32_biased(d[j]);
+            kmin = key[i] < kmin ? key[i] : kmin;
+            kmax = key[i] > kmax ? key[i] : kmax;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const uint32_t a = __shfl_xor(kmin, o, 64), c = __shfl_xor(kmax, o, 64);
+        kmin = a < kmin ? a : kmin;
+        kmax = c > kmax ? c : kmax;
+    }
+    auto count_le = [&](uint32_t t) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) c += key[i] <= t ? 1u : 0u;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+        return c;
+    };
+    // smallest T with count(key <= T) >= nprobe (nprobe <= k, so T <= kmax)
+    uint32_t lo = kmin, hi = kmax, T = kmax;
+    bool exact = false;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        const uint32_t c = count_le(mid);
+        if (c == nprobe) {
+            T = mid;
+            exact = true;
+            break;
+        }
+        if (c > nprobe) hi = mid;
+        else lo = mid + 1;
+    }
+    if (!exact) T = lo;
+    uint32_t J = 0xFFFFFFFFu;  // among keys == T only ids <= J are taken
+    if (!exact) {
+        const uint32_t c_le = count_le(T);
+        if (c_le > nprobe) {  // ties at the threshold: the smallest list ids win
+            const uint32_t c_lt = T ? count_le(T - 1) : 0u;
+            const uint32_t need = nprobe - c_lt;  // >= 1
+            uint32_t jl = 0, jh = k - 1;
+            while (jl < jh) {
+                const uint32_t jm = jl + ((jh - jl) >> 1);
+                uint32_t c = 0;
+#pragma unroll
+                for (int i = 0; i < KPL; ++i) c += (key[i] == T && lane + 64 * i <= jm) ? 1u : 0u;
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+                if (c >= need) jh = jm;
+                else jl = jm + 1;
+            }
+            J = jl;
+        }
+    }
+    // compact the nprobe winners (key, id) into LDS
+    uint32_t base = 0;
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        const uint32_t j = lane + 64 * i;
+        const bool take = key[i] < T || (key[i] == T && j <= J && j < k);
+        const uint64_t m = __ballot(take);
+        if (m) {  // wave-uniform
+            if (take) win[wave][base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)key[i] << 32) | j;
+            base += (uint32_t)__popcll(m);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    unsigned long long v = lane < nprobe ? win[wave][lane] : ~0ull;
+    // bitonic sort across the 64 lanes, ascending
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1)
+#pragma unroll
+        for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+            const unsigned long long other = __shfl_xor(v, stride, 64);
+            const bool up = (lane & size) == 0 || size == 64;
+            const bool lower = (lane & stride) == 0;
+            const bool take_min = lower == up;
+            const unsigned long long mn = other < v ? other : v, mx = other < v ? v : other;
+            v = take_min ? mn : mx;
+        }
+    if (lane < nprobe) {
+        out_cluster[(uint64_t)b * out_stride + lane] = (uint32_t)v + id_offset;
+        out_dist[(uint64_t)b * out_stride + lane] = ord32_unbias((uint32_t)(v >> 32));
+    }
+    for (uint32_t i = nprobe + lane; i < out_stride; i += 64) {  // fewer lists than requested: "no list"
+        out_cluster[(uint64_t)b * out_stride + i] = 0xFFFFFFFFu;
+        out_dist[(uint64_t)b * out_stride + i] = __builtin_inff();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Per-(query, probed list) query quantisation (src/rabitq.rs:304-317):
 //   residual = y - c (src/simd.rs:138), (lo, hi) (:143-157), delta = (hi - lo) * (1/15),

@@ -336,6 +336,19 @@ static uint32_t scan_tile(uint32_t W) {
     }
 }
 
+// probe selection: one wave per query when the row fits in registers and nprobe <= 64, else one block per query
+static void launch_select(const float *dist, uint32_t k, uint32_t nprobe, uint32_t *out_cluster, float *out_dist,
+                          uint32_t id_offset, uint32_t out_stride, uint32_t nq, hipStream_t st) {
+    if (nprobe <= 64 && k <= 8192 && nq >= 8) {
+        const dim3 g(ceil_div(nq, 4)), b(256);
+        if (k <= 1024) select_probe_wave_kernel<16><<<g, b, 0, st>>>(dist, k, nprobe, out_cluster, out_dist, id_offset, out_stride, nq);
+        else if (k <= 4096) select_probe_wave_kernel<64><<<g, b, 0, st>>>(dist, k, nprobe, out_cluster, out_dist, id_offset, out_stride, nq);
+        else select_probe_wave_kernel<128><<<g, b, 0, st>>>(dist, k, nprobe, out_cluster, out_dist, id_offset, out_stride, nq);
+        return;
+    }
+    select_probe_kernel<<<nq, 256, (size_t)nprobe * 8, st>>>(dist, k, nprobe, out_cluster, out_dist, id_offset, out_stride);
+}
+
 // ------------------------------------------------------------------------------------------------
 // the query pipeline
 // ------------------------------------------------------------------------------------------------
@@ -468,8 +481,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                 idx->cent_t.p, ws.y.p, ws.dist.p, k, dim, nq, k);
         pf.end();
         pf.begin(PF_SELECT);
-        select_probe_kernel<<<nq, 256, (size_t)nprobe * 8, st>>>(ws.dist.p, k, nprobe, ws.probe_cluster.p, ws.probe_dist.p, 0,
-                                                                  nprobe);
+        launch_select(ws.dist.p, k, nprobe, ws.probe_cluster.p, ws.probe_dist.p, 0, nprobe, nq, st);
         pf.end();
     }
 
@@ -1371,7 +1383,7 @@ rq_status rq_coarse_topk_device(const rq_index *idx, const float *d_queries, uin
     launch_rotate(qp, idx->P.p, y.p, nq, dim, nq >= 32, nullptr);
     coarse_dist_kernel<4><<<dim3(ceil_div(nq, 4), ceil_div(kc, 256)), 256, 4 * dim * sizeof(float)>>>(
         idx->cent_t.p + list_lo, y.p, dist.p, kc, dim, nq, idx->k);
-    select_probe_kernel<<<nq, 256, (size_t)np * 8>>>(dist.p, kc, np, d_out_cluster, d_out_dist, list_lo, probe);
+    launch_select(dist.p, kc, np, d_out_cluster, d_out_dist, list_lo, probe, nq, nullptr);
     HIPC(hipDeviceSynchronize());
     HIPC(hipGetLastError());
     return RQ_OK;
@@ -1618,7 +1630,7 @@ rq_status rq_coarse_rank(const rq_index *idx, const float *queries, uint32_t nq,
     launch_rotate(qpad.p, idx->P.p, y.p, nq, dim, nq >= 32, nullptr);
     coarse_dist_kernel<4><<<dim3(ceil_div(nq, 4), ceil_div(k, 256)), 256, 4 * dim * sizeof(float)>>>(
         idx->cent_t.p, y.p, dist.p, k, dim, nq, k);
-    select_probe_kernel<<<nq, 256, (size_t)nprobe * 8>>>(dist.p, k, nprobe, pc.p, pd.p, 0, nprobe);
+    launch_select(dist.p, k, nprobe, pc.p, pd.p, 0, nprobe, nq, nullptr);
     HIPC(hipDeviceSynchronize());
     HIPC(hipGetLastError());
     if (out_y) HIPC(hipMemcpy(out_y, y.p, (uint64_t)nq * dim * 4, hipMemcpyDeviceToHost));
