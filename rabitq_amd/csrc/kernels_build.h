@@ -421,9 +421,13 @@ __global__ __launch_bounds__(256) void gather_kernel(const unsigned long long *_
     }
 }
 
+// out[0] = longest list, out[1] = shortest list (0 if any list is empty); out preset to {0, 0xFFFFFFFF}
 __global__ void max_list_len_kernel(const uint32_t *__restrict__ offsets, uint32_t k, uint32_t *__restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < k) atomicMax(out, offsets[i + 1] - offsets[i]);
+    if (i < k) {
+        atomicMax(out, offsets[i + 1] - offsets[i]);
+        atomicMin(out + 1, offsets[i + 1] - offsets[i]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

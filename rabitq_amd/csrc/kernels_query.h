@@ -493,11 +493,13 @@ __device__ __forceinline__ bool pair_in_stage(const PairScalars &ps, uint32_t s_
     return ps.list_len != 0 && b < s_hi && e > s_lo;
 }
 
+// `count` = nq * slot_hi work items: only the first slot_hi slots of every query can be in the stage
 __global__ void group_count_kernel(const PairScalars *__restrict__ scal,
-                                   const uint32_t *__restrict__ probe_cluster, uint32_t npairs, uint32_t s_lo,
-                                   uint32_t s_hi, uint32_t *__restrict__ grp_cnt) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npairs) return;
+                                   const uint32_t *__restrict__ probe_cluster, uint32_t count, uint32_t nprobe,
+                                   uint32_t slot_hi, uint32_t s_lo, uint32_t s_hi, uint32_t *__restrict__ grp_cnt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t b = i / slot_hi, p = b * nprobe + (i - b * slot_hi);
     if (pair_in_stage(scal[p], s_lo, s_hi)) atomicAdd(&grp_cnt[probe_cluster[p]], 1u);
 }
 
@@ -569,16 +571,18 @@ __device__ __forceinline__ float bf16_to_f32(uint32_t b) { return __builtin_bit_
 __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__restrict__ scal,
                                                          const uint32_t *__restrict__ probe_cluster,
                                                          const uint32_t *__restrict__ operand /* opdw dwords per pair */,
-                                                         const float *__restrict__ thr, uint32_t npairs,
-                                                         uint32_t nprobe, uint32_t opdw, uint32_t s_lo, uint32_t s_hi,
+                                                         const float *__restrict__ thr, uint32_t count,
+                                                         uint32_t nprobe, uint32_t slot_hi, uint32_t opdw, uint32_t s_lo,
+                                                         uint32_t s_hi,
                                                          uint32_t cluster_major,
                                                          const uint32_t *__restrict__ grp_start,
                                                          uint32_t *__restrict__ grp_cursor,
                                                          uint32_t *__restrict__ recs, const FactorStats fs,
                                                          uint32_t tile_images) {
     const uint32_t sub = threadIdx.x & 15;                       // 16 lanes per pair
-    const uint32_t p = blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (p >= npairs) return;
+    const uint32_t wi = blockIdx.x * 16 + (threadIdx.x >> 4);  // work item: (query, slot < slot_hi)
+    if (wi >= count) return;
+    const uint32_t wb = wi / slot_hi, p = wb * nprobe + (wi - wb * slot_hi);
     const PairScalars ps = scal[p];
     const bool in = pair_in_stage(ps, s_lo, s_hi);
     if (cluster_major && !in) return;

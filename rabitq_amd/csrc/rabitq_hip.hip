@@ -199,6 +199,7 @@ struct Workspace {
 
 struct rq_index {
     uint32_t dim = 0, k = 0, W = 0, max_list_len = 0;
+    uint32_t min_list_len = 0;  // 0 if some list is empty (then no slot bound can be derived from stream positions)
     uint64_t n = 0;
     DevBuf<float> base, P, centroids, cent_t;
     DevBuf<uint32_t> offsets, map_ids;
@@ -545,10 +546,17 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         ScanArgs a{};
         ScanPtrs sp{};
         a.cluster_major = cluster_major ? 1u : 0u;
+        // slots a stage can touch: slot s starts at stream position >= s * (shortest list), so only the first few
+        // slots of every query need to be looked at in the early stages (not derivable when lists may be empty,
+        // e.g. a shard that does not own every probed list)
+        uint32_t slot_hi = nprobe;
+        if (cluster_major && idx->min_list_len > 0 && !ext_cluster && sg.s_hi != 0xFFFFFFFFu)
+            slot_hi = (uint32_t)std::min<uint64_t>(nprobe, (uint64_t)(sg.s_hi - 1) / idx->min_list_len + 1);
+        const uint32_t stage_pairs = nq * slot_hi;
         if (cluster_major) {
             HIPC(hipMemsetAsync(ws.grp_cnt.p, 0, (size_t)((k + 4) & ~3u) * 4, st));  // 16-byte multiple: one fill kernel
-            group_count_kernel<<<ceil_div(npairs, 256), 256, 0, st>>>(ws.scal.p, probe_cluster, npairs, sg.s_lo,
-                                                                      sg.s_hi, ws.grp_cnt.p);
+            group_count_kernel<<<ceil_div(stage_pairs, 256), 256, 0, st>>>(ws.scal.p, probe_cluster, stage_pairs, nprobe,
+                                                                           slot_hi, sg.s_lo, sg.s_hi, ws.grp_cnt.p);
             group_scan_kernel<<<1, 1024, 0, st>>>(ws.grp_cnt.p, k, ws.grp_start.p, use_mfma ? 1u : 0u);
             a.ngroups = k;
         } else {
@@ -557,8 +565,8 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         // pack the stage's work records (query operand + scalars + current threshold + local range)
         const uint32_t *operand = use_mfma ? ws.qf6.p
                                            : (scan_is_fused(W) ? ws.qnib.p : reinterpret_cast<const uint32_t *>(ws.planes.p));
-        stage_fill_kernel<<<ceil_div(npairs, 16), 256, 0, st>>>(ws.scal.p, probe_cluster, operand, ws.thr.p, npairs,
-                                                                nprobe, use_mfma ? 12 * W : 8 * W, sg.s_lo, sg.s_hi,
+        stage_fill_kernel<<<ceil_div(stage_pairs, 16), 256, 0, st>>>(ws.scal.p, probe_cluster, operand, ws.thr.p, stage_pairs,
+                                                                nprobe, slot_hi, use_mfma ? 12 * W : 8 * W, sg.s_lo, sg.s_hi,
                                                                 a.cluster_major, ws.grp_start.p, ws.grp_cnt.p, ws.recs.p,
                                                                 idx->fstats, use_mfma ? 1u : 0u);
         pf.end();
@@ -889,10 +897,14 @@ static rq_status finish_index(rq_index *idx) {
         transpose_kernel<<<dim3(ceil_div(idx->dim, 32), ceil_div(idx->k, 32)), dim3(32, 8)>>>(
             idx->centroids.p, idx->cent_t.p, idx->k, idx->dim);
     DevBuf<uint32_t> mx;
-    RQC(mx.alloc(1));
-    HIPC(hipMemset(mx.p, 0, 4));
+    RQC(mx.alloc(2));
+    const uint32_t mx_init[2] = {0u, 0xFFFFFFFFu};
+    HIPC(hipMemcpy(mx.p, mx_init, 8, hipMemcpyHostToDevice));
     if (idx->k) max_list_len_kernel<<<ceil_div(idx->k, 256), 256>>>(idx->offsets.p, idx->k, mx.p);
-    HIPC(hipMemcpy(&idx->max_list_len, mx.p, 4, hipMemcpyDeviceToHost));
+    uint32_t mx_out[2];
+    HIPC(hipMemcpy(mx_out, mx.p, 8, hipMemcpyDeviceToHost));
+    idx->max_list_len = mx_out[0];
+    idx->min_list_len = idx->k ? mx_out[1] : 0;
     {  // Factor bounds for the integer-threshold form of the gate
         DevBuf<uint32_t> st4;
         RQC(st4.alloc(4));
