@@ -455,6 +455,94 @@ __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ y,
     }
 }
 
+// The same quantisation for dim = 4 * LP <= 256 with LP lanes per pair (several pairs per wave): every lane
+// owns 4 consecutive dimensions (one 16-byte load of y and of the centroid), the reductions take log2(LP)
+// shuffle steps, and the operand images come out of one neighbour exchange each: a lane's four 4-bit codes
+// are half a qnib dword, its four fp6 fields 24 bits of the 6-dword image of its 32-dimension block.
+// Writes the fused scan's operands only (no bit planes); arithmetic identical to prep_kernel.
+template <int LP>
+__global__ __launch_bounds__(256) void prep_small_kernel(const float *__restrict__ y,
+                                                         const float *__restrict__ centroids,
+                                                         const uint32_t *__restrict__ offsets,
+                                                         const uint32_t *__restrict__ pair_cluster,
+                                                         const float *__restrict__ pair_ycd, uint32_t npairs,
+                                                         uint32_t pairs_per_row, PairScalars *__restrict__ scal,
+                                                         uint32_t *__restrict__ qnib, uint32_t *__restrict__ qf6,
+                                                         uint32_t nlists, uint32_t skip_empty) {
+    constexpr uint32_t DIM = 4 * LP, W = DIM / 64, PPW = 64 / LP;
+    const uint32_t lane = threadIdx.x & 63, sub = lane % LP;
+    const uint32_t p = (blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW + lane / LP;
+    if (p >= npairs) return;  // uniform over the pair's LP lanes
+    const uint32_t row = p / pairs_per_row;
+    const uint32_t c = pair_cluster[p];
+    const uint32_t len_c = c < nlists ? offsets[c + 1] - offsets[c] : 0u;
+    if (len_c == 0 && skip_empty) {  // nothing to scan for this pair (e.g. a list another shard owns)
+        if (sub == 0) {
+            PairScalars s;
+            s.lower = 0.0f, s.delta = 0.0f, s.sumq = 0.0f, s.ycd = pair_ycd[p], s.ycd_sqrt = 0.0f;
+            s.row = row, s.list_begin = 0, s.list_len = 0, s.stream_begin = 0, s.pad = 0;
+            scal[p] = s;
+        }
+        return;
+    }
+    const float4 yv = *reinterpret_cast<const float4 *>(y + (uint64_t)row * DIM + 4 * sub);
+    const float4 cv = *reinterpret_cast<const float4 *>(centroids + (uint64_t)c * DIM + 4 * sub);
+    const float r[4] = {yv.x - cv.x, yv.y - cv.y, yv.z - cv.z, yv.w - cv.w};
+    float mn = r[0], mx = r[0];
+#pragma unroll
+    for (int e = 1; e < 4; ++e) {
+        mn = r[e] < mn ? r[e] : mn;
+        mx = r[e] > mx ? r[e] : mx;
+    }
+#pragma unroll
+    for (int o = LP / 2; o >= 1; o >>= 1) {
+        const float a = __shfl_xor(mn, o, LP), bb = __shfl_xor(mx, o, LP);
+        mn = a < mn ? a : mn;
+        mx = bb > mx ? bb : mx;
+    }
+    const float scalar = 1.0f / 15.0f;          // consts.rs:10
+    const float delta = (mx - mn) * scalar;     // rabitq.rs:307
+    const float one_over_delta = 1.0f / delta;  // :308 f32::recip
+    uint32_t sum = 0, nib16 = 0, f24 = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int32_t q = cvtps_epi32((r[e] - mn) * one_over_delta);
+        sum += (uint32_t)q;
+        const uint32_t v = (uint32_t)q & 15u;
+        nib16 |= v << (4 * e);
+        f24 |= (v < 4 ? 4 * v : (v < 8 ? 8 + 2 * v : 16 + v)) << (6 * e);  // q/2 as fp6 e2m3
+    }
+#pragma unroll
+    for (int o = LP / 2; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, LP);
+    {  // qnib: dword m <-> dims 8m..8m+7 = lanes 2m (low half), 2m+1 (high half)
+        const uint32_t other = __shfl_xor(nib16, 1, LP);
+        if (qnib && (sub & 1) == 0) qnib[(uint64_t)p * 8 * W + (sub >> 1)] = nib16 | (other << 16);
+    }
+    {  // qf6: lane t = sub % 8 of a 32-dimension block holds stream bits [24t, 24t+24) of its 6 dwords
+        const uint32_t nxt = __shfl_down(f24, 1, LP);
+        const uint32_t t = sub & 7, sh = 8 * (t & 3);
+        if (qf6 && (t & 3) != 3) {
+            const uint32_t w = sub >> 4, h = (sub >> 3) & 1;
+            qf6[(uint64_t)p * 12 * W + h * 6 * W + 6 * w + 3 * (t >> 2) + (t & 3)] = (f24 >> sh) | (nxt << (24 - sh));
+        }
+    }
+    if (sub == 0) {
+        PairScalars s;
+        const float ycd = pair_ycd[p];
+        s.lower = mn;
+        s.delta = delta;
+        s.sumq = (float)sum;  // rabitq.rs:322 `scalar_sum as f32`
+        s.ycd = ycd;
+        s.ycd_sqrt = sqrtf(ycd);  // :346
+        s.row = row;
+        s.list_begin = offsets[c];
+        s.list_len = offsets[c + 1] - offsets[c];
+        s.stream_begin = 0;  // filled by pair_prefix_kernel
+        s.pad = 0;
+        scal[p] = s;
+    }
+}
+
 // Position of every probed list in the query's candidate stream (the order the reference visits
 // candidates: lists nearest-first, members in stored order) and the stream length, which is also
 // what the reference adds to METRICS.rough for this query (src/rerank.rs:105).

@@ -489,12 +489,24 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     const int impl = g_scan_impl.load();  // one consistent choice for the whole pass
     // 3. per-pair query quantisation (:304-317)
     pf.begin(PF_PREP);
-    prep_kernel<<<ceil_div(npairs, 4), 256, 0, st>>>(ws.y.p, idx->centroids.p, idx->offsets.p, probe_cluster, probe_dist,
-                                                     npairs, nprobe, dim, ws.scal.p,
-                                                     scan_is_fused(W) ? nullptr : ws.planes.p,   // only the generic-W scan reads bit planes
-                                                     scan_is_fused(W) ? ws.qnib.p : nullptr,
-                                                     scan_has_mfma(W) && impl != 1 ? ws.qf6.p : nullptr,
-                                                     nullptr, k, 1u);
+    {
+        uint32_t *qn = scan_is_fused(W) ? ws.qnib.p : nullptr;
+        uint32_t *q6 = scan_has_mfma(W) && impl != 1 ? ws.qf6.p : nullptr;
+        if (dim == 128)  // 32 lanes per pair, two pairs per wave
+            prep_small_kernel<32><<<ceil_div(npairs, 8), 256, 0, st>>>(ws.y.p, idx->centroids.p, idx->offsets.p, probe_cluster,
+                                                                       probe_dist, npairs, nprobe, ws.scal.p, qn, q6, k, 1u);
+        else if (dim == 64)
+            prep_small_kernel<16><<<ceil_div(npairs, 16), 256, 0, st>>>(ws.y.p, idx->centroids.p, idx->offsets.p, probe_cluster,
+                                                                        probe_dist, npairs, nprobe, ws.scal.p, qn, q6, k, 1u);
+        else if (dim == 256)
+            prep_small_kernel<64><<<ceil_div(npairs, 4), 256, 0, st>>>(ws.y.p, idx->centroids.p, idx->offsets.p, probe_cluster,
+                                                                       probe_dist, npairs, nprobe, ws.scal.p, qn, q6, k, 1u);
+        else
+            prep_kernel<<<ceil_div(npairs, 4), 256, 0, st>>>(ws.y.p, idx->centroids.p, idx->offsets.p, probe_cluster, probe_dist,
+                                                             npairs, nprobe, dim, ws.scal.p,
+                                                             scan_is_fused(W) ? nullptr : ws.planes.p,   // only the generic-W scan reads bit planes
+                                                             qn, q6, nullptr, k, 1u);
+    }
     pair_prefix_kernel<<<ceil_div(nq, 4), 256, 0, st>>>(ws.scal.p, nq, nprobe, ws.rough_cnt.p);
     ReplayState rs;
     rs.thr = ws.thr.p, rs.heap_len = ws.heap_len.p, rs.heap_key = ws.heap_key.p, rs.heap_id = ws.heap_id.p;
