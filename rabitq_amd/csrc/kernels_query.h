@@ -1035,7 +1035,7 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) {
 // blocks per CU the register budget is cut for: the resident operands grow with W (6*W*NT dwords for the
 // candidates, 6*W for the query tile), so wide vectors run one block per CU with the full 512-register file
 template <int W>
-constexpr int scan_mfma_blocks_per_cu() { return W <= 2 ? 3 : (W <= 4 ? 2 : 1); }
+constexpr int scan_mfma_blocks_per_cu() { return W <= 2 ? 4 : (W <= 4 ? 2 : 1); }
 
 template <int W, int NT>
 __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_kernel(const uint32_t *__restrict__ codes,
@@ -1059,7 +1059,7 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
     extern __shared__ __attribute__((aligned(16))) uint32_t ring[];  // 3 x IMG dwords: query tiles in flight (LDS-DMA targets)
     __shared__ __attribute__((aligned(16))) float4 facL[TILE];      // the tile's factors, for the exact path
     // per-wave emit queue: survivors are parked here and written out in bulk (one atomic round trip per flush)
-    constexpr uint32_t QE = 256, QR = 64;
+    constexpr uint32_t QE = 128, QR = 32;
     __shared__ uint32_t q_pos[4][QE];
     __shared__ float q_rough[4][QE];
     __shared__ uint32_t q_run[4][QE];
