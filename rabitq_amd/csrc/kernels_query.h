@@ -1483,7 +1483,7 @@ struct ReplayState {
 // One wave replays a query's survivors (run directory `dir`, records `recs`) through the ranker.
 template <bool HEURISTIC>
 __device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, const RunRec *__restrict__ dir,
-                                            uint32_t nruns, const uint32_t *__restrict__ map_ids, uint32_t topk,
+                                            uint32_t nruns, uint32_t topk,
                                             uint32_t b, const ReplayState &st, int32_t *hkey, uint32_t *hid) {
     const uint32_t lane = threadIdx.x & 63;
     float thr = st.thr[b];
@@ -1679,8 +1679,7 @@ template <bool HEURISTIC>
 __global__ __launch_bounds__(256) void stage_finish_kernel(SurvRec *__restrict__ surv, RunRec *__restrict__ runs,
                                                            unsigned long long *__restrict__ surv_cnt, uint32_t cap,
                                                            const float *__restrict__ base,
-                                                           const float *__restrict__ qpad, uint32_t dim,
-                                                           const uint32_t *__restrict__ map_ids, uint32_t topk,
+                                                           const float *__restrict__ qpad, uint32_t dim, uint32_t topk,
                                                            ReplayState st) {
     __shared__ int32_t hkey[HEURISTIC ? 1 : RQ_MAX_TOPK];
     __shared__ uint32_t hid[HEURISTIC ? 1 : RQ_MAX_TOPK];
@@ -1708,7 +1707,7 @@ __global__ __launch_bounds__(256) void stage_finish_kernel(SurvRec *__restrict__
     sort_segment(runs + (uint64_t)b * cap, nruns);  // (B)
     __syncthreads();                                  // (A)'s stores and (B)'s order visible to wave 0
     if (threadIdx.x < 64)                             // (C)
-        replay_wave<HEURISTIC>(recs, runs + (uint64_t)b * cap, nruns, map_ids, topk, b, st, hkey, hid);
+        replay_wave<HEURISTIC>(recs, runs + (uint64_t)b * cap, nruns, topk, b, st, hkey, hid);
 }
 
 // ---- the same three phases as separate launches: better for large batches, where all queries'
@@ -1743,8 +1742,7 @@ __global__ __launch_bounds__(64) void sort_runs_kernel(RunRec *__restrict__ runs
 
 template <bool HEURISTIC>
 __global__ __launch_bounds__(64) void replay_kernel(const SurvRec *__restrict__ surv, const RunRec *__restrict__ runs,
-                                                    unsigned long long *__restrict__ surv_cnt, uint32_t cap,
-                                                    const uint32_t *__restrict__ map_ids, uint32_t topk,
+                                                    unsigned long long *__restrict__ surv_cnt, uint32_t cap, uint32_t topk,
                                                     ReplayState st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char replay_smem[];  // topk * 8 bytes (heap ranker)
     int32_t *hkey = reinterpret_cast<int32_t *>(replay_smem);
@@ -1761,7 +1759,7 @@ __global__ __launch_bounds__(64) void replay_kernel(const SurvRec *__restrict__ 
         surv_cnt[b] = 0;  // ready for the next stage
     }
     if (n == 0) return;
-    replay_wave<HEURISTIC>(surv + (uint64_t)b * cap, runs + (uint64_t)b * cap, nruns, map_ids, topk, b, st, hkey, hid);
+    replay_wave<HEURISTIC>(surv + (uint64_t)b * cap, runs + (uint64_t)b * cap, nruns, topk, b, st, hkey, hid);
 }
 
 // ranker state of a fresh query (src/rerank.rs:70-77, :129-139) + per-query counters, one launch

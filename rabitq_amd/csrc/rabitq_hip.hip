@@ -607,10 +607,10 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             pf.begin(PF_RERANK);
             if (qp.heuristic)
                 stage_finish_kernel<true><<<nq, 256, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->base.p,
-                                                              qpad, dim, idx->map_ids.p, topk, rs);
+                                                              qpad, dim, topk, rs);
             else
                 stage_finish_kernel<false><<<nq, 256, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->base.p,
-                                                               qpad, dim, idx->map_ids.p, topk, rs);
+                                                               qpad, dim, topk, rs);
             pf.end();
         } else {  // large batch: full-chip rerank, then run-directory sort, then one replay wave per query
             pf.begin(PF_RERANK);
@@ -622,9 +622,9 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             pf.end();
             pf.begin(PF_REPLAY);
             if (qp.heuristic)
-                replay_kernel<true><<<nq, 64, 16, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->map_ids.p, topk, rs);
+                replay_kernel<true><<<nq, 64, 16, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, topk, rs);
             else
-                replay_kernel<false><<<nq, 64, (size_t)topk * 8, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->map_ids.p, topk, rs);
+                replay_kernel<false><<<nq, 64, (size_t)topk * 8, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, topk, rs);
             pf.end();
         }
     }
