@@ -333,7 +333,8 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64 popcount + f32", "data": "synthetic",
             "config": {"workload": f"{n // 1_000_000}Mx{d} synthetic mixture per GPU, {k_local} lists per GPU, "
-                                   f"nprobe={nprobe}, topk={topk}, batch={B} (BASELINE.json configs[2])",
+                                   f"nprobe={nprobe}, topk={topk}, batch={B}" +
+                                   (" (BASELINE.json configs[2])" if (n, d, k_local, nprobe) == (100_000_000, 128, 4096, 64) else ""),
                        "batches_in_flight": depth,
                        "n_per_gpu": n, "dim": d, "lists_total": k, "nprobe": nprobe, "topk": topk, "batch": B,
                        "sigma": args.sigma, "centre_scale": args.centre_scale, "sharding": f"vectors x{world}"},
