@@ -1676,7 +1676,7 @@ __device__ __forceinline__ void accurate_rows(SurvRec *__restrict__ recs, uint32
 // (src/rerank.rs:85-90, 8 lanes = the 8 AVX lanes of src/simd.rs:14-73), (B) sort of the run
 // directory into the reference's visiting order, (C) wave 0 replays the ranker.
 template <bool HEURISTIC>
-__global__ __launch_bounds__(256) void stage_finish_kernel(SurvRec *__restrict__ surv, RunRec *__restrict__ runs,
+__global__ __launch_bounds__(1024) void stage_finish_kernel(SurvRec *__restrict__ surv, RunRec *__restrict__ runs,
                                                            unsigned long long *__restrict__ surv_cnt, uint32_t cap,
                                                            const float *__restrict__ base,
                                                            const float *__restrict__ qpad, uint32_t dim, uint32_t topk,
@@ -1699,10 +1699,10 @@ __global__ __launch_bounds__(256) void stage_finish_kernel(SurvRec *__restrict__
     if (n == 0) return;
     SurvRec *recs = surv + (uint64_t)b * cap;
     {  // (A)
-        for (uint32_t c = threadIdx.x * 4; c < dim; c += 1024)
+        for (uint32_t c = threadIdx.x * 4; c < dim; c += blockDim.x * 4)
             *reinterpret_cast<float4 *>(fin_q + c) = *reinterpret_cast<const float4 *>(qpad + (uint64_t)b * dim + c);
         __syncthreads();
-        accurate_rows(recs, n, base, fin_q, dim, threadIdx.x >> 1, 128);
+        accurate_rows(recs, n, base, fin_q, dim, threadIdx.x >> 1, blockDim.x >> 1);  // 256 or 1024 threads per query
     }
     sort_segment(runs + (uint64_t)b * cap, nruns);  // (B)
     __syncthreads();                                  // (A)'s stores and (B)'s order visible to wave 0

@@ -605,11 +605,12 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         }
         if (nq < 256) {  // small batch: one fused launch per stage (launch-bound regime)
             pf.begin(PF_RERANK);
+            const uint32_t fin_threads = nq <= 16 ? 1024u : 256u;  // a handful of queries: more lanes on each one's rerank
             if (qp.heuristic)
-                stage_finish_kernel<true><<<nq, 256, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->base.p,
+                stage_finish_kernel<true><<<nq, fin_threads, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->base.p,
                                                               qpad, dim, topk, rs);
             else
-                stage_finish_kernel<false><<<nq, 256, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->base.p,
+                stage_finish_kernel<false><<<nq, fin_threads, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->base.p,
                                                                qpad, dim, topk, rs);
             pf.end();
         } else {  // large batch: full-chip rerank, then run-directory sort, then one replay wave per query
