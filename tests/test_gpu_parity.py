@@ -671,3 +671,23 @@ def test_begin_end_overflow_retry_matches_sync(rq):
     assert np.array_equal(res[0][2], res[1][2]) and (res[0][2] == 2000).all()
     assert np.array_equal(res[0][1], res[1][1])
     assert np.array_equal(res[0][0], res[1][0])
+
+
+@pytest.mark.parametrize("k", [2000, 5000])
+def test_many_lists_probe_selection_matches_oracle(rq, oracle, k):
+    # the register-resident probe selection is instantiated per list-count bracket (<= 1024, <= 4096, <= 8192):
+    # exercise the two larger ones (and many tiny / empty lists) against the oracle
+    n, d, nq = 30000, 64, 24
+    x, _, _ = synth.mixture(n, d, 50, sigma=0.9, seed=k, centre_scale=0.8)
+    rng = np.random.default_rng(k)
+    centres = x[rng.choice(n, k, replace=False)] + rng.standard_normal((k, d)).astype(np.float32) * 0.05
+    centres[7] = centres[3]                                   # duplicate centroids: ties in the coarse ranking
+    P = synth.random_orthogonal(d, seed=11)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    gidx = rq.RaBitQ.build(x, centres, P)
+    assert np.array_equal(gidx.offsets, oidx.offsets)
+    queries = (x[rng.choice(n, nq, replace=False)] + 0.05).astype(np.float32)
+    for probe, topk in ((64, 10), (33, 5), (1, 3)):
+        _compare_with_oracle(rq, oracle, oidx, gidx, queries, probe, topk, False)
+    gidx.close()
+    oidx.close()
