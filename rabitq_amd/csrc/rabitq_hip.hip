@@ -1396,20 +1396,34 @@ rq_status rq_coarse_topk_device(const rq_index *idx, const float *d_queries, uin
     if (probe > RQ_MAX_PROBE) return fail(RQ_ERR_UNSUPPORTED, "probe > 16384");
     if (nq == 0) return RQ_OK;
     const uint32_t dim = idx->dim, kc = list_hi - list_lo, np = std::min(probe, kc);
-    DevBuf<float> qpad, y, dist;
-    RQC(y.alloc((uint64_t)nq * dim));
-    RQC(dist.alloc((uint64_t)nq * kc));
+    // runs on a pooled workspace (its buffers and stream): this entry sits in the per-batch loop of sharded
+    // deployments, so nothing may be allocated or freed per call
+    rq_index *mi = const_cast<rq_index *>(idx);
+    Workspace *ws = ws_acquire(mi);
+    struct Rel {
+        rq_index *i;
+        Workspace *w;
+        ~Rel() { ws_release(i, w); }
+    } rel{mi, ws};
+    if (!ws->stream) HIPC(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
+    hipStream_t st = ws->stream;
+    RQC(ws->y.ensure((uint64_t)nq * dim));
+    RQC(ws->dist.ensure((uint64_t)nq * std::max(kc, idx->k)));
     const float *qp = d_queries;
     if (len != dim) {
-        RQC(qpad.alloc((uint64_t)nq * dim));
-        pad_rows_kernel<<<ceil_div((uint64_t)nq * dim, 256), 256>>>(d_queries, qpad.p, nq, len, dim);
-        qp = qpad.p;
+        RQC(ws->qpad.ensure((uint64_t)nq * dim));
+        pad_rows_kernel<<<ceil_div((uint64_t)nq * dim, 256), 256, 0, st>>>(d_queries, ws->qpad.p, nq, len, dim);
+        qp = ws->qpad.p;
     }
-    launch_rotate(qp, idx->P.p, y.p, nq, dim, nq >= 32, nullptr);
-    coarse_dist_kernel<4><<<dim3(ceil_div(nq, 4), ceil_div(kc, 256)), 256, 4 * dim * sizeof(float)>>>(
-        idx->cent_t.p + list_lo, y.p, dist.p, kc, dim, nq, idx->k);
-    launch_select(dist.p, kc, np, d_out_cluster, d_out_dist, list_lo, probe, nq, nullptr);
-    HIPC(hipDeviceSynchronize());
+    launch_rotate(qp, idx->P.p, ws->y.p, nq, dim, nq >= 32, st);
+    if (nq >= 64 && dim <= 2048)
+        coarse_dist_kernel<8><<<dim3(ceil_div(nq, 8), ceil_div(kc, 256)), 256, 8 * dim * sizeof(float), st>>>(
+            idx->cent_t.p + list_lo, ws->y.p, ws->dist.p, kc, dim, nq, idx->k);
+    else
+        coarse_dist_kernel<4><<<dim3(ceil_div(nq, 4), ceil_div(kc, 256)), 256, 4 * dim * sizeof(float), st>>>(
+            idx->cent_t.p + list_lo, ws->y.p, ws->dist.p, kc, dim, nq, idx->k);
+    launch_select(ws->dist.p, kc, np, d_out_cluster, d_out_dist, list_lo, probe, nq, st);
+    HIPC(hipStreamSynchronize(st));
     HIPC(hipGetLastError());
     return RQ_OK;
 }
