@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--small-batch", type=int, default=64, help="queries of the HBM-regime scan measurement")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo = single-GPU rehearsal)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--sharded-path", action="store_true",
+                    help="rehearsal on one GPU: run the multi-GPU step (sharded coarse ranking, probe-list merge, probed "
+                         "query, top-k merge) with a world of 1, to see what the extra plumbing costs")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="batches kept in flight in the timed loop (rq_query_batch_device_begin/_end); 1 = one blocking "
                          "call per step (default: per-kernel times are then clean); the 2-in-flight rate is always "
@@ -147,7 +150,8 @@ def main():
     torch.cuda.empty_cache()
     log(f"index built in {build_s:.1f}s: n={idx.n} dim={idx.dim} k={idx.k} max_list_len={idx.max_list_len}")
 
-    depth = max(1, args.pipeline) if world == 1 else 1
+    sharded = world > 1 or args.sharded_path
+    depth = max(1, args.pipeline) if not sharded else 1
     outs = [(torch.empty((B, topk), device=dev, dtype=torch.float32), torch.zeros((B, topk), device=dev, dtype=torch.int32),
              torch.zeros((B,), device=dev, dtype=torch.int32)) for _ in range(max(depth, 2))]
     out_d, out_i, out_n = outs[0]
@@ -156,19 +160,22 @@ def main():
     pd_local = torch.zeros((B, nprobe), device=dev, dtype=torch.float32)
 
     def step():
-        if world > 1:
+        if sharded:
             # each rank ranks only the lists it owns; one all-gather merges the per-rank nearest lists
             idx.coarse_topk_device(queries.data_ptr(), B, d, rank * k_local, (rank + 1) * k_local, nprobe,
                                    pc_local.data_ptr(), pd_local.data_ptr())
             pcl, pdl = (pc_local.cpu(), pd_local.cpu()) if args.backend == "gloo" else (pc_local, pd_local)
             pc, pdist = sharding.merge_probe_lists(pcl, pdl, nprobe)
             pc, pdist = pc.to(dev), pdist.to(dev)
+            # the engine runs on its own (non-blocking) HIP streams: torch's merge kernels must have finished
+            # before it reads their output
+            torch.cuda.current_stream().synchronize()
             idx.query_batch_device_probed(queries.data_ptr(), B, d, pc.data_ptr(), pdist.data_ptr(), nprobe, topk,
                                           out_d.data_ptr(), out_i.data_ptr(), out_n.data_ptr())
         else:
             idx.query_batch_device(queries.data_ptr(), B, d, nprobe, topk, out_d.data_ptr(), out_i.data_ptr(),
                                    out_n.data_ptr())
-        if world > 1:
+        if sharded:
             pay = sharding.pack_topk(out_d, out_i.to(torch.int64) & 0xFFFFFFFF, out_n, rank * n)
             if args.backend == "gloo":
                 pay = pay.cpu()
@@ -219,7 +226,7 @@ def main():
     elapsed = time.perf_counter() - t1
     # the same loop with two batches in flight: one batch's HBM-bound stages overlap the other's compute-bound scan
     overlap = None
-    if world == 1:
+    if not sharded:
         run_steps(2, False, 2)
         fence()
         t2 = time.perf_counter()

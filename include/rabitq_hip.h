@@ -124,7 +124,9 @@ rq_status rq_query(const rq_index *idx, const float *query, uint32_t len, uint32
 rq_status rq_query_batch(const rq_index *idx, const float *queries, uint32_t nq, uint32_t len,
                          uint32_t probe, uint32_t topk, int heuristic_rank, float *out_dist,
                          uint32_t *out_id, uint32_t *out_n);
-/* Same with queries and outputs in device memory. */
+/* Same with queries and outputs in device memory.  Every entry point that takes device pointers runs on
+ * HIP streams of its own (non-blocking with respect to the caller's streams) and returns with its outputs
+ * complete: inputs produced on another stream must be complete before the call (synchronise that stream). */
 rq_status rq_query_batch_device(const rq_index *idx, const float *d_queries, uint32_t nq,
                                 uint32_t len, uint32_t probe, uint32_t topk, int heuristic_rank,
                                 float *d_out_dist, uint32_t *d_out_id, uint32_t *d_out_n);

@@ -56,7 +56,9 @@ def merge_probe_lists(cluster: torch.Tensor, dist_t: torch.Tensor, nprobe: int, 
     passes its (nq, nprobe) nearest OWN lists (global ids as int32/uint32 bits, f32 distances, padded
     with id 0xFFFFFFFF / +inf); one all-gather, then the nprobe nearest overall per query, ascending
     by (distance, list id) -- the same order a single index would visit them in.
-    Returns (cluster int32 (nq, nprobe) with the u32 bit patterns, dist f32 (nq, nprobe))."""
+    Returns (cluster int32 (nq, nprobe) with the u32 bit patterns, dist f32 (nq, nprobe)).
+    The result is produced on torch's current stream: synchronise it before handing the tensors to the
+    engine (`rq_query_batch_device_probed` runs on its own streams)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     bits = dist_t.contiguous().view(torch.int32).to(torch.int64)          # distances are >= 0: bits order like values
     ids = cluster.to(torch.int64) & 0xFFFFFFFF
