@@ -1035,7 +1035,12 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) {
 // blocks per CU the register budget is cut for: the resident operands grow with W (6*W*NT dwords for the
 // candidates, 6*W for the query tile), so wide vectors run one block per CU with the full 512-register file
 template <int W>
-constexpr int scan_mfma_blocks_per_cu() { return W <= 2 ? 4 : (W <= 4 ? 2 : 1); }
+constexpr int scan_mfma_blocks_per_cu() { return W <= 2 ? 4 : (W <= 12 ? 2 : 1); }
+// Wide vectors (dim >= 384) do not keep the query tile's operand in registers: the candidates' expanded codes
+// (6*W*NT dwords) already fill most of the file, so the query fragments are streamed from the LDS image one
+// 64-dimension slab at a time (3 ds_read_b64 per slab, each feeding the MFMAs of all NT sub-tiles).
+template <int W>
+constexpr bool scan_mfma_stream_a() { return W > 4; }
 
 template <int W, int NT>
 __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_kernel(const uint32_t *__restrict__ codes,
@@ -1209,14 +1214,38 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
 
         // A: query row j (= lane & 31), dims 64m + 32h .. +31 as fp6.  Rows >= nvalid hold stale bytes: harmless,
         // every fp6 pattern is a finite number and such a row's accumulator starts at -inf (below)
-        uint32_t aop[W][6];
-#pragma unroll
-        for (int m = 0; m < W; ++m)
+        constexpr bool STREAM_A = scan_mfma_stream_a<W>();
+        uint32_t aop[STREAM_A ? 1 : W][6];
+        auto load_a = [&](int m) {  // the 6 dwords of slab m of this lane's query row
+            v8i32 av = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int e = 0; e < 6; e += 2) {
                 const uint2 v = *reinterpret_cast<const uint2 *>(&img[j * OPLD + 6 * W * h + 6 * m + e]);
-                aop[m][e] = v.x, aop[m][e + 1] = v.y;
+                av[e] = (int)v.x, av[e + 1] = (int)v.y;
             }
+            return av;
+        };
+        if constexpr (!STREAM_A) {
+#pragma unroll
+            for (int m = 0; m < W; ++m) {
+                const v8i32 av = load_a(m);
+#pragma unroll
+                for (int e = 0; e < 6; ++e) aop[m][e] = (uint32_t)av[e];
+            }
+        }
+        auto get_a = [&](int m) {
+            if constexpr (STREAM_A) {
+                return load_a(m);
+            } else {
+                const v8i32 av = {(int)aop[m][0], (int)aop[m][1], (int)aop[m][2], (int)aop[m][3], (int)aop[m][4], (int)aop[m][5], 0, 0};
+                return av;
+            }
+        };
+        auto get_b = [&](int t, int m) {
+            const v8i32 bv = {(int)bexp[t][m][0], (int)bexp[t][m][1], (int)bexp[t][m][2], (int)bexp[t][m][3],
+                              (int)bexp[t][m][4], (int)bexp[t][m][5], 0, 0};
+            return bv;
+        };
         // A operand of the threshold MFMA: slots 8h .. 8h+7 of query row j
         v4i32 ua = *reinterpret_cast<const v4i32 *>(&img[IMG_OP + j * RQ_REC_TAIL + RQ_REC_V0 + 4 * h]);
         if (nvalid < 32) {  // wave-uniform, last tile of a list only
@@ -1226,18 +1255,35 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
         }
         auto tail = [&](uint32_t f, uint32_t row) { return img[IMG_OP + row * RQ_REC_TAIL + f]; };
 
+        // accumulator tiles = -S*/2 (query row, candidate col) + s/2, all on the matrix pipe
+        f32x16 accs[STREAM_A ? NT : 1];
+        if constexpr (STREAM_A) {  // slab-outer: one fragment load feeds every sub-tile's accumulator
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            // accumulator tile = -S*/2 (query row, candidate col) + s/2, all on the matrix pipe
-            const v4i32 ubv = {(int)ub[t][0], (int)ub[t][1], (int)ub[t][2], (int)ub[t][3]};
-            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ua), __builtin_bit_cast(bf16x8, ubv), acc, 0, 0, 0);
+            for (int t = 0; t < NT; ++t) {
+                const v4i32 ubv = {(int)ub[t][0], (int)ub[t][1], (int)ub[t][2], (int)ub[t][3]};
+                const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ua), __builtin_bit_cast(bf16x8, ubv), z, 0, 0, 0);
+            }
 #pragma unroll
             for (int m = 0; m < W; ++m) {
-                const v8i32 av = {(int)aop[m][0], (int)aop[m][1], (int)aop[m][2], (int)aop[m][3], (int)aop[m][4], (int)aop[m][5], 0, 0};
-                const v8i32 bv = {(int)bexp[t][m][0], (int)bexp[t][m][1], (int)bexp[t][m][2], (int)bexp[t][m][3],
-                                  (int)bexp[t][m][4], (int)bexp[t][m][5], 0, 0};
-                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 2 /*A e2m3*/, 2 /*B e2m3*/, 0, 0, 0, 0);
+                const v8i32 av = load_a(m);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    accs[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, get_b(t, m), accs[t], 2, 2, 0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x16 acc;
+            if constexpr (STREAM_A) {
+                acc = accs[t];
+            } else {
+                const v4i32 ubv = {(int)ub[t][0], (int)ub[t][1], (int)ub[t][2], (int)ub[t][3]};
+                const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ua), __builtin_bit_cast(bf16x8, ubv), z, 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < W; ++m)
+                    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(get_a(m), get_b(t, m), acc, 2 /*A e2m3*/, 2 /*B e2m3*/, 0, 0, 0, 0);
             }
             // hot path: is any of the 1024 (query, candidate) cells positive?  A float is positive iff its bit
             // pattern is a positive int32 (a NaN with a clear sign bit counts as positive: conservative), so the
@@ -1255,12 +1301,8 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
                 for (int gq = 0; gq < 16; ++gq) gmask |= (__ballot(acc[gq] > 0.0f) != 0ull ? 1u : 0u) << gq;
                 // the flagged cells need s itself: the same products again on a clean accumulator (exact)
 #pragma unroll
-                for (int m = 0; m < W; ++m) {
-                    const v8i32 av = {(int)aop[m][0], (int)aop[m][1], (int)aop[m][2], (int)aop[m][3], (int)aop[m][4], (int)aop[m][5], 0, 0};
-                    const v8i32 bv = {(int)bexp[t][m][0], (int)bexp[t][m][1], (int)bexp[t][m][2], (int)bexp[t][m][3],
-                                      (int)bexp[t][m][4], (int)bexp[t][m][5], 0, 0};
-                    sc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, sc, 2, 2, 0, 0, 0, 0);
-                }
+                for (int m = 0; m < W; ++m)
+                    sc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(get_a(m), get_b(t, m), sc, 2, 2, 0, 0, 0, 0);
                 if (a.dbg & 1u) gmask = 0;
                 // exact evaluation + emit, for the flagged registers only
                 const float4 fc = facL[lpos[t] - first];

@@ -290,7 +290,7 @@ static bool scan_has_mfma(uint32_t W) {
         default: return false;
     }
 }
-static uint32_t scan_mfma_nt(uint32_t W) { return W == 2 ? 3 : (W == 4 || W == 16 ? 2 : 4); }
+static uint32_t scan_mfma_nt(uint32_t W) { return W == 2 ? 3 : (W >= 4 ? 2 : 4); }
 static uint32_t scan_mfma_tile(uint32_t W) { return 128 * scan_mfma_nt(W); }
 static size_t scan_mfma_ring_bytes(uint32_t W) { return 3ull * (32 * (12 * W + 2) + RQ_REC_TAIL * 32) * 4; }
 template <int W, int NT>
@@ -316,9 +316,9 @@ static void launch_scan_mfma(const ScanPtrs &p, const ScanArgs &a, uint32_t W, h
         case 2: launch_scan_mfma_t<2, 3>(p, a, g, st); break;
         case 3: launch_scan_mfma_t<3, 4>(p, a, g, st); break;
         case 4: launch_scan_mfma_t<4, 2>(p, a, g, st); break;
-        case 6: launch_scan_mfma_t<6, 4>(p, a, g, st); break;
-        case 8: launch_scan_mfma_t<8, 4>(p, a, g, st); break;
-        case 12: launch_scan_mfma_t<12, 4>(p, a, g, st); break;
+        case 6: launch_scan_mfma_t<6, 2>(p, a, g, st); break;
+        case 8: launch_scan_mfma_t<8, 2>(p, a, g, st); break;
+        case 12: launch_scan_mfma_t<12, 2>(p, a, g, st); break;
         case 16: launch_scan_mfma_t<16, 2>(p, a, g, st); break;
         default: abort();
     }
