@@ -455,12 +455,13 @@ __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ y,
     }
 }
 
-// The same quantisation for dim = 4 * LP <= 256 with LP lanes per pair (several pairs per wave): every lane
+// The same quantisation for dim in {64, 128, 256, 512, 768, 1024} with LP lanes per pair (several pairs per wave
+// up to dim 128, R rounds of 256 dimensions from dim 512): every lane
 // owns 4 consecutive dimensions (one 16-byte load of y and of the centroid), the reductions take log2(LP)
 // shuffle steps, and the operand images come out of one neighbour exchange each: a lane's four 4-bit codes
 // are half a qnib dword, its four fp6 fields 24 bits of the 6-dword image of its 32-dimension block.
 // Writes the fused scan's operands only (no bit planes); arithmetic identical to prep_kernel.
-template <int LP>
+template <int LP, int R>
 __global__ __launch_bounds__(256) void prep_small_kernel(const float *__restrict__ y,
                                                          const float *__restrict__ centroids,
                                                          const uint32_t *__restrict__ offsets,
@@ -469,7 +470,10 @@ __global__ __launch_bounds__(256) void prep_small_kernel(const float *__restrict
                                                          uint32_t pairs_per_row, PairScalars *__restrict__ scal,
                                                          uint32_t *__restrict__ qnib, uint32_t *__restrict__ qf6,
                                                          uint32_t nlists, uint32_t skip_empty) {
-    constexpr uint32_t DIM = 4 * LP, W = DIM / 64, PPW = 64 / LP;
+    // dim = 4 * LP * R: LP lanes per pair, each owning 4 consecutive dimensions in each of R rounds of 4*LP
+    // dimensions (R > 1 only with LP = 64: dim 512, 768, 1024)
+    static_assert(R == 1 || LP == 64, "several rounds only with a full wave per pair");
+    constexpr uint32_t DIM = 4 * LP * R, W = DIM / 64, PPW = 64 / LP;
     const uint32_t lane = threadIdx.x & 63, sub = lane % LP;
     const uint32_t p = (blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW + lane / LP;
     if (p >= npairs) return;  // uniform over the pair's LP lanes
@@ -485,14 +489,18 @@ __global__ __launch_bounds__(256) void prep_small_kernel(const float *__restrict
         }
         return;
     }
-    const float4 yv = *reinterpret_cast<const float4 *>(y + (uint64_t)row * DIM + 4 * sub);
-    const float4 cv = *reinterpret_cast<const float4 *>(centroids + (uint64_t)c * DIM + 4 * sub);
-    const float r[4] = {yv.x - cv.x, yv.y - cv.y, yv.z - cv.z, yv.w - cv.w};
-    float mn = r[0], mx = r[0];
+    float r[R][4];
+    float mn = 3.402823466e+38f, mx = -3.402823466e+38f;
 #pragma unroll
-    for (int e = 1; e < 4; ++e) {
-        mn = r[e] < mn ? r[e] : mn;
-        mx = r[e] > mx ? r[e] : mx;
+    for (int rd = 0; rd < R; ++rd) {
+        const float4 yv = *reinterpret_cast<const float4 *>(y + (uint64_t)row * DIM + 4 * LP * rd + 4 * sub);
+        const float4 cv = *reinterpret_cast<const float4 *>(centroids + (uint64_t)c * DIM + 4 * LP * rd + 4 * sub);
+        r[rd][0] = yv.x - cv.x, r[rd][1] = yv.y - cv.y, r[rd][2] = yv.z - cv.z, r[rd][3] = yv.w - cv.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mn = r[rd][e] < mn ? r[rd][e] : mn;
+            mx = r[rd][e] > mx ? r[rd][e] : mx;
+        }
     }
 #pragma unroll
     for (int o = LP / 2; o >= 1; o >>= 1) {
@@ -503,29 +511,34 @@ __global__ __launch_bounds__(256) void prep_small_kernel(const float *__restrict
     const float scalar = 1.0f / 15.0f;          // consts.rs:10
     const float delta = (mx - mn) * scalar;     // rabitq.rs:307
     const float one_over_delta = 1.0f / delta;  // :308 f32::recip
-    uint32_t sum = 0, nib16 = 0, f24 = 0;
+    uint32_t sum = 0;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int32_t q = cvtps_epi32((r[e] - mn) * one_over_delta);
-        sum += (uint32_t)q;
-        const uint32_t v = (uint32_t)q & 15u;
-        nib16 |= v << (4 * e);
-        f24 |= (v < 4 ? 4 * v : (v < 8 ? 8 + 2 * v : 16 + v)) << (6 * e);  // q/2 as fp6 e2m3
+    for (int rd = 0; rd < R; ++rd) {
+        uint32_t nib16 = 0, f24 = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int32_t q = cvtps_epi32((r[rd][e] - mn) * one_over_delta);
+            sum += (uint32_t)q;
+            const uint32_t v = (uint32_t)q & 15u;
+            nib16 |= v << (4 * e);
+            f24 |= (v < 4 ? 4 * v : (v < 8 ? 8 + 2 * v : 16 + v)) << (6 * e);  // q/2 as fp6 e2m3
+        }
+        const uint32_t dsub = LP * rd + sub;  // this lane's 4-dimension group among the dim/4 of the vector
+        {  // qnib: dword m <-> dims 8m..8m+7 = groups 2m (low half), 2m+1 (high half)
+            const uint32_t other = __shfl_xor(nib16, 1, LP);
+            if (qnib && (sub & 1) == 0) qnib[(uint64_t)p * 8 * W + (dsub >> 1)] = nib16 | (other << 16);
+        }
+        {  // qf6: group t = dsub % 8 of a 32-dimension block holds stream bits [24t, 24t+24) of its 6 dwords
+            const uint32_t nxt = __shfl_down(f24, 1, LP);
+            const uint32_t t = dsub & 7, sh = 8 * (t & 3);
+            if (qf6 && (t & 3) != 3) {
+                const uint32_t w = dsub >> 4, h = (dsub >> 3) & 1;
+                qf6[(uint64_t)p * 12 * W + h * 6 * W + 6 * w + 3 * (t >> 2) + (t & 3)] = (f24 >> sh) | (nxt << (24 - sh));
+            }
+        }
     }
 #pragma unroll
     for (int o = LP / 2; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, LP);
-    {  // qnib: dword m <-> dims 8m..8m+7 = lanes 2m (low half), 2m+1 (high half)
-        const uint32_t other = __shfl_xor(nib16, 1, LP);
-        if (qnib && (sub & 1) == 0) qnib[(uint64_t)p * 8 * W + (sub >> 1)] = nib16 | (other << 16);
-    }
-    {  // qf6: lane t = sub % 8 of a 32-dimension block holds stream bits [24t, 24t+24) of its 6 dwords
-        const uint32_t nxt = __shfl_down(f24, 1, LP);
-        const uint32_t t = sub & 7, sh = 8 * (t & 3);
-        if (qf6 && (t & 3) != 3) {
-            const uint32_t w = sub >> 4, h = (sub >> 3) & 1;
-            qf6[(uint64_t)p * 12 * W + h * 6 * W + 6 * w + 3 * (t >> 2) + (t & 3)] = (f24 >> sh) | (nxt << (24 - sh));
-        }
-    }
     if (sub == 0) {
         PairScalars s;
         const float ycd = pair_ycd[p];
