@@ -543,6 +543,9 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             if (last) break;
             lo = hi;
             hi = std::min<uint64_t>(hi * growth, 0xFFFFFFF0ull);
+            // the geometric step must not carry an early (VALU) stage over many lists when lists are short:
+            // past two lists' worth the rest belongs to the final stage
+            if (lo < 2 * avg && hi > 2 * avg) hi = 2 * avg;
         }
     }
     ws.pend_matrix_ranges.clear();
