@@ -360,7 +360,7 @@ struct QueryParams {
 };
 
 #define RQ_DEFAULT_CAP 4096u
-#define RQ_MAX_NQ_PER_PASS 16384u
+#define RQ_MAX_NQ_PER_PASS 65536u
 #define RQ_MAX_PROBE 16384u
 
 static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParams &qp) {
@@ -554,9 +554,10 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     for (const Stage &sg : stages) {
         const uint64_t span = (uint64_t)std::min<uint64_t>(sg.s_hi, (uint64_t)nprobe * idx->max_list_len) - sg.s_lo;
         const uint64_t est_pairs = (uint64_t)nq * std::min<uint64_t>(nprobe, span / avg_len + 2);
-        // matrix cores pay once many queries share each list AND survivors are rare (late stages): with ~7 pairs
-        // per list and hundreds of survivors per query the exact path dominates and the VALU kernel wins (measured)
-        const bool use_mfma = scan_has_mfma(W) && impl != 1 && (impl == 2 || est_pairs >= 8ull * k);
+        // matrix cores pay once many queries share each list AND survivors are rare, i.e. past the nearest list
+        // (stages inside it leave hundreds of survivors per query: the exact path dominates there and the VALU
+        // kernel wins, measured at any batch size)
+        const bool use_mfma = scan_has_mfma(W) && impl != 1 && (impl == 2 || (est_pairs >= 8ull * k && sg.s_lo >= avg_len));
         const bool cluster_major = use_mfma || (est_pairs >= k / 2 && est_pairs > 64);
         pf.begin(PF_GROUP);
         ScanArgs a{};
