@@ -54,10 +54,13 @@ def main():
     ap.add_argument("--sharded-path", action="store_true",
                     help="rehearsal on one GPU: run the multi-GPU step (sharded coarse ranking, probe-list merge, probed "
                          "query, top-k merge) with a world of 1, to see what the extra plumbing costs")
+    ap.add_argument("--two-in-flight", action="store_true",
+                    help="also measure the throughput with two batches in flight (rq_query_batch_device_begin/_end); off by "
+                         "default so that every launch of the default command runs alone and per-kernel times (HIP events, "
+                         "rocprofv3 --stats of the same command) stay comparable")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="batches kept in flight in the timed loop (rq_query_batch_device_begin/_end); 1 = one blocking "
-                         "call per step (default: per-kernel times are then clean); the 2-in-flight rate is always "
-                         "measured as well and reported as `two_batches_in_flight`")
+                         "call per step (default: per-kernel times are then clean); see --two-in-flight")
     args = ap.parse_args()
 
     import torch
@@ -228,7 +231,7 @@ def main():
     elapsed = time.perf_counter() - t1
     # the same loop with two batches in flight: one batch's HBM-bound stages overlap the other's compute-bound scan
     overlap = None
-    if not sharded:
+    if not sharded and args.two_in_flight:
         run_steps(2, False, 2)
         fence()
         t2 = time.perf_counter()

@@ -26,9 +26,11 @@ rows = list(csv.DictReader(open(stats)))
 shutil.copy(stats, os.path.join(OUT, f"{ROUND}_kernel_stats_full.csv"))
 ours = [r for r in rows if not any(t in r["Name"] for t in ("at::native", "Cijk_", "__amd_rocclr", "at::cuda", "rocprim", "hipcub"))]
 with open(os.path.join(OUT, f"{ROUND}_kernel_stats.csv"), "w") as f:
+    bcfg = json.load(open(newest("bench_final.json")))["config"]
     f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline\n")
-    f.write("# (100Mx128, 4096 lists, nprobe 64, batch 10000: 2 warm-up + 3 timed + 1 breakdown query batches, 12 small batches,\n")
-    f.write("#  68 single queries, one 100M build); engine kernels only, torch data-generation / ground-truth kernels are in the _full file\n")
+    f.write(f"# ({bcfg['workload']}: 2 warm-up + 3 timed + 1 breakdown query batches, every launch alone on the device,\n")
+    f.write("#  12 small batches, 68 single queries, one 100M build); engine kernels only, torch data-generation / ground-truth\n")
+    f.write("#  kernels are in the _full file\n")
     w = csv.writer(f)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs"])
     for r in ours:
@@ -80,5 +82,13 @@ traffic = {
     "launches_of_one_batch": launches,
 }
 json.dump(traffic, open(os.path.join(OUT, "scan_traffic.json"), "w"), indent=1)
-shutil.copy(newest("bench_final.json"), os.path.join(OUT, f"{ROUND}_bench_100M.json"))
+# the bench line read the previous scan_traffic.json (or none, if the workload changed): attach this pass's figures
+if bench.get("roofline", {}).get("bound") == "mfma":
+    bench["roofline"]["traffic"] = traffic["dominant_launch"]["hbm_read_bytes"]
+if "roofline_scan_all_launches" in bench:
+    bench["roofline_scan_all_launches"]["traffic"] = traffic["hbm_bytes_per_launch"]
+json.dump(bench, open(os.path.join(OUT, f"{ROUND}_bench_100M.json"), "w"))
+tif = glob.glob(os.path.join(ROOT, "gpurun_out", "bench_two_in_flight.json"))
+if tif:
+    shutil.copy(tif[0], os.path.join(OUT, f"{ROUND}_bench_100M_two_in_flight.json"))
 print(json.dumps(traffic, indent=1)[:1500])

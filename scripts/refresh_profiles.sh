@@ -13,4 +13,5 @@ timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
     --no-cpu-baseline --gt-queries 10 --small-batch 0 > /dev/null 2> gpurun_out/pmc_fetch.log
 echo "pmc pass done"
 timeout -k 10 900 python3 bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.log
+timeout -k 10 600 python3 bench.py --two-in-flight --no-cpu-baseline --gt-queries 100 > gpurun_out/bench_two_in_flight.json 2> gpurun_out/bench_two_in_flight.log
 tail -c 600 gpurun_out/bench_final.json
