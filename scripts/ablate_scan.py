@@ -17,7 +17,7 @@ import rabitq_amd  # noqa: E402
 from rabitq_amd import index as rqi  # noqa: E402
 from tests import synth  # noqa: E402
 
-n, d, k, nprobe, topk, B = int(os.environ.get("N", 100_000_000)), 128, 4096, 64, 10, 10000
+n, d, k, nprobe, topk, B = int(os.environ.get("N", 100_000_000)), 128, 4096, 64, 10, int(os.environ.get("B", 10000))
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev)
 g.manual_seed(1234)
