@@ -179,6 +179,7 @@ struct Workspace {
     uint32_t pend_nq = 0;
     std::vector<StreamRange> pend_matrix_ranges;  // stream ranges scanned on the matrix cores (profiling only)
     DevBuf<float> qpad, y, dist, probe_dist, thr, recent;
+    DevBuf<uint32_t> q_hist, q_start, q_order;  // rerank order of a large batch (queries grouped by nearest list)
     DevBuf<uint32_t> probe_cluster, recs, grp_cnt, grp_start, heap_len, heap_id, precise, need,
         nsurv, win_count, arr_len, row_map;
     DevBuf<int32_t> heap_key;
@@ -383,6 +384,9 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
     RQC(ws.recs.ensure((npairs + 32ull * idx->k + 32) * (12ull * idx->W + 2 + RQ_REC_TAIL)));
     RQC(ws.grp_cnt.ensure(idx->k + 4));
     RQC(ws.grp_start.ensure(idx->k + 1));
+    RQC(ws.q_hist.ensure(idx->k + 2));
+    RQC(ws.q_start.ensure(idx->k + 2));
+    RQC(ws.q_order.ensure(nq));
     RQC(ws.thr.ensure(nq));
     RQC(ws.surv.ensure(nq * qp.cap));
     RQC(ws.runs.ensure(nq * qp.cap));
@@ -509,6 +513,15 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                                                              qn, q6, nullptr, k, 1u);
     }
     pair_prefix_kernel<<<ceil_div(nq, 4), 256, 0, st>>>(ws.scal.p, nq, nprobe, ws.rough_cnt.p);
+    const uint32_t *rerank_order = nullptr;
+    if (nq >= 256) {  // large batch: rerank queries of the same nearest list back to back (cache locality of the row gather)
+        HIPC(hipMemsetAsync(ws.q_hist.p, 0, (size_t)(k + 2) * 4, st));
+        order_count_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(probe_cluster, nprobe, nq, k, ws.q_hist.p);
+        group_scan_kernel<<<1, 1024, 0, st>>>(ws.q_hist.p, k + 1, ws.q_start.p, 0u);  // also zeroes the histogram: cursor
+        order_scatter_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(probe_cluster, nprobe, nq, k, ws.q_start.p, ws.q_hist.p,
+                                                                ws.q_order.p);
+        rerank_order = ws.q_order.p;
+    }
     ReplayState rs;
     rs.thr = ws.thr.p, rs.heap_len = ws.heap_len.p, rs.heap_key = ws.heap_key.p, rs.heap_id = ws.heap_id.p;
     rs.precise = ws.precise.p, rs.need = ws.need.p, rs.nsurv = ws.nsurv.p, rs.recent_max = ws.recent.p, rs.win_count = ws.win_count.p;
@@ -621,7 +634,8 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         } else {  // large batch: full-chip rerank, then run-directory sort, then one replay wave per query
             pf.begin(PF_RERANK);
             const uint32_t gx = std::max(1u, std::min(16u, 4096u / std::max(nq, 1u)));
-            accurate_kernel<<<dim3(gx, nq), 256, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.surv_cnt.p, qp.cap, idx->base.p, qpad, dim);
+            accurate_kernel<<<dim3(gx, nq), 256, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.surv_cnt.p, qp.cap, idx->base.p, qpad, dim,
+                                                                                    rerank_order);
             pf.end();
             pf.begin(PF_SORT);
             sort_runs_kernel<<<nq, 64, 0, st>>>(ws.runs.p, ws.surv_cnt.p, qp.cap);

@@ -31,6 +31,8 @@ for ci, i0 in enumerate(range(0, n, 4_000_000)):
 g.manual_seed(7)
 uq = torch.randint(0, k, (B,), generator=g, device=dev)
 queries = (centres[uq] + 0.5 * torch.randn(B, d, generator=g, device=dev)).contiguous()
+if os.environ.get("SORTQ"):  # queries grouped by the cluster they were drawn from: does the rerank gather like locality?
+    queries = queries[torch.argsort(uq)].contiguous()
 P = synth.random_orthogonal(d, seed=99)
 idx = rabitq_amd.RaBitQ.build_device(x.data_ptr(), n, d, centres.data_ptr(), k, orthogonal=P)
 del x
