@@ -691,3 +691,18 @@ def test_many_lists_probe_selection_matches_oracle(rq, oracle, k):
         _compare_with_oracle(rq, oracle, oidx, gidx, queries, probe, topk, False)
     gidx.close()
     oidx.close()
+
+
+def test_wide_probe_and_deep_topk_match_oracle(rq, oracle):
+    # nprobe > 64 (block-wide probe selection, many pairs per query) together with a deep top-k, on a batch large
+    # enough for the matrix-core final stage and the rerank-order grouping (nq >= 256)
+    n, d, k, nq = 40000, 128, 160, 288
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.8, seed=77, centre_scale=0.7)
+    P = synth.random_orthogonal(d, seed=13)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    gidx = rq.RaBitQ.build(x, centres, P)
+    queries, _, _ = synth.mixture(nq, d, k, sigma=0.8, seed=78, centre_scale=0.7)
+    _compare_with_oracle(rq, oracle, oidx, gidx, queries, 128, 100, False)
+    _compare_with_oracle(rq, oracle, oidx, gidx, queries[:40], 160, 300, True)
+    gidx.close()
+    oidx.close()
