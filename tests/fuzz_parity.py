@@ -1,6 +1,6 @@
 """Randomised parity fuzz on the GPU box: random index / query shapes, both scan implementations, both rankers,
 against the CPU oracle (ids in order, distance bits, rough/precise counters).  Not part of the test suite (run
-time grows with ROUNDS);  gpurun -- 'ROUNDS=40 python scripts/fuzz_parity.py'."""
+time grows with ROUNDS);  gpurun -- 'ROUNDS=40 python tests/fuzz_parity.py'."""
 import os
 import sys
 import time
