@@ -343,7 +343,7 @@ def main():
     line = {"metric": "queries/sec at recall@10>=0.95, 100Mx128; HBM GB/s on popcount scan", "value": round(qps, 1),
             "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u64 popcount + f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "exact integer dot (fp6 MFMA, v_dot8_u32_u4) + f32", "data": "synthetic",
             "config": {"workload": f"{n // 1_000_000}Mx{d} synthetic mixture per GPU, {k_local} lists per GPU, "
                                    f"nprobe={nprobe}, topk={topk}, batch={B}" +
                                    (" (BASELINE.json configs[2])" if (n, d, k_local, nprobe) == (100_000_000, 128, 4096, 64) else ""),
