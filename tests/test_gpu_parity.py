@@ -706,3 +706,28 @@ def test_wide_probe_and_deep_topk_match_oracle(rq, oracle):
     _compare_with_oracle(rq, oracle, oidx, gidx, queries[:40], 160, 300, True)
     gidx.close()
     oidx.close()
+
+
+def test_begin_end_heuristic_ranker_matches_sync(rq):
+    import torch
+    n, d, k, nq = 8000, 64, 8, 260
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.8, seed=21, centre_scale=0.6)
+    gidx = rq.RaBitQ.build(x, centres, synth.random_orthogonal(d, seed=4))
+    dev = torch.device("cuda", 0)
+    q = torch.from_numpy(synth.mixture(nq, d, k, sigma=0.8, seed=22, centre_scale=0.6)[0]).to(dev)
+    outs = []
+    for split in (False, True):
+        od = torch.zeros((nq, 7), device=dev)
+        oi = torch.zeros((nq, 7), device=dev, dtype=torch.int32)
+        on = torch.zeros((nq,), device=dev, dtype=torch.int32)
+        if split:
+            t = gidx.query_batch_device_begin(q.data_ptr(), nq, d, 5, 7, od.data_ptr(), oi.data_ptr(), on.data_ptr(), True)
+            gidx.query_batch_device_end(t)
+        else:
+            gidx.query_batch_device(q.data_ptr(), nq, d, 5, 7, od.data_ptr(), oi.data_ptr(), on.data_ptr(), True)
+        outs.append((od.cpu().numpy().view(np.uint32), oi.cpu().numpy(), on.cpu().numpy()))
+    assert np.array_equal(outs[0][2], outs[1][2]) and (outs[0][2] > 0).all()
+    valid = np.arange(7)[None, :] < outs[0][2][:, None]
+    assert np.array_equal(outs[0][1][valid], outs[1][1][valid])
+    assert np.array_equal(outs[0][0][valid], outs[1][0][valid])
+    gidx.close()
