@@ -129,7 +129,7 @@ def main():
         pay = sharding.pack_topk(best_d.float(), best_i - rank * n, torch.full((ngt,), topk, device=dev), rank * n)
         if args.backend == "gloo":
             pay = pay.cpu()
-        _, best_i, _ = sharding.merge_shard_topk(pay, topk)
+        _, best_i, _ = sharding.merge_shard_topk(pay, topk, id_bound=world * n)
     gt = best_i.cpu().numpy()
     torch.cuda.synchronize()
     log(f"ground truth done ({time.time() - t0:.1f}s)")
@@ -184,7 +184,7 @@ def main():
             pay = sharding.pack_topk(out_d, out_i.to(torch.int64) & 0xFFFFFFFF, out_n, rank * n)
             if args.backend == "gloo":
                 pay = pay.cpu()
-            return sharding.merge_shard_topk(pay, topk)
+            return sharding.merge_shard_topk(pay, topk, id_bound=world * n)
         return out_d, out_i.to(torch.int64) & 0xFFFFFFFF, out_n
 
     def fence():

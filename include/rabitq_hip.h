@@ -151,6 +151,12 @@ rq_status rq_query_batch_device_end(rq_ticket *ticket);
 rq_status rq_coarse_topk_device(const rq_index *idx, const float *d_queries, uint32_t nq, uint32_t len,
                                 uint32_t list_lo, uint32_t list_hi, uint32_t probe, uint32_t *d_out_cluster,
                                 float *d_out_dist);
+/* Shard merge: per query the m_out smallest of the world x width u64 keys in d_in[world][nq][width] (rows in
+ * any order), ascending, into d_out[nq][m_out] (padded with ~0).  Keys: (f32 distance bits << 32 | list id) for
+ * probe lists, (Ord32 image << 32 | global id) for per-shard top-k.  Launched asynchronously on the legacy
+ * default stream (ordered with the caller's default-stream work, e.g. the all-gather that produced d_in). */
+rq_status rq_merge_smallest_u64_device(const uint64_t *d_in, uint32_t world, uint32_t nq, uint32_t width,
+                                       uint32_t m_out, uint64_t *d_out);
 /* rq_query_batch_device with the probe lists supplied by the caller (nq x probe, visiting order,
  * 0xFFFFFFFF = no list; probe <= k) instead of ranked internally. */
 rq_status rq_query_batch_device_probed(const rq_index *idx, const float *d_queries, uint32_t nq, uint32_t len,

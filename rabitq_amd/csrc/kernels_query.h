@@ -342,6 +342,27 @@ __global__ __launch_bounds__(256) void select_probe_wave_kernel(const float *__r
 }
 
 // ------------------------------------------------------------------------------------------------
+// Shard merge (multi-GPU fan-out): per query, the m_out smallest of the `world` x `width` u64 keys the ranks
+// contributed (all-gathered as in[world][nq][width], rows in any order), ascending.  Used for the probe lists
+// (key = distance bits << 32 | list id) and for the per-shard top-k (key = Ord32 image << 32 | global id).
+// One block per query, LDS bitonic sort; dynamic LDS: pow2_ceil(world * width) * 8 bytes.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void merge_smallest_u64_kernel(const unsigned long long *__restrict__ in, uint32_t world,
+                                                                 uint32_t nq, uint32_t width, uint32_t m_out,
+                                                                 unsigned long long *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char merge_smem[];
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(merge_smem);
+    const uint32_t b = blockIdx.x, m = world * width;
+    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+        const uint32_t w = i / width, e = i - w * width;
+        keys[i] = in[((uint64_t)w * nq + b) * width + e];
+    }
+    __syncthreads();
+    bitonic_sort_block(keys, m, [](unsigned long long v) { return v; });
+    for (uint32_t i = threadIdx.x; i < m_out; i += blockDim.x) out[(uint64_t)b * m_out + i] = i < m ? keys[i] : ~0ull;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Per-(query, probed list) query quantisation (src/rabitq.rs:304-317):
 //   residual = y - c (src/simd.rs:138), (lo, hi) (:143-157), delta = (hi - lo) * (1/15),
 //   q = cvtps_epi32((res - lo) * (1/delta)) (:215, sub then mul, RNE, no bias), sum of q,

@@ -1447,6 +1447,26 @@ rq_status rq_coarse_topk_device(const rq_index *idx, const float *d_queries, uin
     return RQ_OK;
 }
 
+rq_status rq_merge_smallest_u64_device(const uint64_t *d_in, uint32_t world, uint32_t nq, uint32_t width, uint32_t m_out,
+                                       uint64_t *d_out) {
+    RQC(ensure_device());
+    if (!d_in || !d_out) return fail(RQ_ERR_INVALID, "null argument");
+    if (nq == 0 || m_out == 0) return RQ_OK;
+    const uint64_t m = (uint64_t)world * width;
+    if (m == 0 || m > 16384) return fail(RQ_ERR_UNSUPPORTED, "world * width must be in [1, 16384]");
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(merge_smallest_u64_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+    });
+    // on the legacy default stream, asynchronously: ordered with the caller's default-stream work (torch's
+    // current stream is that stream unless the caller changed it), like a library call of its own framework
+    merge_smallest_u64_kernel<<<nq, 256, (size_t)pow2_ceil((uint32_t)m) * 8, nullptr>>>(
+        reinterpret_cast<const unsigned long long *>(d_in), world, nq, width, m_out, reinterpret_cast<unsigned long long *>(d_out));
+    HIPC(hipGetLastError());
+    return RQ_OK;
+}
+
 rq_status rq_query_batch_device_probed(const rq_index *idx, const float *d_queries, uint32_t nq, uint32_t len,
                                        const uint32_t *d_probe_cluster, const float *d_probe_dist, uint32_t probe,
                                        uint32_t topk, int heuristic_rank, float *d_out_dist, uint32_t *d_out_id,

@@ -8,8 +8,25 @@ so a single fused all-gather per batch is the right collective -- not a ring all
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 import torch.distributed as dist
+
+
+def _engine_merge(gathered: torch.Tensor, world: int, nq: int, width: int, m_out: int) -> torch.Tensor:
+    """Per query the m_out smallest u64 keys of gathered[world][nq][width] (int64 tensor holding the bit
+    patterns, on the GPU), ascending: the engine's merge kernel (rq_merge_smallest_u64_device), launched on
+    the default stream like torch's own kernels."""
+    from ._lib import check, lib
+    out = torch.empty((nq, m_out), dtype=torch.int64, device=gathered.device)
+    check(lib().rq_merge_smallest_u64_device(C.c_void_p(gathered.data_ptr()), world, nq, width, m_out,
+                                             C.c_void_p(out.data_ptr())))
+    return out
+
+
+def _use_engine(t: torch.Tensor, world: int, width: int) -> bool:
+    return t.is_cuda and world * width <= 16384 and torch.cuda.current_stream(t.device).cuda_stream == 0
 
 
 def pack_topk(dist_t: torch.Tensor, ids_t: torch.Tensor, counts: torch.Tensor, id_offset: int) -> torch.Tensor:
@@ -25,10 +42,31 @@ def pack_topk(dist_t: torch.Tensor, ids_t: torch.Tensor, counts: torch.Tensor, i
     return torch.stack([key, gid], dim=-1)
 
 
-def merge_shard_topk(payload: torch.Tensor, topk: int, group=None):
+def merge_shard_topk(payload: torch.Tensor, topk: int, group=None, id_bound: int | None = None):
     """All-gather every rank's (nq, topk, 2) payload and keep the topk smallest per query.
-    Returns (dist f32 (nq, topk), ids i64 (nq, topk), counts i64 (nq,)), identical on every rank."""
+    Returns (dist f32 (nq, topk), ids i64 (nq, topk), counts i64 (nq,)), identical on every rank.
+    id_bound: if every global id is below it and it fits 32 bits, a (key, id) pair travels as ONE u64 (half the
+    all-gather payload) and the merge runs in the engine's kernel on the GPU; otherwise in torch."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
+    nq = payload.shape[0]
+    if id_bound is not None and id_bound < 2**32 - 1 and _use_engine(payload, world, payload.shape[1]):
+        key, gid = payload[..., 0], payload[..., 1]
+        valid = key < 2**31
+        k32 = torch.where(valid, key + 2**31, torch.full_like(key, 0xFFFFFFFF))      # monotone u32 image, invalid last
+        g32 = torch.where(valid, gid, torch.full_like(gid, 0xFFFFFFFF)) & 0xFFFFFFFF
+        packed = ((k32 << 32) | g32).contiguous()                                     # bit pattern of the u64 key
+        if world > 1:
+            gathered = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+            dist.all_gather_into_tensor(gathered.reshape(-1), packed.reshape(-1), group=group)
+        else:
+            gathered = packed[None]
+        out = _engine_merge(gathered, world, nq, packed.shape[1], topk)
+        k32o, gido = (out >> 32) & 0xFFFFFFFF, out & 0xFFFFFFFF
+        ok = ~((k32o == 0xFFFFFFFF) & (gido == 0xFFFFFFFF))
+        counts = ok.sum(dim=1)
+        key_o = (k32o - 2**31).clamp(min=-2**31, max=2**31 - 1).to(torch.int32)
+        bits = torch.where(key_o < 0, key_o ^ 0x7FFFFFFF, key_o)
+        return bits.view(torch.float32), torch.where(ok, gido, torch.full_like(gido, -1)), counts
     if world > 1:
         flat = payload.contiguous().reshape(-1)
         gathered = torch.empty(world * flat.numel(), dtype=payload.dtype, device=payload.device)
@@ -36,7 +74,6 @@ def merge_shard_topk(payload: torch.Tensor, topk: int, group=None):
         gathered = gathered.reshape((world,) + tuple(payload.shape))
     else:
         gathered = payload[None]
-    nq = payload.shape[0]
     allp = gathered.permute(1, 0, 2, 3).reshape(nq, -1, 2)       # (nq, world*topk, 2)
     # order by (key, global id): deterministic on every rank
     by_id = torch.argsort(allp[..., 1], dim=1, stable=True)      # two stable passes = lexicographic
@@ -63,12 +100,20 @@ def merge_probe_lists(cluster: torch.Tensor, dist_t: torch.Tensor, nprobe: int, 
     bits = dist_t.contiguous().view(torch.int32).to(torch.int64)          # distances are >= 0: bits order like values
     ids = cluster.to(torch.int64) & 0xFFFFFFFF
     key = (bits << 32) | ids
+    nq, width = key.shape
     if world > 1:
         flat = key.contiguous().reshape(-1)
         gathered = torch.empty(world * flat.numel(), dtype=key.dtype, device=key.device)
         dist.all_gather_into_tensor(gathered, flat, group=group)
-        key = gathered.reshape(world, *key.shape).permute(1, 0, 2).reshape(key.shape[0], -1)
-    key = torch.sort(key, dim=1).values[:, :nprobe]
+        if _use_engine(key, world, width):
+            key = _engine_merge(gathered.reshape(world, nq, width), world, nq, width, nprobe)
+        else:
+            key = gathered.reshape(world, nq, width).permute(1, 0, 2).reshape(nq, -1)
+            key = torch.sort(key, dim=1).values[:, :nprobe]
+    elif _use_engine(key, 1, width):
+        key = _engine_merge(key.contiguous()[None], 1, nq, width, nprobe)
+    else:
+        key = torch.sort(key, dim=1).values[:, :nprobe]
     out_ids = (key & 0xFFFFFFFF).to(torch.int32)      # wraps to the u32 bit pattern
     out_dist = (key >> 32).to(torch.int32).view(torch.float32)
     return out_ids.contiguous(), out_dist.contiguous()

@@ -21,7 +21,7 @@ def test_exports_every_declared_symbol(L):
     from rabitq_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "rabitq_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = sorted(set(re.findall(r"\b(rq_[a-z_]+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"\b(rq_[a-z_0-9]+)\s*\(", hdr)))
     assert declared == sorted(_lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name

@@ -731,3 +731,40 @@ def test_begin_end_heuristic_ranker_matches_sync(rq):
     assert np.array_equal(outs[0][1][valid], outs[1][1][valid])
     assert np.array_equal(outs[0][0][valid], outs[1][0][valid])
     gidx.close()
+
+
+def test_engine_shard_merge_matches_torch(rq):
+    # the GPU merge kernel behind sharding.merge_probe_lists / merge_shard_topk against the torch formulation
+    import torch
+    from rabitq_amd import sharding
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    for world, nq, width, m_out in ((1, 50, 64, 64), (4, 300, 64, 64), (8, 77, 10, 10), (3, 5, 700, 100), (2, 9, 5, 8)):
+        keys = torch.randint(0, 2**62, (world, nq, width), generator=g, device=dev, dtype=torch.int64)
+        keys[:, :, : width // 3] = keys[:, :, :1]                       # duplicates
+        if world > 1:
+            keys[1, :, -1] = -1                                         # all-ones pattern: sorts last as u64
+        got = sharding._engine_merge(keys.contiguous(), world, nq, width, m_out).cpu().numpy().view(np.uint64)
+        flat = keys.permute(1, 0, 2).reshape(nq, -1).cpu().numpy().view(np.uint64)
+        want = np.sort(flat, axis=1)[:, :m_out]
+        if want.shape[1] < m_out:
+            want = np.concatenate([want, np.full((nq, m_out - want.shape[1]), np.uint64(2**64 - 1))], axis=1)
+        assert np.array_equal(got, want), (world, nq, width, m_out)
+    # whole functions, world of one: engine path (GPU tensors) == torch path (CPU tensors)
+    nq, nprobe, topk = 200, 64, 10
+    cl = torch.randint(0, 4096, (nq, nprobe), generator=g, device=dev, dtype=torch.int32)
+    dd = torch.sort(torch.rand((nq, nprobe), generator=g, device=dev), dim=1).values
+    a_c, a_d = sharding.merge_probe_lists(cl, dd, nprobe)
+    b_c, b_d = sharding.merge_probe_lists(cl.cpu(), dd.cpu(), nprobe)
+    assert torch.equal(a_c.cpu(), b_c) and torch.equal(a_d.cpu(), b_d)
+    d = torch.rand((nq, topk), generator=g, device=dev)
+    i = torch.randint(0, 10**8, (nq, topk), generator=g, device=dev)
+    n = torch.randint(0, topk + 1, (nq,), generator=g, device=dev)
+    pay = sharding.pack_topk(d, i, n, 5)
+    a = sharding.merge_shard_topk(pay, topk, id_bound=2 * 10**8)
+    b = sharding.merge_shard_topk(pay.cpu(), topk)
+    assert torch.equal(a[2].cpu(), b[2])
+    valid = (torch.arange(topk)[None, :] < b[2][:, None])
+    assert torch.equal(a[1].cpu()[valid], b[1][valid])
+    assert torch.equal(a[0].cpu().view(torch.int32)[valid], b[0].view(torch.int32)[valid])
