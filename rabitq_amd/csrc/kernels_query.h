@@ -1075,6 +1075,13 @@ constexpr int scan_mfma_blocks_per_cu() { return W <= 2 ? 4 : (W <= 12 ? 2 : 1);
 // 64-dimension slab at a time (3 ds_read_b64 per slab, each feeding the MFMAs of all NT sub-tiles).
 template <int W>
 constexpr bool scan_mfma_stream_a() { return W > 4; }
+// Query tiles consumed per block barrier.  The four waves of a block sit on four SIMDs that each serve other
+// blocks as well, so a barrier per 32-query tile makes every wave advance at the pace of the slowest; narrow
+// vectors (small tile images) afford two tiles per barrier with a 4-slot ring.
+template <int W>
+constexpr uint32_t scan_mfma_tiles_per_barrier() { return W <= 2 ? 2u : 1u; }
+template <int W>
+constexpr uint32_t scan_mfma_ring_slots() { return scan_mfma_tiles_per_barrier<W>() > 1 ? 2 * scan_mfma_tiles_per_barrier<W>() : 3u; }
 
 template <int W, int NT>
 __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_kernel(const uint32_t *__restrict__ codes,
@@ -1095,7 +1102,7 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
     static_assert(IMG % 16 == 0, "tile image must split into four 16-byte-aligned quarters");
     constexpr uint32_t TILE = 128 * NT;
     __shared__ __attribute__((aligned(16))) uint2 lut[256];
-    extern __shared__ __attribute__((aligned(16))) uint32_t ring[];  // 3 x IMG dwords: query tiles in flight (LDS-DMA targets)
+    extern __shared__ __attribute__((aligned(16))) uint32_t ring[];  // scan_mfma_ring_slots<W>() x IMG dwords: query tiles in flight (LDS-DMA targets)
     __shared__ __attribute__((aligned(16))) float4 facL[TILE];      // the tile's factors, for the exact path
     // per-wave emit queue: survivors are parked here and written out in bulk (one atomic round trip per flush)
     constexpr uint32_t QE = 128, QR = 32;
@@ -1140,6 +1147,7 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
             if (q4 < WQ4) glds16(src + q4 * 4, dst + i * 1024);  // same active lanes in every wave: NI issues each
         }
     };
+    constexpr uint32_t QPB = scan_mfma_tiles_per_barrier<W>();
     dma_tile(0, 0);
     if (ntiles > 1) dma_tile(1, 1);
     {  // byte -> 8 fp6 fields (bit e -> 1.0 = 0b001000 at bits 6e .. 6e+5)
@@ -1236,12 +1244,22 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
 
     uint32_t slot = 0;  // ring slot of query tile qt
     for (uint32_t qt = 0; qt < ((a.dbg & 4u) ? 0u : ntiles); ++qt) {
-        // tile qt has landed once at most the NI copies of tile qt+1 are still in flight (in-order counter)
-        if (qt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // every wave's quarter of tile qt is in; everyone is done with tile qt-1
-        if (qt + 2 < ntiles) dma_tile(qt + 2, slot == 0 ? 2 : slot - 1);  // into the slot tile qt-1 occupied
+        if constexpr (QPB == 1) {  // 3 slots, one barrier per tile, two tiles in flight
+            // tile qt has landed once at most the NI copies of tile qt+1 are still in flight (in-order counter)
+            if (qt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // every wave's quarter of tile qt is in; everyone is done with tile qt-1
+            if (qt + 2 < ntiles) dma_tile(qt + 2, slot == 0 ? 2 : slot - 1);  // into the slot tile qt-1 occupied
+        } else if (qt % QPB == 0) {  // 2*QPB slots, one barrier per QPB tiles: tiles qt .. qt+QPB-1 were requested one
+                                     // barrier ago (a period of QPB tiles of compute), the next QPB go out now
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (uint32_t i = 0; i < QPB; ++i)
+                if (qt + QPB + i < ntiles) dma_tile(qt + QPB + i, (slot + QPB + i) % (2 * QPB));
+        }
         const uint32_t *img = ring + slot * IMG;
         const uint32_t nvalid = cnt - 32 * qt;  // rows >= nvalid of the last tile are stale memory: masked here
         const bool valid = j < nvalid;
@@ -1379,7 +1397,7 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
                 }
             }
         }
-        slot = slot == 2 ? 0 : slot + 1;
+        slot = slot + 1 == scan_mfma_ring_slots<W>() ? 0 : slot + 1;
     }
     if (nE) flush();
 }

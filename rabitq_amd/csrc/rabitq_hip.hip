@@ -293,7 +293,7 @@ static bool scan_has_mfma(uint32_t W) {
 }
 static uint32_t scan_mfma_nt(uint32_t W) { return W == 2 ? 3 : (W >= 4 ? 2 : 4); }
 static uint32_t scan_mfma_tile(uint32_t W) { return 128 * scan_mfma_nt(W); }
-static size_t scan_mfma_ring_bytes(uint32_t W) { return 3ull * (32 * (12 * W + 2) + RQ_REC_TAIL * 32) * 4; }
+static size_t scan_mfma_ring_bytes(uint32_t W) { return (W <= 2 ? 4ull : 3ull) * (32 * (12 * W + 2) + RQ_REC_TAIL * 32) * 4; }  // scan_mfma_ring_slots<W>()
 template <int W, int NT>
 static void launch_scan_mfma_t(const ScanPtrs &p, const ScanArgs &a, dim3 g, hipStream_t st) {
     static std::once_flag once;  // the ring (dynamic LDS) of wide vectors exceeds the 64 KiB default
