@@ -1182,6 +1182,9 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
         if (!ok) forced = true;
     }
     const uint64_t forcemask = __ballot(forced);
+    // as a scalar, together with the developer switch: the hot loop tests one SGPR instead of rebuilding the condition
+    const uint32_t force_any = __builtin_amdgcn_readfirstlane(forcemask != 0ull ? 1u : 0u);
+    const uint32_t exact_off = __builtin_amdgcn_readfirstlane((a.dbg & 64u) ? 1u : 0u);
     if (h == 0) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) facL[lpos[t] - first] = fac0[t];
@@ -1345,9 +1348,9 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
 #pragma unroll
             for (int gq = 3; gq < 15; gq += 2) mxi = imax3(mxi, ai[gq], ai[gq + 1]);
             mxi = mxi > ai[15] ? mxi : ai[15];
-            if ((forcemask != 0ull || __ballot(mxi > 0) != 0ull) && !(a.dbg & 64u)) {  // wave-uniform; everything below
+            if ((force_any | (__ballot(mxi > 0) != 0ull ? 1u : 0u)) & (exact_off ^ 1u)) {  // wave-uniform; everything below
                 // lives inside this branch so that the common path carries no state of it (not even a zeroed tile)
-                uint32_t gmask = forcemask ? 0xFFFFu : 0u;  // accumulator registers with at least one flagged lane
+                uint32_t gmask = force_any ? 0xFFFFu : 0u;  // accumulator registers with at least one flagged lane
                 f32x16 sc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                 for (int gq = 0; gq < 16; ++gq) gmask |= (__ballot(acc[gq] > 0.0f) != 0ull ? 1u : 0u) << gq;
