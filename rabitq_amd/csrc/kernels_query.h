@@ -1854,8 +1854,9 @@ __global__ __launch_bounds__(64) void sort_runs_kernel(RunRec *__restrict__ runs
     const uint32_t b = blockIdx.x;
     const unsigned long long c = surv_cnt[b];
     if ((uint32_t)c > cap) return;
-    // a stage rarely leaves more than a few dozen runs per query: a small LDS image keeps residency high
-    sort_segment<RunRec, 256>(runs + (uint64_t)b * cap, (uint32_t)(c >> 32));
+    // early stages leave a few dozen runs per query, the stages around one list's worth a few hundred (more at dim 64,
+    // where the estimates are noisier): 512 descriptors = 8 KiB of LDS per 64-thread block keep them out of global memory
+    sort_segment<RunRec, 512>(runs + (uint64_t)b * cap, (uint32_t)(c >> 32));
 }
 
 template <bool HEURISTIC>
