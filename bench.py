@@ -46,9 +46,11 @@ def main():
     ap.add_argument("--sigma", type=float, default=0.5)
     ap.add_argument("--centre-scale", type=float, default=1.0)
     ap.add_argument("--gt-queries", type=int, default=1000)
-    ap.add_argument("--cpu-queries", type=int, default=32, help="CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-queries", type=int, default=1000,
+                    help="CPU-baseline sample: the 1000-query subset of SURVEY.md 8(d) (0 = skip); bounded to ~25 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--small-batch", type=int, default=64, help="queries of the HBM-regime scan measurement")
+    ap.add_argument("--small-batch", default="64,16",
+                    help="batch sizes of the HBM-regime scan measurement (lists hardly shared; '0' or '' = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo = single-GPU rehearsal)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--sharded-path", action="store_true",
@@ -62,6 +64,11 @@ def main():
                     help="batches kept in flight in the timed loop (rq_query_batch_device_begin/_end); 1 = one blocking "
                          "call per step (default: per-kernel times are then clean); see --two-in-flight")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) and wait.
+        # This parent never imports torch or touches the GPU, and nothing is exec'd from a process that has.
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -89,20 +96,14 @@ def main():
     t0 = time.time()
 
     # ---- synthetic inputs: mixture of Gaussians, generated on device ------------
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234)
-    centres = torch.randn(k, d, generator=g, device=dev, dtype=torch.float32) * args.centre_scale
+    centres = synth.device_centres(k, d, dev, args.centre_scale)
     my_lo = rank * k_local                   # this rank's points come from its own k_local centres
     x = torch.empty((n, d), device=dev, dtype=torch.float32)
     chunk = 4_000_000
     for ci, i0 in enumerate(range(0, n, chunk)):
         m = min(chunk, n - i0)
-        g.manual_seed(42 + 1000 * rank + ci)
-        u = torch.randint(0, k_local, (m,), generator=g, device=dev) + my_lo
-        x[i0:i0 + m] = centres[u] + args.sigma * torch.randn(m, d, generator=g, device=dev, dtype=torch.float32)
-    g.manual_seed(7)
-    uq = torch.randint(0, k, (B,), generator=g, device=dev)
-    queries = (centres[uq] + args.sigma * torch.randn(B, d, generator=g, device=dev, dtype=torch.float32)).contiguous()
+        x[i0:i0 + m], _ = synth.device_mixture_chunk(centres, i0, m, args.sigma, ci, 42 + 1000 * rank, my_lo, k_local)
+    queries = synth.device_queries(centres, B, args.sigma, dev)
     P = synth.random_orthogonal(d, seed=99)
     torch.cuda.synchronize()
     log(f"data generated: {n} x {d} per GPU, k={k}, B={B}  ({time.time() - t0:.1f}s)")
@@ -268,7 +269,9 @@ def main():
     scan_s = prof["ms_scan"] * 1e-3
     launches = max(prof["scan_launches"], 1)
     achieved = prof["scan_bytes"] / scan_s / 1e9 if scan_s > 0 else 0.0
-    traffic, dom_traffic = None, None
+    # HBM bytes are NOT measured in this run (PMC counters need their own rocprofv3 pass): when the committed PMC summary
+    # was taken on this exact workload its figures are quoted, labelled as such; otherwise traffic is null.
+    traffic, dom_traffic, traffic_src = None, None, None
     tr_path = os.path.join(ROOT, "profiles", "scan_traffic.json")
     if os.path.exists(tr_path):
         try:
@@ -276,10 +279,11 @@ def main():
             if tj.get("config", {}) == {"vectors": n, "dim": d, "lists": k_local, "nprobe": nprobe, "batch": B}:  # same workload only
                 traffic = tj.get("hbm_bytes_per_launch")
                 dom_traffic = tj.get("dominant_launch", {}).get("hbm_read_bytes")
+                traffic_src = "committed PMC pass profiles/scan_traffic.json (FETCH_SIZE x2, same workload), not measured in this run"
         except Exception:
             traffic = None
     scan_all = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "all scan launches of a batch: scan_kernel<W,CPL> (early stages) + scan_mfma_kernel<W,NT>",
                 "launches": int(launches), "avg_launch_ms": round(prof["ms_scan"] / launches, 4),
                 "algorithmic_bytes_per_launch": int(prof["scan_bytes"] / launches),
@@ -289,40 +293,28 @@ def main():
     PEAK_FP6 = 256 * 4 * 2.4e9 * (2 * 32 * 32 * 64 / 32) / 1e12   # v_mfma_f32_32x32x64_f8f6f4 (fp6): 32 cycles per SIMD
     if prof.get("matrix_launches", 0) > 0 and prof["ms_scan_matrix"] > 0:
         ml, mm, mp = prof["matrix_launches"], prof["ms_scan_matrix"] * 1e-3, prof["matrix_pairs"]
-        flops = mp * (2.0 * idx.dim + 2.0 * 16)          # the dim-long dot product + the 16-slot threshold product per pair
+        flops = mp * 2.0 * idx.dim                       # USEFUL work only: the dim-long integer dot product of every pair
+        over = mp * 2.0 * 16                             # overhead: the 16-slot bf16 threshold MFMA per pair (not counted)
         mbytes = mp * (idx.dim / 8 + 16)
         roofline = {"bound": "mfma", "achieved": round(flops / mm / 1e12, 1), "peak": round(PEAK_FP6, 1), "unit": "TFLOP/s",
-                    "frac": round(flops / mm / 1e12 / PEAK_FP6, 4), "traffic": dom_traffic,
-                    "kernel": "scan_mfma_kernel<W,NT> (v_mfma_f32_32x32x64_f8f6f4 e2m3 x e2m3 + v_mfma_f32_32x32x16_bf16 threshold)",
+                    "frac": round(flops / mm / 1e12 / PEAK_FP6, 4), "traffic": dom_traffic, "traffic_source": traffic_src,
+                    "kernel": "scan_mfma_kernel<W,NT> (v_mfma_f32_32x32x64_f8f6f4 e2m3 x e2m3)",
                     "launches": int(ml), "avg_launch_ms": round(mm / ml * 1e3, 4),
                     "algorithmic_flops_per_launch": int(flops / ml), "pairs_per_launch": int(mp / ml),
+                    "overhead_flops_per_launch_threshold_mfma": int(over / ml),
                     "algorithmic_bytes_per_launch": int(mbytes / ml),
                     "algorithmic_GBps": round(mbytes / mm / 1e9, 1), "algorithmic_GBps_over_hbm_peak": round(mbytes / mm / 1e9 / 8000.0, 2),
-                    "note": "flops = (query, candidate) pairs scored x (2*dim + 32); the launch is shared-list compute: its "
-                            "algorithmic byte rate is far above the 8 TB/s HBM peak and `traffic` (PMC FETCH_SIZE x2) far "
-                            "below the algorithmic bytes"}
+                    "note": "achieved = (query, candidate) pairs scored x 2*dim useful flops / launch time (HIP events); the "
+                            "threshold MFMA is overhead and listed separately; the launch is shared-list compute: its algorithmic "
+                            "byte rate is far above the 8 TB/s HBM peak and the PMC-measured HBM traffic far below the algorithmic bytes"}
     else:
         roofline = scan_all
 
     # ---- the same scan kernel in its HBM-bound regime: a small batch, (almost) no list shared --------
-    small = None
-    sb = min(args.small_batch, B)
-    if sb > 0:
-        for _ in range(2):
-            idx.query_batch_device(queries.data_ptr(), sb, d, nprobe, topk, out_d.data_ptr(), out_i.data_ptr(),
-                                   out_n.data_ptr())
-        sp = {}
-        reps = 10
-        for _ in range(reps):
-            idx.query_batch_device(queries.data_ptr(), sb, d, nprobe, topk, out_d.data_ptr(), out_i.data_ptr(),
-                                   out_n.data_ptr())
-            for key, v in rqi.last_profile().items():
-                sp[key] = sp.get(key, 0) + v
-        gbs = sp["scan_bytes"] / (sp["ms_scan"] * 1e-3) / 1e9
-        small = {"batch": sb, "scan_ms_per_batch": round(sp["ms_scan"] / reps, 4),
-                 "total_ms_per_batch": round(sp["ms_total"] / reps, 4),
-                 "scan_algorithmic_GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / 8000.0, 4),
-                 "queries_per_s": round(sb * reps / (sp["ms_total"] * 1e-3), 1)}
+    small = []
+    for sb in [min(int(v), B) for v in str(args.small_batch).split(",") if v.strip() and int(v) > 0]:
+        small.append(small_batch_regime(idx, queries, sb, d, nprobe, topk, out_d, out_i, out_n, n, k_local))
+    small = small or None
 
     # ---- one query at a time through the host-pointer API, as crates/cli/src/main.rs:69-75 does -------
     single = None
@@ -340,7 +332,8 @@ def main():
                   "p50_ms": round(float(np.median(lat) * 1e3), 4), "p99_ms": round(float(np.quantile(lat, 0.99) * 1e3), 4),
                   "queries_per_s": round(len(lat) / float(lat.sum()), 1), "device_ms": round(rqi.last_profile()["ms_total"], 4)}
 
-    line = {"metric": "queries/sec at recall@10>=0.95, 100Mx128; HBM GB/s on popcount scan", "value": round(qps, 1),
+    size_txt = f"{n // 1_000_000}Mx{d}" if n % 1_000_000 == 0 else f"{n}x{d}"
+    line = {"metric": f"queries/sec at recall@10>=0.95, {size_txt}; HBM GB/s on popcount scan", "value": round(qps, 1),
             "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "exact integer dot (fp6 MFMA, v_dot8_u32_u4) + f32", "data": "synthetic",
@@ -365,6 +358,63 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def small_batch_regime(idx, queries, sb, d, nprobe, topk, out_d, out_i, out_n, n, k_local):
+    """The scan kernel in its HBM-bound regime: a small batch, (almost) no list shared between queries."""
+    from rabitq_amd import index as rqi
+    for _ in range(2):
+        idx.query_batch_device(queries.data_ptr(), sb, d, nprobe, topk, out_d.data_ptr(), out_i.data_ptr(), out_n.data_ptr())
+    sp = {}
+    reps = 10
+    for r in range(reps):
+        q0 = (r * sb) % max(1, queries.shape[0] - sb + 1)      # different queries per call
+        idx.query_batch_device(queries[q0:q0 + sb].data_ptr(), sb, d, nprobe, topk, out_d.data_ptr(), out_i.data_ptr(),
+                               out_n.data_ptr())
+        for key, v in rqi.last_profile().items():
+            sp[key] = sp.get(key, 0) + v
+    gbs = sp["scan_bytes"] / (sp["ms_scan"] * 1e-3) / 1e9
+    small = {"batch": sb, "scan_ms_per_batch": round(sp["ms_scan"] / reps, 4),
+             "total_ms_per_batch": round(sp["ms_total"] / reps, 4),
+             "scan_algorithmic_GBps": round(gbs, 1), "algorithmic_frac_of_8TBps": round(gbs / 8000.0, 4),
+             "queries_per_s": round(sb * reps / (sp["ms_total"] * 1e-3), 1)}
+    # physical HBM rate of the same regime: PMC FETCH_SIZE (x2) over kernel-trace durations, committed profile
+    hp = os.path.join(ROOT, "profiles", "r02_hbm_regime.json")
+    if os.path.exists(hp):
+        try:
+            for wl in json.load(open(hp))["workloads"]:
+                c = wl["config"]
+                if (c["vectors"], c["dim"], c["lists"], c["nprobe"]) == (n, d, k_local, nprobe):
+                    for rg in wl["regimes"]:
+                        if rg["batch"] == sb:
+                            small["physical_GBps_committed_pmc"] = round(rg["physical_GBps"], 1)
+                            small["physical_frac_of_8TBps_committed_pmc"] = round(rg["physical_frac_of_8TBps"], 4)
+                            small["dominant_launch_physical_GBps_committed_pmc"] = round(rg["dominant_launch"]["physical_GBps"], 1)
+                            small["physical_source"] = ("profiles/r02_hbm_regime.json (rocprofv3 --pmc FETCH_SIZE x2 / "
+                                                        "kernel-trace time; not measured in this run)")
+        except Exception:
+            pass
+    return small
+
+
+def self_launch(n: int) -> int:
+    """One child process per rank, the environment torch.distributed.run would have set; rank 0's stdout (the JSON
+    line) and everybody's stderr pass through.  Equivalent to
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    return rc
 
 
 def cpu_baseline(idx, qs, nprobe, topk, gpu_ids, d):

@@ -820,6 +820,9 @@ struct ScanArgs {   // scalars only; pointers are explicit __restrict__ kernel p
                     // compiler keeps the wave-uniform operand fetches on the scalar unit (s_load)
     uint32_t cap, tiles_per_group, ngroups, cluster_major;
     uint32_t dbg;  // developer ablations (scripts/ablate_scan.py); 0 in production
+    // A stage whose grid would exceed the launch bound is issued as several launches: this one covers groups
+    // group_base .. and, per group, tiles tile_base .. tile_base + tiles_per_group (host: launch_scan_chunks)
+    uint32_t group_base, tile_base;
 };
 struct ScanPtrs {   // host-side bundle only
     const uint32_t *codes;        // n * 2W dwords (x_binary_vec, src/rabitq.rs:66)
@@ -866,8 +869,9 @@ __device__ __forceinline__ float rough_distance(uint32_t s, const float4 &f, flo
 template <int W, int CPL>
 __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
     constexpr uint32_t STRIDE = 8 * W + RQ_REC_TAIL;
-    const uint32_t g = blockIdx.x / a.tiles_per_group;
-    const uint32_t tile = blockIdx.x - g * a.tiles_per_group;
+    const uint32_t gl = blockIdx.x / a.tiles_per_group;
+    const uint32_t g = a.group_base + gl;
+    const uint32_t tile = a.tile_base + (blockIdx.x - gl * a.tiles_per_group);
     uint32_t pb, pe;
     if (a.cluster_major) {
         pb = grp_start[g];
@@ -1111,8 +1115,9 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
     __shared__ uint32_t q_run[4][QE];
     __shared__ uint32_t r_b[4][QR], r_slot[4][QR], r_pos[4][QR], r_cnt[4][QR], r_off[4][QR], r_base[4][QR];
 
-    const uint32_t g = blockIdx.x / a.tiles_per_group;
-    const uint32_t tile = blockIdx.x - g * a.tiles_per_group;
+    const uint32_t gl = blockIdx.x / a.tiles_per_group;
+    const uint32_t g = a.group_base + gl;
+    const uint32_t tile = a.tile_base + (blockIdx.x - gl * a.tiles_per_group);
     // one round trip: the group's records (cluster-major only) and its list
     const uint32_t pb = grp_start[g], cnt = grp_cnt[g];
     const uint32_t list_begin = offsets[g], list_len = offsets[g + 1] - list_begin;
@@ -1408,8 +1413,9 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
 // generic-W fallback (dim/64 not in the templated set): code words re-read per query (L1-resident)
 __global__ __launch_bounds__(256) void scan_generic_kernel(SCAN_PARAMS, uint32_t W) {
     const uint32_t STRIDE = 8 * W + RQ_REC_TAIL;
-    const uint32_t g = blockIdx.x / a.tiles_per_group;
-    const uint32_t tile = blockIdx.x - g * a.tiles_per_group;
+    const uint32_t gl = blockIdx.x / a.tiles_per_group;
+    const uint32_t g = a.group_base + gl;
+    const uint32_t tile = a.tile_base + (blockIdx.x - gl * a.tiles_per_group);
     uint32_t pb, pe;
     if (a.cluster_major) {
         pb = grp_start[g];

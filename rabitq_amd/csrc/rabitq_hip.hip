@@ -115,10 +115,15 @@ struct Prof {
     size_t used = 0;
     bool open = false;          // the last begin() was recorded (not filtered out)
     hipEvent_t last_b = nullptr;  // end event of the previous span, reusable as the next begin while nothing ran since
+    bool failed = false;  // an event could not be created: this pass reports no timings (never a wrong one)
     hipEvent_t get() {
         if (used == pool.size()) {
-            hipEvent_t e;
-            (void)hipEventCreate(&e);
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess || !e) {
+                failed = true;
+                on = false;
+                return nullptr;
+            }
             pool.push_back(e);
         }
         return pool[used++];
@@ -131,11 +136,16 @@ struct Prof {
             return;
         }
         Span s{last_b, get(), cat};
-        if (!s.a) {
+        if (s.b && !s.a) {
             s.a = get();
-            (void)hipEventRecord(s.a, stream);
+            if (s.a) (void)hipEventRecord(s.a, stream);
         }
         last_b = nullptr;
+        if (!s.a || !s.b) {  // event creation failed: profiling is off for the rest of the pass
+            open = false;
+            spans.clear();
+            return;
+        }
         spans.push_back(s);
     }
     void end() {
@@ -152,8 +162,10 @@ struct Prof {
         used = 0;
         open = false;
         last_b = nullptr;
+        failed = false;
     }
     void collect(float *ms /*PF_N*/) {
+        if (failed) return;
         for (auto &s : spans) {
             float t = 0;
             (void)hipEventElapsedTime(&t, s.a, s.b);
@@ -256,26 +268,42 @@ static void launch_rotate(const float *x, const float *P, float *out, uint64_t n
 // ------------------------------------------------------------------------------------------------
 // scan dispatch on W = dim / 64
 // ------------------------------------------------------------------------------------------------
+// A stage's grid is ngroups x tiles_per_group blocks.  Shapes whose grid exceeds the launch bound (few huge lists
+// x many pairs, ~1e9 vectors with skewed lists) are issued as several launches over (group, tile) sub-ranges; the
+// survivors of one stage are unordered until the run directory is sorted, so the split changes nothing.
+static std::atomic<uint32_t> g_max_scan_blocks{RQ_MAX_BLOCKS_256};  // lowered by tests ("max_scan_blocks")
+template <typename F>
+static void launch_scan_chunks(const ScanArgs &a, F &&launch) {
+    if (a.ngroups == 0 || a.tiles_per_group == 0) return;
+    const uint32_t maxb = std::max(1u, g_max_scan_blocks.load());
+    const uint32_t tchunk = std::min(a.tiles_per_group, maxb);
+    const uint32_t gchunk = std::max(1u, maxb / tchunk);
+    for (uint32_t t0 = 0; t0 < a.tiles_per_group; t0 += tchunk)
+        for (uint32_t g0 = 0; g0 < a.ngroups; g0 += gchunk) {
+            ScanArgs c = a;
+            c.tile_base = t0, c.group_base = g0;
+            c.tiles_per_group = std::min(tchunk, a.tiles_per_group - t0);
+            c.ngroups = std::min(gchunk, a.ngroups - g0);
+            launch(c, dim3(c.ngroups * c.tiles_per_group));
+        }
+}
+
 #define SCAN_ARGS p.codes, p.factors, p.offsets, p.grp_start, p.recs, p.surv, p.runs, p.surv_cnt, a
-static void launch_scan(const ScanPtrs &p, const ScanArgs &a, uint32_t W, hipStream_t st) {
-    const uint64_t blocks = (uint64_t)a.ngroups * a.tiles_per_group;
-    if (blocks == 0) return;
-    if (blocks > RQ_MAX_BLOCKS_256) {  // cannot happen for k <= 2^16 lists of < 2^32 vectors; never wrap silently
-        fprintf(stderr, "rabitq_hip: scan grid of %llu blocks exceeds the launch bound\n", (unsigned long long)blocks);
-        abort();
-    }
-    dim3 g((uint32_t)blocks), b(256);
-    switch (W) {
-        case 1: scan_kernel<1, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
-        case 2: scan_kernel<2, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
-        case 3: scan_kernel<3, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
-        case 4: scan_kernel<4, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
-        case 6: scan_kernel<6, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
-        case 8: scan_kernel<8, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
-        case 12: scan_kernel<12, 1><<<g, b, 0, st>>>(SCAN_ARGS); break;
-        case 16: scan_kernel<16, 1><<<g, b, 0, st>>>(SCAN_ARGS); break;
-        default: scan_generic_kernel<<<g, b, 0, st>>>(SCAN_ARGS, W); break;
-    }
+static void launch_scan(const ScanPtrs &p, const ScanArgs &args, uint32_t W, hipStream_t st) {
+    launch_scan_chunks(args, [&](const ScanArgs &a, dim3 g) {
+        const dim3 b(256);
+        switch (W) {
+            case 1: scan_kernel<1, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
+            case 2: scan_kernel<2, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
+            case 3: scan_kernel<3, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
+            case 4: scan_kernel<4, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
+            case 6: scan_kernel<6, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
+            case 8: scan_kernel<8, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
+            case 12: scan_kernel<12, 1><<<g, b, 0, st>>>(SCAN_ARGS); break;
+            case 16: scan_kernel<16, 1><<<g, b, 0, st>>>(SCAN_ARGS); break;
+            default: scan_generic_kernel<<<g, b, 0, st>>>(SCAN_ARGS, W); break;
+        }
+    });
 }
 // scan implementation: 0 = auto (matrix cores when many queries share each list, VALU otherwise),
 // 1 = VALU (v_dot8_u32_u4) only, 2 = matrix cores wherever the kernel exists (test hook)
@@ -296,33 +324,24 @@ static uint32_t scan_mfma_tile(uint32_t W) { return 128 * scan_mfma_nt(W); }
 static size_t scan_mfma_ring_bytes(uint32_t W) { return (W <= 2 ? 4ull : 3ull) * (32 * (12 * W + 2) + RQ_REC_TAIL * 32) * 4; }  // scan_mfma_ring_slots<W>()
 template <int W, int NT>
 static void launch_scan_mfma_t(const ScanPtrs &p, const ScanArgs &a, dim3 g, hipStream_t st) {
-    static std::once_flag once;  // the ring (dynamic LDS) of wide vectors exceeds the 64 KiB default
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(scan_mfma_kernel<W, NT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_mfma_ring_bytes(W));
-    });
     scan_mfma_kernel<W, NT><<<g, dim3(256), scan_mfma_ring_bytes(W), st>>>(p.codes, p.factors, p.offsets, p.grp_start, p.grp_cnt,
                                                                              p.recs, p.surv, p.runs, p.surv_cnt, a);
 }
-static void launch_scan_mfma(const ScanPtrs &p, const ScanArgs &a, uint32_t W, hipStream_t st) {
-    const uint64_t blocks = (uint64_t)a.ngroups * a.tiles_per_group;
-    if (blocks == 0) return;
-    if (blocks > RQ_MAX_BLOCKS_256) {
-        fprintf(stderr, "rabitq_hip: scan grid of %llu blocks exceeds the launch bound\n", (unsigned long long)blocks);
-        abort();
-    }
-    dim3 g((uint32_t)blocks);
-    switch (W) {
-        case 1: launch_scan_mfma_t<1, 4>(p, a, g, st); break;
-        case 2: launch_scan_mfma_t<2, 3>(p, a, g, st); break;
-        case 3: launch_scan_mfma_t<3, 4>(p, a, g, st); break;
-        case 4: launch_scan_mfma_t<4, 2>(p, a, g, st); break;
-        case 6: launch_scan_mfma_t<6, 2>(p, a, g, st); break;
-        case 8: launch_scan_mfma_t<8, 2>(p, a, g, st); break;
-        case 12: launch_scan_mfma_t<12, 2>(p, a, g, st); break;
-        case 16: launch_scan_mfma_t<16, 2>(p, a, g, st); break;
-        default: abort();
-    }
+// callers check scan_has_mfma(W) first
+static void launch_scan_mfma(const ScanPtrs &p, const ScanArgs &args, uint32_t W, hipStream_t st) {
+    launch_scan_chunks(args, [&](const ScanArgs &a, dim3 g) {
+        switch (W) {
+            case 1: launch_scan_mfma_t<1, 4>(p, a, g, st); break;
+            case 2: launch_scan_mfma_t<2, 3>(p, a, g, st); break;
+            case 3: launch_scan_mfma_t<3, 4>(p, a, g, st); break;
+            case 4: launch_scan_mfma_t<4, 2>(p, a, g, st); break;
+            case 6: launch_scan_mfma_t<6, 2>(p, a, g, st); break;
+            case 8: launch_scan_mfma_t<8, 2>(p, a, g, st); break;
+            case 12: launch_scan_mfma_t<12, 2>(p, a, g, st); break;
+            case 16: launch_scan_mfma_t<16, 2>(p, a, g, st); break;
+            default: break;
+        }
+    });
 }
 
 static bool scan_is_fused(uint32_t W) {
@@ -349,6 +368,48 @@ static void launch_select(const float *dist, uint32_t k, uint32_t nprobe, uint32
         return;
     }
     select_probe_kernel<<<nq, 256, (size_t)nprobe * 8, st>>>(dist, k, nprobe, out_cluster, out_dist, id_offset, out_stride);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Kernels whose dynamic LDS can exceed the 64 KiB default: the attribute is set once per process, before the
+// first launch of any of them (every entry point that can reach such a launch calls this first), and a refusal
+// is reported instead of surfacing later as a failed launch.
+// ------------------------------------------------------------------------------------------------
+template <int W, int NT>
+static hipError_t set_scan_mfma_attr() {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(scan_mfma_kernel<W, NT>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_mfma_ring_bytes(W));
+}
+static rq_status ensure_kernel_attributes() {
+    static std::once_flag once;
+    static hipError_t err = hipSuccess;
+    static const char *what = "";
+    std::call_once(once, [] {
+        auto set = [&](const void *fn, int bytes, const char *name) {
+            if (err != hipSuccess) return;
+            err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (err != hipSuccess) what = name;
+        };
+        set(reinterpret_cast<const void *>(select_probe_kernel), 140 * 1024, "select_probe_kernel");
+        set(reinterpret_cast<const void *>(coarse_dist_kernel<4>), 140 * 1024, "coarse_dist_kernel<4>");
+        set(reinterpret_cast<const void *>(coarse_dist_kernel<8>), 140 * 1024, "coarse_dist_kernel<8>");
+        set(reinterpret_cast<const void *>(assign_generic_kernel<8>), 140 * 1024, "assign_generic_kernel<8>");
+        set(reinterpret_cast<const void *>(merge_smallest_u64_kernel), 16384 * 8, "merge_smallest_u64_kernel");
+        auto chk = [&](hipError_t e, const char *name) {
+            if (err == hipSuccess && e != hipSuccess) err = e, what = name;
+        };
+        chk(set_scan_mfma_attr<1, 4>(), "scan_mfma_kernel<1,4>");
+        chk(set_scan_mfma_attr<2, 3>(), "scan_mfma_kernel<2,3>");
+        chk(set_scan_mfma_attr<3, 4>(), "scan_mfma_kernel<3,4>");
+        chk(set_scan_mfma_attr<4, 2>(), "scan_mfma_kernel<4,2>");
+        chk(set_scan_mfma_attr<6, 2>(), "scan_mfma_kernel<6,2>");
+        chk(set_scan_mfma_attr<8, 2>(), "scan_mfma_kernel<8,2>");
+        chk(set_scan_mfma_attr<12, 2>(), "scan_mfma_kernel<12,2>");
+        chk(set_scan_mfma_attr<16, 2>(), "scan_mfma_kernel<16,2>");
+    });
+    if (err != hipSuccess)
+        return fail(RQ_ERR_HIP, std::string("hipFuncSetAttribute(") + what + "): " + hipGetErrorString(err));
+    return RQ_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -690,6 +751,7 @@ static void ws_release(rq_index *idx, Workspace *w) {
 static rq_status validate_query(const rq_index *idx, const float *d_q, uint32_t len, uint32_t probe, uint32_t topk,
                                 const float *d_out_dist, const uint32_t *d_out_id, const uint32_t *d_out_n) {
     RQC(ensure_device());
+    RQC(ensure_kernel_attributes());
     if (!idx || !d_q || !d_out_dist || !d_out_id || !d_out_n) return fail(RQ_ERR_INVALID, "null argument");
     if (idx->dim != (len + 63) / 64 * 64)  // rabitq.rs:275
         return fail(RQ_ERR_DIM_MISMATCH, "query length " + std::to_string(len) + " does not pad to index dim " +
@@ -914,17 +976,7 @@ static rq_status finish_index(rq_index *idx) {
     // derived state: transposed centroids, longest list
     idx->W = idx->dim / 64;
     RQC(idx->cent_t.alloc((size_t)idx->dim * idx->k));
-    static std::once_flag once;
-    std::call_once(once, [] {  // kernels whose dynamic LDS can exceed the 64 KiB default
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(select_probe_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(coarse_dist_kernel<4>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(coarse_dist_kernel<8>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(assign_generic_kernel<8>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-    });
+    RQC(ensure_kernel_attributes());
     if (idx->k)
         transpose_kernel<<<dim3(ceil_div(idx->dim, 32), ceil_div(idx->k, 32)), dim3(32, 8)>>>(
             idx->centroids.p, idx->cent_t.p, idx->k, idx->dim);
@@ -1012,6 +1064,7 @@ static void launch_assign(const float *xrot, const rq_index *idx, uint64_t n, ui
 static rq_status build_device(const float *d_base, uint64_t n, uint32_t d, const float *d_centroids, uint32_t k,
                               const float *orthogonal_host, uint64_t seed, rq_index **out) {
     RQC(ensure_device());
+    RQC(ensure_kernel_attributes());
     if (!out) return fail(RQ_ERR_INVALID, "null out pointer");
     *out = nullptr;
     if ((n && !d_base) || !d_centroids || d == 0 || k == 0) return fail(RQ_ERR_INVALID, "bad build arguments");
@@ -1139,6 +1192,7 @@ static rq_status from_arrays(uint32_t dim, uint64_t n, uint32_t k, const float *
                              const float *centroids, const uint32_t *offsets, const uint32_t *map_ids,
                              const uint64_t *codes, const rq_factor_t *factors, rq_index **out) {
     RQC(ensure_device());
+    RQC(ensure_kernel_attributes());
     if (!out) return fail(RQ_ERR_INVALID, "null out pointer");
     *out = nullptr;
     if (dim == 0 || dim % 64 != 0) return fail(RQ_ERR_DIM_MISMATCH, "dim must be a non-zero multiple of 64 (rabitq.rs:109)");
@@ -1189,6 +1243,7 @@ rq_status rq_init(int device) {
 rq_status rq_kmeans_device(const float *d_base, uint64_t n, uint32_t d, uint32_t k, uint32_t iters,
                            uint32_t points_per_centroid, uint64_t seed, float *d_centroids_out) {
     RQC(ensure_device());
+    RQC(ensure_kernel_attributes());
     if (!d_base || !d_centroids_out || n == 0 || d == 0 || k == 0) return fail(RQ_ERR_INVALID, "bad k-means arguments");
     const uint32_t dim = (d + 63) / 64 * 64;
     if (dim > 4096) return fail(RQ_ERR_UNSUPPORTED, "dim > 4096 not supported");
@@ -1279,8 +1334,16 @@ rq_status rq_load_dir(const char *dir, rq_index **out) {
     RQC(read_vecs_file(d + "/base.fvecs", 4, base));
     const uint32_t dim = (uint32_t)ortho.lens.size();  // :108 dim = orthogonal.nrows()
     if (dim == 0 || dim % 64 != 0) return fail(RQ_ERR_DIM_MISMATCH, "orthogonal.fvecs: dim % 64 != 0 (rabitq.rs:109)");
-    if (cent.lens.size() != dim || oi.lens.empty()) return fail(RQ_ERR_IO, "malformed index directory");
+    if (cent.lens.size() != dim || oi.lens.size() != 2) return fail(RQ_ERR_IO, "malformed index directory");
     const uint32_t k = cent.lens[0];
+    // every record length is checked before anything is indexed by it (the reference's matrix_from_fvecs panics on
+    // ragged input, src/utils.rs:44-49)
+    for (uint32_t l : ortho.lens)
+        if (l != dim) return fail(RQ_ERR_IO, "orthogonal.fvecs is not dim x dim");
+    for (uint32_t l : cent.lens)
+        if (l != k) return fail(RQ_ERR_IO, "centroids.fvecs is not dim records of k values");
+    for (uint32_t l : base.lens)
+        if (l != dim) return fail(RQ_ERR_IO, "base.fvecs record length != dim");
     // centroids.fvecs holds the dim x k matrix row-wise: un-transpose to k x dim
     std::vector<float> c((size_t)k * dim);
     const float *ct = reinterpret_cast<const float *>(cent.data.data());
@@ -1292,8 +1355,12 @@ rq_status rq_load_dir(const char *dir, rq_index **out) {
     for (uint32_t l : oi.lens) total += l;
     if (first != k + 1) return fail(RQ_ERR_IO, "offsets record length != k + 1");
     const uint64_t n = last;
-    if (fac.data.size() != n * 16 || bin.data.size() != n * (dim / 64) * 8 || base.data.size() != n * dim * 4)
+    if (fac.data.size() != n * 16 || bin.data.size() != n * (dim / 64) * 8 || base.data.size() != n * dim * 4 ||
+        base.lens.size() != n)
         return fail(RQ_ERR_IO, "index arrays disagree on n");
+    if (oip[k] != n) return fail(RQ_ERR_IO, "offsets[k] != number of vectors");
+    for (uint32_t j = 0; j < k; ++j)
+        if (oip[j] > oip[j + 1]) return fail(RQ_ERR_IO, "offsets are not non-decreasing");
     return from_arrays(dim, n, k, reinterpret_cast<const float *>(base.data.data()),
                        reinterpret_cast<const float *>(ortho.data.data()), c.data(), oip, oip + (total - last),
                        reinterpret_cast<const uint64_t *>(bin.data.data()),
@@ -1454,11 +1521,7 @@ rq_status rq_merge_smallest_u64_device(const uint64_t *d_in, uint32_t world, uin
     if (nq == 0 || m_out == 0) return RQ_OK;
     const uint64_t m = (uint64_t)world * width;
     if (m == 0 || m > 16384) return fail(RQ_ERR_UNSUPPORTED, "world * width must be in [1, 16384]");
-    static std::once_flag once;
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(merge_smallest_u64_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
-    });
+    RQC(ensure_kernel_attributes());
     // on the legacy default stream, asynchronously: ordered with the caller's default-stream work (torch's
     // current stream is that stream unless the caller changed it), like a library call of its own framework
     merge_smallest_u64_kernel<<<nq, 256, (size_t)pow2_ceil((uint32_t)m) * 8, nullptr>>>(
@@ -1593,6 +1656,11 @@ rq_status rq_set_option(const char *name, int value) {
         g_stage_growth = value;
         return RQ_OK;
     }
+    if (std::string(name) == "max_scan_blocks") {  // test hook: blocks per scan launch (0 = the hardware bound), forces chunked stages
+        if (value < 0) return fail(RQ_ERR_INVALID, "max_scan_blocks must be >= 0");
+        g_max_scan_blocks = value == 0 ? RQ_MAX_BLOCKS_256 : std::min<uint32_t>((uint32_t)value, RQ_MAX_BLOCKS_256);
+        return RQ_OK;
+    }
     if (std::string(name) == "scan_debug") {  // developer ablations of the matrix-core scan (results are WRONG when != 0)
         g_scan_dbg = value;
         return RQ_OK;
@@ -1651,6 +1719,7 @@ rq_status rq_rotate_device(const rq_index *idx, const float *d_x, uint64_t n, fl
 rq_status rq_quantize_pack(const float *x_rot, uint64_t n, uint32_t dim, const float *centroids_rot, uint32_t k,
                            uint32_t *out_label, float *out_dist, uint64_t *out_codes, rq_factor_t *out_factors) {
     RQC(ensure_device());
+    RQC(ensure_kernel_attributes());
     if (!x_rot || !centroids_rot || !out_label || !out_dist || !out_codes || !out_factors)
         return fail(RQ_ERR_INVALID, "null argument");
     if (dim == 0 || dim % 64 || k == 0) return fail(RQ_ERR_DIM_MISMATCH, "dim must be a multiple of 64, k > 0");
