@@ -164,6 +164,24 @@ rq_status rq_query_batch_device_probed(const rq_index *idx, const float *d_queri
                                        uint32_t topk, int heuristic_rank, float *d_out_dist, uint32_t *d_out_id,
                                        uint32_t *d_out_n);
 
+/* List partitioner: whole IVF lists to `world` shards, greedy by list length (longest first,
+ * each to the least-loaded shard; deterministic).  out_owner[c] = shard of list c (k entries, host);
+ * out_load (world entries, host, may be NULL) = vectors per shard.  The reference has no counterpart (single process). */
+rq_status rq_partition_lists(const rq_index *idx, uint32_t world, uint32_t *out_owner, uint64_t *out_load);
+/* Carve shard `rank` out of an index: a new index with the same dim / k / rotation / (replicated) centroids that
+ * holds only the lists with owner[c] == rank (the others are empty); map_ids keep the ORIGINAL ids, so per-shard
+ * results are global.  The source index is unchanged; free both with rq_free. */
+rq_status rq_shard_index(const rq_index *idx, const uint32_t *owner, uint32_t rank, rq_index **out);
+/* The whole multi-GPU step behind the C ABI, for hosts without torch: answer the batch against this rank's shard
+ * (all ranks rank the same replicated centroids, so they walk the same probe list), all-gather the per-shard top-k
+ * as u64 keys with ONE ncclAllGather on `nccl_comm` (an ncclComm_t of `world` ranks created by the caller with
+ * ncclCommInitRank; may be NULL when world == 1) and merge: every rank receives the same global top-k, ascending
+ * by (distance, id); ids are shard-local map_ids + id_offset (u32).  RCCL is resolved at first use from the
+ * host process (or RABITQ_RCCL_LIB), so the library itself does not link against it. */
+rq_status rq_query_batch_sharded_device(const rq_index *shard, void *nccl_comm, uint32_t world, uint32_t id_offset,
+                                        const float *d_queries, uint32_t nq, uint32_t len, uint32_t probe, uint32_t topk,
+                                        int heuristic_rank, float *d_out_dist, uint32_t *d_out_id, uint32_t *d_out_n);
+
 /* ---- metrics: METRICS, src/metrics.rs:65 ------------------------------------------------------ */
 rq_status rq_metrics(rq_metrics_t *out);
 rq_status rq_metrics_reset(void);

@@ -22,7 +22,7 @@ STATUS_NAMES = {0: "RQ_OK", -1: "RQ_ERR_INVALID", -2: "RQ_ERR_DIM_MISMATCH", -3:
 EXPORTS = [
     "rq_version", "rq_last_error", "rq_init", "rq_build", "rq_build_device", "rq_build_from_path", "rq_kmeans_device", "rq_load_dir",
     "rq_dump_dir", "rq_free", "rq_from_arrays", "rq_info", "rq_get_array", "rq_get_device_ptr", "rq_query",
-    "rq_query_batch", "rq_query_batch_device", "rq_query_batch_device_begin", "rq_query_batch_device_end", "rq_coarse_topk_device", "rq_merge_smallest_u64_device", "rq_query_batch_device_probed", "rq_metrics", "rq_metrics_reset", "rq_rotate", "rq_rotate_device",
+    "rq_query_batch", "rq_query_batch_device", "rq_query_batch_device_begin", "rq_query_batch_device_end", "rq_coarse_topk_device", "rq_merge_smallest_u64_device", "rq_query_batch_device_probed", "rq_partition_lists", "rq_shard_index", "rq_query_batch_sharded_device", "rq_metrics", "rq_metrics_reset", "rq_rotate", "rq_rotate_device",
     "rq_quantize_pack",
     "rq_coarse_rank", "rq_query_prep", "rq_scan", "rq_rerank", "rq_set_profiling", "rq_set_option", "rq_last_profile",
 ]
@@ -94,6 +94,9 @@ def lib():
         "rq_coarse_topk_device": (i32, [vp, f32p, u32, u32, u32, u32, u32, u32p, f32p]),
         "rq_merge_smallest_u64_device": (i32, [vp, u32, u32, u32, u32, vp]),
         "rq_query_batch_device_probed": (i32, [vp, f32p, u32, u32, u32p, f32p, u32, u32, C.c_int, f32p, u32p, u32p]),
+        "rq_partition_lists": (i32, [vp, u32, u32p, u64p]),
+        "rq_shard_index": (i32, [vp, u32p, u32, pp]),
+        "rq_query_batch_sharded_device": (i32, [vp, vp, u32, u32, f32p, u32, u32, u32, u32, C.c_int, f32p, u32p, u32p]),
         "rq_metrics": (i32, [C.POINTER(MetricsT)]),
         "rq_metrics_reset": (i32, []),
         "rq_rotate": (i32, [f32p, u64, u32, f32p, C.c_int, f32p]),

@@ -20,6 +20,8 @@
 #include <string>
 #include <vector>
 #include <sys/stat.h>
+#include <dlfcn.h>
+#include <queue>
 
 #include "common.h"
 #include "kernels_build.h"
@@ -202,6 +204,10 @@ struct Workspace {
     DevBuf<unsigned long long> rough_cnt, totals, surv_cnt;
     DevBuf<SurvRec> surv, arr;
     DevBuf<RunRec> runs;
+    // multi-GPU step (rq_query_batch_sharded_device): this shard's results, the all-gathered keys, the merged keys
+    DevBuf<float> sh_dist;
+    DevBuf<uint32_t> sh_id, sh_n;
+    DevBuf<unsigned long long> sh_packed, sh_gathered, sh_merged;
     unsigned long long *h_totals = nullptr;  // pinned, 8
     Prof prof;
     ~Workspace() {
@@ -237,6 +243,57 @@ __global__ void gather_rows_kernel(const float *__restrict__ in, const uint32_t 
     if (i >= (uint64_t)nrows * len) return;
     uint32_t r = (uint32_t)(i / len), c = (uint32_t)(i - (uint64_t)r * len);
     out[i] = in[(uint64_t)rows[r] * len + c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU helpers: carving a shard out of an index, (distance, id) <-> u64 merge keys
+// ------------------------------------------------------------------------------------------------
+// one wave per destination position p of the shard: its list c is found by bisection over the shard's offsets,
+// its source position is old_offsets[c] + (p - new_offsets[c])
+__global__ __launch_bounds__(256) void shard_gather_kernel(const uint32_t *__restrict__ new_off, const uint32_t *__restrict__ old_off,
+                                                           uint32_t k, uint64_t n_local, uint32_t dim,
+                                                           const float *__restrict__ base_in, const uint64_t *__restrict__ codes_in,
+                                                           const float4 *__restrict__ factors_in, const uint32_t *__restrict__ ids_in,
+                                                           float *__restrict__ base_out, uint64_t *__restrict__ codes_out,
+                                                           float4 *__restrict__ factors_out, uint32_t *__restrict__ ids_out) {
+    const uint32_t lane = threadIdx.x & 63, W = dim >> 6;
+    for (uint64_t p = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < n_local; p += (uint64_t)gridDim.x * 4) {
+        uint32_t lo = 0, hi = k;  // largest c with new_off[c] <= p (empty lists share their start with the next one)
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (new_off[mid] <= p) lo = mid;
+            else hi = mid;
+        }
+        const uint64_t src = (uint64_t)old_off[lo] + (p - new_off[lo]);
+        for (uint32_t e = lane; e < dim; e += 64) base_out[p * dim + e] = base_in[src * dim + e];
+        for (uint32_t w = lane; w < W; w += 64) codes_out[p * W + w] = codes_in[src * W + w];
+        if (lane == 0) {
+            factors_out[p] = factors_in[src];
+            ids_out[p] = ids_in[src];
+        }
+    }
+}
+// per-shard top-k -> merge keys (Ord32 image << 32 | global id); entries past the valid count sort last
+__global__ void pack_topk_keys_kernel(const float *__restrict__ dist, const uint32_t *__restrict__ id, const uint32_t *__restrict__ cnt,
+                                      uint32_t nq, uint32_t topk, uint32_t id_offset, unsigned long long *__restrict__ keys) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq * topk) return;
+    const uint32_t b = i / topk, e = i - b * topk;
+    keys[i] = e < cnt[b] ? (((unsigned long long)ord32_biased(dist[i]) << 32) | (uint32_t)(id[i] + id_offset)) : ~0ull;
+}
+__global__ void unpack_topk_keys_kernel(const unsigned long long *__restrict__ keys, uint32_t nq, uint32_t topk,
+                                        float *__restrict__ dist, uint32_t *__restrict__ id, uint32_t *__restrict__ cnt) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nq) return;
+    uint32_t c = 0;
+    for (uint32_t e = 0; e < topk; ++e) {
+        const unsigned long long key = keys[(uint64_t)b * topk + e];
+        if (key == ~0ull) break;  // ascending: the padding comes last
+        dist[(uint64_t)b * topk + e] = ord32_unbias((uint32_t)(key >> 32));
+        id[(uint64_t)b * topk + e] = (uint32_t)key;
+        ++c;
+    }
+    cnt[b] = c;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -871,17 +928,19 @@ static rq_status conclude_query(uint32_t nq, bool heuristic, const uint32_t *d_o
 static rq_status query_device(rq_index *idx, const float *d_q, uint32_t nq, uint32_t len, uint32_t probe,
                               uint32_t topk, bool heuristic, float *d_out_dist, uint32_t *d_out_id,
                               uint32_t *d_out_n, const uint32_t *ext_cluster = nullptr,
-                              const float *ext_dist = nullptr) {
+                              const float *ext_dist = nullptr, Workspace *use_ws = nullptr) {
     RQC(validate_query(idx, d_q, len, probe, topk, d_out_dist, d_out_id, d_out_n));
     if (nq == 0) return RQ_OK;
     rq_profile_t prof;
     memset(&prof, 0, sizeof prof);
-    Workspace *ws = ws_acquire(idx);
+    Workspace *ws = use_ws ? use_ws : ws_acquire(idx);  // use_ws: the caller holds (and releases) the workspace
     struct Rel {
         rq_index *i;
         Workspace *w;
-        ~Rel() { ws_release(i, w); }
-    } rel{idx, ws};
+        ~Rel() {
+            if (w) ws_release(i, w);
+        }
+    } rel{idx, use_ws ? nullptr : ws};
     uint64_t tot_rough = 0, tot_precise = 0;
     const uint32_t npb = std::min(probe, idx->k);
     for (uint32_t q0 = 0, step_nq = 0; q0 < nq; q0 += step_nq) {
@@ -1632,6 +1691,156 @@ rq_status rq_query_batch(const rq_index *idx, const float *queries, uint32_t nq,
 rq_status rq_query(const rq_index *idx, const float *query, uint32_t len, uint32_t probe, uint32_t topk,
                    int heuristic_rank, float *out_dist, uint32_t *out_id, uint32_t *out_n) {
     return rq_query_batch(idx, query, 1, len, probe, topk, heuristic_rank, out_dist, out_id, out_n);
+}
+
+// ---- multi-GPU: list partitioner, shard carving, the sharded step over an RCCL communicator ------------------
+rq_status rq_partition_lists(const rq_index *idx, uint32_t world, uint32_t *out_owner, uint64_t *out_load) {
+    if (!idx || !out_owner || world == 0) return fail(RQ_ERR_INVALID, "bad partition arguments");
+    // whole lists to shards, greedy by list length (longest first, each to the least-loaded shard; ties: lower list
+    // id first, lower shard first): deterministic, so every rank computes the same assignment on its own
+    std::vector<uint32_t> off((size_t)idx->k + 1);
+    RQC(rq_get_array(idx, RQ_ARR_OFFSETS, off.data(), off.size() * 4));
+    std::vector<uint32_t> order(idx->k);
+    for (uint32_t c = 0; c < idx->k; ++c) order[c] = c;
+    std::stable_sort(order.begin(), order.end(),
+                     [&](uint32_t a, uint32_t b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
+    typedef std::pair<uint64_t, uint32_t> LS;  // (load, shard): min-heap
+    std::priority_queue<LS, std::vector<LS>, std::greater<LS>> heap;
+    for (uint32_t r = 0; r < world; ++r) heap.push({0, r});
+    for (uint32_t c : order) {
+        LS t = heap.top();
+        heap.pop();
+        out_owner[c] = t.second;
+        t.first += off[c + 1] - off[c];
+        heap.push(t);
+    }
+    if (out_load) {
+        for (uint32_t r = 0; r < world; ++r) out_load[r] = 0;
+        for (uint32_t c = 0; c < idx->k; ++c) out_load[out_owner[c]] += off[c + 1] - off[c];
+    }
+    return RQ_OK;
+}
+
+rq_status rq_shard_index(const rq_index *idx, const uint32_t *owner, uint32_t rank, rq_index **out) {
+    RQC(ensure_device());
+    RQC(ensure_kernel_attributes());
+    if (!idx || !owner || !out) return fail(RQ_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const uint32_t k = idx->k, dim = idx->dim;
+    std::vector<uint32_t> off((size_t)k + 1), noff((size_t)k + 1);
+    RQC(rq_get_array(idx, RQ_ARR_OFFSETS, off.data(), off.size() * 4));
+    uint64_t n_local = 0;
+    for (uint32_t c = 0; c < k; ++c) {
+        noff[c] = (uint32_t)n_local;
+        if (owner[c] == rank) n_local += off[c + 1] - off[c];
+    }
+    noff[k] = (uint32_t)n_local;
+    std::unique_ptr<rq_index> sh(new rq_index());
+    sh->dim = dim, sh->k = k, sh->n = n_local, sh->W = idx->W;
+    RQC(sh->P.alloc((size_t)dim * dim));
+    RQC(sh->centroids.alloc((size_t)k * dim));
+    RQC(sh->offsets.alloc((size_t)k + 1));
+    RQC(sh->base.alloc(n_local * dim));
+    RQC(sh->codes.alloc(n_local * sh->W));
+    RQC(sh->factors.alloc(n_local));
+    RQC(sh->map_ids.alloc(n_local));
+    HIPC(hipMemcpy(sh->P.p, idx->P.p, (size_t)dim * dim * 4, hipMemcpyDeviceToDevice));
+    HIPC(hipMemcpy(sh->centroids.p, idx->centroids.p, (size_t)k * dim * 4, hipMemcpyDeviceToDevice));  // all centroids replicated
+    HIPC(hipMemcpy(sh->offsets.p, noff.data(), ((size_t)k + 1) * 4, hipMemcpyHostToDevice));
+    if (n_local)
+        shard_gather_kernel<<<(uint32_t)std::min<uint64_t>(ceil_div(n_local, 4), 1u << 20), 256>>>(
+            sh->offsets.p, idx->offsets.p, k, n_local, dim, idx->base.p, idx->codes.p, idx->factors.p, idx->map_ids.p,
+            sh->base.p, sh->codes.p, sh->factors.p, sh->map_ids.p);
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipGetLastError());
+    RQC(finish_index(sh.get()));
+    *out = sh.release();
+    return RQ_OK;
+}
+
+// RCCL is bound at first use, not at link time: the library loads (and every single-GPU entry works) on a host
+// without RCCL, and a host that already carries RCCL (a Rust binary linked against it, torch) shares its copy, so
+// the communicator handle and the collective come from the same library.
+struct RcclApi {
+    int (*all_gather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    const char *(*error_string)(int) = nullptr;
+    std::string err;
+};
+static RcclApi *rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void *h = nullptr;
+        const char *env = getenv("RABITQ_RCCL_LIB");
+        if (env && *env) h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+        void *sym = h ? dlsym(h, "ncclAllGather") : dlsym(RTLD_DEFAULT, "ncclAllGather");
+        if (!sym && !h) {
+            for (const char *name : {"librccl.so.1", "librccl.so"}) {
+                h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (h) break;
+            }
+            sym = h ? dlsym(h, "ncclAllGather") : nullptr;
+        }
+        if (!sym) {
+            api.err = "RCCL not found (ncclAllGather): set RABITQ_RCCL_LIB to the librccl.so the communicator came from";
+            return;
+        }
+        api.all_gather = reinterpret_cast<decltype(api.all_gather)>(sym);
+        void *es = h ? dlsym(h, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString");
+        api.error_string = reinterpret_cast<decltype(api.error_string)>(es);
+    });
+    return &api;
+}
+#define RQ_NCCL_UINT64 5  // ncclUint64 (rccl.h: ncclDataType_t)
+
+rq_status rq_query_batch_sharded_device(const rq_index *shard, void *nccl_comm, uint32_t world, uint32_t id_offset,
+                                        const float *d_queries, uint32_t nq, uint32_t len, uint32_t probe, uint32_t topk,
+                                        int heuristic_rank, float *d_out_dist, uint32_t *d_out_id, uint32_t *d_out_n) {
+    RQC(ensure_device());
+    RQC(ensure_kernel_attributes());
+    if (!shard || !d_queries || !d_out_dist || !d_out_id || !d_out_n || world == 0)
+        return fail(RQ_ERR_INVALID, "null argument");
+    if (world > 1 && !nccl_comm) return fail(RQ_ERR_INVALID, "world > 1 needs an RCCL communicator");
+    if (topk == 0 || (uint64_t)world * topk > 16384) return fail(RQ_ERR_UNSUPPORTED, "world * topk must be in [1, 16384]");
+    if (nq == 0) return RQ_OK;
+    rq_index *mi = const_cast<rq_index *>(shard);
+    Workspace *ws = ws_acquire(mi);  // one workspace for the whole step: the local query, then the collective on its stream
+    struct Rel {
+        rq_index *i;
+        Workspace *w;
+        ~Rel() { ws_release(i, w); }
+    } rel{mi, ws};
+    if (!ws->stream) HIPC(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
+    hipStream_t st = ws->stream;
+    const uint64_t cells = (uint64_t)nq * topk;
+    RQC(ws->sh_dist.ensure(cells));
+    RQC(ws->sh_id.ensure(cells));
+    RQC(ws->sh_n.ensure(nq));
+    RQC(ws->sh_packed.ensure(cells));
+    RQC(ws->sh_gathered.ensure(cells * world));
+    RQC(ws->sh_merged.ensure(cells));
+    // 1. this shard's answer: every rank ranks all (replicated) centroids, so all ranks walk the same probe list and a
+    //    list another rank owns is simply empty here (skipped before any per-pair work)
+    rq_status qs = query_device(mi, d_queries, nq, len, probe, topk, heuristic_rank != 0, ws->sh_dist.p, ws->sh_id.p, ws->sh_n.p,
+                                nullptr, nullptr, ws);
+    if (qs != RQ_OK && qs != RQ_ERR_EMPTY) return qs;  // an empty shard result is fine: another shard may hold the neighbours
+    // 2. one all-gather of nq x topk u64 keys per rank (latency-bound on xGMI), 3. k-way merge on every rank
+    pack_topk_keys_kernel<<<ceil_div(cells, 256), 256, 0, st>>>(ws->sh_dist.p, ws->sh_id.p, ws->sh_n.p, nq, topk, id_offset,
+                                                                ws->sh_packed.p);
+    const unsigned long long *gathered = ws->sh_packed.p;
+    if (nccl_comm) {  // also with a communicator of one rank (the collective then copies)
+        RcclApi *api = rccl_api();
+        if (!api->all_gather) return fail(RQ_ERR_UNSUPPORTED, api->err);
+        const int rc = api->all_gather(ws->sh_packed.p, ws->sh_gathered.p, cells, RQ_NCCL_UINT64, nccl_comm, st);
+        if (rc != 0)
+            return fail(RQ_ERR_HIP, std::string("ncclAllGather: ") + (api->error_string ? api->error_string(rc) : "error"));
+        gathered = ws->sh_gathered.p;
+    }
+    merge_smallest_u64_kernel<<<nq, 256, (size_t)pow2_ceil(world * topk) * 8, st>>>(gathered, world, nq, topk, topk, ws->sh_merged.p);
+    unpack_topk_keys_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(ws->sh_merged.p, nq, topk, d_out_dist, d_out_id, d_out_n);
+    HIPC(hipStreamSynchronize(st));
+    HIPC(hipGetLastError());
+    return RQ_OK;
 }
 
 rq_status rq_metrics(rq_metrics_t *out) {

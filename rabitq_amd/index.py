@@ -208,6 +208,31 @@ class RaBitQ:
                                                  C.c_void_p(out_dist_ptr), C.c_void_p(out_id_ptr), C.c_void_p(out_n_ptr)))
 
 
+    def partition_lists(self, world: int):
+        """Greedy-by-length assignment of whole lists to `world` shards -> (owner u32[k], load u64[world])."""
+        owner = np.zeros(self.k, dtype=np.uint32)
+        load = np.zeros(world, dtype=np.uint64)
+        check(lib().rq_partition_lists(self._h, world, _addr(owner), _addr(load)))
+        return owner, load
+
+    def shard(self, owner, rank: int) -> "RaBitQ":
+        """The shard of `rank`: same centroids and rotation, only the lists with owner[c] == rank (original ids kept)."""
+        owner = np.ascontiguousarray(owner, dtype=np.uint32)
+        assert owner.size == self.k
+        h = C.c_void_p()
+        check(lib().rq_shard_index(self._h, _addr(owner), rank, C.byref(h)))
+        return RaBitQ(h)
+
+    def query_batch_sharded_device(self, comm: int, world: int, id_offset: int, q_ptr: int, nq: int, length: int,
+                                   probe: int, topk: int, out_dist_ptr: int, out_id_ptr: int, out_n_ptr: int,
+                                   heuristic_rank: bool = False) -> None:
+        """The multi-GPU step through the C ABI: local shard query, ONE ncclAllGather on `comm` (an ncclComm_t address;
+        0 when world == 1), k-way merge.  Every rank gets the same global top-k."""
+        check(lib().rq_query_batch_sharded_device(self._h, C.c_void_p(comm), world, id_offset, C.c_void_p(q_ptr), nq, length,
+                                                  probe, topk, int(heuristic_rank), C.c_void_p(out_dist_ptr),
+                                                  C.c_void_p(out_id_ptr), C.c_void_p(out_n_ptr)))
+
+
 # ---- METRICS (src/metrics.rs) --------------------------------------------------------------------
 def metrics() -> dict:
     m = MetricsT()

@@ -1,0 +1,89 @@
+"""One rank of the two-rank HIP sharded step (tests/test_sharded_gpu.py starts two of these on the same GPU with
+the gloo backend: RCCL refuses two ranks on one device, and only the collective differs).
+
+Every rank builds the same index from the same seeded data, carves its shard out of it, and answers the same
+batch two ways:
+  A  arbitrary partition (rq_partition_lists, greedy by list length), replicated coarse ranking: the shard runs the
+     ordinary pipeline (lists it does not own are empty), ONE all-gather of per-shard top-k, merge;
+  B  contiguous partition, sharded coarse ranking: rq_coarse_topk_device over the rank's own lists -> all-gather ->
+     merged probe lists -> rq_query_batch_device_probed -> all-gather of per-shard top-k, merge.
+Rank 0 writes the merged results to argv[1] (npz)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def case_data():
+    from tests import synth
+    n, d, k, nq = 20000, 128, 40, 200
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.9, seed=71, centre_scale=0.6)     # overlapping clusters
+    rng = np.random.default_rng(72)
+    sizes = rng.zipf(1.5, size=k).clip(1, 60)                                        # unbalanced lists
+    x[: int(n * 0.3)] = (centres[rng.choice(k, int(n * 0.3), p=sizes / sizes.sum())] +
+                         0.9 * rng.standard_normal((int(n * 0.3), d))).astype(np.float32)
+    queries, _, _ = synth.mixture(nq, d, k, sigma=0.9, seed=73, centre_scale=0.6)
+    return x, centres, synth.random_orthogonal(d, seed=74), queries, 12, 10
+
+
+def main():
+    out_path = sys.argv[1]
+    import torch
+    import torch.distributed as dist
+    import rabitq_amd
+    from rabitq_amd import _lib, sharding
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _lib.check(_lib.lib().rq_init(0))
+    dev = torch.device("cuda", 0)
+    x, centres, P, queries, probe, topk = case_data()
+    n, d = x.shape
+    k, nq = centres.shape[0], queries.shape[0]
+    full = rabitq_amd.RaBitQ.build(x, centres, P)
+    q = torch.from_numpy(queries).to(dev)
+    od = torch.empty((nq, topk), device=dev)
+    oi = torch.zeros((nq, topk), device=dev, dtype=torch.int32)
+    on = torch.zeros(nq, device=dev, dtype=torch.int32)
+    res = {}
+
+    # ---- A: greedy partition, replicated coarse ranking ------------------------------------------------------
+    owner, load = full.partition_lists(world)
+    sh = full.shard(owner, rank)
+    assert sh.n == int(load[rank]) and sh.k == k
+    sh.query_batch_device(q.data_ptr(), nq, d, probe, topk, od.data_ptr(), oi.data_ptr(), on.data_ptr())
+    pay = sharding.pack_topk(od, oi.to(torch.int64) & 0xFFFFFFFF, on, 0).cpu()      # shard map_ids are global already
+    md, mi, mn = sharding.merge_shard_topk(pay, topk, id_bound=n)
+    res.update(a_dist=md.numpy(), a_ids=mi.numpy(), a_cnt=mn.numpy(), owner=owner, load=load)
+    sh.close()
+
+    # ---- B: contiguous halves, sharded coarse ranking + caller-supplied probe lists ---------------------------
+    bounds = [(r * k) // world for r in range(world + 1)]
+    owner_b = np.zeros(k, np.uint32)
+    for r in range(world):
+        owner_b[bounds[r]:bounds[r + 1]] = r
+    shb = full.shard(owner_b, rank)
+    pc = torch.zeros((nq, probe), device=dev, dtype=torch.int32)
+    pdd = torch.zeros((nq, probe), device=dev, dtype=torch.float32)
+    shb.coarse_topk_device(q.data_ptr(), nq, d, bounds[rank], bounds[rank + 1], probe, pc.data_ptr(), pdd.data_ptr())
+    mc, mdist = sharding.merge_probe_lists(pc.cpu(), pdd.cpu(), probe)               # one all-gather (gloo)
+    mc_d, md_d = mc.to(dev), mdist.to(dev)
+    torch.cuda.synchronize()
+    shb.query_batch_device_probed(q.data_ptr(), nq, d, mc_d.data_ptr(), md_d.data_ptr(), probe, topk, od.data_ptr(),
+                                  oi.data_ptr(), on.data_ptr())
+    pay = sharding.pack_topk(od, oi.to(torch.int64) & 0xFFFFFFFF, on, 0).cpu()
+    bd, bi, bn = sharding.merge_shard_topk(pay, topk, id_bound=n)
+    res.update(b_dist=bd.numpy(), b_ids=bi.numpy(), b_cnt=bn.numpy(), b_probe=mc.numpy().view(np.uint32),
+               b_probe_dist=mdist.numpy())
+    shb.close()
+    full.close()
+    dist.barrier()
+    if rank == 0:
+        np.savez(out_path, **res)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

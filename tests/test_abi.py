@@ -66,3 +66,45 @@ def test_vecs_roundtrip(tmp_path):
     assert len(raw) == 3 * (4 + 16) and int.from_bytes(raw[:4], "little") == 4
     vecs.write_vecs(tmp_path / "b.u64vecs", [np.array([1, 2**63], dtype=np.uint64)])
     assert vecs.read_vecs(tmp_path / "b.u64vecs", np.uint64)[0].tolist() == [1, 2**63]
+
+
+def _write_dir(tmp, dim=64, k=3, n=5, **bad):
+    """A well-formed five-file index directory (src/rabitq.rs:128-156), optionally broken in one place."""
+    from rabitq_amd import vecs
+    rng = np.random.default_rng(0)
+    os.makedirs(tmp, exist_ok=True)
+    ortho = [rng.standard_normal(dim).astype(np.float32) for _ in range(dim)]
+    cent = [rng.standard_normal(k).astype(np.float32) for _ in range(dim)]
+    base = [rng.standard_normal(dim).astype(np.float32) for _ in range(n)]
+    offsets = np.array([0, 2, 2, n], np.uint32)
+    ids = np.arange(n, dtype=np.uint32)
+    if bad.get("short_ortho_row"):
+        ortho[7] = ortho[7][:-1]
+    if bad.get("ragged_centroids"):
+        cent[3] = cent[3][:-1]
+    if bad.get("short_base_row"):
+        base[1] = base[1][:-4]
+    if bad.get("bad_offsets"):
+        offsets = np.array([0, 4, 2, n], np.uint32)
+    if bad.get("offsets_end"):
+        offsets = np.array([0, 2, 2, n - 1], np.uint32)
+    vecs.write_vecs(os.path.join(tmp, "orthogonal.fvecs"), ortho)
+    vecs.write_vecs(os.path.join(tmp, "centroids.fvecs"), cent)
+    vecs.write_vecs(os.path.join(tmp, "base.fvecs"), base)
+    recs = [offsets, ids] + ([ids] if bad.get("three_records") else [])
+    vecs.write_vecs(os.path.join(tmp, "offsets_ids.ivecs"), recs)
+    vecs.write_vecs(os.path.join(tmp, "factors.fvecs"), [rng.standard_normal(4 * n).astype(np.float32)])
+    vecs.write_vecs(os.path.join(tmp, "x_binary_vec.u64vecs"), [np.arange(n * dim // 64, dtype=np.uint64)])
+
+
+@pytest.mark.parametrize("bad", ["short_ortho_row", "ragged_centroids", "short_base_row", "bad_offsets", "offsets_end",
+                                 "three_records"])
+def test_load_dir_rejects_malformed_directories(L, tmp_path, bad):
+    """rq_load_dir validates every record length before indexing by it (the reference's matrix_from_fvecs panics on
+    ragged input): RQ_ERR_IO, no heap over-read, and no device needed to say so."""
+    import ctypes as C
+    _write_dir(str(tmp_path / "idx"), **{bad: True})
+    h = C.c_void_p()
+    st = L.rq_load_dir(os.fsencode(str(tmp_path / "idx")), C.byref(h))
+    assert st == -3, (bad, st, L.rq_last_error())
+    assert not h.value

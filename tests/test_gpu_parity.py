@@ -541,6 +541,53 @@ def test_scan_implementations_match_oracle(rq, oracle, impl, n, d, k, nq):
     oidx.close()
 
 
+# A stage whose grid exceeds the launch bound is issued as several launches over (group, tile) sub-ranges
+# (launch_scan_chunks): lowered test-only bound, one artificially long list, both implementations, both work layouts.
+@pytest.mark.parametrize("impl", [1, 2])
+@pytest.mark.parametrize("max_blocks", [1, 5])
+def test_scan_grid_chunking_matches_oracle(rq, oracle, impl, max_blocks):
+    from rabitq_amd import index as ix
+    n, d = 9000, 128
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    centres = np.concatenate([np.zeros((1, d), np.float32), rng.standard_normal((5, d)).astype(np.float32) * 4])
+    x[:300] += centres[1 + (np.arange(300) % 5)]           # one list of ~8700 (many tiles), five short ones
+    P = synth.random_orthogonal(d, seed=78)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    gidx = rq.RaBitQ.build(x, centres, P)
+    assert gidx.max_list_len > 8000
+    queries = (rng.standard_normal((70, d)) * 0.5).astype(np.float32)
+    ix.set_option("scan_impl", impl)
+    ix.set_option("max_scan_blocks", max_blocks)
+    try:
+        _compare_with_oracle(rq, oracle, oidx, gidx, queries, 6, 10, False)      # cluster-major stages
+        _compare_with_oracle(rq, oracle, oidx, gidx, queries[:3], 6, 10, False)  # pair-major stages
+        _compare_with_oracle(rq, oracle, oidx, gidx, queries, 2, 30, True)
+    finally:
+        ix.set_option("max_scan_blocks", 0)
+        ix.set_option("scan_impl", 0)
+    gidx.close()
+    oidx.close()
+
+
+def test_wide_vectors_dim_3072(rq, oracle):
+    # dim in (2048, 4096]: assign_generic_kernel<8> needs > 64 KiB of dynamic LDS, so the attribute must be in
+    # place before the FIRST build / quantize of a process (ensure_kernel_attributes); generic-W scan (W = 48)
+    n, d, k = 600, 3072, 5
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.8, seed=31, centre_scale=0.6)
+    P = synth.random_orthogonal(d, seed=32)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    gidx = rq.RaBitQ.build(x, centres, P)
+    assert np.array_equal(gidx.map_ids, oidx.map_ids) and np.array_equal(gidx.offsets, oidx.offsets)
+    assert_bits_equal(gidx.codes, oidx.codes, "codes")
+    assert_bits_equal(gidx.factors, oidx.factors, "factors")
+    queries, _, _ = synth.mixture(12, d, k, sigma=0.8, seed=33, centre_scale=0.6)
+    _compare_with_oracle(rq, oracle, oidx, gidx, queries, k, 10, False)
+    _compare_with_oracle(rq, oracle, oidx, gidx, queries, 2, 5, True)
+    gidx.close()
+    oidx.close()
+
+
 @pytest.mark.parametrize("impl", [1, 2])
 def test_scan_degenerate_factors_both_implementations(rq, oracle, impl):
     # vectors that coincide with their centroid (zero residual: norm not `is_normal` -> ip = 0.8, factor_ip = -0,
