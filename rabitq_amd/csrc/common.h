@@ -98,3 +98,19 @@ struct __attribute__((aligned(8))) PairScalars {
 struct FactorStats {
     float cds_max, ppc_absmax, eb_max, invfip_absmax;
 };
+
+// The raw vectors the re-ranker gathers (src/rerank.rs:85-90; `base`, src/rabitq.rs:59, cluster order).  At
+// 100M x 768 they are 307 GB, more than the 288 GB of HBM: rows [0, n_dev) live in HBM, rows [n_dev, n) in pinned
+// host memory that the kernels address directly over the host link (the reference's own answer to base > memory
+// is a tiered store as well: crates/disk/src/cache.rs).  Small indexes have n_dev == n and never touch `host`.
+struct BaseView {
+    const float *dev;   // rows [0, n_dev)
+    const float *host;  // rows [n_dev, n): device-visible address of the pinned host tier (nullptr if none)
+    uint64_t n_dev;
+    __host__ __device__ __forceinline__ const float *row(uint64_t p, uint32_t dim) const {
+        return p < n_dev ? dev + p * dim : host + (p - n_dev) * dim;
+    }
+    __host__ __device__ __forceinline__ float *row_mut(uint64_t p, uint32_t dim) const {
+        return const_cast<float *>(row(p, dim));
+    }
+};

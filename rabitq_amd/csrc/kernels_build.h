@@ -397,27 +397,35 @@ __global__ __launch_bounds__(1024) void list_sort_kernel(unsigned long long *__r
     }
 }
 
-// gather into cluster order: one wave per destination position, grid-stride (HIP silently wraps a
-// launch whose gridDim.x * blockDim.x reaches 2^32, so the grid is capped and the kernel loops)
-__global__ __launch_bounds__(256) void gather_kernel(const unsigned long long *__restrict__ keys, uint64_t n,
-                                                     const float *__restrict__ base_in, uint32_t d,
-                                                     uint32_t dim, const uint64_t *__restrict__ codes_in,
-                                                     const float4 *__restrict__ factors_in,
-                                                     float *__restrict__ base_out,
-                                                     uint64_t *__restrict__ codes_out,
-                                                     float4 *__restrict__ factors_out,
-                                                     uint32_t *__restrict__ map_ids) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t W = dim >> 6;
-    for (uint64_t p = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < n; p += (uint64_t)gridDim.x * 4) {
+// Cluster order, small arrays: destination position p takes the code / factors of original vector id = low 32 bits of
+// the sorted key; map_ids[p] = id (src/rabitq.rs:250) and the inverse permutation pos_of_id[id] = p, which the
+// placement pass uses to put every raw vector at its final position.  Grid-stride (HIP silently wraps a launch
+// whose gridDim.x * blockDim.x reaches 2^32).
+__global__ __launch_bounds__(256) void order_gather_kernel(const unsigned long long *__restrict__ keys, uint64_t n, uint32_t W,
+                                                           const uint64_t *__restrict__ codes_in,
+                                                           const float4 *__restrict__ factors_in,
+                                                           uint64_t *__restrict__ codes_out, float4 *__restrict__ factors_out,
+                                                           uint32_t *__restrict__ map_ids, uint32_t *__restrict__ pos_of_id) {
+    for (uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (uint64_t)gridDim.x * 256) {
         const uint32_t id = (uint32_t)keys[p];
-        for (uint32_t e = lane; e < dim; e += 64)
-            base_out[p * dim + e] = e < d ? base_in[(uint64_t)id * d + e] : 0.0f;
-        for (uint32_t w = lane; w < W; w += 64) codes_out[p * W + w] = codes_in[(uint64_t)id * W + w];
-        if (lane == 0) {
-            factors_out[p] = factors_in[id];
-            map_ids[p] = id;
-        }
+        for (uint32_t w = 0; w < W; ++w) codes_out[p * W + w] = codes_in[(uint64_t)id * W + w];
+        factors_out[p] = factors_in[id];
+        map_ids[p] = id;
+        pos_of_id[id] = (uint32_t)p;
+    }
+}
+
+// Cluster order, raw vectors (src/rabitq.rs:244-247): rows i0 .. i0+m of the input (m x d, un-rotated) go to their
+// final positions, zero-padded to dim, in whichever tier holds that position (HBM, or pinned host memory written
+// over the host link).  One wave per row: contiguous read, contiguous 4*dim-byte write.
+__global__ __launch_bounds__(256) void place_rows_kernel(const float *__restrict__ rows, uint64_t i0, uint64_t m, uint32_t d,
+                                                         uint32_t dim, const uint32_t *__restrict__ pos_of_id,
+                                                         const BaseView out) {
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < m; r += (uint64_t)gridDim.x * 4) {
+        float *dst = out.row_mut(pos_of_id[i0 + r], dim);
+        const float *src = rows + r * d;
+        for (uint32_t e = lane; e < dim; e += 64) dst[e] = e < d ? src[e] : 0.0f;
     }
 }
 

@@ -1511,13 +1511,13 @@ __global__ __launch_bounds__(256) void scan_dense_kernel(const uint32_t *__restr
 // ------------------------------------------------------------------------------------------------
 // flat variant for the per-stage test entry rq_rerank: positions given directly
 __global__ __launch_bounds__(256) void accurate_flat_kernel(const uint32_t *__restrict__ pos, uint32_t m,
-                                                            const float *__restrict__ base,
+                                                            const BaseView base,
                                                             const float *__restrict__ q, uint32_t dim,
                                                             float *__restrict__ out) {
     const uint32_t l = threadIdx.x & 7;
     uint32_t i = blockIdx.x * 32 + (threadIdx.x >> 3);
     if (i >= m) return;
-    const float *x = base + (uint64_t)pos[i] * dim;
+    const float *x = base.row(pos[i], dim);
     float acc = 0.0f;
     for (uint32_t c = 0; c < dim; c += 8) {
         float d = x[c + l] - q[c + l];
@@ -1750,11 +1750,11 @@ __device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, co
 // ((a0+a4)+(a1+a5)) + ((a2+a6)+(a3+a7)) needs one exchange between the two lanes.  A row is fetched 8
 // chunks (64 dimensions, 8 x 16 bytes per lane) at a time so that every lane keeps 8 loads in flight
 // (this is a random 512-byte-row gather: latency-bound unless enough bytes are outstanding).
-__device__ __forceinline__ void accurate_rows(SurvRec *__restrict__ recs, uint32_t n, const float *__restrict__ base,
+__device__ __forceinline__ void accurate_rows(SurvRec *__restrict__ recs, uint32_t n, const BaseView &base,
                                               const float *q_lds, uint32_t dim, uint32_t first, uint32_t step) {
     const uint32_t hf = threadIdx.x & 1;
     for (uint32_t i = first; i < n; i += step) {
-        const float *x = base + (uint64_t)recs[i].pos * dim + 4 * hf;
+        const float *x = base.row(recs[i].pos, dim) + 4 * hf;  // HBM tier, or the pinned host tier over the host link
         float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
         for (uint32_t c = 0; c < dim; c += 64) {  // dim is a multiple of 64
             float4 xv[8];
@@ -1781,7 +1781,7 @@ __device__ __forceinline__ void accurate_rows(SurvRec *__restrict__ recs, uint32
 template <bool HEURISTIC>
 __global__ __launch_bounds__(1024) void stage_finish_kernel(SurvRec *__restrict__ surv, RunRec *__restrict__ runs,
                                                            unsigned long long *__restrict__ surv_cnt, uint32_t cap,
-                                                           const float *__restrict__ base,
+                                                           const BaseView base,
                                                            const float *__restrict__ qpad, uint32_t dim, uint32_t topk,
                                                            ReplayState st) {
     __shared__ int32_t hkey[HEURISTIC ? 1 : RQ_MAX_TOPK];
@@ -1838,7 +1838,7 @@ __global__ void order_scatter_kernel(const uint32_t *__restrict__ probe_cluster,
 // grid (gx, nq); block 256
 __global__ __launch_bounds__(256) void accurate_kernel(SurvRec *__restrict__ surv,
                                                        const unsigned long long *__restrict__ surv_cnt,
-                                                       uint32_t cap, const float *__restrict__ base,
+                                                       uint32_t cap, const BaseView base,
                                                        const float *__restrict__ qpad, uint32_t dim,
                                                        const uint32_t *__restrict__ order) {
     // TWO lanes per candidate: lane half hf carries AVX lanes 4hf..4hf+3 (elements 8c + 4hf + 0..3, one

@@ -220,6 +220,15 @@ struct rq_index {
     uint32_t dim = 0, k = 0, W = 0, max_list_len = 0;
     uint32_t min_list_len = 0;  // 0 if some list is empty (then no slot bound can be derived from stream positions)
     uint64_t n = 0;
+    // raw vectors (cluster order, un-rotated): rows [0, n_dev) in HBM, rows [n_dev, n) in pinned host memory mapped
+    // into the device address space (BaseView); n_dev == n unless the vectors do not fit the HBM budget
+    uint64_t n_dev = 0;
+    float *base_host = nullptr;      // hipHostMalloc'ed (mapped); host address
+    float *base_host_dev = nullptr;  // the same memory as the kernels address it
+    BaseView view() const { return BaseView{base.p, base_host_dev, n_dev}; }
+    ~rq_index() {
+        if (base_host) (void)hipHostFree(base_host);
+    }
     DevBuf<float> base, P, centroids, cent_t;
     DevBuf<uint32_t> offsets, map_ids;
     DevBuf<uint64_t> codes;
@@ -743,16 +752,16 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             pf.begin(PF_RERANK);
             const uint32_t fin_threads = nq <= 16 ? 1024u : 256u;  // a handful of queries: more lanes on each one's rerank
             if (qp.heuristic)
-                stage_finish_kernel<true><<<nq, fin_threads, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->base.p,
+                stage_finish_kernel<true><<<nq, fin_threads, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->view(),
                                                               qpad, dim, topk, rs);
             else
-                stage_finish_kernel<false><<<nq, fin_threads, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->base.p,
+                stage_finish_kernel<false><<<nq, fin_threads, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->view(),
                                                                qpad, dim, topk, rs);
             pf.end();
         } else {  // large batch: full-chip rerank, then run-directory sort, then one replay wave per query
             pf.begin(PF_RERANK);
             const uint32_t gx = std::max(1u, std::min(16u, 4096u / std::max(nq, 1u)));
-            accurate_kernel<<<dim3(gx, nq), 256, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.surv_cnt.p, qp.cap, idx->base.p, qpad, dim,
+            accurate_kernel<<<dim3(gx, nq), 256, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.surv_cnt.p, qp.cap, idx->view(), qpad, dim,
                                                                                     rerank_order);
             pf.end();
             pf.begin(PF_SORT);
@@ -2065,7 +2074,7 @@ rq_status rq_rerank(const rq_index *idx, const float *query_padded, const uint32
     RQC(dp.alloc(m));
     HIPC(hipMemcpy(dq.p, query_padded, idx->dim * 4, hipMemcpyHostToDevice));
     HIPC(hipMemcpy(dp.p, pos, m * 4, hipMemcpyHostToDevice));
-    accurate_flat_kernel<<<ceil_div(m, 32), 256>>>(dp.p, m, idx->base.p, dq.p, idx->dim, dout.p);
+    accurate_flat_kernel<<<ceil_div(m, 32), 256>>>(dp.p, m, idx->view(), dq.p, idx->dim, dout.p);
     HIPC(hipDeviceSynchronize());
     HIPC(hipGetLastError());
     HIPC(hipMemcpy(out_accurate, dout.p, m * 4, hipMemcpyDeviceToHost));

@@ -340,15 +340,21 @@ def test_cli_harness_build_then_load(rq, oracle, tmp_path, capsys):
 
 
 # ---- properties at larger sizes (what the oracle cannot check in seconds) ---------------------------
-@pytest.mark.parametrize("n,d,k,probe", [(2_000_000, 128, 1024, 32), (200_000, 768, 256, 32)])
+# (100M x 128, 4096 lists, nprobe 64) is BASELINE.json configs[2] at its full size.
+@pytest.mark.parametrize("n,d,k,probe", [(2_000_000, 128, 1024, 32), (200_000, 768, 256, 32), (100_000_000, 128, 4096, 64)])
 def test_large_index_properties(rq, n, d, k, probe):
     import torch
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)
     g.manual_seed(5)
     centres = torch.randn(k, d, generator=g, device=dev)
-    u = torch.randint(0, k, (n,), generator=g, device=dev)
-    x = centres[u] + 0.5 * torch.randn(n, d, generator=g, device=dev)
+    x = torch.empty((n, d), device=dev)
+    counts = torch.zeros(k, dtype=torch.int64, device=dev)
+    for ci, i0 in enumerate(range(0, n, 4_000_000)):       # chunked: no n x d temporaries beside the base itself
+        m = min(4_000_000, n - i0)
+        x[i0:i0 + m], u = synth.device_mixture_chunk(centres, i0, m, 0.5, ci, seed_base=500)
+        counts += torch.bincount(u, minlength=k)
+    del u
     nq = 256
     uq = torch.randint(0, k, (nq,), generator=g, device=dev)
     q = (centres[uq] + 0.5 * torch.randn(nq, d, generator=g, device=dev)).contiguous()
@@ -357,12 +363,12 @@ def test_large_index_properties(rq, n, d, k, probe):
     off, ids = idx.offsets.astype(np.int64), idx.map_ids
     assert off[0] == 0 and off[-1] == n and np.all(np.diff(off) >= 0)
     assert np.array_equal(np.sort(ids), np.arange(n, dtype=np.uint32))              # a permutation
-    assert np.array_equal(np.diff(off), torch.bincount(u, minlength=k).cpu().numpy())  # well separated mixture
+    assert np.array_equal(np.diff(off), counts.cpu().numpy())  # well separated mixture
     fac, codes = idx.factors, idx.codes
-    pop = np.zeros(n, np.int64)
+    pop = np.zeros(2000, np.int64)
     for w in range(codes.shape[1]):
-        pop += np.array([bin(int(v)).count("1") for v in codes[:2000, w]] + [0] * (n - 2000))
-    np.testing.assert_array_equal(fac[:2000, 1], fac[:2000, 0] * (2 * pop[:2000] - idx.dim).astype(np.float32))
+        pop += np.array([bin(int(v)).count("1") for v in codes[:2000, w]])
+    np.testing.assert_array_equal(fac[:2000, 1], fac[:2000, 0] * (2 * pop - idx.dim).astype(np.float32))
     # rotation is orthogonal and codes are the signs of the rotated residual: check a sample
     cent = idx.centroids
     sample = np.arange(0, n, n // 500)[:500]
