@@ -44,6 +44,13 @@ def main():
                     help="queries per step (throughput grows with the batch: more queries share each list in the matrix-core "
                          "scan; 10000 -> 1.6 M/s, 32768 -> 1.9 M/s on one MI355X)")
     ap.add_argument("--sigma", type=float, default=0.5)
+    ap.add_argument("--distribution", choices=["easy", "hard"], default="easy",
+                    help="easy = SURVEY.md 8(d) mixture with the true centres as centroids; hard = overlapping clusters, "
+                         "Zipf list sizes, k-means-trained centroids")
+    ap.add_argument("--hard-centre-ratio", type=float, default=1.0, help="hard: centre std / sigma (1 = clusters overlap)")
+    ap.add_argument("--zipf", type=float, default=0.7, help="hard: list-size exponent")
+    ap.add_argument("--device-base-gb", type=float, default=0.0,
+                    help="HBM budget of the raw vectors (0 = automatic); the rest is kept in pinned host memory")
     ap.add_argument("--centre-scale", type=float, default=1.0)
     ap.add_argument("--gt-queries", type=int, default=1000)
     ap.add_argument("--cpu-queries", type=int, default=1000,
@@ -73,7 +80,7 @@ def main():
     import torch
     import torch.distributed as dist
     import rabitq_amd
-    from rabitq_amd import _lib, index as rqi, sharding
+    from rabitq_amd import _lib, index as rqi, ops, sharding
     from tests import synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,65 +103,116 @@ def main():
     t0 = time.time()
 
     # ---- synthetic inputs: mixture of Gaussians, generated on device ------------
-    centres = synth.device_centres(k, d, dev, args.centre_scale)
+    # "easy": true centres as centroids, uniform list sizes, centres far apart (every query's neighbours sit in its
+    # first list).  "hard": overlapping clusters (centre spacing ~ cluster radius), Zipf list sizes, and centroids
+    # TRAINED by rq_kmeans_device on a sample instead of the generating centres.
+    hard = args.distribution == "hard"
+    centre_scale = args.centre_scale if not hard else args.sigma * args.hard_centre_ratio
+    centres = synth.device_centres(k, d, dev, centre_scale)
+    weights = None
+    if hard:
+        wz = 1.0 / torch.arange(1, k_local + 1, device=dev, dtype=torch.float64) ** args.zipf
+        weights = (wz / wz.sum()).float()[torch.randperm(k_local, device=dev, generator=torch.Generator(device=dev).manual_seed(5))]
     my_lo = rank * k_local                   # this rank's points come from its own k_local centres
-    x = torch.empty((n, d), device=dev, dtype=torch.float32)
-    chunk = 4_000_000
-    for ci, i0 in enumerate(range(0, n, chunk)):
-        m = min(chunk, n - i0)
-        x[i0:i0 + m], _ = synth.device_mixture_chunk(centres, i0, m, args.sigma, ci, 42 + 1000 * rank, my_lo, k_local)
-    queries = synth.device_queries(centres, B, args.sigma, dev)
+    qweights = None if weights is None else weights.repeat(world) / world
+    queries = synth.device_queries(centres, B, args.sigma, dev, weights=qweights)
     P = synth.random_orthogonal(d, seed=99)
-    torch.cuda.synchronize()
-    log(f"data generated: {n} x {d} per GPU, k={k}, B={B}  ({time.time() - t0:.1f}s)")
+    chunk = max(262_144, min(4_000_000, (512 << 20) // d))     # rows per generated chunk (4M at d = 128)
+    chunks = [(ci, i0, min(chunk, n - i0)) for ci, i0 in enumerate(range(0, n, chunk))]
 
-    # ---- brute-force ground truth for the first gt_queries queries (before x is released) ---------
-    # f64 on purpose: the f32 GEMM form |q|^2 - 2 q.x + |x|^2 cancels catastrophically here (neighbour
+    def gen(ci, i0, m):
+        return synth.device_mixture_chunk(centres, i0, m, args.sigma, ci, 42 + 1000 * rank, my_lo, k_local, weights)[0]
+
+    centroids = centres
+    kmeans_s = None
+    if hard:   # centroid training (scripts/cluster.py's role): Lloyd on a 256-points-per-centroid sample of the same mixture
+        tk = time.time()
+        ns = min(n, 256 * k_local)
+        sample = synth.device_mixture_chunk(centres, 0, ns, args.sigma, 999_983, 42 + 1000 * rank, my_lo, k_local, weights)[0].contiguous()
+        learnt = torch.zeros((k_local, d), device=dev, dtype=torch.float32)
+        ops.kmeans_device(sample.data_ptr(), ns, d, k_local, learnt.data_ptr(), iters=10, seed=3)
+        if world > 1:   # every rank needs all centroids: one all-gather at build time
+            allc = [torch.zeros_like(learnt) for _ in range(world)] if args.backend != "gloo" else None
+            if allc is None:
+                lc = [torch.zeros((k_local, d)) for _ in range(world)]
+                dist.all_gather(lc, learnt.cpu())
+                centroids = torch.cat(lc).to(dev)
+            else:
+                dist.all_gather(allc, learnt)
+                centroids = torch.cat(allc)
+        else:
+            centroids = learnt
+        del sample
+        kmeans_s = time.time() - tk
+        log(f"centroids trained on {ns} samples in {kmeans_s:.1f}s")
+
+    # ---- pass 1 of the streamed build + brute-force ground truth, chunk by chunk (the base is never resident as
+    # a whole: 100M x 768 would not fit beside its own cluster-ordered copy) ------------------------------------
+    # Ground truth in f64 on purpose: the f32 GEMM form |q|^2 - 2 q.x + |x|^2 cancels catastrophically here (neighbour
     # distances differ by ~0.1 under norms of ~160) and an f32 library GEMM gave a wrong ground truth.
     ngt = min(args.gt_queries, B)
     qg = queries[:ngt].double()
     best_d = torch.full((ngt, topk), float("inf"), device=dev, dtype=torch.float64)
     best_i = torch.full((ngt, topk), -1, device=dev, dtype=torch.int64)
     qn = (qg * qg).sum(1, keepdim=True)
-    gchunk = 1_000_000
-    for i0 in range(0, n, gchunk):
-        xb = x[i0:i0 + gchunk].double()
-        d2 = qn - 2.0 * (qg @ xb.T) + (xb * xb).sum(1)[None, :]
-        cd, ci_ = torch.topk(d2, topk, dim=1, largest=False)
-        alld = torch.cat([best_d, cd], 1)
-        alli = torch.cat([best_i, ci_ + i0 + rank * n], 1)
-        sel = torch.topk(alld, topk, dim=1, largest=False).indices
-        best_d, best_i = torch.gather(alld, 1, sel), torch.gather(alli, 1, sel)
-        del d2
-    if world > 1:   # global ground truth = merge of the shards' exact top-k
+    gchunk = max(65_536, min(1_000_000, (128 << 20) // d))
+    build_s = 0.0
+    builder = rabitq_amd.RaBitQ.builder(n, d, centroids.data_ptr(), k, orthogonal=P,
+                                        max_device_base_bytes=int(args.device_base_gb * (1 << 30)))
+    for ci, i0, m in chunks:
+        xc = gen(ci, i0, m)
+        for j0 in range(0, m if ngt else 0, gchunk):
+            xb = xc[j0:j0 + gchunk].double()
+            d2 = qn - 2.0 * (qg @ xb.T) + (xb * xb).sum(1)[None, :]
+            cd, ci_ = torch.topk(d2, topk, dim=1, largest=False)
+            alld = torch.cat([best_d, cd], 1)
+            alli = torch.cat([best_i, ci_ + i0 + j0 + rank * n], 1)
+            sel = torch.topk(alld, topk, dim=1, largest=False).indices
+            best_d, best_i = torch.gather(alld, 1, sel), torch.gather(alli, 1, sel)
+            del d2, xb
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        builder.assign_chunk(xc.data_ptr(), i0, m)
+        build_s += time.perf_counter() - tb
+        del xc
+    if world > 1 and ngt:   # global ground truth = merge of the shards' exact top-k
         pay = sharding.pack_topk(best_d.float(), best_i - rank * n, torch.full((ngt,), topk, device=dev), rank * n)
         if args.backend == "gloo":
             pay = pay.cpu()
         _, best_i, _ = sharding.merge_shard_topk(pay, topk, id_bound=world * n)
     gt = best_i.cpu().numpy()
-    torch.cuda.synchronize()
-    log(f"ground truth done ({time.time() - t0:.1f}s)")
-
-    # ---- build (RaBitQ::from_path on device-resident arrays) -----------------------------------------
-    tb = time.time()
-    idx = rabitq_amd.RaBitQ.build_device(x.data_ptr(), n, d, centres.data_ptr(), k, orthogonal=P)
-    torch.cuda.synchronize()
-    build_s = time.time() - tb
-    # rotation (a5) on the matrix cores: X' = X P for a 4M-row slice of the base, HIP-event timed
-    rot_rows = min(n, 4_000_000)
-    rot_out = torch.empty((rot_rows, idx.dim), device=dev, dtype=torch.float32) if d == idx.dim else None
-    rotation = None
-    if rot_out is not None:
-        idx.rotate_device(x.data_ptr(), rot_rows, rot_out.data_ptr())          # warm-up
-        ms = min(idx.rotate_device(x.data_ptr(), rot_rows, rot_out.data_ptr()) for _ in range(3))
-        tf = 2.0 * rot_rows * idx.dim * idx.dim / (ms * 1e-3) / 1e12
-        rotation = {"bound": "mfma", "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s",
-                    "frac": round(tf / 157.3, 4), "kernel": "rotate_mfma_kernel (v_mfma_f32_32x32x2_f32, exact f32)",
-                    "rows": rot_rows, "ms": round(ms, 4), "GBps_in_plus_out": round(2 * rot_rows * idx.dim * 4 / (ms * 1e-3) / 1e9, 1)}
-        del rot_out
-    del x
+    del best_d, best_i, qg, qn
+    torch.cuda.empty_cache()     # the engine sizes the HBM tier of the raw vectors by what is free now
+    log(f"pass 1 (rotate, assign, quantise) + ground truth done ({time.time() - t0:.1f}s)")
+    tb = time.perf_counter()
+    builder.order()
+    build_s += time.perf_counter() - tb
+    bstats = builder.stats()
+    # ---- pass 2: the raw vectors to their cluster-order positions (HBM tier, or pinned host memory beyond it) -----
+    for ci, i0, m in chunks:
+        xc = gen(ci, i0, m).contiguous()
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        builder.place_chunk(xc.data_ptr(), i0, m)
+        build_s += time.perf_counter() - tb
+        del xc
+    tb = time.perf_counter()
+    idx = builder.finish()
+    build_s += time.perf_counter() - tb
     torch.cuda.empty_cache()
-    log(f"index built in {build_s:.1f}s: n={idx.n} dim={idx.dim} k={idx.k} max_list_len={idx.max_list_len}")
+    # rotation (a5) on the matrix cores over the WHOLE build: 2 n dim^2 flop in the rotate kernel's summed device time
+    rot_ms = bstats["ms_rotate"]
+    tf = 2.0 * n * idx.dim * idx.dim / (rot_ms * 1e-3) / 1e12
+    rotation = {"bound": "mfma", "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
+                "kernel": "rotate_mfma_kernel (v_mfma_f32_32x32x2_f32, exact f32)", "rows": n,
+                "flops": 2.0 * n * idx.dim * idx.dim, "ms": round(rot_ms, 3),
+                "GBps_in_plus_out": round(2 * n * idx.dim * 4 / (rot_ms * 1e-3) / 1e9, 1),
+                "note": "every row of the build, HIP events around the kernel on its launch stream, summed over chunks"}
+    build_info = {"assign_ms": round(bstats["ms_assign"], 1), "quantize_ms": round(bstats["ms_quantize"], 1),
+                  "rotate_ms": round(rot_ms, 1), "rows_in_hbm": idx.n_hbm, "rows_in_pinned_host_memory": idx.n - idx.n_hbm,
+                  "centroid_training_seconds": None if kmeans_s is None else round(kmeans_s, 1)}
+    log(f"index built in {build_s:.1f}s of engine time: n={idx.n} dim={idx.dim} k={idx.k} max_list_len={idx.max_list_len} "
+        f"rows in HBM {idx.n_hbm} / host {idx.n - idx.n_hbm}")
 
     sharded = world > 1 or args.sharded_path
     depth = max(1, args.pipeline) if not sharded else 1
@@ -342,8 +400,11 @@ def main():
                                    (" (BASELINE.json configs[2])" if (n, d, k_local, nprobe) == (100_000_000, 128, 4096, 64) else ""),
                        "batches_in_flight": depth,
                        "n_per_gpu": n, "dim": d, "lists_total": k, "nprobe": nprobe, "topk": topk, "batch": B,
-                       "sigma": args.sigma, "centre_scale": args.centre_scale, "sharding": f"vectors x{world}"},
-            "recall_at_10": round(recall, 4), "recall_queries": ngt, "build_seconds": round(build_s, 2),
+                       "sigma": args.sigma, "centre_scale": centre_scale, "sharding": f"vectors x{world}",
+                       "distribution": args.distribution if not hard else
+                       f"hard: centre std = {args.hard_centre_ratio} x sigma (overlapping clusters), Zipf({args.zipf}) list sizes, "
+                       f"centroids trained by rq_kmeans_device"},
+            "recall_at_10": round(recall, 4), "recall_queries": ngt, "build_seconds": round(build_s, 2), "build": build_info,
             "rough_per_query": m["rough"] / max(m["query"], 1), "precise_per_query": m["precise"] / max(m["query"], 1),
             "kernel_ms_per_step": breakdown, "scan_ms_per_step_timed": round(prof["ms_scan"] / args.steps, 3),
             "rerank_candidates_per_query": prof["rerank_candidates"] / (B * args.steps),
@@ -353,7 +414,13 @@ def main():
 
     # ---- CPU baseline: the oracle (port of the reference's AVX2 path) on this box's host cores ------
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_queries > 0:
-        line["cpu_baseline"] = cpu_baseline(idx, queries[:args.cpu_queries].cpu().numpy(), nprobe, topk, ri, d)
+        if idx.n * idx.dim * 4 > (150 << 30):
+            # the CPU path needs all raw vectors in host memory (src/rabitq.rs:59); beyond what the box allows a process
+            line["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 1, "kind": "port",
+                                    "sample": f"skipped: {idx.n * idx.dim * 4 / 1e9:.0f} GB of raw vectors do not fit the host memory "
+                                              "a process may use here; measured on the 100Mx128 configuration instead"}
+        else:
+            line["cpu_baseline"] = cpu_baseline(idx, queries[:args.cpu_queries].cpu().numpy(), nprobe, topk, ri, d)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -61,6 +61,7 @@ typedef struct {
     uint64_t n;            /* number of vectors */
     uint32_t max_list_len; /* longest IVF list */
     uint32_t reserved;
+    uint64_t n_hbm;        /* raw vectors resident in HBM; the other n - n_hbm are in pinned host memory */
 } rq_info_t;
 
 /* ---- library ------------------------------------------------------------------------------- */
@@ -81,6 +82,32 @@ rq_status rq_build_device(const float *d_base, uint64_t n, uint32_t d, const flo
 /* From .fvecs files exactly as RaBitQ::from_path(base_path, centroid_path). */
 rq_status rq_build_from_path(const char *base_fvecs, const char *centroid_fvecs,
                              const float *orthogonal, uint64_t seed, rq_index **out);
+
+/* ---- streamed two-pass build: from_path for inputs that need not be resident (e.g. 100M x 768 = 307 GB) ---- */
+/* The same result as rq_build_device, with the n x d input fed chunk by chunk, twice:
+ *   rq_builder_create -> rq_builder_assign_chunk (every row once: rotate src/rabitq.rs:188, nearest list :203, sign-pack +
+ *   factors :205-229) -> rq_builder_order (cluster ordering :232-243) -> rq_builder_place_chunk (every row once more:
+ *   raw vectors to their cluster-order positions :244-247) -> rq_builder_finish.
+ * Chunks are m x d row-major f32 in DEVICE memory covering rows [i0, i0 + m); any order, any sizes; each call returns
+ * when the chunk buffer may be reused.  max_device_base_bytes: HBM budget of the raw vectors (0 = automatic: what is
+ * free minus a reserve; UINT64_MAX = all in HBM); vectors beyond it are kept in pinned host memory and gathered over
+ * the host link by the rerank (results identical).  rq_builder_finish consumes the builder (also on
+ * error); rq_builder_free abandons one. */
+typedef struct rq_builder rq_builder;
+typedef struct {
+    float ms_rotate, ms_assign, ms_quantize;   /* device time of the three pass-1 kernels, HIP events, summed over chunks */
+    uint32_t reserved;
+    uint64_t rows_assigned;                    /* rotation flops so far = 2 * rows_assigned * dim^2 */
+    uint64_t rows_in_hbm, rows_in_host_memory; /* base tiers (known after rq_builder_order) */
+} rq_build_stats_t;
+rq_status rq_builder_create(uint64_t n, uint32_t d, const float *d_centroids, uint32_t k, const float *orthogonal_host,
+                            uint64_t seed, uint64_t max_device_base_bytes, rq_builder **out);
+rq_status rq_builder_assign_chunk(rq_builder *b, const float *d_rows, uint64_t i0, uint64_t m);
+rq_status rq_builder_order(rq_builder *b);
+rq_status rq_builder_place_chunk(rq_builder *b, const float *d_rows, uint64_t i0, uint64_t m);
+rq_status rq_builder_finish(rq_builder *b, rq_index **out);
+void rq_builder_free(rq_builder *b);
+rq_status rq_builder_stats(const rq_builder *b, rq_build_stats_t *out);
 
 /* ---- centroid training (scripts/cluster.py:63-108 does this offline with faiss k-means) -------- */
 /* Lloyd k-means on a sample of min(n, points_per_centroid * k) vectors (points_per_centroid = 256
@@ -109,7 +136,7 @@ enum { RQ_ARR_BASE = 0, RQ_ARR_ORTHOGONAL, RQ_ARR_CENTROIDS, RQ_ARR_OFFSETS, RQ_
        RQ_ARR_CODES, RQ_ARR_FACTORS };
 rq_status rq_get_array(const rq_index *idx, int which, void *dst, uint64_t dst_bytes);
 /* Device pointer of one array (valid until rq_free); for zero-copy hand-over to a caller that
- * already lives on the GPU. */
+ * already lives on the GPU.  RQ_ARR_BASE gives the HBM tier (rows [0, n_hbm), all rows unless the index is tiered). */
 rq_status rq_get_device_ptr(const rq_index *idx, int which, const void **out_ptr, uint64_t *out_bytes);
 
 /* ---- query: RaBitQ::query, src/rabitq.rs:268-333 --------------------------------------------- */
@@ -246,6 +273,9 @@ rq_status rq_set_profiling(int level);
 /* Engine options.  "scan_impl": 0 = auto (default: fp6 matrix-core scan when many queries share each
  * list, v_dot8 VALU scan otherwise), 1 = VALU only, 2 = matrix cores wherever available.  All
  * settings return identical results; the option exists for tests and measurements.
+ * "base_device_mb": HBM budget (MiB) of the raw vectors of indexes built / loaded from now on (-1 = automatic, the
+ * default); vectors beyond it live in pinned host memory.  Results never depend on it.
+ * "max_scan_blocks": test hook, blocks per scan launch (0 = hardware bound).
  * Developer knobs: "stage_growth" (geometric growth of the early stages, 0 = default; results are
  * identical for every value), "scan_debug" (timing ablations of the matrix-core scan: results are
  * WRONG while it is non-zero). */

@@ -20,7 +20,7 @@ STATUS_NAMES = {0: "RQ_OK", -1: "RQ_ERR_INVALID", -2: "RQ_ERR_DIM_MISMATCH", -3:
 
 # every symbol include/rabitq_hip.h declares (checked by tests/test_abi.py against the header)
 EXPORTS = [
-    "rq_version", "rq_last_error", "rq_init", "rq_build", "rq_build_device", "rq_build_from_path", "rq_kmeans_device", "rq_load_dir",
+    "rq_version", "rq_last_error", "rq_init", "rq_build", "rq_build_device", "rq_build_from_path", "rq_kmeans_device", "rq_builder_create", "rq_builder_assign_chunk", "rq_builder_order", "rq_builder_place_chunk", "rq_builder_finish", "rq_builder_free", "rq_builder_stats", "rq_load_dir",
     "rq_dump_dir", "rq_free", "rq_from_arrays", "rq_info", "rq_get_array", "rq_get_device_ptr", "rq_query",
     "rq_query_batch", "rq_query_batch_device", "rq_query_batch_device_begin", "rq_query_batch_device_end", "rq_coarse_topk_device", "rq_merge_smallest_u64_device", "rq_query_batch_device_probed", "rq_partition_lists", "rq_shard_index", "rq_query_batch_sharded_device", "rq_metrics", "rq_metrics_reset", "rq_rotate", "rq_rotate_device",
     "rq_quantize_pack",
@@ -36,11 +36,16 @@ class RabitqError(RuntimeError):
 
 class Info(C.Structure):
     _fields_ = [("dim", C.c_uint32), ("k", C.c_uint32), ("n", C.c_uint64), ("max_list_len", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("reserved", C.c_uint32), ("n_hbm", C.c_uint64)]
 
 
 class MetricsT(C.Structure):
     _fields_ = [("rough", C.c_uint64), ("precise", C.c_uint64), ("query", C.c_uint64), ("miss", C.c_uint64)]
+
+
+class BuildStatsT(C.Structure):
+    _fields_ = [("ms_rotate", C.c_float), ("ms_assign", C.c_float), ("ms_quantize", C.c_float), ("reserved", C.c_uint32),
+                ("rows_assigned", C.c_uint64), ("rows_in_hbm", C.c_uint64), ("rows_in_host_memory", C.c_uint64)]
 
 
 class ProfileT(C.Structure):
@@ -79,6 +84,13 @@ def lib():
         "rq_build_device": (i32, [f32p, u64, u32, f32p, u32, f32p, u64, pp]),
         "rq_build_from_path": (i32, [C.c_char_p, C.c_char_p, f32p, u64, pp]),
         "rq_kmeans_device": (i32, [f32p, u64, u32, u32, u32, u32, u64, f32p]),
+        "rq_builder_create": (i32, [u64, u32, f32p, u32, f32p, u64, u64, pp]),
+        "rq_builder_assign_chunk": (i32, [vp, f32p, u64, u64]),
+        "rq_builder_order": (i32, [vp]),
+        "rq_builder_place_chunk": (i32, [vp, f32p, u64, u64]),
+        "rq_builder_finish": (i32, [vp, pp]),
+        "rq_builder_free": (None, [vp]),
+        "rq_builder_stats": (i32, [vp, C.POINTER(BuildStatsT)]),
         "rq_load_dir": (i32, [C.c_char_p, pp]),
         "rq_dump_dir": (i32, [vp, C.c_char_p]),
         "rq_free": (None, [vp]),

@@ -261,9 +261,9 @@ __global__ void gather_rows_kernel(const float *__restrict__ in, const uint32_t 
 // its source position is old_offsets[c] + (p - new_offsets[c])
 __global__ __launch_bounds__(256) void shard_gather_kernel(const uint32_t *__restrict__ new_off, const uint32_t *__restrict__ old_off,
                                                            uint32_t k, uint64_t n_local, uint32_t dim,
-                                                           const float *__restrict__ base_in, const uint64_t *__restrict__ codes_in,
+                                                           const BaseView base_in, const uint64_t *__restrict__ codes_in,
                                                            const float4 *__restrict__ factors_in, const uint32_t *__restrict__ ids_in,
-                                                           float *__restrict__ base_out, uint64_t *__restrict__ codes_out,
+                                                           const BaseView base_out, uint64_t *__restrict__ codes_out,
                                                            float4 *__restrict__ factors_out, uint32_t *__restrict__ ids_out) {
     const uint32_t lane = threadIdx.x & 63, W = dim >> 6;
     for (uint64_t p = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < n_local; p += (uint64_t)gridDim.x * 4) {
@@ -274,7 +274,9 @@ __global__ __launch_bounds__(256) void shard_gather_kernel(const uint32_t *__res
             else hi = mid;
         }
         const uint64_t src = (uint64_t)old_off[lo] + (p - new_off[lo]);
-        for (uint32_t e = lane; e < dim; e += 64) base_out[p * dim + e] = base_in[src * dim + e];
+        const float *srow = base_in.row(src, dim);
+        float *drow = base_out.row_mut(p, dim);
+        for (uint32_t e = lane; e < dim; e += 64) drow[e] = srow[e];
         for (uint32_t w = lane; w < W; w += 64) codes_out[p * W + w] = codes_in[src * W + w];
         if (lane == 0) {
             factors_out[p] = factors_in[src];
@@ -1129,18 +1131,84 @@ static void launch_assign(const float *xrot, const rq_index *idx, uint64_t n, ui
             xrot, idx->cent_t.p, n, idx->k, idx->dim, label, dist);
 }
 
-static rq_status build_device(const float *d_base, uint64_t n, uint32_t d, const float *d_centroids, uint32_t k,
-                              const float *orthogonal_host, uint64_t seed, rq_index **out) {
+// ------------------------------------------------------------------------------------------------
+// Base tiers: how many raw vectors stay in HBM.  budget_bytes: 0 = automatic (what is free now minus a reserve for
+// query workspaces and the caller), ~0 = everything in HBM, else an explicit cap ("base_device_mb" option / the
+// builder's argument).  The rest goes to pinned, device-mapped host memory.
+// ------------------------------------------------------------------------------------------------
+static std::atomic<int64_t> g_base_device_mb{-1};  // -1 = automatic
+#define RQ_HBM_RESERVE_BYTES (12ull << 30)
+static rq_status alloc_base_tiers(rq_index *idx, uint64_t budget_bytes) {
+    const uint64_t row = (uint64_t)idx->dim * 4, want = idx->n * row;
+    uint64_t cap = budget_bytes;
+    if (budget_bytes == 0) {
+        const int64_t opt = g_base_device_mb.load();
+        if (opt >= 0) {
+            cap = (uint64_t)opt << 20;
+        } else {
+            size_t free_b = 0, total_b = 0;
+            HIPC(hipMemGetInfo(&free_b, &total_b));
+            cap = free_b > RQ_HBM_RESERVE_BYTES ? free_b - RQ_HBM_RESERVE_BYTES : 0;
+            if (want <= cap || want <= (256ull << 20)) cap = ~0ull;  // fits (or is small): no host tier
+        }
+    }
+    idx->n_dev = cap == ~0ull ? idx->n : std::min<uint64_t>(idx->n, cap / row);
+    RQC(idx->base.alloc(idx->n_dev * idx->dim));
+    const uint64_t n_host = idx->n - idx->n_dev;
+    if (n_host) {
+        hipError_t e = hipHostMalloc((void **)&idx->base_host, n_host * row, hipHostMallocMapped | hipHostMallocPortable);
+        if (e != hipSuccess) {
+            idx->base_host = nullptr;
+            return fail(RQ_ERR_OOM, "pinned host tier of " + std::to_string(n_host * row) + " bytes: " + hipGetErrorString(e));
+        }
+        HIPC(hipHostGetDevicePointer((void **)&idx->base_host_dev, idx->base_host, 0));
+    }
+    return RQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Streamed two-pass build (RaBitQ::from_path, src/rabitq.rs:159-265, for inputs that need not be resident):
+//   pass 1  rq_builder_assign_chunk  rotate (:188) -> nearest list (:203) -> sign-pack + factors (:205-229), per chunk
+//           rq_builder_order         cluster ordering (:232-243), codes / factors / map_ids gathered, base tiers allocated
+//   pass 2  rq_builder_place_chunk   raw vectors to their cluster-order positions (:244-247), HBM or host tier
+//           rq_builder_finish        derived state, hand the index over
+// The input is fed twice, chunk by chunk, so neither the n x d input nor a rotated copy ever has to coexist with the
+// cluster-ordered base (the reference holds base + rotated copy + per-vector Vecs at once, :188-197).
+// ------------------------------------------------------------------------------------------------
+struct rq_builder {
+    std::unique_ptr<rq_index> idx;
+    uint32_t d = 0;
+    uint64_t budget = 0;
+    DevBuf<uint32_t> label, pos_of_id;
+    DevBuf<float> mind, xpad, xrot;
+    DevBuf<uint64_t> codes_tmp;
+    DevBuf<float4> factors_tmp;
+    uint64_t assigned = 0, placed = 0;
+    bool ordered = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    rq_build_stats_t stats{};
+    ~rq_builder() {
+        for (auto e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+};
+#define RQ_BUILD_CHUNK (1ull << 20)
+
+static rq_status builder_create(uint64_t n, uint32_t d, const float *d_centroids, uint32_t k, const float *orthogonal_host,
+                                uint64_t seed, uint64_t max_device_base_bytes, rq_builder **out) {
     RQC(ensure_device());
     RQC(ensure_kernel_attributes());
     if (!out) return fail(RQ_ERR_INVALID, "null out pointer");
     *out = nullptr;
-    if ((n && !d_base) || !d_centroids || d == 0 || k == 0) return fail(RQ_ERR_INVALID, "bad build arguments");
+    if (!d_centroids || d == 0 || k == 0) return fail(RQ_ERR_INVALID, "bad build arguments");
     if (n >= 0xFFFFFFFFull) return fail(RQ_ERR_UNSUPPORTED, "n must fit u32 ids (rabitq.rs:64-65)");
     const uint32_t dim = (d + 63) / 64 * 64;  // rabitq.rs:168-179
     if (dim > 4096) return fail(RQ_ERR_UNSUPPORTED, "dim > 4096 not supported");
-    std::unique_ptr<rq_index> idx(new rq_index());
+    std::unique_ptr<rq_builder> b(new rq_builder());
+    b->idx.reset(new rq_index());
+    rq_index *idx = b->idx.get();
     idx->dim = dim, idx->k = k, idx->n = n, idx->W = dim / 64;
+    b->d = d, b->budget = max_device_base_bytes;
 
     std::vector<float> Pgen;
     if (!orthogonal_host) {
@@ -1158,61 +1226,138 @@ static rq_status build_device(const float *d_base, uint64_t n, uint32_t d, const
     launch_rotate(cpad.p, idx->P.p, idx->centroids.p, k, dim, true, nullptr);
     RQC(idx->cent_t.alloc((size_t)dim * k));
     transpose_kernel<<<dim3(ceil_div(dim, 32), ceil_div(k, 32)), dim3(32, 8)>>>(idx->centroids.p, idx->cent_t.p, k, dim);
-    cpad.release();
-
-    // per-vector pass in chunks: rotate (:188) -> nearest list (:203) -> sign-pack + factors (:205-229)
-    DevBuf<uint32_t> label;
-    DevBuf<float> mind;
-    DevBuf<uint64_t> codes_tmp;
-    DevBuf<float4> factors_tmp;
-    RQC(label.alloc(n));
-    RQC(mind.alloc(n));
-    RQC(codes_tmp.alloc(n * idx->W));
-    RQC(factors_tmp.alloc(n));
-    const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(n, 1), 1ull << 20);
-    DevBuf<float> xpad, xrot;
-    if (d != dim) RQC(xpad.alloc(chunk * dim));
-    RQC(xrot.alloc(chunk * dim));
-    for (uint64_t i0 = 0; i0 < n; i0 += chunk) {
-        const uint64_t m = std::min(chunk, n - i0);
-        const float *src = d_base + i0 * d;
-        if (d != dim) {
-            pad_rows_kernel<<<ceil_div(m * dim, 256), 256>>>(src, xpad.p, m, d, dim);
-            src = xpad.p;
-        }
-        launch_rotate(src, idx->P.p, xrot.p, m, dim, true, nullptr);
-        launch_assign(xrot.p, idx.get(), m, label.p + i0, mind.p + i0, nullptr);
-        quantize_kernel<<<ceil_div(m, 32), 256>>>(xrot.p, idx->centroids.p, label.p + i0, m, dim,
-                                                  codes_tmp.p + i0 * idx->W, factors_tmp.p + i0);
-    }
     HIPC(hipDeviceSynchronize());
     HIPC(hipGetLastError());
-    xpad.release();
-    xrot.release();
 
-    // cluster ordering (rabitq.rs:232-252)
+    RQC(b->label.alloc(n));
+    RQC(b->mind.alloc(n));
+    RQC(b->codes_tmp.alloc(n * idx->W));
+    RQC(b->factors_tmp.alloc(n));
+    const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(n, 1), RQ_BUILD_CHUNK);
+    if (d != dim) RQC(b->xpad.alloc(chunk * dim));
+    RQC(b->xrot.alloc(chunk * dim));
+    for (auto &e : b->ev) HIPC(hipEventCreate(&e));
+    *out = b.release();
+    return RQ_OK;
+}
+
+// pass 1 for rows [i0, i0 + m) of the input (d_rows: m x d, device)
+static rq_status builder_assign(rq_builder *b, const float *d_rows, uint64_t i0, uint64_t m) {
+    if (!b || (m && !d_rows)) return fail(RQ_ERR_INVALID, "null argument");
+    if (b->ordered) return fail(RQ_ERR_INVALID, "rq_builder_assign_chunk after rq_builder_order");
+    rq_index *idx = b->idx.get();
+    if (i0 > idx->n || m > idx->n - i0) return fail(RQ_ERR_INVALID, "chunk outside [0, n)");
+    const uint32_t d = b->d, dim = idx->dim;
+    for (uint64_t c0 = 0; c0 < m; c0 += RQ_BUILD_CHUNK) {
+        const uint64_t mm = std::min<uint64_t>(RQ_BUILD_CHUNK, m - c0), at = i0 + c0;
+        const float *src = d_rows + c0 * d;
+        if (d != dim) {
+            pad_rows_kernel<<<ceil_div(mm * dim, 256), 256>>>(src, b->xpad.p, mm, d, dim);
+            src = b->xpad.p;
+        }
+        HIPC(hipEventRecord(b->ev[0], nullptr));
+        launch_rotate(src, idx->P.p, b->xrot.p, mm, dim, true, nullptr);
+        HIPC(hipEventRecord(b->ev[1], nullptr));
+        launch_assign(b->xrot.p, idx, mm, b->label.p + at, b->mind.p + at, nullptr);
+        HIPC(hipEventRecord(b->ev[2], nullptr));
+        quantize_kernel<<<ceil_div(mm, 32), 256>>>(b->xrot.p, idx->centroids.p, b->label.p + at, mm, dim,
+                                                   b->codes_tmp.p + at * idx->W, b->factors_tmp.p + at);
+        HIPC(hipEventRecord(b->ev[3], nullptr));
+        HIPC(hipEventSynchronize(b->ev[3]));  // the chunk buffers are reused by the next chunk (and by the caller)
+        HIPC(hipGetLastError());
+        float t01 = 0, t12 = 0, t23 = 0;
+        HIPC(hipEventElapsedTime(&t01, b->ev[0], b->ev[1]));
+        HIPC(hipEventElapsedTime(&t12, b->ev[1], b->ev[2]));
+        HIPC(hipEventElapsedTime(&t23, b->ev[2], b->ev[3]));
+        b->stats.ms_rotate += t01, b->stats.ms_assign += t12, b->stats.ms_quantize += t23;
+    }
+    b->assigned += m;
+    b->stats.rows_assigned = b->assigned;
+    return RQ_OK;
+}
+
+// cluster ordering (rabitq.rs:232-252) of everything but the raw vectors
+static rq_status builder_order(rq_builder *b) {
+    if (!b) return fail(RQ_ERR_INVALID, "null builder");
+    if (b->ordered) return fail(RQ_ERR_INVALID, "rq_builder_order called twice");
+    rq_index *idx = b->idx.get();
+    const uint64_t n = idx->n;
+    const uint32_t k = idx->k;
+    if (b->assigned != n) return fail(RQ_ERR_INVALID, "rq_builder_order before every row was assigned");
+    b->xpad.release();
+    b->xrot.release();
     DevBuf<uint32_t> cnt;
     DevBuf<unsigned long long> keys;
     RQC(cnt.alloc((size_t)k + 1));
     RQC(idx->offsets.alloc((size_t)k + 1));
     RQC(keys.alloc(n));
     HIPC(hipMemset(cnt.p, 0, ((size_t)k + 1) * 4));
-    if (n) label_hist_kernel<<<ceil_div(n, 256), 256>>>(label.p, n, cnt.p);
+    const uint32_t g256 = (uint32_t)std::min<uint64_t>(ceil_div(std::max<uint64_t>(n, 1), 256), 1u << 22);
+    if (n) label_hist_kernel<<<ceil_div(n, 256), 256>>>(b->label.p, n, cnt.p);
     group_scan_kernel<<<1, 1024>>>(cnt.p, k, idx->offsets.p, 0u);  // also zeroes cnt -> cursor
-    if (n) label_scatter_kernel<<<ceil_div(n, 256), 256>>>(label.p, mind.p, n, 0, idx->offsets.p, cnt.p, keys.p);
+    if (n) label_scatter_kernel<<<ceil_div(n, 256), 256>>>(b->label.p, b->mind.p, n, 0, idx->offsets.p, cnt.p, keys.p);
     list_sort_kernel<<<k, 1024>>>(keys.p, idx->offsets.p);
-    RQC(idx->base.alloc(n * dim));
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipGetLastError());
+    b->label.release();
+    b->mind.release();
     RQC(idx->codes.alloc(n * idx->W));
     RQC(idx->factors.alloc(n));
     RQC(idx->map_ids.alloc(n));
+    RQC(b->pos_of_id.alloc(n));
     if (n)
-        gather_kernel<<<std::min<uint32_t>(ceil_div(n, 4), 1u << 20), 256>>>(keys.p, n, d_base, d, dim, codes_tmp.p, factors_tmp.p, idx->base.p,
-                                               idx->codes.p, idx->factors.p, idx->map_ids.p);
+        order_gather_kernel<<<g256, 256>>>(keys.p, n, idx->W, b->codes_tmp.p, b->factors_tmp.p, idx->codes.p, idx->factors.p,
+                                           idx->map_ids.p, b->pos_of_id.p);
     HIPC(hipDeviceSynchronize());
     HIPC(hipGetLastError());
-    RQC(finish_index(idx.get()));
-    *out = idx.release();
+    b->codes_tmp.release();
+    b->factors_tmp.release();
+    keys.release();
+    RQC(alloc_base_tiers(idx, b->budget));
+    b->stats.rows_in_hbm = idx->n_dev, b->stats.rows_in_host_memory = n - idx->n_dev;
+    b->ordered = true;
     return RQ_OK;
+}
+
+// pass 2 for rows [i0, i0 + m)
+static rq_status builder_place(rq_builder *b, const float *d_rows, uint64_t i0, uint64_t m) {
+    if (!b || (m && !d_rows)) return fail(RQ_ERR_INVALID, "null argument");
+    if (!b->ordered) return fail(RQ_ERR_INVALID, "rq_builder_place_chunk before rq_builder_order");
+    rq_index *idx = b->idx.get();
+    if (i0 > idx->n || m > idx->n - i0) return fail(RQ_ERR_INVALID, "chunk outside [0, n)");
+    if (m) {
+        place_rows_kernel<<<(uint32_t)std::min<uint64_t>(ceil_div(m, 4), 1u << 20), 256>>>(d_rows, i0, m, b->d, idx->dim,
+                                                                                          b->pos_of_id.p, idx->view());
+        HIPC(hipDeviceSynchronize());  // the caller may reuse d_rows right away
+        HIPC(hipGetLastError());
+    }
+    b->placed += m;
+    return RQ_OK;
+}
+
+static rq_status builder_finish(rq_builder *bp, rq_index **out) {
+    if (!bp || !out) return fail(RQ_ERR_INVALID, "null argument");
+    std::unique_ptr<rq_builder> b(bp);  // consumed whatever happens
+    *out = nullptr;
+    if (!b->ordered || b->placed != b->idx->n) return fail(RQ_ERR_INVALID, "rq_builder_finish before every row was placed");
+    b->pos_of_id.release();
+    RQC(finish_index(b->idx.get()));
+    *out = b->idx.release();
+    return RQ_OK;
+}
+
+static rq_status build_device(const float *d_base, uint64_t n, uint32_t d, const float *d_centroids, uint32_t k,
+                              const float *orthogonal_host, uint64_t seed, rq_index **out) {
+    if (!out) return fail(RQ_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    if (n && !d_base) return fail(RQ_ERR_INVALID, "bad build arguments");
+    rq_builder *b = nullptr;
+    RQC(builder_create(n, d, d_centroids, k, orthogonal_host, seed, 0, &b));
+    std::unique_ptr<rq_builder> guard(b);
+    RQC(builder_assign(b, d_base, 0, n));
+    RQC(builder_order(b));
+    RQC(builder_place(b, d_base, 0, n));
+    return builder_finish(guard.release(), out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1269,15 +1414,16 @@ static rq_status from_arrays(uint32_t dim, uint64_t n, uint32_t k, const float *
     if (n >= 0xFFFFFFFFull) return fail(RQ_ERR_UNSUPPORTED, "n must fit u32");
     std::unique_ptr<rq_index> idx(new rq_index());
     idx->dim = dim, idx->n = n, idx->k = k, idx->W = dim / 64;
-    RQC(idx->base.alloc(n * dim));
     RQC(idx->P.alloc((size_t)dim * dim));
     RQC(idx->centroids.alloc((size_t)k * dim));
     RQC(idx->offsets.alloc((size_t)k + 1));
     RQC(idx->map_ids.alloc(n));
     RQC(idx->codes.alloc(n * idx->W));
     RQC(idx->factors.alloc(n));
+    RQC(alloc_base_tiers(idx.get(), 0));
     if (n) {
-        HIPC(hipMemcpy(idx->base.p, base, n * dim * 4, hipMemcpyHostToDevice));
+        if (idx->n_dev) HIPC(hipMemcpy(idx->base.p, base, idx->n_dev * dim * 4, hipMemcpyHostToDevice));
+        if (n > idx->n_dev) memcpy(idx->base_host, base + idx->n_dev * dim, (n - idx->n_dev) * dim * 4);
         HIPC(hipMemcpy(idx->map_ids.p, map_ids, n * 4, hipMemcpyHostToDevice));
         HIPC(hipMemcpy(idx->codes.p, codes, n * idx->W * 8, hipMemcpyHostToDevice));
         HIPC(hipMemcpy(idx->factors.p, factors, n * 16, hipMemcpyHostToDevice));
@@ -1287,6 +1433,20 @@ static rq_status from_arrays(uint32_t dim, uint64_t n, uint32_t k, const float *
     HIPC(hipMemcpy(idx->offsets.p, offsets, ((size_t)k + 1) * 4, hipMemcpyHostToDevice));
     RQC(finish_index(idx.get()));
     *out = idx.release();
+    return RQ_OK;
+}
+
+// rows [i0, i0 + m) of the cluster-ordered base to host memory, from whichever tier holds them
+static rq_status copy_base_rows(const rq_index *idx, uint64_t i0, uint64_t m, float *dst) {
+    const uint64_t dim = idx->dim, i1 = i0 + m;
+    if (i0 < idx->n_dev) {
+        const uint64_t md = std::min(i1, idx->n_dev) - i0;
+        HIPC(hipMemcpy(dst, idx->base.p + i0 * dim, md * dim * 4, hipMemcpyDeviceToHost));
+    }
+    if (i1 > idx->n_dev) {
+        const uint64_t h0 = std::max(i0, idx->n_dev);
+        memcpy(dst + (h0 - i0) * dim, idx->base_host + (h0 - idx->n_dev) * dim, (i1 - h0) * dim * 4);
+    }
     return RQ_OK;
 }
 
@@ -1352,6 +1512,21 @@ rq_status rq_kmeans_device(const float *d_base, uint64_t n, uint32_t d, uint32_t
 rq_status rq_build_device(const float *d_base, uint64_t n, uint32_t d, const float *d_centroids, uint32_t k,
                           const float *orthogonal_host, uint64_t seed, rq_index **out) {
     return build_device(d_base, n, d, d_centroids, k, orthogonal_host, seed, out);
+}
+
+rq_status rq_builder_create(uint64_t n, uint32_t d, const float *d_centroids, uint32_t k, const float *orthogonal_host,
+                            uint64_t seed, uint64_t max_device_base_bytes, rq_builder **out) {
+    return builder_create(n, d, d_centroids, k, orthogonal_host, seed, max_device_base_bytes, out);
+}
+rq_status rq_builder_assign_chunk(rq_builder *b, const float *d_rows, uint64_t i0, uint64_t m) { return builder_assign(b, d_rows, i0, m); }
+rq_status rq_builder_order(rq_builder *b) { return builder_order(b); }
+rq_status rq_builder_place_chunk(rq_builder *b, const float *d_rows, uint64_t i0, uint64_t m) { return builder_place(b, d_rows, i0, m); }
+rq_status rq_builder_finish(rq_builder *b, rq_index **out) { return builder_finish(b, out); }
+void rq_builder_free(rq_builder *b) { delete b; }
+rq_status rq_builder_stats(const rq_builder *b, rq_build_stats_t *out) {
+    if (!b || !out) return fail(RQ_ERR_INVALID, "null argument");
+    *out = b->stats;
+    return RQ_OK;
 }
 
 rq_status rq_build(const float *base, uint64_t n, uint32_t d, const float *centroids, uint32_t k,
@@ -1457,9 +1632,9 @@ rq_status rq_dump_dir(const rq_index *idx, const char *dir) {
         std::vector<float> buf(std::min<uint64_t>(chunk, std::max<uint64_t>(n, 1)) * dim);
         for (uint64_t i0 = 0; i0 < n; i0 += chunk) {
             uint64_t m = std::min(chunk, n - i0);
-            if (hipMemcpy(buf.data(), idx->base.p + i0 * dim, m * dim * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+            if (copy_base_rows(idx, i0, m, buf.data()) != RQ_OK) {
                 fclose(f);
-                return fail(RQ_ERR_HIP, "copy base failed");
+                return RQ_ERR_HIP;
             }
             for (uint64_t i = 0; i < m; ++i) {
                 rq_status s = write_record(f, buf.data() + i * dim, dim, 4, "base.fvecs");
@@ -1513,13 +1688,14 @@ void rq_free(rq_index *idx) { delete idx; }
 rq_status rq_info(const rq_index *idx, rq_info_t *out) {
     if (!idx || !out) return fail(RQ_ERR_INVALID, "null argument");
     out->dim = idx->dim, out->k = idx->k, out->n = idx->n, out->max_list_len = idx->max_list_len, out->reserved = 0;
+    out->n_hbm = idx->n_dev;
     return RQ_OK;
 }
 
 rq_status rq_get_device_ptr(const rq_index *idx, int which, const void **out_ptr, uint64_t *out_bytes) {
     if (!idx || !out_ptr || !out_bytes) return fail(RQ_ERR_INVALID, "null argument");
     switch (which) {
-        case RQ_ARR_BASE: *out_ptr = idx->base.p, *out_bytes = idx->n * idx->dim * 4; break;
+        case RQ_ARR_BASE: *out_ptr = idx->base.p, *out_bytes = idx->n_dev * idx->dim * 4; break;  // the HBM tier (all rows unless tiered)
         case RQ_ARR_ORTHOGONAL: *out_ptr = idx->P.p, *out_bytes = (uint64_t)idx->dim * idx->dim * 4; break;
         case RQ_ARR_CENTROIDS: *out_ptr = idx->centroids.p, *out_bytes = (uint64_t)idx->k * idx->dim * 4; break;
         case RQ_ARR_OFFSETS: *out_ptr = idx->offsets.p, *out_bytes = ((uint64_t)idx->k + 1) * 4; break;
@@ -1534,6 +1710,10 @@ rq_status rq_get_device_ptr(const rq_index *idx, int which, const void **out_ptr
 rq_status rq_get_array(const rq_index *idx, int which, void *dst, uint64_t dst_bytes) {
     const void *p;
     uint64_t bytes;
+    if (idx && which == RQ_ARR_BASE && idx->n_dev < idx->n) {  // both tiers
+        if (!dst || dst_bytes < idx->n * idx->dim * 4) return fail(RQ_ERR_INVALID, "destination too small");
+        return copy_base_rows(idx, 0, idx->n, static_cast<float *>(dst));
+    }
     RQC(rq_get_device_ptr(idx, which, &p, &bytes));
     if (!dst || dst_bytes < bytes) return fail(RQ_ERR_INVALID, "destination too small");
     if (bytes) HIPC(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
@@ -1749,7 +1929,7 @@ rq_status rq_shard_index(const rq_index *idx, const uint32_t *owner, uint32_t ra
     RQC(sh->P.alloc((size_t)dim * dim));
     RQC(sh->centroids.alloc((size_t)k * dim));
     RQC(sh->offsets.alloc((size_t)k + 1));
-    RQC(sh->base.alloc(n_local * dim));
+    RQC(alloc_base_tiers(sh.get(), 0));
     RQC(sh->codes.alloc(n_local * sh->W));
     RQC(sh->factors.alloc(n_local));
     RQC(sh->map_ids.alloc(n_local));
@@ -1758,8 +1938,8 @@ rq_status rq_shard_index(const rq_index *idx, const uint32_t *owner, uint32_t ra
     HIPC(hipMemcpy(sh->offsets.p, noff.data(), ((size_t)k + 1) * 4, hipMemcpyHostToDevice));
     if (n_local)
         shard_gather_kernel<<<(uint32_t)std::min<uint64_t>(ceil_div(n_local, 4), 1u << 20), 256>>>(
-            sh->offsets.p, idx->offsets.p, k, n_local, dim, idx->base.p, idx->codes.p, idx->factors.p, idx->map_ids.p,
-            sh->base.p, sh->codes.p, sh->factors.p, sh->map_ids.p);
+            sh->offsets.p, idx->offsets.p, k, n_local, dim, idx->view(), idx->codes.p, idx->factors.p, idx->map_ids.p,
+            sh->view(), sh->codes.p, sh->factors.p, sh->map_ids.p);
     HIPC(hipDeviceSynchronize());
     HIPC(hipGetLastError());
     RQC(finish_index(sh.get()));
@@ -1872,6 +2052,12 @@ rq_status rq_set_option(const char *name, int value) {
     if (std::string(name) == "stage_growth") {  // geometric growth of the early stages (0 = default: 8, or 16 for small batches)
         if (value != 0 && (value < 2 || value > 64)) return fail(RQ_ERR_INVALID, "stage_growth must be 0 or in [2, 64]");
         g_stage_growth = value;
+        return RQ_OK;
+    }
+    if (std::string(name) == "base_device_mb") {  // HBM budget of the raw vectors for indexes built / loaded from now on:
+                                                  // -1 = automatic (default), else MiB; the rest goes to pinned host memory
+        if (value < -1) return fail(RQ_ERR_INVALID, "base_device_mb must be >= -1");
+        g_base_device_mb = value;
         return RQ_OK;
     }
     if (std::string(name) == "max_scan_blocks") {  // test hook: blocks per scan launch (0 = the hardware bound), forces chunked stages

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import Info, MetricsT, ProfileT, check, lib
+from ._lib import BuildStatsT, Info, MetricsT, ProfileT, check, lib
 
 ARR_BASE, ARR_ORTHOGONAL, ARR_CENTROIDS, ARR_OFFSETS, ARR_MAP_IDS, ARR_CODES, ARR_FACTORS = range(7)
 
@@ -33,6 +33,7 @@ class RaBitQ:
         info = Info()
         check(lib().rq_info(self._h, C.byref(info)))
         self.dim, self.k, self.n, self.max_list_len = int(info.dim), int(info.k), int(info.n), int(info.max_list_len)
+        self.n_hbm = int(info.n_hbm)      # raw vectors in HBM; the other n - n_hbm live in pinned host memory
 
     # ---- RaBitQ::from_path (src/rabitq.rs:159) ------------------------------------------------
     @classmethod
@@ -64,6 +65,12 @@ class RaBitQ:
         h = C.c_void_p()
         check(lib().rq_build_device(C.c_void_p(base_ptr), n, d, C.c_void_p(centroids_ptr), k, _addr(P), seed, C.byref(h)))
         return cls(h)
+
+    @classmethod
+    def builder(cls, n: int, d: int, centroids_ptr: int, k: int, orthogonal=None, seed: int = 0,
+                max_device_base_bytes: int = 0) -> "Builder":
+        """Streamed two-pass build for inputs that are not resident (include/rabitq_hip.h: rq_builder_*)."""
+        return Builder(n, d, centroids_ptr, k, orthogonal, seed, max_device_base_bytes)
 
     # ---- load_from_dir / dump_to_dir (src/rabitq.rs:84, :128) ---------------------------------
     @classmethod
@@ -231,6 +238,40 @@ class RaBitQ:
         check(lib().rq_query_batch_sharded_device(self._h, C.c_void_p(comm), world, id_offset, C.c_void_p(q_ptr), nq, length,
                                                   probe, topk, int(heuristic_rank), C.c_void_p(out_dist_ptr),
                                                   C.c_void_p(out_id_ptr), C.c_void_p(out_n_ptr)))
+
+
+class Builder:
+    """assign_chunk every row -> order() -> place_chunk every row -> finish() -> RaBitQ.  Chunks are device pointers."""
+
+    def __init__(self, n, d, centroids_ptr, k, orthogonal=None, seed=0, max_device_base_bytes=0):
+        P = _f32(orthogonal) if orthogonal is not None else None
+        self._b = C.c_void_p()
+        check(lib().rq_builder_create(n, d, C.c_void_p(centroids_ptr), k, _addr(P), seed, max_device_base_bytes, C.byref(self._b)))
+
+    def assign_chunk(self, rows_ptr: int, i0: int, m: int) -> None:
+        check(lib().rq_builder_assign_chunk(self._b, C.c_void_p(rows_ptr), i0, m))
+
+    def order(self) -> None:
+        check(lib().rq_builder_order(self._b))
+
+    def place_chunk(self, rows_ptr: int, i0: int, m: int) -> None:
+        check(lib().rq_builder_place_chunk(self._b, C.c_void_p(rows_ptr), i0, m))
+
+    def stats(self) -> dict:
+        st = BuildStatsT()
+        check(lib().rq_builder_stats(self._b, C.byref(st)))
+        return {name: getattr(st, name) for name, _ in BuildStatsT._fields_ if name != "reserved"}
+
+    def finish(self) -> RaBitQ:
+        h = C.c_void_p()
+        b, self._b = self._b, None
+        check(lib().rq_builder_finish(b, C.byref(h)))
+        return RaBitQ(h)
+
+    def __del__(self):
+        if getattr(self, "_b", None):
+            lib().rq_builder_free(self._b)
+            self._b = None
 
 
 # ---- METRICS (src/metrics.rs) --------------------------------------------------------------------

@@ -31,7 +31,7 @@ def test_struct_layouts_match_reference():
     from rabitq_amd import _lib
     import ctypes as C
     assert C.sizeof(_lib.MetricsT) == 32            # 4 x u64, src/metrics.rs:7-18
-    assert C.sizeof(_lib.Info) == 24
+    assert C.sizeof(_lib.Info) == 32            # rq_info_t: dim, k, n, max_list_len, reserved, n_hbm
     # Factor is repr(C) 4 x f32 (src/rabitq.rs:21-32): (n, 4) f32 arrays are passed as rq_factor_t*
     assert np.dtype(np.float32).itemsize * 4 == 16
 

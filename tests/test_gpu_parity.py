@@ -821,3 +821,93 @@ def test_engine_shard_merge_matches_torch(rq):
     valid = (torch.arange(topk)[None, :] < b[2][:, None])
     assert torch.equal(a[1].cpu()[valid], b[1][valid])
     assert torch.equal(a[0].cpu().view(torch.int32)[valid], b[0].view(torch.int32)[valid])
+
+
+# ---- beyond-HBM indexes: raw vectors tiered between HBM and pinned host memory; streamed two-pass build ------------
+@pytest.mark.parametrize("dev_mb", [0, 1])
+def test_host_resident_rerank_matches_oracle(rq, oracle, tmp_path, dev_mb):
+    """The rerank gathers rows from pinned host memory (all of them with a 0 MiB HBM budget, all but the first 2048
+    with 1 MiB): ids, order, distances and counters still equal the oracle's, in both rerank kernels (the fused
+    small-batch finish and the full-chip accurate_kernel), both rankers; base / dump / shard read through the tiers."""
+    from rabitq_amd import index as ix
+    n, d, k = 12000, 128, 24
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.8, seed=91, centre_scale=0.6)
+    P = synth.random_orthogonal(d, seed=92)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    ix.set_option("base_device_mb", dev_mb)
+    try:
+        gidx = rq.RaBitQ.build(x, centres, P)
+        lidx = rq.RaBitQ.from_arrays(oidx.base, P, oidx.centroids, oidx.offsets, oidx.map_ids, oidx.codes, oidx.factors)
+    finally:
+        ix.set_option("base_device_mb", -1)
+    assert gidx.n_hbm == lidx.n_hbm == (0 if dev_mb == 0 else 2048)
+    assert_bits_equal(gidx.base, oidx.base, "base through both tiers")
+    queries, _, _ = synth.mixture(300, d, k, sigma=0.8, seed=93, centre_scale=0.6)
+    for g in (gidx, lidx):
+        _compare_with_oracle(rq, oracle, oidx, g, queries, 8, 10, False)        # nq >= 256: accurate_kernel
+        _compare_with_oracle(rq, oracle, oidx, g, queries[:40], k, 20, False)   # nq < 256: stage_finish_kernel
+        _compare_with_oracle(rq, oracle, oidx, g, queries[:40], 4, 10, True)
+    for j in (0, 5):
+        single = gidx.query(queries[j], 8, 10)
+        od, oi = oidx.query(queries[j], 8, 10)
+        assert [i for _, i in single] == oi.tolist()
+    pos = np.array([0, 1, 2047, 2048, 2049, n - 1], np.uint32)
+    qp = queries[3]
+    assert_bits_equal(rq.ops.rerank(gidx, qp, pos), np.array([oracle.l2_squared_distance(oidx.base[p], qp) for p in pos], np.float32),
+                      "rq_rerank across the tier boundary")
+    gidx.dump_to_dir(str(tmp_path / "g"))
+    oidx.dump_to_dir(str(tmp_path / "o"))
+    assert (tmp_path / "g" / "base.fvecs").read_bytes() == (tmp_path / "o" / "base.fvecs").read_bytes()
+    owner, _ = gidx.partition_lists(2)
+    ix.set_option("base_device_mb", dev_mb)
+    try:
+        sh = gidx.shard(owner, 1)
+    finally:
+        ix.set_option("base_device_mb", -1)
+    keep = np.concatenate([np.arange(oidx.offsets[c], oidx.offsets[c + 1]) for c in range(k) if owner[c] == 1])
+    assert_bits_equal(sh.base, oidx.base[keep], "shard of a tiered index")
+    assert np.array_equal(sh.map_ids, oidx.map_ids[keep])
+    for g in (gidx, lidx, sh):
+        g.close()
+    oidx.close()
+
+
+@pytest.mark.parametrize("d,budget", [(128, 2**64 - 1), (100, 300 * 512), (768, 0)])
+def test_streamed_builder_equals_one_shot_build(rq, oracle, d, budget):
+    """rq_builder_* (input fed twice in ragged, out-of-order chunks) == rq_build == the oracle, array for array."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n, k = 5000, 12
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.8, seed=d, centre_scale=0.6)
+    P = synth.random_orthogonal((d + 63) // 64 * 64, seed=d + 1)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    xd, cd = torch.from_numpy(x).to(dev), torch.from_numpy(centres).to(dev)
+    b = rq.RaBitQ.builder(n, d, cd.data_ptr(), k, orthogonal=P, max_device_base_bytes=budget)
+    cuts = [0, 1, 700, 701, 3000, 4999, n]
+    chunks = [(cuts[i], cuts[i + 1] - cuts[i]) for i in range(len(cuts) - 1)]
+    for i0, m in reversed(chunks):
+        buf = xd[i0:i0 + m].clone()                 # a chunk buffer of its own, as a streaming caller would have
+        b.assign_chunk(buf.data_ptr(), i0, m)
+    with pytest.raises(rq.RabitqError):
+        b.place_chunk(xd.data_ptr(), 0, 1)          # before order()
+    b.order()
+    st = b.stats()
+    assert st["rows_assigned"] == n and st["rows_in_hbm"] + st["rows_in_host_memory"] == n and st["ms_rotate"] > 0
+    if budget == 300 * 512:
+        assert st["rows_in_hbm"] == 300
+    for i0, m in chunks[::2] + chunks[1::2]:
+        buf = xd[i0:i0 + m].clone()
+        b.place_chunk(buf.data_ptr(), i0, m)
+    gidx = b.finish()
+    for name in ("base", "centroids", "offsets", "map_ids", "codes", "factors"):
+        assert_bits_equal(getattr(gidx, name), getattr(oidx, name), name)
+    queries, _, _ = synth.mixture(50, d, k, sigma=0.8, seed=d + 2, centre_scale=0.6)
+    _compare_with_oracle(rq, oracle, oidx, gidx, queries, 6, 10, False)
+    # an unfinished builder can be abandoned; finishing early is refused
+    b2 = rq.RaBitQ.builder(n, d, cd.data_ptr(), k, orthogonal=P)
+    b2.assign_chunk(xd.data_ptr(), 0, 10)
+    with pytest.raises(rq.RabitqError):
+        b2.order()
+    del b2
+    gidx.close()
+    oidx.close()
