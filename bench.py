@@ -164,7 +164,7 @@ def main():
         for j0 in range(0, m if ngt else 0, gchunk):
             xb = xc[j0:j0 + gchunk].double()
             d2 = qn - 2.0 * (qg @ xb.T) + (xb * xb).sum(1)[None, :]
-            cd, ci_ = torch.topk(d2, topk, dim=1, largest=False)
+            cd, ci_ = torch.topk(d2, min(topk, xb.shape[0]), dim=1, largest=False)
             alld = torch.cat([best_d, cd], 1)
             alli = torch.cat([best_i, ci_ + i0 + j0 + rank * n], 1)
             sel = torch.topk(alld, topk, dim=1, largest=False).indices
