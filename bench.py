@@ -306,6 +306,14 @@ def main():
     step()
     fence()
     breakdown = {key[3:]: round(v, 3) for key, v in rqi.last_profile().items() if key.startswith("ms_")}
+    # share of the matrix-core scan's 32x32 sub-tile steps that were flagged by the integer gate and took the exact f32 path
+    # (one more untimed step with the counting hook on; results are unchanged by it)
+    rqi.set_option("scan_debug", 128)
+    step()
+    fence()
+    ep = rqi.last_profile()
+    rqi.set_option("scan_debug", 0)
+    exact_rate = ep["matrix_exact_steps"] / ep["matrix_subtile_steps"] if ep["matrix_subtile_steps"] else None
     rqi.set_profiling(2)
     if world > 1:
         t = torch.tensor([elapsed], device="cpu" if args.backend == "gloo" else dev, dtype=torch.float64)
@@ -408,6 +416,7 @@ def main():
             "rough_per_query": m["rough"] / max(m["query"], 1), "precise_per_query": m["precise"] / max(m["query"], 1),
             "kernel_ms_per_step": breakdown, "scan_ms_per_step_timed": round(prof["ms_scan"] / args.steps, 3),
             "rerank_candidates_per_query": prof["rerank_candidates"] / (B * args.steps),
+            "matrix_exact_path_rate": None if exact_rate is None else round(exact_rate, 5),
             "retries": int(prof["retries"]), "roofline": roofline, "roofline_scan_all_launches": scan_all,
             "roofline_rotation": rotation,
             "scan_small_batch": small, "single_query": single, "two_batches_in_flight": overlap}

@@ -266,6 +266,9 @@ typedef struct {
     float ms_scan_matrix;      /* device time of the scan_mfma_kernel launches           */
     uint32_t matrix_launches;
     uint64_t matrix_pairs;     /* (query, candidate) pairs they scored                   */
+    /* only with rq_set_option("scan_debug", 128) (a measurement hook; results unchanged): 32x32 (query x candidate)
+     * sub-tile steps of the matrix-core scan, and how many of them were flagged and took the exact f32 path */
+    uint64_t matrix_subtile_steps, matrix_exact_steps;
 } rq_profile_t;
 /* level: 0 = off; 1 = every kernel group bracketed (each event costs a few microseconds of stream
  * time); 2 = only the scan launches and the whole pass (ms_scan, ms_total; the other fields stay 0). */
@@ -277,8 +280,8 @@ rq_status rq_set_profiling(int level);
  * default); vectors beyond it live in pinned host memory.  Results never depend on it.
  * "max_scan_blocks": test hook, blocks per scan launch (0 = hardware bound).
  * Developer knobs: "stage_growth" (geometric growth of the early stages, 0 = default; results are
- * identical for every value), "scan_debug" (timing ablations of the matrix-core scan: results are
- * WRONG while it is non-zero). */
+ * identical for every value), "scan_debug" (bit 128: count sub-tile / exact-path steps into rq_profile_t, results unchanged;
+ * the other bits are timing ablations of the matrix-core scan: results are WRONG while they are set). */
 rq_status rq_set_option(const char *name, int value);
 rq_status rq_last_profile(rq_profile_t *out);
 

@@ -834,6 +834,7 @@ struct ScanPtrs {   // host-side bundle only
     SurvRec *surv;                // per query `cap` records
     RunRec *runs;                 // per query `cap` run descriptors
     unsigned long long *surv_cnt; // per query: low 32 bits = records, high 32 bits = runs
+    unsigned long long *stat;     // matrix-core scan measurement hook (ScanArgs::dbg & 128)
 };
 #define SCAN_PARAMS                                                                                  \
     const uint32_t *__restrict__ codes, const float4 *__restrict__ factors,                          \
@@ -1096,6 +1097,7 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
                                                            const uint32_t *__restrict__ recs,
                                                            SurvRec *__restrict__ surv, RunRec *__restrict__ runs,
                                                            unsigned long long *__restrict__ surv_cnt,
+                                                           unsigned long long *__restrict__ stat /* [2], only with a.dbg & 128 */,
                                                            const ScanArgs a) {
     constexpr uint32_t OPDW = 12 * W;            // operand dwords per record: dim fp6 fields
     constexpr uint32_t OPLD = OPDW + 2;          // row stride (dwords) of the operand image: conflict-free ds_read_b64
@@ -1250,6 +1252,9 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
             bexp[t][m][5] = (p3.x >> 16) | (p3.y << 16);
         }
 
+    // measurement hook (results unchanged): 32x32 sub-tile steps taken, and how many of them took the exact path
+    const uint32_t count_stat = __builtin_amdgcn_readfirstlane((a.dbg & 128u) ? 1u : 0u);
+    uint32_t n_steps = 0, n_flag = 0;
     uint32_t slot = 0;  // ring slot of query tile qt
     for (uint32_t qt = 0; qt < ((a.dbg & 4u) ? 0u : ntiles); ++qt) {
         if constexpr (QPB == 1) {  // 3 slots, one barrier per tile, two tiles in flight
@@ -1353,7 +1358,9 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
 #pragma unroll
             for (int gq = 3; gq < 15; gq += 2) mxi = imax3(mxi, ai[gq], ai[gq + 1]);
             mxi = mxi > ai[15] ? mxi : ai[15];
+            if (count_stat) ++n_steps;
             if ((force_any | (__ballot(mxi > 0) != 0ull ? 1u : 0u)) & (exact_off ^ 1u)) {  // wave-uniform; everything below
+                if (count_stat) ++n_flag;
                 // lives inside this branch so that the common path carries no state of it (not even a zeroed tile)
                 uint32_t gmask = force_any ? 0xFFFFu : 0u;  // accumulator registers with at least one flagged lane
                 f32x16 sc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1408,6 +1415,10 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
         slot = slot + 1 == scan_mfma_ring_slots<W>() ? 0 : slot + 1;
     }
     if (nE) flush();
+    if (count_stat && lane == 0) {
+        atomicAdd(stat, (unsigned long long)n_steps);
+        atomicAdd(stat + 1, (unsigned long long)n_flag);
+    }
 }
 
 // generic-W fallback (dim/64 not in the templated set): code words re-read per query (L1-resident)
@@ -1547,6 +1558,87 @@ __device__ __forceinline__ void sort_segment(T *__restrict__ recs, uint32_t n) {
         bitonic_sort_block(recs, n, key);  // in global memory (L2), rare
     }
 }
+// The run directory ordered by (slot, position) without a comparison sort over the whole directory: runs are
+// bucketed by probe slot into a second buffer (LDS histogram + scatter: O(n)), then every bucket -- the runs one list
+// contributed -- is ordered by position by ONE wave through rank counting (a run's final place is the number of
+// smaller positions in its bucket; the bucket's positions are staged through LDS in chunks and compared four at a
+// time) and written back to the directory at its final index.  Block-cooperative; needs nslots <= MAX_SLOTS.
+#define RQ_BUCKET_CHUNK 1024u
+template <uint32_t MAX_SLOTS>
+__device__ __forceinline__ void sort_runs_by_slot(RunRec *__restrict__ dir, RunRec *__restrict__ tmp, uint32_t n, uint32_t nslots) {
+    __shared__ uint32_t start[MAX_SLOTS + 1], cursor[MAX_SLOTS];
+    __shared__ uint32_t wsum[16];
+    __shared__ __attribute__((aligned(16))) uint32_t keys[4][RQ_BUCKET_CHUNK];  // per wave (blocks of 256 threads)
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
+    for (uint32_t i = tid; i < nslots; i += nthr) cursor[i] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += nthr) atomicAdd(&cursor[dir[i].slot], 1u);
+    __syncthreads();
+    {  // exclusive scan of the bucket sizes: each thread owns a contiguous stretch of buckets
+        const uint32_t per = (nslots + nthr - 1) / nthr, b0 = tid * per < nslots ? tid * per : nslots;
+        const uint32_t b1 = b0 + per < nslots ? b0 + per : nslots;
+        uint32_t sum = 0;
+        for (uint32_t i = b0; i < b1; ++i) sum += cursor[i];
+        uint32_t incl = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o, 64);
+            if ((int)lane >= o) incl += up;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (uint32_t w = 0; w < wave; ++w) run += wsum[w];
+        for (uint32_t i = b0; i < b1; ++i) {
+            const uint32_t c = cursor[i];
+            start[i] = run;
+            cursor[i] = run;
+            run += c;
+        }
+        if (tid == 0) start[nslots] = n;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += nthr) {
+        const RunRec r = dir[i];
+        tmp[atomicAdd(&cursor[r.slot], 1u)] = r;
+    }
+    __threadfence_block();
+    __syncthreads();  // every record is in tmp (bucketed); dir is free to receive the final order
+    for (uint32_t sl = wave; sl < nslots; sl += nwaves) {  // one wave per bucket
+        const uint32_t b0 = start[sl], m = start[sl + 1] - b0;
+        if (m == 0) continue;
+        const RunRec *seg = tmp + b0;
+        if (m == 1) {
+            if (lane == 0) dir[b0] = seg[0];
+            continue;
+        }
+        const bool one_chunk = m <= RQ_BUCKET_CHUNK;  // the usual case: the bucket's positions are staged once
+        auto stage_keys = [&](uint32_t c0, uint32_t cm) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // the previous contents have been consumed by every lane
+            for (uint32_t t = lane; t < ((cm + 3) & ~3u); t += 64) keys[wave][t] = t < cm ? seg[c0 + t].pos : 0xFFFFFFFFu;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+        if (one_chunk) stage_keys(0, m);
+        for (uint32_t e0 = 0; e0 < m; e0 += 64) {  // 64 runs of the bucket at a time, one per lane
+            RunRec mine;
+            mine.pos = 0xFFFFFFFFu;
+            if (e0 + lane < m) mine = seg[e0 + lane];
+            uint32_t rank = 0;
+            for (uint32_t c0 = 0; c0 < m; c0 += RQ_BUCKET_CHUNK) {
+                const uint32_t cm = m - c0 < RQ_BUCKET_CHUNK ? m - c0 : RQ_BUCKET_CHUNK;
+                if (!one_chunk) stage_keys(c0, cm);
+                for (uint32_t t = 0; t < cm; t += 4) {
+                    const uint4 kq = *reinterpret_cast<const uint4 *>(&keys[wave][t]);  // same address in every lane: broadcast
+                    rank += (kq.x < mine.pos ? 1u : 0u) + (kq.y < mine.pos ? 1u : 0u) + (kq.z < mine.pos ? 1u : 0u) +
+                            (kq.w < mine.pos ? 1u : 0u);
+                }
+            }
+            if (e0 + lane < m) dir[b0 + rank] = mine;  // positions are unique within a bucket: ranks are a permutation
+        }
+    }
+}
+
 // heuristic ranker's accepted array (src/rerank.rs:170-176): by (Ord32(accurate), arrival)
 __global__ __launch_bounds__(256) void sort_survivors_kernel(SurvRec *__restrict__ surv,
                                                              const uint32_t *__restrict__ surv_cnt,
@@ -1856,13 +1948,44 @@ __global__ __launch_bounds__(256) void accurate_kernel(SurvRec *__restrict__ sur
 
 __global__ __launch_bounds__(64) void sort_runs_kernel(RunRec *__restrict__ runs,
                                                         const unsigned long long *__restrict__ surv_cnt,
-                                                        uint32_t cap) {
+                                                        uint32_t cap, uint32_t *__restrict__ big_list,
+                                                        uint32_t *__restrict__ big_count) {
     const uint32_t b = blockIdx.x;
     const unsigned long long c = surv_cnt[b];
     if ((uint32_t)c > cap) return;
     // early stages leave a few dozen runs per query, the stages around one list's worth a few hundred (more at dim 64,
     // where the estimates are noisier): 512 descriptors = 8 KiB of LDS per 64-thread block keep them out of global memory
-    sort_segment<RunRec, 512>(runs + (uint64_t)b * cap, (uint32_t)(c >> 32));
+    const uint32_t nruns = (uint32_t)(c >> 32);
+    if (nruns > 512) {  // a loose threshold: handed to sort_runs_mid_kernel (slot buckets + rank counting)
+        if (threadIdx.x == 0) big_list[atomicAdd(big_count, 1u)] = b;
+        return;
+    }
+    sort_segment<RunRec, 512>(runs + (uint64_t)b * cap, nruns);
+}
+
+// Directories of more than 512 runs, listed by sort_runs_kernel, are ordered by a persistent launch that walks the
+// list (it exits at once when the list is empty, the common case): slot-bucketing + per-bucket rank counting through
+// the second directory buffer; the last block out resets the counter for the next stage.
+__global__ __launch_bounds__(256) void sort_runs_mid_kernel(RunRec *__restrict__ runs, RunRec *__restrict__ runs_tmp,
+                                                            const unsigned long long *__restrict__ surv_cnt, uint32_t cap,
+                                                            const uint32_t *__restrict__ big_list,
+                                                            uint32_t *__restrict__ big_count /* [0] entries, [1] blocks done */,
+                                                            uint32_t nslots) {
+    const uint32_t total = big_count[0];
+    for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
+        const uint32_t b = big_list[i], n = (uint32_t)(surv_cnt[b] >> 32);
+        if (nslots <= 1024) sort_runs_by_slot<1024>(runs + (uint64_t)b * cap, runs_tmp + (uint64_t)b * cap, n, nslots);
+        else sort_segment<RunRec, 16>(runs + (uint64_t)b * cap, n);  // more than 1024 probe slots: plain bitonic sort (global memory)
+        __syncthreads();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // every block reads `total` before it counts itself done: the last one out may reset both
+        __threadfence();
+        if (atomicAdd(big_count + 1, 1u) + 1 == gridDim.x) {
+            big_count[0] = 0;
+            big_count[1] = 0;
+        }
+    }
 }
 
 template <bool HEURISTIC>

@@ -195,7 +195,7 @@ struct Workspace {
     DevBuf<float> qpad, y, dist, probe_dist, thr, recent;
     DevBuf<uint32_t> q_hist, q_start, q_order;  // rerank order of a large batch (queries grouped by nearest list)
     DevBuf<uint32_t> probe_cluster, recs, grp_cnt, grp_start, heap_len, heap_id, precise, need,
-        nsurv, win_count, arr_len, row_map;
+        nsurv, win_count, arr_len, row_map, big_list;
     DevBuf<int32_t> heap_key;
     DevBuf<PairScalars> scal;
     DevBuf<uint64_t> planes;
@@ -203,7 +203,7 @@ struct Workspace {
     DevBuf<uint32_t> qf6;
     DevBuf<unsigned long long> rough_cnt, totals, surv_cnt;
     DevBuf<SurvRec> surv, arr;
-    DevBuf<RunRec> runs;
+    DevBuf<RunRec> runs, runs_tmp;
     // multi-GPU step (rq_query_batch_sharded_device): this shard's results, the all-gathered keys, the merged keys
     DevBuf<float> sh_dist;
     DevBuf<uint32_t> sh_id, sh_n;
@@ -237,6 +237,7 @@ struct rq_index {
     std::vector<std::unique_ptr<Workspace>> ws_pool;
     FactorStats fstats{0, 0, 0, 0};
     std::atomic<uint32_t> cap_hint{0};  // survivor-buffer capacity learnt from earlier batches
+    uint64_t pass_budget = 24ull << 30;  // bytes of survivor / run buffers one query pass may use (set by finish_index)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -393,7 +394,7 @@ static size_t scan_mfma_ring_bytes(uint32_t W) { return (W <= 2 ? 4ull : 3ull) *
 template <int W, int NT>
 static void launch_scan_mfma_t(const ScanPtrs &p, const ScanArgs &a, dim3 g, hipStream_t st) {
     scan_mfma_kernel<W, NT><<<g, dim3(256), scan_mfma_ring_bytes(W), st>>>(p.codes, p.factors, p.offsets, p.grp_start, p.grp_cnt,
-                                                                             p.recs, p.surv, p.runs, p.surv_cnt, a);
+                                                                             p.recs, p.surv, p.runs, p.surv_cnt, p.stat, a);
 }
 // callers check scan_has_mfma(W) first
 static void launch_scan_mfma(const ScanPtrs &p, const ScanArgs &args, uint32_t W, hipStream_t st) {
@@ -490,6 +491,7 @@ struct QueryParams {
 };
 
 #define RQ_DEFAULT_CAP 4096u
+#define RQ_MAX_CAP_HINT 32768u
 #define RQ_MAX_NQ_PER_PASS 65536u
 #define RQ_MAX_PROBE 16384u
 
@@ -519,6 +521,7 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
     RQC(ws.thr.ensure(nq));
     RQC(ws.surv.ensure(nq * qp.cap));
     RQC(ws.runs.ensure(nq * qp.cap));
+    if (nq >= 256) RQC(ws.runs_tmp.ensure(nq * qp.cap));  // large batches order long run directories through it
     RQC(ws.surv_cnt.ensure(nq));
     RQC(ws.heap_len.ensure(nq));
     RQC(ws.heap_key.ensure(nq * qp.topk));
@@ -530,6 +533,7 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
     RQC(ws.win_count.ensure(nq));
     RQC(ws.arr_len.ensure(nq));
     RQC(ws.row_map.ensure(nq));
+    RQC(ws.big_list.ensure(nq + 2));  // [nq] = entries, [nq + 1] = blocks done
     if (qp.heuristic) RQC(ws.arr.ensure(nq * qp.hcap));
     return RQ_OK;
 }
@@ -568,6 +572,8 @@ static rq_status finish_pass(const rq_index *idx, Workspace &ws, PassResult *res
         prof_acc->scan_candidates += res->rough;
         prof_acc->scan_bytes += res->rough * (uint64_t)(dim / 8 + 16);
         prof_acc->rerank_candidates += ws.h_totals[3];
+        prof_acc->matrix_subtile_steps += ws.h_totals[5];
+        prof_acc->matrix_exact_steps += ws.h_totals[6];
     }
     return RQ_OK;
 }
@@ -658,6 +664,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     // 4. ranker state (rerank.rs:70-77, :129-139) and per-query counters
     init_state_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(rs, ws.surv_cnt.p, nq);
     HIPC(hipMemsetAsync(ws.totals.p, 0, 8 * sizeof(unsigned long long), st));
+    HIPC(hipMemsetAsync(ws.big_list.p + nq, 0, 8, st));
     pf.end();
 
     // 5. stages.  The reference visits a query's candidates as ONE stream: probed lists nearest-first,
@@ -677,10 +684,14 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         const uint64_t growth = gopt >= 2 ? (uint64_t)gopt : (nq >= 256 ? 8 : 16);
         uint64_t lo = 0, hi = std::max<uint32_t>(topk, 1);
         const uint64_t avg = std::max<uint64_t>(1, idx->n / std::max<uint32_t>(k, 1));
+        // the threshold has settled once a query has seen its whole nearest list; with unbalanced lists (Zipf sizes) the
+        // nearest list of many queries is one of the long ones, so the bar is the LONGEST list (capped: a single
+        // monster list must not push the whole batch through many thin stages)
+        const uint64_t settle = std::max<uint64_t>(avg, std::min<uint64_t>(idx->max_list_len, 16 * avg));
         while (lo < total_max) {
             // past the first two lists' worth of candidates the threshold is already tight: scan the rest of
             // the stream as ONE stage (every list then meets all its queries at once: full 32-query tiles)
-            const bool last = hi >= total_max || lo >= avg;
+            const bool last = hi >= total_max || lo >= settle;
             stages.push_back({(uint32_t)lo, last ? 0xFFFFFFFFu : (uint32_t)hi});
             if (last) break;
             lo = hi;
@@ -738,6 +749,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         sp.surv = ws.surv.p;
         sp.runs = ws.runs.p;
         sp.surv_cnt = ws.surv_cnt.p;
+        sp.stat = ws.totals.p + 5;  // totals[5], [6]: sub-tile steps / exact-path steps of the matrix-core scan (dbg & 128)
         a.cap = qp.cap;
         a.dbg = (uint32_t)g_scan_dbg.load();
         a.tiles_per_group = ceil_div(std::min<uint64_t>(idx->max_list_len, sg.s_hi), use_mfma ? scan_mfma_tile(W) : tile);
@@ -767,7 +779,9 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                                                                                     rerank_order);
             pf.end();
             pf.begin(PF_SORT);
-            sort_runs_kernel<<<nq, 64, 0, st>>>(ws.runs.p, ws.surv_cnt.p, qp.cap);
+            sort_runs_kernel<<<nq, 64, 0, st>>>(ws.runs.p, ws.surv_cnt.p, qp.cap, ws.big_list.p, ws.big_list.p + nq);
+            // queries with long run directories (loose thresholds): slot-bucketed ordering, persistent blocks walking the list
+            sort_runs_mid_kernel<<<2048, 256, 0, st>>>(ws.runs.p, ws.runs_tmp.p, ws.surv_cnt.p, qp.cap, ws.big_list.p, ws.big_list.p + nq, nprobe);
             pf.end();
             pf.begin(PF_REPLAY);
             if (qp.heuristic)
@@ -834,8 +848,10 @@ static rq_status validate_query(const rq_index *idx, const float *d_q, uint32_t 
 // queries per pass: survivor / run buffers are 32 B per slot per query (keep one pass under ~24 GiB) and
 // (query, list) pairs per pass <= 2^22 (bounds the per-pair buffers and every launch size)
 static uint32_t pass_queries(const rq_index *idx, uint32_t remaining, uint32_t probe, uint32_t cap0) {
+    // survivor records + two run directories: 48 B per slot per query; the budget is a third of the HBM that was free
+    // once the index was resident (at least 4 GiB: an index that fills the HBM still answers 20 000-query passes)
     uint32_t step_nq = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(remaining, RQ_MAX_NQ_PER_PASS),
-                                                    std::max<uint64_t>(1, (24ull << 30) / ((uint64_t)cap0 * 32)));
+                                                    std::max<uint64_t>(1, idx->pass_budget / ((uint64_t)cap0 * 48)));
     return std::min<uint32_t>(step_nq, std::max<uint32_t>(1, (1u << 22) / std::min(probe, idx->k)));
 }
 
@@ -848,7 +864,10 @@ static rq_status after_pass(rq_index *idx, Workspace *ws, const QueryParams &qp,
     const bool heuristic = qp.heuristic;
     const uint32_t npb = std::min(probe, idx->k);
     if (pr.max_need > qp.cap) {  // remember (with headroom) so that later batches do not overflow
-        uint32_t want = pow2_ceil((uint32_t)std::min<uint64_t>(pr.max_need + pr.max_need / 4, 1u << 22));
+        // ... but only up to RQ_MAX_CAP_HINT: survivor buffers are cap x 32 B for EVERY query of the pass, so one outlier
+        // query (a loose threshold after an unlucky nearest list) must not shrink the passes of all later batches; beyond
+        // the bound the outliers are simply re-run below with the capacity they asked for
+        uint32_t want = pow2_ceil((uint32_t)std::min<uint64_t>(pr.max_need + pr.max_need / 4, RQ_MAX_CAP_HINT));
         uint32_t cur = idx->cap_hint.load();
         while (cur < want && !idx->cap_hint.compare_exchange_weak(cur, want)) {}
     }
@@ -1069,6 +1088,11 @@ static rq_status finish_index(rq_index *idx) {
     }
     HIPC(hipDeviceSynchronize());
     HIPC(hipGetLastError());
+    {
+        size_t free_b = 0, total_b = 0;
+        HIPC(hipMemGetInfo(&free_b, &total_b));
+        idx->pass_budget = std::min<uint64_t>(std::max<uint64_t>(free_b / 3, 4ull << 30), 96ull << 30);
+    }
     return RQ_OK;
 }
 

@@ -911,3 +911,28 @@ def test_streamed_builder_equals_one_shot_build(rq, oracle, d, budget):
     del b2
     gidx.close()
     oidx.close()
+
+
+def test_long_run_directories_large_batch(rq, oracle):
+    """Loose thresholds (deep top-k, one long list) leave more than 512 survivor runs per query in a large batch:
+    the directories are ordered by the slot-bucketed rank sort (sort_runs_mid_kernel), several stages in a row."""
+    from rabitq_amd import index as ix
+    n, d, k = 200_000, 64, 2
+    rng = np.random.default_rng(15)
+    centres = np.stack([np.zeros(d, np.float32), np.full(d, 5.0, np.float32)])
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x[:3000] += 5.0
+    P = synth.random_orthogonal(d, seed=16)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    gidx = rq.RaBitQ.build(x, centres, P)
+    # queries at the data's own radius: their neighbours are spread over the whole (centre-distance ordered) list, so the
+    # threshold learnt from the list's head stays loose and every later stage leaves thousands of sparse survivors
+    queries = (x[rng.integers(3000, n, 260)] + 0.1 * rng.standard_normal((260, d))).astype(np.float32)
+    _compare_with_oracle(rq, oracle, oidx, gidx, queries, 2, 200, False)   # default buffers overflow: re-runs, capacity learnt
+    _compare_with_oracle(rq, oracle, oidx, gidx, queries, 2, 200, False)   # now the whole batch stays on the large-batch path
+    pr = ix.last_profile()
+    assert pr["retries"] == 0 and pr["rerank_candidates"] / 260 > 4096, (pr["retries"], pr["rerank_candidates"] / 260)
+    _compare_with_oracle(rq, oracle, oidx, gidx, queries, 1, 100, False)
+    _compare_with_oracle(rq, oracle, oidx, gidx, queries, 2, 50, True)
+    gidx.close()
+    oidx.close()
