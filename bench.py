@@ -88,7 +88,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.backend, rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        keep = os.dup(1)          # some backends (gloo) chat on stdout while connecting: stdout carries the JSON line only
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
     if args.same_device:
         local_rank = 0
     assert world == max(args.gpus, 1), f"--gpus {args.gpus} but WORLD_SIZE {world}"

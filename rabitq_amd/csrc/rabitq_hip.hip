@@ -699,6 +699,9 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             // the geometric step must not carry an early (VALU) stage over many lists when lists are short:
             // past two lists' worth the rest belongs to the final stage
             if (lo < 2 * avg && hi > 2 * avg) hi = 2 * avg;
+            // ... and the last early stage ends exactly where the threshold has settled: everything beyond belongs to the
+            // final (matrix-core) stage, where a list meets all its queries at once
+            if (lo < settle && hi > settle) hi = settle;
         }
     }
     ws.pend_matrix_ranges.clear();
@@ -781,7 +784,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             pf.begin(PF_SORT);
             sort_runs_kernel<<<nq, 64, 0, st>>>(ws.runs.p, ws.surv_cnt.p, qp.cap, ws.big_list.p, ws.big_list.p + nq);
             // queries with long run directories (loose thresholds): slot-bucketed ordering, persistent blocks walking the list
-            sort_runs_mid_kernel<<<2048, 256, 0, st>>>(ws.runs.p, ws.runs_tmp.p, ws.surv_cnt.p, qp.cap, ws.big_list.p, ws.big_list.p + nq, nprobe);
+            sort_runs_mid_kernel<<<512, 256, 0, st>>>(ws.runs.p, ws.runs_tmp.p, ws.surv_cnt.p, qp.cap, ws.big_list.p, ws.big_list.p + nq, nprobe);
             pf.end();
             pf.begin(PF_REPLAY);
             if (qp.heuristic)
