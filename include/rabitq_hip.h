@@ -120,6 +120,11 @@ rq_status rq_kmeans_device(const float *d_base, uint64_t n, uint32_t d, uint32_t
 /* Byte-compatible with the crate's five-file directory (vecs framing: src/utils.rs:280-364). */
 rq_status rq_load_dir(const char *dir, rq_index **out);
 rq_status rq_dump_dir(const rq_index *idx, const char *dir);
+/* load_from_json / dump_to_json, src/rabitq.rs:72-81: the serde_json image of the `RaBitQ` struct (faer `Mat`s as
+ * {"nrows","ncols","data": row-major}; base dim x n, centroids dim x k).  A debugging format in the reference too: the
+ * text is ~10x the binary directory, so use rq_load_dir / rq_dump_dir for anything large. */
+rq_status rq_load_json(const char *path, rq_index **out);
+rq_status rq_dump_json(const rq_index *idx, const char *path);
 void rq_free(rq_index *idx);
 
 /* Construct an index from the reference's in-memory arrays (what load_from_dir ends up with):

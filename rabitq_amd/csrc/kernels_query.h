@@ -1097,7 +1097,7 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
                                                            const uint32_t *__restrict__ recs,
                                                            SurvRec *__restrict__ surv, RunRec *__restrict__ runs,
                                                            unsigned long long *__restrict__ surv_cnt,
-                                                           unsigned long long *__restrict__ stat /* [2], only with a.dbg & 128 */,
+                                                           unsigned long long *__restrict__ stat /* [128], only with a.dbg & 128 */,
                                                            const ScanArgs a) {
     constexpr uint32_t OPDW = 12 * W;            // operand dwords per record: dim fp6 fields
     constexpr uint32_t OPLD = OPDW + 2;          // row stride (dwords) of the operand image: conflict-free ds_read_b64
@@ -1415,9 +1415,9 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
         slot = slot + 1 == scan_mfma_ring_slots<W>() ? 0 : slot + 1;
     }
     if (nE) flush();
-    if (count_stat && lane == 0) {
-        atomicAdd(stat, (unsigned long long)n_steps);
-        atomicAdd(stat + 1, (unsigned long long)n_flag);
+    if (count_stat && lane == 0) {  // 64 pairs of counters, by block: a single address would serialise a million atomics
+        atomicAdd(stat + 2 * (blockIdx.x & 63u), (unsigned long long)n_steps);
+        atomicAdd(stat + 2 * (blockIdx.x & 63u) + 1, (unsigned long long)n_flag);
     }
 }
 

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <charconv>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -201,7 +202,7 @@ struct Workspace {
     DevBuf<uint64_t> planes;
     DevBuf<uint32_t> qnib;
     DevBuf<uint32_t> qf6;
-    DevBuf<unsigned long long> rough_cnt, totals, surv_cnt;
+    DevBuf<unsigned long long> rough_cnt, totals, surv_cnt, stat;
     DevBuf<SurvRec> surv, arr;
     DevBuf<RunRec> runs, runs_tmp;
     // multi-GPU step (rq_query_batch_sharded_device): this shard's results, the all-gathered keys, the merged keys
@@ -511,6 +512,7 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
     RQC(ws.qf6.ensure(npairs * 12 * idx->W));
     RQC(ws.rough_cnt.ensure(nq));
     RQC(ws.totals.ensure(8));
+    RQC(ws.stat.ensure(128));
     // record-major (8W + tail per pair) or tile images (pairs padded to 32 per list, 12W + 2 + tail per slot)
     RQC(ws.recs.ensure((npairs + 32ull * idx->k + 32) * (12ull * idx->W + 2 + RQ_REC_TAIL)));
     RQC(ws.grp_cnt.ensure(idx->k + 4));
@@ -572,8 +574,11 @@ static rq_status finish_pass(const rq_index *idx, Workspace &ws, PassResult *res
         prof_acc->scan_candidates += res->rough;
         prof_acc->scan_bytes += res->rough * (uint64_t)(dim / 8 + 16);
         prof_acc->rerank_candidates += ws.h_totals[3];
-        prof_acc->matrix_subtile_steps += ws.h_totals[5];
-        prof_acc->matrix_exact_steps += ws.h_totals[6];
+        if (g_scan_dbg.load() & 128) {
+            unsigned long long hs[128];
+            HIPC(hipMemcpy(hs, ws.stat.p, sizeof hs, hipMemcpyDeviceToHost));
+            for (int i = 0; i < 64; ++i) prof_acc->matrix_subtile_steps += hs[2 * i], prof_acc->matrix_exact_steps += hs[2 * i + 1];
+        }
     }
     return RQ_OK;
 }
@@ -665,6 +670,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     init_state_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(rs, ws.surv_cnt.p, nq);
     HIPC(hipMemsetAsync(ws.totals.p, 0, 8 * sizeof(unsigned long long), st));
     HIPC(hipMemsetAsync(ws.big_list.p + nq, 0, 8, st));
+    if (g_scan_dbg.load() & 128) HIPC(hipMemsetAsync(ws.stat.p, 0, 128 * sizeof(unsigned long long), st));
     pf.end();
 
     // 5. stages.  The reference visits a query's candidates as ONE stream: probed lists nearest-first,
@@ -752,7 +758,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         sp.surv = ws.surv.p;
         sp.runs = ws.runs.p;
         sp.surv_cnt = ws.surv_cnt.p;
-        sp.stat = ws.totals.p + 5;  // totals[5], [6]: sub-tile steps / exact-path steps of the matrix-core scan (dbg & 128)
+        sp.stat = ws.stat.p;  // 64 x {sub-tile steps, exact-path steps} of the matrix-core scan (dbg & 128)
         a.cap = qp.cap;
         a.dbg = (uint32_t)g_scan_dbg.load();
         a.tiles_per_group = ceil_div(std::min<uint64_t>(idx->max_list_len, sg.s_hi), use_mfma ? scan_mfma_tile(W) : tile);
@@ -1463,6 +1469,142 @@ static rq_status from_arrays(uint32_t dim, uint64_t n, uint32_t k, const float *
     return RQ_OK;
 }
 
+// ---- JSON reader / writer of rq_load_json / rq_dump_json (serde_json image of `RaBitQ`, src/rabitq.rs:72-81) ----
+namespace {
+struct JsonOut {
+    FILE *f;
+    bool ok = true;
+    void raw(const char *s) { ok = ok && fputs(s, f) >= 0; }
+    void f32(float v) {
+        if (!std::isfinite(v)) return raw("null");
+        char buf[48];
+        auto r = std::to_chars(buf, buf + 40, v);  // shortest representation that round-trips
+        *r.ptr = 0;
+        bool plain = true;
+        for (char *c = buf; c < r.ptr; ++c) plain = plain && ((*c >= '0' && *c <= '9') || *c == '-');
+        if (plain) strcpy(r.ptr, ".0");  // serde_json always marks a float ("1.0")
+        raw(buf);
+    }
+    void u64(unsigned long long v) {
+        char buf[32];
+        snprintf(buf, sizeof buf, "%llu", v);
+        raw(buf);
+    }
+    // Mat with nrows x ncols where element (i, j) = src[j * ld + i]  (col_major = our row-per-vector arrays) or src[i * ld + j]
+    void mat(const float *src, uint64_t nrows, uint64_t ncols, bool transposed) {
+        raw("{\"nrows\":"), u64(nrows), raw(",\"ncols\":"), u64(ncols), raw(",\"data\":[");
+        for (uint64_t i = 0; i < nrows; ++i)
+            for (uint64_t j = 0; j < ncols; ++j) {
+                if (i || j) raw(",");
+                f32(transposed ? src[j * nrows + i] : src[i * ncols + j]);
+            }
+        raw("]}");
+    }
+};
+struct JsonIn {
+    const char *p, *end;
+    std::string err;
+    void ws() {
+        while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p;
+    }
+    bool lit(char c) {
+        ws();
+        if (p < end && *p == c) {
+            ++p;
+            return true;
+        }
+        return false;
+    }
+    bool need(char c) {
+        if (lit(c)) return true;
+        if (err.empty()) err = std::string("expected '") + c + "'";
+        return false;
+    }
+    bool key(std::string &out) {
+        ws();
+        if (p >= end || *p != '"') return false;
+        const char *q = ++p;
+        while (p < end && *p != '"') ++p;
+        if (p >= end) return false;
+        out.assign(q, p);
+        ++p;
+        return need(':');
+    }
+    bool num_f32(float &v) {
+        ws();
+        if (end - p >= 4 && !strncmp(p, "null", 4)) {
+            err = "null where a number is required (serde_json writes non-finite floats as null and cannot load them)";
+            return false;
+        }
+        char *e = nullptr;
+        v = strtof(p, &e);
+        if (e == p) return false;
+        p = e;
+        return true;
+    }
+    bool num_u64(unsigned long long &v) {
+        ws();
+        char *e = nullptr;
+        v = strtoull(p, &e, 10);
+        if (e == p) return false;
+        p = e;
+        return true;
+    }
+    template <typename T, typename F>
+    bool array(std::vector<T> &out, F &&one) {
+        if (!need('[')) return false;
+        if (lit(']')) return true;
+        do {
+            T v;
+            if (!one(v)) return false;
+            out.push_back(v);
+        } while (lit(','));
+        return need(']');
+    }
+    bool skip() {  // any value
+        ws();
+        if (p >= end) return false;
+        if (*p == '{' || *p == '[') {
+            const char open = *p, close = open == '{' ? '}' : ']';
+            ++p;
+            if (lit(close)) return true;
+            do {
+                if (open == '{') {
+                    std::string k;
+                    if (!key(k)) return false;
+                }
+                if (!skip()) return false;
+            } while (lit(','));
+            return need(close);
+        }
+        if (*p == '"') {
+            ++p;
+            while (p < end && *p != '"') p += (*p == '\\') ? 2 : 1;
+            return p < end && *p++ == '"';
+        }
+        while (p < end && *p != ',' && *p != '}' && *p != ']') ++p;
+        return true;
+    }
+    bool mat(std::vector<float> &data, unsigned long long &nrows, unsigned long long &ncols) {
+        if (!need('{')) return false;
+        do {
+            std::string k;
+            if (!key(k)) return false;
+            if (k == "nrows") {
+                if (!num_u64(nrows)) return false;
+            } else if (k == "ncols") {
+                if (!num_u64(ncols)) return false;
+            } else if (k == "data") {
+                if (!array(data, [&](float &v) { return num_f32(v); })) return false;
+            } else if (!skip()) {
+                return false;
+            }
+        } while (lit(','));
+        return need('}');
+    }
+};
+}  // namespace
+
 // rows [i0, i0 + m) of the cluster-ordered base to host memory, from whichever tier holds them
 static rq_status copy_base_rows(const rq_index *idx, uint64_t i0, uint64_t m, float *dst) {
     const uint64_t dim = idx->dim, i1 = i0 + m;
@@ -1708,6 +1850,124 @@ rq_status rq_dump_dir(const rq_index *idx, const char *dir) {
     s = write_record(f, codes.data(), (uint32_t)(n * (dim / 64)), 8, "x_binary_vec.u64vecs");
     fclose(f);
     return s;
+}
+
+// ---- JSON persistence: load_from_json / dump_to_json, src/rabitq.rs:72-81 ------------------------------------
+// serde_json of `RaBitQ` (src/rabitq.rs:56-68): {"dim", "base": Mat, "orthogonal": Mat, "centroids": Mat, "rand_bias",
+// "offsets", "map_ids", "x_binary_vec", "factors": [{factor_ip, factor_ppc, error_bound, center_distance_square}]}.
+// A faer 0.19 `Mat` serialises as {"nrows", "ncols", "data": row-major sequence}; base is dim x n (one vector per
+// column, :188), centroids dim x k (:189).  faer's source is not in the reference tree, so the Mat layout is restated
+// from its published serde impl (parity unpinned, like every faer call site: DESIGN.md section 2).  Numbers are
+// written in shortest round-trip form; f32 non-finite values become null as serde_json writes them (and, as in
+// serde_json, a null does not load).  rand_bias is not used by the AVX2 path (src/simd.rs:177): 0.5 per dimension.
+
+rq_status rq_dump_json(const rq_index *idx, const char *path) {
+    if (!idx || !path) return fail(RQ_ERR_INVALID, "null argument");
+    const uint64_t n = idx->n, dim = idx->dim, k = idx->k;
+    std::vector<float> base(n * dim), P(dim * dim), C(k * dim), fac(n * 4);
+    std::vector<uint32_t> off(k + 1), ids(n);
+    std::vector<uint64_t> codes(n * idx->W);
+    RQC(rq_get_array(idx, RQ_ARR_BASE, base.data(), base.size() * 4));
+    RQC(rq_get_array(idx, RQ_ARR_ORTHOGONAL, P.data(), P.size() * 4));
+    RQC(rq_get_array(idx, RQ_ARR_CENTROIDS, C.data(), C.size() * 4));
+    RQC(rq_get_array(idx, RQ_ARR_OFFSETS, off.data(), off.size() * 4));
+    RQC(rq_get_array(idx, RQ_ARR_MAP_IDS, ids.data(), ids.size() * 4));
+    RQC(rq_get_array(idx, RQ_ARR_FACTORS, fac.data(), fac.size() * 4));
+    RQC(rq_get_array(idx, RQ_ARR_CODES, codes.data(), codes.size() * 8));
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(RQ_ERR_IO, std::string("cannot create ") + path);
+    JsonOut o{f};
+    o.raw("{\"dim\":"), o.u64(dim);
+    o.raw(",\"base\":"), o.mat(base.data(), dim, n, true);          // dim x n: column j = vector j
+    o.raw(",\"orthogonal\":"), o.mat(P.data(), dim, dim, false);
+    o.raw(",\"centroids\":"), o.mat(C.data(), dim, k, true);       // dim x k: column j = rotated centroid j
+    o.raw(",\"rand_bias\":[");
+    for (uint64_t i = 0; i < dim; ++i) o.raw(i ? ",0.5" : "0.5");
+    o.raw("],\"offsets\":[");
+    for (uint64_t i = 0; i <= k; ++i) o.raw(i ? "," : ""), o.u64(off[i]);
+    o.raw("],\"map_ids\":[");
+    for (uint64_t i = 0; i < n; ++i) o.raw(i ? "," : ""), o.u64(ids[i]);
+    o.raw("],\"x_binary_vec\":[");
+    for (uint64_t i = 0; i < codes.size(); ++i) o.raw(i ? "," : ""), o.u64(codes[i]);
+    o.raw("],\"factors\":[");
+    for (uint64_t i = 0; i < n; ++i) {
+        o.raw(i ? ",{\"factor_ip\":" : "{\"factor_ip\":"), o.f32(fac[4 * i]);
+        o.raw(",\"factor_ppc\":"), o.f32(fac[4 * i + 1]);
+        o.raw(",\"error_bound\":"), o.f32(fac[4 * i + 2]);
+        o.raw(",\"center_distance_square\":"), o.f32(fac[4 * i + 3]), o.raw("}");
+    }
+    o.raw("]}");
+    const bool closed = fclose(f) == 0;
+    if (!o.ok || !closed) return fail(RQ_ERR_IO, std::string("write error on ") + path);
+    return RQ_OK;
+}
+
+rq_status rq_load_json(const char *path, rq_index **out) {
+    if (!path || !out) return fail(RQ_ERR_INVALID, "null argument");
+    *out = nullptr;
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(RQ_ERR_IO, std::string("cannot open ") + path);  // "open json error"
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::string text((size_t)std::max(sz, 0l), '\0');
+    const bool read_ok = sz <= 0 || fread(&text[0], 1, (size_t)sz, f) == (size_t)sz;
+    fclose(f);
+    if (!read_ok) return fail(RQ_ERR_IO, std::string("short read on ") + path);
+    JsonIn in{text.data(), text.data() + text.size(), {}};
+    unsigned long long dim = 0, br = 0, bc = 0, pr = 0, pc = 0, cr = 0, cc = 0;
+    std::vector<float> base, P, cent, bias;
+    std::vector<unsigned long long> off, ids, codes;
+    std::vector<rq_factor_t> fac;
+    bool good = in.need('{');
+    if (good && !in.lit('}')) {
+        do {
+            std::string k;
+            if (!(good = in.key(k))) break;
+            if (k == "dim") good = in.num_u64(dim);
+            else if (k == "base") good = in.mat(base, br, bc);
+            else if (k == "orthogonal") good = in.mat(P, pr, pc);
+            else if (k == "centroids") good = in.mat(cent, cr, cc);
+            else if (k == "rand_bias") good = in.array(bias, [&](float &v) { return in.num_f32(v); });
+            else if (k == "offsets") good = in.array(off, [&](unsigned long long &v) { return in.num_u64(v); });
+            else if (k == "map_ids") good = in.array(ids, [&](unsigned long long &v) { return in.num_u64(v); });
+            else if (k == "x_binary_vec") good = in.array(codes, [&](unsigned long long &v) { return in.num_u64(v); });
+            else if (k == "factors")
+                good = in.array(fac, [&](rq_factor_t &fv) {
+                    fv = rq_factor_t{0, 0, 0, 0};
+                    if (!in.need('{')) return false;
+                    do {
+                        std::string fk;
+                        if (!in.key(fk)) return false;
+                        float *dst = fk == "factor_ip" ? &fv.factor_ip : fk == "factor_ppc" ? &fv.factor_ppc
+                                   : fk == "error_bound" ? &fv.error_bound
+                                   : fk == "center_distance_square" ? &fv.center_distance_square : nullptr;
+                        if (dst ? !in.num_f32(*dst) : !in.skip()) return false;
+                    } while (in.lit(','));
+                    return in.need('}');
+                });
+            else good = in.skip();
+        } while (good && in.lit(','));
+        good = good && in.need('}');
+    }
+    if (!good) return fail(RQ_ERR_IO, std::string("deserialize error in ") + path + (in.err.empty() ? "" : ": " + in.err));
+    const uint64_t n = ids.size(), k = off.empty() ? 0 : off.size() - 1;
+    if (dim == 0 || dim % 64 || pr != dim || pc != dim || P.size() != dim * dim || br != dim || bc != n || base.size() != dim * n ||
+        cr != dim || cc != k || cent.size() != dim * k || off.empty() || fac.size() != n || codes.size() != n * (dim / 64) ||
+        off.back() != n)
+        return fail(RQ_ERR_IO, std::string("inconsistent index in ") + path);
+    for (uint64_t j = 0; j + 1 < off.size(); ++j)
+        if (off[j] > off[j + 1]) return fail(RQ_ERR_IO, "offsets are not non-decreasing");
+    // Mat (dim x cols, row-major sequence) -> one vector per row
+    std::vector<float> base_rows(n * dim), cent_rows(k * dim);
+    for (uint64_t i = 0; i < dim; ++i) {
+        for (uint64_t j = 0; j < n; ++j) base_rows[j * dim + i] = base[i * n + j];
+        for (uint64_t j = 0; j < k; ++j) cent_rows[j * dim + i] = cent[i * k + j];
+    }
+    std::vector<uint32_t> off32(off.begin(), off.end()), ids32(ids.begin(), ids.end());
+    std::vector<uint64_t> codes64(codes.begin(), codes.end());
+    return from_arrays((uint32_t)dim, n, (uint32_t)k, base_rows.data(), P.data(), cent_rows.data(), off32.data(), ids32.data(),
+                       codes64.data(), fac.data(), out);
 }
 
 void rq_free(rq_index *idx) { delete idx; }

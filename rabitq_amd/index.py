@@ -82,6 +82,16 @@ class RaBitQ:
     def dump_to_dir(self, path) -> None:
         check(lib().rq_dump_dir(self._h, os.fsencode(path)))
 
+    # ---- load_from_json / dump_to_json (src/rabitq.rs:72-81) -------------------------------------
+    @classmethod
+    def load_from_json(cls, path) -> "RaBitQ":
+        h = C.c_void_p()
+        check(lib().rq_load_json(os.fsencode(path), C.byref(h)))
+        return cls(h)
+
+    def dump_to_json(self, path) -> None:
+        check(lib().rq_dump_json(self._h, os.fsencode(path)))
+
     @classmethod
     def from_arrays(cls, base, orthogonal, centroids, offsets, map_ids, codes, factors) -> "RaBitQ":
         """From the reference's in-memory arrays (what load_from_dir produces)."""

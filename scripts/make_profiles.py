@@ -8,9 +8,10 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r01"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"
 csv.field_size_limit(10**9)
-OUT = os.path.join(ROOT, "profiles")
+OUT = os.environ.get("RQ_PROFILE_OUT", os.path.join(ROOT, "profiles"))
+os.makedirs(OUT, exist_ok=True)
 
 
 def newest(pattern):
@@ -29,7 +30,7 @@ with open(os.path.join(OUT, f"{ROUND}_kernel_stats.csv"), "w") as f:
     bcfg = json.load(open(newest("bench_final.json")))["config"]
     f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline\n")
     f.write(f"# ({bcfg['workload']}: 2 warm-up + 3 timed + 1 breakdown query batches, every launch alone on the device,\n")
-    f.write("#  12 small batches, 68 single queries, one 100M build); engine kernels only, torch data-generation / ground-truth\n")
+    f.write("#  small batches, 68 single queries, one streamed 100M build); engine kernels only, torch data-generation / ground-truth\n")
     f.write("#  kernels are in the _full file\n")
     w = csv.writer(f)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs"])
@@ -56,10 +57,12 @@ with open(os.path.join(OUT, f"{ROUND}_pmc_fetch_size.csv"), "w") as f:
 import re
 is_scan = re.compile(r"^(void )?scan_(kernel|mfma_kernel|generic_kernel)")
 scans = [(i, d) for i, d in engine if is_scan.match(d["name"])]
-# the launches of the LAST full batch: walk back from the last matrix-core launch to the previous one
+# the launches of one full batch end with its matrix-core launch; bench.py runs warm-up, timed, breakdown and counting
+# batches: take the TIMED one (the second), never the counting step
 mf = [n for n, (i, d) in enumerate(scans) if "scan_mfma_kernel" in d["name"]]
-last = mf[-1]
-first = mf[-2] + 1 if len(mf) > 1 else 0
+pick = 1 if len(mf) > 1 else 0
+last = mf[pick]
+first = mf[pick - 1] + 1 if pick > 0 else 0
 batch = scans[first:last + 1]
 bench = json.load(open(newest("bench_final.json")))
 ra = bench.get("roofline_scan_all_launches", bench["roofline"])
@@ -70,8 +73,8 @@ launches = [{"kernel": d["name"].split("(")[0].replace("void ", ""), "ms_under_p
 traffic = {
     "config": {"vectors": bench["config"]["n_per_gpu"], "dim": bench["config"]["dim"], "lists": bench["config"]["lists_total"] // bench["n_gpus"],
                "nprobe": bench["config"]["nprobe"], "batch": bench["config"]["batch"]},
-    "source": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline "
-              "(100Mx128, 4096 lists, nprobe 64, batch 10000)",
+    "source": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --gt-queries 10 "
+              f"--small-batch 0 ({bench['config']['workload']})",
     "correction": "gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM section) -> x2",
     "dominant_launch": {"kernel": launches[-1]["kernel"] + " (final stage: stream positions past the first list)",
                         "ms_under_pmc": launches[-1]["ms_under_pmc"], "fetch_bytes_raw": int(dom["fetch_kb"] * 1024),
@@ -82,6 +85,7 @@ traffic = {
     "launches_of_one_batch": launches,
 }
 json.dump(traffic, open(os.path.join(OUT, "scan_traffic.json"), "w"), indent=1)
+json.dump(traffic, open(os.path.join(OUT, f"{ROUND}_scan_traffic.json"), "w"), indent=1)
 # the bench line read the previous scan_traffic.json (or none, if the workload changed): attach this pass's figures
 if bench.get("roofline", {}).get("bound") == "mfma":
     bench["roofline"]["traffic"] = traffic["dominant_launch"]["hbm_read_bytes"]

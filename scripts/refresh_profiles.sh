@@ -14,4 +14,6 @@ timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 echo "pmc pass done"
 timeout -k 10 900 python3 bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.log
 timeout -k 10 600 python3 bench.py --two-in-flight --no-cpu-baseline --gt-queries 100 > gpurun_out/bench_two_in_flight.json 2> gpurun_out/bench_two_in_flight.log
+RQ_PROFILE_OUT=$PWD/gpurun_out/profiles python3 scripts/make_profiles.py r02 > gpurun_out/make_profiles.log 2>&1 || tail -5 gpurun_out/make_profiles.log
+find gpurun_out/kstats gpurun_out/pmc_fetch -name "*.db" -delete 2>/dev/null || true
 tail -c 600 gpurun_out/bench_final.json

@@ -108,3 +108,16 @@ def test_load_dir_rejects_malformed_directories(L, tmp_path, bad):
     st = L.rq_load_dir(os.fsencode(str(tmp_path / "idx")), C.byref(h))
     assert st == -3, (bad, st, L.rq_last_error())
     assert not h.value
+
+
+@pytest.mark.parametrize("text", ["", "{", '{"dim": 64}', '{"dim":64,"base":{"nrows":64,"ncols":1,"data":[null]}}',
+                                  '{"dim":63,"orthogonal":{"nrows":63,"ncols":63,"data":[]}}'])
+def test_load_json_rejects_malformed_text(L, tmp_path, text):
+    """rq_load_json: "deserialize error" (src/rabitq.rs:74) is RQ_ERR_IO, decided before any device work."""
+    import ctypes as C
+    f = tmp_path / "idx.json"
+    f.write_text(text)
+    h = C.c_void_p()
+    assert L.rq_load_json(os.fsencode(str(f)), C.byref(h)) == -3, L.rq_last_error()
+    assert not h.value
+    assert L.rq_load_json(os.fsencode(str(tmp_path / "missing.json")), C.byref(h)) == -3

@@ -936,3 +936,35 @@ def test_long_run_directories_large_batch(rq, oracle):
     _compare_with_oracle(rq, oracle, oidx, gidx, queries, 2, 50, True)
     gidx.close()
     oidx.close()
+
+
+def test_json_persistence_round_trip(rq, oracle, tmp_path):
+    """dump_to_json / load_from_json (src/rabitq.rs:72-81): the serde_json image of the struct (faer Mats as
+    {"nrows","ncols","data": row-major}, base dim x n, centroids dim x k); every f32 survives the text bit for bit."""
+    import json
+    n, d, k = 300, 64, 5
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.8, seed=41, centre_scale=0.6)
+    x[7] = centres[2]                          # a zero residual: non-normal norm -> default ip, factor edge values
+    gidx = rq.RaBitQ.build(x, centres, synth.random_orthogonal(d, seed=42))
+    gidx.dump_to_json(tmp_path / "idx.json")
+    j = json.loads((tmp_path / "idx.json").read_text())
+    assert list(j) == ["dim", "base", "orthogonal", "centroids", "rand_bias", "offsets", "map_ids", "x_binary_vec", "factors"]
+    assert j["dim"] == d and (j["base"]["nrows"], j["base"]["ncols"]) == (d, n) and j["centroids"]["ncols"] == k
+    assert np.array_equal(np.array(j["base"]["data"], np.float32).reshape(d, n).T, gidx.base)          # column j = vector j
+    assert np.array_equal(np.array(j["centroids"]["data"], np.float32).reshape(d, k).T, gidx.centroids)
+    assert np.array_equal(np.array(j["x_binary_vec"], np.uint64).reshape(n, d // 64), gidx.codes)
+    assert list(j["factors"][0]) == ["factor_ip", "factor_ppc", "error_bound", "center_distance_square"]
+    lidx = rq.RaBitQ.load_from_json(tmp_path / "idx.json")
+    for name in ("base", "orthogonal", "centroids", "offsets", "map_ids", "codes", "factors"):
+        assert_bits_equal(getattr(lidx, name), getattr(gidx, name), name)
+    # key order and whitespace are free, unknown keys are skipped (serde's derive accepts any order)
+    shuffled = {key: j[key] for key in reversed(list(j))}
+    shuffled["extra"] = {"a": [1, 2, {"b": "x"}]}
+    (tmp_path / "idx2.json").write_text(json.dumps(shuffled, indent=1))
+    l2 = rq.RaBitQ.load_from_json(tmp_path / "idx2.json")
+    assert_bits_equal(l2.factors, gidx.factors, "factors (shuffled text)")
+    queries, _, _ = synth.mixture(20, d, k, sigma=0.8, seed=43, centre_scale=0.6)
+    a, b = gidx.query_batch(queries, 3, 5), l2.query_batch(queries, 3, 5)
+    assert all(np.array_equal(u.view(np.uint32), v.view(np.uint32)) for u, v in zip(a, b))
+    for g in (gidx, lidx, l2):
+        g.close()
