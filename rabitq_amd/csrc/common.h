@@ -100,15 +100,38 @@ struct FactorStats {
 };
 
 // The raw vectors the re-ranker gathers (src/rerank.rs:85-90; `base`, src/rabitq.rs:59, cluster order).  At
-// 100M x 768 they are 307 GB, more than the 288 GB of HBM: rows [0, n_dev) live in HBM, rows [n_dev, n) in pinned
-// host memory that the kernels address directly over the host link (the reference's own answer to base > memory
-// is a tiered store as well: crates/disk/src/cache.rs).  Small indexes have n_dev == n and never touch `host`.
+// 100M x 768 they are 307 GB, more than the HBM: part of them lives in pinned host memory that the kernels address
+// directly over the host link (the reference's own answer to base > memory is a tiered store as well:
+// crates/disk/src/cache.rs).  The split is PER LIST: the first h_c members of list c stay in HBM, its tail goes to
+// the host tier.  Lists are ordered by centroid distance (src/rabitq.rs:232-238) and near-centroid vectors are the
+// ones the re-ranker asks for most (a small center_distance_square lowers the distance to every query of the
+// list), so the host tier holds the rows least likely to be gathered.  Small indexes have no host tier at all.
+struct ListTier {  // one per list
+    uint32_t off;        // first position of the list (offsets[c])
+    uint32_t h;          // members kept in HBM
+    uint32_t hbm_base;   // HBM rows of the lists before this one
+    uint32_t host_base;  // host rows of the lists before this one
+};
 struct BaseView {
-    const float *dev;   // rows [0, n_dev)
-    const float *host;  // rows [n_dev, n): device-visible address of the pinned host tier (nullptr if none)
-    uint64_t n_dev;
+    const float *dev;    // HBM tier
+    const float *host;   // device-visible address of the pinned host tier; nullptr = every row is in HBM, at its position
+    const ListTier *lt;  // k entries (tiered indexes only)
+    uint32_t k;
+    // row of position p that belongs to list c
+    __host__ __device__ __forceinline__ const float *row_in_list(uint64_t p, const ListTier &t, uint32_t dim) const {
+        const uint64_t local = p - t.off;
+        return local < t.h ? dev + ((uint64_t)t.hbm_base + local) * dim : host + ((uint64_t)t.host_base + (local - t.h)) * dim;
+    }
+    // row of position p, list unknown: bisection over the lists (cold paths: placement, dumps, shards, rq_rerank)
     __host__ __device__ __forceinline__ const float *row(uint64_t p, uint32_t dim) const {
-        return p < n_dev ? dev + p * dim : host + (p - n_dev) * dim;
+        if (!host) return dev + p * dim;
+        uint32_t lo = 0, hi = k;  // largest c with lt[c].off <= p (empty lists share their start with the next one)
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (lt[mid].off <= p) lo = mid;
+            else hi = mid;
+        }
+        return row_in_list(p, lt[lo], dim);
     }
     __host__ __device__ __forceinline__ float *row_mut(uint64_t p, uint32_t dim) const {
         return const_cast<float *>(row(p, dim));

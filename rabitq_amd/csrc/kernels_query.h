@@ -1843,10 +1843,17 @@ __device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, co
 // chunks (64 dimensions, 8 x 16 bytes per lane) at a time so that every lane keeps 8 loads in flight
 // (this is a random 512-byte-row gather: latency-bound unless enough bytes are outstanding).
 __device__ __forceinline__ void accurate_rows(SurvRec *__restrict__ recs, uint32_t n, const BaseView &base,
-                                              const float *q_lds, uint32_t dim, uint32_t first, uint32_t step) {
+                                              const float *q_lds, uint32_t dim, uint32_t first, uint32_t step,
+                                              const uint32_t *__restrict__ probe_row /* the query's probed lists, by slot */) {
     const uint32_t hf = threadIdx.x & 1;
     for (uint32_t i = first; i < n; i += step) {
-        const float *x = base.row(recs[i].pos, dim) + 4 * hf;  // HBM tier, or the pinned host tier over the host link
+        const float *x;
+        if (base.host == nullptr) {
+            x = base.dev + (uint64_t)recs[i].pos * dim + 4 * hf;
+        } else {  // tiered: the survivor's slot names its list, the list's tier record places the row (HBM or host link)
+            const ListTier t = base.lt[probe_row[recs[i].slot]];
+            x = base.row_in_list(recs[i].pos, t, dim) + 4 * hf;
+        }
         float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
         for (uint32_t c = 0; c < dim; c += 64) {  // dim is a multiple of 64
             float4 xv[8];
@@ -1875,7 +1882,8 @@ __global__ __launch_bounds__(1024) void stage_finish_kernel(SurvRec *__restrict_
                                                            unsigned long long *__restrict__ surv_cnt, uint32_t cap,
                                                            const BaseView base,
                                                            const float *__restrict__ qpad, uint32_t dim, uint32_t topk,
-                                                           ReplayState st) {
+                                                           ReplayState st, const uint32_t *__restrict__ probe_cluster,
+                                                           uint32_t nprobe) {
     __shared__ int32_t hkey[HEURISTIC ? 1 : RQ_MAX_TOPK];
     __shared__ uint32_t hid[HEURISTIC ? 1 : RQ_MAX_TOPK];
     extern __shared__ __attribute__((aligned(16))) float fin_q[];  // dim floats: the padded query
@@ -1897,7 +1905,7 @@ __global__ __launch_bounds__(1024) void stage_finish_kernel(SurvRec *__restrict_
         for (uint32_t c = threadIdx.x * 4; c < dim; c += blockDim.x * 4)
             *reinterpret_cast<float4 *>(fin_q + c) = *reinterpret_cast<const float4 *>(qpad + (uint64_t)b * dim + c);
         __syncthreads();
-        accurate_rows(recs, n, base, fin_q, dim, threadIdx.x >> 1, blockDim.x >> 1);  // 256 or 1024 threads per query
+        accurate_rows(recs, n, base, fin_q, dim, threadIdx.x >> 1, blockDim.x >> 1, probe_cluster + (uint64_t)b * nprobe);  // 256 or 1024 threads per query
     }
     sort_segment(runs + (uint64_t)b * cap, nruns);  // (B)
     __syncthreads();                                  // (A)'s stores and (B)'s order visible to wave 0
@@ -1932,7 +1940,8 @@ __global__ __launch_bounds__(256) void accurate_kernel(SurvRec *__restrict__ sur
                                                        const unsigned long long *__restrict__ surv_cnt,
                                                        uint32_t cap, const BaseView base,
                                                        const float *__restrict__ qpad, uint32_t dim,
-                                                       const uint32_t *__restrict__ order) {
+                                                       const uint32_t *__restrict__ order,
+                                                       const uint32_t *__restrict__ probe_cluster, uint32_t nprobe) {
     // TWO lanes per candidate: lane half hf carries AVX lanes 4hf..4hf+3 (elements 8c + 4hf + 0..3, one
     // 16-byte load per chunk), so a row is fetched with float4 loads; the fold
     // ((a0+a4)+(a1+a5)) + ((a2+a6)+(a3+a7)) needs one exchange between the two lanes.
@@ -1943,7 +1952,8 @@ __global__ __launch_bounds__(256) void accurate_kernel(SurvRec *__restrict__ sur
     for (uint32_t c = threadIdx.x * 4; c < dim; c += 1024)
         *reinterpret_cast<float4 *>(acc_q + c) = *reinterpret_cast<const float4 *>(qpad + (uint64_t)b * dim + c);
     __syncthreads();
-    accurate_rows(surv + (uint64_t)b * cap, n, base, acc_q, dim, blockIdx.x * 128 + (threadIdx.x >> 1), gridDim.x * 128);
+    accurate_rows(surv + (uint64_t)b * cap, n, base, acc_q, dim, blockIdx.x * 128 + (threadIdx.x >> 1), gridDim.x * 128,
+                  probe_cluster + (uint64_t)b * nprobe);
 }
 
 __global__ __launch_bounds__(64) void sort_runs_kernel(RunRec *__restrict__ runs,

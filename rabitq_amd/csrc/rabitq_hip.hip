@@ -221,12 +221,15 @@ struct rq_index {
     uint32_t dim = 0, k = 0, W = 0, max_list_len = 0;
     uint32_t min_list_len = 0;  // 0 if some list is empty (then no slot bound can be derived from stream positions)
     uint64_t n = 0;
-    // raw vectors (cluster order, un-rotated): rows [0, n_dev) in HBM, rows [n_dev, n) in pinned host memory mapped
-    // into the device address space (BaseView); n_dev == n unless the vectors do not fit the HBM budget
+    // raw vectors (cluster order, un-rotated).  Untiered (n_dev == n, the usual case): row p at base + p*dim.  Tiered
+    // (they do not fit the HBM budget): per list the first h_c members in HBM, the tail in pinned host memory mapped
+    // into the device address space (BaseView / ListTier); n_dev = sum of h_c.
     uint64_t n_dev = 0;
     float *base_host = nullptr;      // hipHostMalloc'ed (mapped); host address
     float *base_host_dev = nullptr;  // the same memory as the kernels address it
-    BaseView view() const { return BaseView{base.p, base_host_dev, n_dev}; }
+    DevBuf<ListTier> list_tier;      // k entries, tiered indexes only
+    std::vector<ListTier> h_list_tier;
+    BaseView view() const { return BaseView{base.p, base_host_dev, list_tier.p, k}; }
     ~rq_index() {
         if (base_host) (void)hipHostFree(base_host);
     }
@@ -776,16 +779,16 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             const uint32_t fin_threads = nq <= 16 ? 1024u : 256u;  // a handful of queries: more lanes on each one's rerank
             if (qp.heuristic)
                 stage_finish_kernel<true><<<nq, fin_threads, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->view(),
-                                                              qpad, dim, topk, rs);
+                                                              qpad, dim, topk, rs, probe_cluster, nprobe);
             else
                 stage_finish_kernel<false><<<nq, fin_threads, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->view(),
-                                                               qpad, dim, topk, rs);
+                                                               qpad, dim, topk, rs, probe_cluster, nprobe);
             pf.end();
         } else {  // large batch: full-chip rerank, then run-directory sort, then one replay wave per query
             pf.begin(PF_RERANK);
             const uint32_t gx = std::max(1u, std::min(16u, 4096u / std::max(nq, 1u)));
             accurate_kernel<<<dim3(gx, nq), 256, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.surv_cnt.p, qp.cap, idx->view(), qpad, dim,
-                                                                                    rerank_order);
+                                                                                    rerank_order, probe_cluster, nprobe);
             pf.end();
             pf.begin(PF_SORT);
             sort_runs_kernel<<<nq, 64, 0, st>>>(ws.runs.p, ws.surv_cnt.p, qp.cap, ws.big_list.p, ws.big_list.p + nq);
@@ -1171,7 +1174,8 @@ static void launch_assign(const float *xrot, const rq_index *idx, uint64_t n, ui
 // ------------------------------------------------------------------------------------------------
 static std::atomic<int64_t> g_base_device_mb{-1};  // -1 = automatic
 #define RQ_HBM_RESERVE_BYTES (12ull << 30)
-static rq_status alloc_base_tiers(rq_index *idx, uint64_t budget_bytes) {
+// h_offsets: the k+1 list offsets on the host (the split is per list)
+static rq_status alloc_base_tiers(rq_index *idx, uint64_t budget_bytes, const uint32_t *h_offsets) {
     const uint64_t row = (uint64_t)idx->dim * 4, want = idx->n * row;
     uint64_t cap = budget_bytes;
     if (budget_bytes == 0) {
@@ -1185,17 +1189,32 @@ static rq_status alloc_base_tiers(rq_index *idx, uint64_t budget_bytes) {
             if (want <= cap || want <= (256ull << 20)) cap = ~0ull;  // fits (or is small): no host tier
         }
     }
-    idx->n_dev = cap == ~0ull ? idx->n : std::min<uint64_t>(idx->n, cap / row);
-    RQC(idx->base.alloc(idx->n_dev * idx->dim));
-    const uint64_t n_host = idx->n - idx->n_dev;
-    if (n_host) {
-        hipError_t e = hipHostMalloc((void **)&idx->base_host, n_host * row, hipHostMallocMapped | hipHostMallocPortable);
-        if (e != hipSuccess) {
-            idx->base_host = nullptr;
-            return fail(RQ_ERR_OOM, "pinned host tier of " + std::to_string(n_host * row) + " bytes: " + hipGetErrorString(e));
-        }
-        HIPC(hipHostGetDevicePointer((void **)&idx->base_host_dev, idx->base_host, 0));
+    const uint64_t budget_rows = cap == ~0ull ? idx->n : std::min<uint64_t>(idx->n, cap / row);
+    if (budget_rows >= idx->n) {  // everything in HBM, rows at their positions
+        idx->n_dev = idx->n;
+        RQC(idx->base.alloc(idx->n * idx->dim));
+        return RQ_OK;
     }
+    // every list keeps the same share of its members (its head: the vectors nearest the centroid) in HBM
+    const uint32_t k = idx->k;
+    idx->h_list_tier.resize(k);
+    uint64_t hbm = 0, host = 0;
+    for (uint32_t c = 0; c < k; ++c) {
+        const uint64_t len = h_offsets[c + 1] - h_offsets[c];
+        const uint64_t h = idx->n ? len * budget_rows / idx->n : 0;  // floor: the sum never exceeds the budget
+        idx->h_list_tier[c] = ListTier{h_offsets[c], (uint32_t)h, (uint32_t)hbm, (uint32_t)host};
+        hbm += h, host += len - h;
+    }
+    idx->n_dev = hbm;
+    RQC(idx->base.alloc(hbm * idx->dim));
+    RQC(idx->list_tier.alloc(k));
+    HIPC(hipMemcpy(idx->list_tier.p, idx->h_list_tier.data(), (size_t)k * sizeof(ListTier), hipMemcpyHostToDevice));
+    hipError_t e = hipHostMalloc((void **)&idx->base_host, std::max<uint64_t>(host, 1) * row, hipHostMallocMapped | hipHostMallocPortable);
+    if (e != hipSuccess) {
+        idx->base_host = nullptr;
+        return fail(RQ_ERR_OOM, "pinned host tier of " + std::to_string(host * row) + " bytes: " + hipGetErrorString(e));
+    }
+    HIPC(hipHostGetDevicePointer((void **)&idx->base_host_dev, idx->base_host, 0));
     return RQ_OK;
 }
 
@@ -1346,7 +1365,9 @@ static rq_status builder_order(rq_builder *b) {
     b->codes_tmp.release();
     b->factors_tmp.release();
     keys.release();
-    RQC(alloc_base_tiers(idx, b->budget));
+    std::vector<uint32_t> h_off((size_t)k + 1);
+    HIPC(hipMemcpy(h_off.data(), idx->offsets.p, ((size_t)k + 1) * 4, hipMemcpyDeviceToHost));
+    RQC(alloc_base_tiers(idx, b->budget, h_off.data()));
     b->stats.rows_in_hbm = idx->n_dev, b->stats.rows_in_host_memory = n - idx->n_dev;
     b->ordered = true;
     return RQ_OK;
@@ -1434,6 +1455,7 @@ static rq_status write_record(FILE *f, const void *data, uint32_t count, size_t 
     return RQ_OK;
 }
 
+static rq_status copy_base_rows(const rq_index *idx, uint64_t i0, uint64_t m, float *buf, bool to_index);
 static rq_status from_arrays(uint32_t dim, uint64_t n, uint32_t k, const float *base, const float *orthogonal,
                              const float *centroids, const uint32_t *offsets, const uint32_t *map_ids,
                              const uint64_t *codes, const rq_factor_t *factors, rq_index **out) {
@@ -1453,10 +1475,12 @@ static rq_status from_arrays(uint32_t dim, uint64_t n, uint32_t k, const float *
     RQC(idx->map_ids.alloc(n));
     RQC(idx->codes.alloc(n * idx->W));
     RQC(idx->factors.alloc(n));
-    RQC(alloc_base_tiers(idx.get(), 0));
+    for (uint32_t c = 0; c < k; ++c)
+        if (offsets[c] > offsets[c + 1] || offsets[c + 1] > n) return fail(RQ_ERR_INVALID, "offsets are not a non-decreasing partition of [0, n]");
+    if (k && offsets[k] != n) return fail(RQ_ERR_INVALID, "offsets[k] != n");
+    RQC(alloc_base_tiers(idx.get(), 0, offsets));
     if (n) {
-        if (idx->n_dev) HIPC(hipMemcpy(idx->base.p, base, idx->n_dev * dim * 4, hipMemcpyHostToDevice));
-        if (n > idx->n_dev) memcpy(idx->base_host, base + idx->n_dev * dim, (n - idx->n_dev) * dim * 4);
+        RQC(copy_base_rows(idx.get(), 0, n, const_cast<float *>(base), /*to_index=*/true));
         HIPC(hipMemcpy(idx->map_ids.p, map_ids, n * 4, hipMemcpyHostToDevice));
         HIPC(hipMemcpy(idx->codes.p, codes, n * idx->W * 8, hipMemcpyHostToDevice));
         HIPC(hipMemcpy(idx->factors.p, factors, n * 16, hipMemcpyHostToDevice));
@@ -1605,16 +1629,44 @@ struct JsonIn {
 };
 }  // namespace
 
-// rows [i0, i0 + m) of the cluster-ordered base to host memory, from whichever tier holds them
-static rq_status copy_base_rows(const rq_index *idx, uint64_t i0, uint64_t m, float *dst) {
+// rows [i0, i0 + m) of the cluster-ordered base between host memory (`buf`, m x dim) and whichever tier holds them
+// (to_index = false: index -> buf; true: buf -> index)
+static rq_status copy_base_rows(const rq_index *idx, uint64_t i0, uint64_t m, float *buf, bool to_index) {
     const uint64_t dim = idx->dim, i1 = i0 + m;
-    if (i0 < idx->n_dev) {
-        const uint64_t md = std::min(i1, idx->n_dev) - i0;
-        HIPC(hipMemcpy(dst, idx->base.p + i0 * dim, md * dim * 4, hipMemcpyDeviceToHost));
+    auto dev_copy = [&](uint64_t dev_row, uint64_t rows, float *hp) -> rq_status {
+        if (!rows) return RQ_OK;
+        if (to_index) HIPC(hipMemcpy(idx->base.p + dev_row * dim, hp, rows * dim * 4, hipMemcpyHostToDevice));
+        else HIPC(hipMemcpy(hp, idx->base.p + dev_row * dim, rows * dim * 4, hipMemcpyDeviceToHost));
+        return RQ_OK;
+    };
+    if (!idx->base_host) return dev_copy(i0, m, buf);
+    // tiered: walk the lists that overlap the range; per list an HBM piece and a host piece
+    const std::vector<ListTier> &lt = idx->h_list_tier;
+    uint32_t c = 0;
+    {
+        uint32_t lo = 0, hi = idx->k;
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (lt[mid].off <= i0) lo = mid;
+            else hi = mid;
+        }
+        c = lo;
     }
-    if (i1 > idx->n_dev) {
-        const uint64_t h0 = std::max(i0, idx->n_dev);
-        memcpy(dst + (h0 - i0) * dim, idx->base_host + (h0 - idx->n_dev) * dim, (i1 - h0) * dim * 4);
+    for (; c < idx->k && lt[c].off < i1; ++c) {
+        const uint64_t lb = lt[c].off, le = c + 1 < idx->k ? lt[c + 1].off : idx->n;
+        const uint64_t a = std::max<uint64_t>(lb, i0), e = std::min<uint64_t>(le, i1);
+        if (a >= e) continue;
+        const uint64_t split = lb + lt[c].h;  // positions [lb, split) in HBM, [split, le) on the host
+        if (a < split) {
+            const uint64_t e2 = std::min(e, split);
+            RQC(dev_copy(lt[c].hbm_base + (a - lb), e2 - a, buf + (a - i0) * dim));
+        }
+        if (e > split) {
+            const uint64_t a2 = std::max(a, split);
+            float *hrow = idx->base_host + ((uint64_t)lt[c].host_base + (a2 - split)) * dim;
+            if (to_index) memcpy(hrow, buf + (a2 - i0) * dim, (e - a2) * dim * 4);
+            else memcpy(buf + (a2 - i0) * dim, hrow, (e - a2) * dim * 4);
+        }
     }
     return RQ_OK;
 }
@@ -1801,7 +1853,7 @@ rq_status rq_dump_dir(const rq_index *idx, const char *dir) {
         std::vector<float> buf(std::min<uint64_t>(chunk, std::max<uint64_t>(n, 1)) * dim);
         for (uint64_t i0 = 0; i0 < n; i0 += chunk) {
             uint64_t m = std::min(chunk, n - i0);
-            if (copy_base_rows(idx, i0, m, buf.data()) != RQ_OK) {
+            if (copy_base_rows(idx, i0, m, buf.data(), false) != RQ_OK) {
                 fclose(f);
                 return RQ_ERR_HIP;
             }
@@ -1982,7 +2034,7 @@ rq_status rq_info(const rq_index *idx, rq_info_t *out) {
 rq_status rq_get_device_ptr(const rq_index *idx, int which, const void **out_ptr, uint64_t *out_bytes) {
     if (!idx || !out_ptr || !out_bytes) return fail(RQ_ERR_INVALID, "null argument");
     switch (which) {
-        case RQ_ARR_BASE: *out_ptr = idx->base.p, *out_bytes = idx->n_dev * idx->dim * 4; break;  // the HBM tier (all rows unless tiered)
+        case RQ_ARR_BASE: *out_ptr = idx->base.p, *out_bytes = idx->n_dev * idx->dim * 4; break;  // the HBM tier (every row, at its position, unless tiered)
         case RQ_ARR_ORTHOGONAL: *out_ptr = idx->P.p, *out_bytes = (uint64_t)idx->dim * idx->dim * 4; break;
         case RQ_ARR_CENTROIDS: *out_ptr = idx->centroids.p, *out_bytes = (uint64_t)idx->k * idx->dim * 4; break;
         case RQ_ARR_OFFSETS: *out_ptr = idx->offsets.p, *out_bytes = ((uint64_t)idx->k + 1) * 4; break;
@@ -1999,7 +2051,7 @@ rq_status rq_get_array(const rq_index *idx, int which, void *dst, uint64_t dst_b
     uint64_t bytes;
     if (idx && which == RQ_ARR_BASE && idx->n_dev < idx->n) {  // both tiers
         if (!dst || dst_bytes < idx->n * idx->dim * 4) return fail(RQ_ERR_INVALID, "destination too small");
-        return copy_base_rows(idx, 0, idx->n, static_cast<float *>(dst));
+        return copy_base_rows(idx, 0, idx->n, static_cast<float *>(dst), false);
     }
     RQC(rq_get_device_ptr(idx, which, &p, &bytes));
     if (!dst || dst_bytes < bytes) return fail(RQ_ERR_INVALID, "destination too small");
@@ -2216,7 +2268,7 @@ rq_status rq_shard_index(const rq_index *idx, const uint32_t *owner, uint32_t ra
     RQC(sh->P.alloc((size_t)dim * dim));
     RQC(sh->centroids.alloc((size_t)k * dim));
     RQC(sh->offsets.alloc((size_t)k + 1));
-    RQC(alloc_base_tiers(sh.get(), 0));
+    RQC(alloc_base_tiers(sh.get(), 0, noff.data()));
     RQC(sh->codes.alloc(n_local * sh->W));
     RQC(sh->factors.alloc(n_local));
     RQC(sh->map_ids.alloc(n_local));
