@@ -1074,19 +1074,24 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) {
 // blocks per CU the register budget is cut for: the resident operands grow with W (6*W*NT dwords for the
 // candidates, 6*W for the query tile), so wide vectors run one block per CU with the full 512-register file
 template <int W>
-constexpr int scan_mfma_blocks_per_cu() { return W <= 2 ? 4 : (W <= 12 ? 2 : 1); }
+constexpr int scan_mfma_blocks_per_cu() { return W <= 2 ? 4 : (W <= 8 ? 2 : 1); }
 // Wide vectors (dim >= 384) do not keep the query tile's operand in registers: the candidates' expanded codes
 // (6*W*NT dwords) already fill most of the file, so the query fragments are streamed from the LDS image one
 // 64-dimension slab at a time (3 ds_read_b64 per slab, each feeding the MFMAs of all NT sub-tiles).
 template <int W>
-constexpr bool scan_mfma_stream_a() { return W > 4; }
+constexpr bool scan_mfma_stream_a() { return W > 4 && W <= 8; }  // one block per CU (W >= 12) has the registers to keep A resident
 // Query tiles consumed per block barrier.  The four waves of a block sit on four SIMDs that each serve other
 // blocks as well, so a barrier per 32-query tile makes every wave advance at the pace of the slowest; narrow
 // vectors (small tile images) afford two tiles per barrier with a 4-slot ring.
 template <int W>
 constexpr uint32_t scan_mfma_tiles_per_barrier() { return W <= 2 ? 2u : 1u; }
 template <int W>
-constexpr uint32_t scan_mfma_ring_slots() { return scan_mfma_tiles_per_barrier<W>() > 1 ? 2 * scan_mfma_tiles_per_barrier<W>() : 3u; }
+constexpr uint32_t scan_mfma_ring_slots() {
+    // one tile per barrier: slots - 1 tiles in flight.  The wide instantiations run one block per CU and wait on the
+    // arrival of their (large) tile images, not on the matrix pipe: they take the LDS a second block would have used
+    // for a deeper ring
+    return scan_mfma_tiles_per_barrier<W>() > 1 ? 2 * scan_mfma_tiles_per_barrier<W>() : (W >= 12 ? 5u : 3u);
+}
 
 template <int W, int NT>
 __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_kernel(const uint32_t *__restrict__ codes,
@@ -1129,6 +1134,7 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
     const uint32_t tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t ntiles = (cnt + 31) / 32;
+    const unsigned long long tm_begin = (a.dbg & 256u) ? __builtin_readcyclecounter() : 0ull;
 
     // everything the block needs from memory is requested up front: this lane's candidates (its half of
     // every code word + factors) and the first two query tiles
@@ -1146,6 +1152,7 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
     }
     const uint32_t ring0 = lds_addr(&ring[0]);
     auto dma_tile = [&](uint32_t qt, uint32_t slot) {  // this wave's quarter of query tile qt -> ring[slot]
+        if ((a.dbg & 2u) && qt >= scan_mfma_ring_slots<W>()) return;  // ablation: no re-staging (tiles re-use stale slots)
         const uint32_t *src = recs + ((uint64_t)(pb >> 5) + qt) * IMG + wave * (IMG / 4);
         const uint32_t dst = ring0 + (slot * IMG + wave * (IMG / 4)) * 4;
 #pragma unroll
@@ -1155,8 +1162,14 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
         }
     };
     constexpr uint32_t QPB = scan_mfma_tiles_per_barrier<W>();
-    dma_tile(0, 0);
-    if (ntiles > 1) dma_tile(1, 1);
+    if constexpr (QPB == 1) {
+#pragma unroll
+        for (uint32_t i = 0; i + 1 < scan_mfma_ring_slots<W>(); ++i)
+            if (i < ntiles) dma_tile(i, i);
+    } else {
+        dma_tile(0, 0);
+        if (ntiles > 1) dma_tile(1, 1);
+    }
     {  // byte -> 8 fp6 fields (bit e -> 1.0 = 0b001000 at bits 6e .. 6e+5)
         const uint32_t b = tid;
         uint64_t f = 0;
@@ -1255,15 +1268,28 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
     // measurement hook (results unchanged): 32x32 sub-tile steps taken, and how many of them took the exact path
     const uint32_t count_stat = __builtin_amdgcn_readfirstlane((a.dbg & 128u) ? 1u : 0u);
     uint32_t n_steps = 0, n_flag = 0;
+    // developer hook (dbg & 256): cycles of the block's start-up, of the waits at the top of the tile loop and of the
+    // tile bodies, summed over blocks into stat[128..131) (+ block count): where a wave's lifetime goes
+    const uint32_t time_stat = __builtin_amdgcn_readfirstlane((a.dbg & 256u) ? 1u : 0u);
+    unsigned long long tm_wait = 0, tm_body = 0, tm_mark = 0, tm_startup = 0;
+    if (time_stat) {
+        tm_mark = __builtin_readcyclecounter();
+        tm_startup = tm_mark - tm_begin;
+    }
     uint32_t slot = 0;  // ring slot of query tile qt
     for (uint32_t qt = 0; qt < ((a.dbg & 4u) ? 0u : ntiles); ++qt) {
-        if constexpr (QPB == 1) {  // 3 slots, one barrier per tile, two tiles in flight
-            // tile qt has landed once at most the NI copies of tile qt+1 are still in flight (in-order counter)
-            if (qt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (QPB == 1) {  // SLOTS slots, one barrier per tile, PD = SLOTS - 1 tiles in flight
+            constexpr uint32_t SLOTS = scan_mfma_ring_slots<W>(), PD = SLOTS - 1;
+            // tile qt has landed once only the copies of the (up to PD - 1) later tiles are still in flight (in-order counter)
+            const uint32_t later = ntiles - 1 - qt < PD - 1 ? ntiles - 1 - qt : PD - 1;  // wave-uniform
+            if (later == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+            else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NI) : "memory");
+            static_assert(PD <= 4 && 3 * NI < 64, "vmcnt immediates are spelled out for up to three later tiles");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // every wave's quarter of tile qt is in; everyone is done with tile qt-1
-            if (qt + 2 < ntiles) dma_tile(qt + 2, slot == 0 ? 2 : slot - 1);  // into the slot tile qt-1 occupied
+            if (qt + PD < ntiles) dma_tile(qt + PD, slot == 0 ? SLOTS - 1 : slot - 1);  // into the slot tile qt-1 occupied
         } else if (qt % QPB == 0) {  // 2*QPB slots, one barrier per QPB tiles: tiles qt .. qt+QPB-1 were requested one
                                      // barrier ago (a period of QPB tiles of compute), the next QPB go out now
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1272,6 +1298,11 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
 #pragma unroll
             for (uint32_t i = 0; i < QPB; ++i)
                 if (qt + QPB + i < ntiles) dma_tile(qt + QPB + i, (slot + QPB + i) % (2 * QPB));
+        }
+        if (time_stat) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            tm_wait += now - tm_mark;
+            tm_mark = now;
         }
         const uint32_t *img = ring + slot * IMG;
         const uint32_t nvalid = cnt - 32 * qt;  // rows >= nvalid of the last tile are stale memory: masked here
@@ -1413,6 +1444,15 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
             }
         }
         slot = slot + 1 == scan_mfma_ring_slots<W>() ? 0 : slot + 1;
+        if (time_stat) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            tm_body += now - tm_mark;
+            tm_mark = now;
+        }
+    }
+    if (time_stat && tid == 0) {
+        atomicAdd(stat + 128, tm_startup), atomicAdd(stat + 129, tm_wait), atomicAdd(stat + 130, tm_body);
+        atomicAdd(stat + 131, 1ull), atomicAdd(stat + 132, (unsigned long long)ntiles);
     }
     if (nE) flush();
     if (count_stat && lane == 0) {  // 64 pairs of counters, by block: a single address would serialise a million atomics

@@ -394,7 +394,7 @@ static bool scan_has_mfma(uint32_t W) {
 }
 static uint32_t scan_mfma_nt(uint32_t W) { return W == 2 ? 3 : (W >= 4 ? 2 : 4); }
 static uint32_t scan_mfma_tile(uint32_t W) { return 128 * scan_mfma_nt(W); }
-static size_t scan_mfma_ring_bytes(uint32_t W) { return (W <= 2 ? 4ull : 3ull) * (32 * (12 * W + 2) + RQ_REC_TAIL * 32) * 4; }  // scan_mfma_ring_slots<W>()
+static size_t scan_mfma_ring_bytes(uint32_t W) { return (W <= 2 ? 4ull : (W >= 12 ? 5ull : 3ull)) * (32 * (12 * W + 2) + RQ_REC_TAIL * 32) * 4; }  // scan_mfma_ring_slots<W>()
 template <int W, int NT>
 static void launch_scan_mfma_t(const ScanPtrs &p, const ScanArgs &a, dim3 g, hipStream_t st) {
     scan_mfma_kernel<W, NT><<<g, dim3(256), scan_mfma_ring_bytes(W), st>>>(p.codes, p.factors, p.offsets, p.grp_start, p.grp_cnt,
@@ -515,7 +515,7 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
     RQC(ws.qf6.ensure(npairs * 12 * idx->W));
     RQC(ws.rough_cnt.ensure(nq));
     RQC(ws.totals.ensure(8));
-    RQC(ws.stat.ensure(128));
+    RQC(ws.stat.ensure(256));
     // record-major (8W + tail per pair) or tile images (pairs padded to 32 per list, 12W + 2 + tail per slot)
     RQC(ws.recs.ensure((npairs + 32ull * idx->k + 32) * (12ull * idx->W + 2 + RQ_REC_TAIL)));
     RQC(ws.grp_cnt.ensure(idx->k + 4));
@@ -577,6 +577,15 @@ static rq_status finish_pass(const rq_index *idx, Workspace &ws, PassResult *res
         prof_acc->scan_candidates += res->rough;
         prof_acc->scan_bytes += res->rough * (uint64_t)(dim / 8 + 16);
         prof_acc->rerank_candidates += ws.h_totals[3];
+        if (g_scan_dbg.load() & 256) {  // developer hook: where the matrix-core scan's waves spend their cycles
+            unsigned long long ht[8];
+            HIPC(hipMemcpy(ht, ws.stat.p + 128, sizeof ht, hipMemcpyDeviceToHost));
+            if (ht[3])
+                fprintf(stderr, "[rabitq_hip] scan_mfma timing: %llu blocks, %.1f tiles/block; per block cycles: start-up %.0f, "
+                        "tile-loop waits %.0f, tile bodies %.0f (per tile: wait %.0f, body %.0f)\n", ht[3], (double)ht[4] / ht[3],
+                        (double)ht[0] / ht[3], (double)ht[1] / ht[3], (double)ht[2] / ht[3], (double)ht[1] / std::max(1ull, ht[4]),
+                        (double)ht[2] / std::max(1ull, ht[4]));
+        }
         if (g_scan_dbg.load() & 128) {
             unsigned long long hs[128];
             HIPC(hipMemcpy(hs, ws.stat.p, sizeof hs, hipMemcpyDeviceToHost));
@@ -673,7 +682,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     init_state_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(rs, ws.surv_cnt.p, nq);
     HIPC(hipMemsetAsync(ws.totals.p, 0, 8 * sizeof(unsigned long long), st));
     HIPC(hipMemsetAsync(ws.big_list.p + nq, 0, 8, st));
-    if (g_scan_dbg.load() & 128) HIPC(hipMemsetAsync(ws.stat.p, 0, 128 * sizeof(unsigned long long), st));
+    if (g_scan_dbg.load() & (128 | 256)) HIPC(hipMemsetAsync(ws.stat.p, 0, 256 * sizeof(unsigned long long), st));
     pf.end();
 
     // 5. stages.  The reference visits a query's candidates as ONE stream: probed lists nearest-first,
