@@ -823,6 +823,10 @@ struct ScanArgs {   // scalars only; pointers are explicit __restrict__ kernel p
     // A stage whose grid would exceed the launch bound is issued as several launches: this one covers groups
     // group_base .. and, per group, tiles tile_base .. tile_base + tiles_per_group (host: launch_scan_chunks)
     uint32_t group_base, tile_base;
+    // use_table: block b scans entry group_base + b of the index's tile table (one entry per existing (list, tile):
+    // unbalanced lists launch no empty blocks, and the list's bounds arrive with the entry instead of a second
+    // dependent load); ngroups then counts table entries and tiles_per_group is 1
+    uint32_t use_table;
 };
 struct ScanPtrs {   // host-side bundle only
     const uint32_t *codes;        // n * 2W dwords (x_binary_vec, src/rabitq.rs:66)
@@ -835,12 +839,13 @@ struct ScanPtrs {   // host-side bundle only
     RunRec *runs;                 // per query `cap` run descriptors
     unsigned long long *surv_cnt; // per query: low 32 bits = records, high 32 bits = runs
     unsigned long long *stat;     // matrix-core scan measurement hook (ScanArgs::dbg & 128)
+    const uint4 *tile_table;      // {list, first position of the tile in the list, list begin, list length} (use_table)
 };
 #define SCAN_PARAMS                                                                                  \
     const uint32_t *__restrict__ codes, const float4 *__restrict__ factors,                          \
         const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ grp_start,                \
         const uint32_t *__restrict__ recs, SurvRec *__restrict__ surv, RunRec *__restrict__ runs,    \
-        unsigned long long *__restrict__ surv_cnt, const ScanArgs a
+        unsigned long long *__restrict__ surv_cnt, const uint4 *__restrict__ tile_table, const ScanArgs a
 
 // 8 code bits -> 8 nibbles (bit i -> nibble i), so that sum_j bit_j * q_j becomes v_dot8_u32_u4
 __device__ __forceinline__ uint32_t spread8(uint32_t b) {
@@ -870,9 +875,21 @@ __device__ __forceinline__ float rough_distance(uint32_t s, const float4 &f, flo
 template <int W, int CPL>
 __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
     constexpr uint32_t STRIDE = 8 * W + RQ_REC_TAIL;
-    const uint32_t gl = blockIdx.x / a.tiles_per_group;
-    const uint32_t g = a.group_base + gl;
-    const uint32_t tile = a.tile_base + (blockIdx.x - gl * a.tiles_per_group);
+    uint32_t g, first, list_begin = 0, list_len = 0;
+    if (a.use_table) {  // cluster-major, one block per existing (list, tile)
+        const uint4 d = tile_table[a.group_base + blockIdx.x];
+        g = d.x, first = d.y, list_begin = d.z, list_len = d.w;
+    } else {
+        const uint32_t gl = blockIdx.x / a.tiles_per_group;
+        g = a.group_base + gl;
+        first = (a.tile_base + (blockIdx.x - gl * a.tiles_per_group)) * (256 * CPL);  // first list position of this tile
+        // the list of this group (all its pairs share it); cluster-major: straight from the index, in the same
+        // round trip as the group bounds
+        if (a.cluster_major) {
+            list_begin = offsets[g];
+            list_len = offsets[g + 1] - list_begin;
+        }
+    }
     uint32_t pb, pe;
     if (a.cluster_major) {
         pb = grp_start[g];
@@ -881,19 +898,11 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
         pb = g;
         pe = g + 1;
     }
-    // the list of this group (all its pairs share it); cluster-major: straight from the index, in the same
-    // round trip as the group bounds
-    uint32_t list_begin = 0, list_len = 0;
-    if (a.cluster_major) {
-        list_begin = offsets[g];
-        list_len = offsets[g + 1] - list_begin;
-    }
     if (pb >= pe) return;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t *rec = recs + (uint64_t)pb * STRIDE;
     if (!a.cluster_major) list_begin = rec[8 * W + RQ_REC_LIST_BEGIN], list_len = rec[8 * W + RQ_REC_LIST_LEN];
-    const uint32_t first = tile * (256 * CPL);  // first list position of this tile
     if (first >= list_len) return;
     if (!a.cluster_major && rec[8 * W + RQ_REC_LO] >= rec[8 * W + RQ_REC_HI]) return;  // pair not in this stage
 
@@ -1103,6 +1112,7 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
                                                            SurvRec *__restrict__ surv, RunRec *__restrict__ runs,
                                                            unsigned long long *__restrict__ surv_cnt,
                                                            unsigned long long *__restrict__ stat /* [128], only with a.dbg & 128 */,
+                                                           const uint4 *__restrict__ tile_table,
                                                            const ScanArgs a) {
     constexpr uint32_t OPDW = 12 * W;            // operand dwords per record: dim fp6 fields
     constexpr uint32_t OPLD = OPDW + 2;          // row stride (dwords) of the operand image: conflict-free ds_read_b64
@@ -1122,14 +1132,19 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
     __shared__ uint32_t q_run[4][QE];
     __shared__ uint32_t r_b[4][QR], r_slot[4][QR], r_pos[4][QR], r_cnt[4][QR], r_off[4][QR], r_base[4][QR];
 
-    const uint32_t gl = blockIdx.x / a.tiles_per_group;
-    const uint32_t g = a.group_base + gl;
-    const uint32_t tile = a.tile_base + (blockIdx.x - gl * a.tiles_per_group);
-    // one round trip: the group's records (cluster-major only) and its list
+    uint32_t g, first, list_begin, list_len;
+    if (a.use_table) {  // one block per existing (list, tile); the list's bounds come with the entry
+        const uint4 d = tile_table[a.group_base + blockIdx.x];
+        g = d.x, first = d.y, list_begin = d.z, list_len = d.w;
+    } else {
+        const uint32_t gl = blockIdx.x / a.tiles_per_group;
+        g = a.group_base + gl;
+        first = (a.tile_base + (blockIdx.x - gl * a.tiles_per_group)) * TILE;
+        list_begin = offsets[g], list_len = offsets[g + 1] - list_begin;
+    }
+    // the group's records (cluster-major only)
     const uint32_t pb = grp_start[g], cnt = grp_cnt[g];
-    const uint32_t list_begin = offsets[g], list_len = offsets[g + 1] - list_begin;
     if (cnt == 0) return;
-    const uint32_t first = tile * TILE;
     if (first >= list_len) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2019,7 +2034,7 @@ __global__ __launch_bounds__(64) void sort_runs_kernel(RunRec *__restrict__ runs
 __global__ __launch_bounds__(256) void sort_runs_mid_kernel(RunRec *__restrict__ runs, RunRec *__restrict__ runs_tmp,
                                                             const unsigned long long *__restrict__ surv_cnt, uint32_t cap,
                                                             const uint32_t *__restrict__ big_list,
-                                                            uint32_t *__restrict__ big_count /* [0] entries, [1] blocks done */,
+                                                            uint32_t *__restrict__ big_count /* [0] entries, [1] blocks done, [2] most entries of a stage */,
                                                             uint32_t nslots) {
     const uint32_t total = big_count[0];
     for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
@@ -2032,6 +2047,7 @@ __global__ __launch_bounds__(256) void sort_runs_mid_kernel(RunRec *__restrict__
     if (threadIdx.x == 0) {  // every block reads `total` before it counts itself done: the last one out may reset both
         __threadfence();
         if (atomicAdd(big_count + 1, 1u) + 1 == gridDim.x) {
+            if (total > big_count[2]) big_count[2] = total;  // for the host: sizes the next pass's launch
             big_count[0] = 0;
             big_count[1] = 0;
         }

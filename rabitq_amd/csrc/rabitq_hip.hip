@@ -23,6 +23,7 @@
 #include <sys/stat.h>
 #include <dlfcn.h>
 #include <queue>
+#include <map>
 
 #include "common.h"
 #include "kernels_build.h"
@@ -241,7 +242,13 @@ struct rq_index {
     std::vector<std::unique_ptr<Workspace>> ws_pool;
     FactorStats fstats{0, 0, 0, 0};
     std::atomic<uint32_t> cap_hint{0};  // survivor-buffer capacity learnt from earlier batches
+    std::atomic<uint32_t> big_dirs_hint{0};  // most long run directories (> 512 runs) a stage of a recent pass produced
     uint64_t pass_budget = 24ull << 30;  // bytes of survivor / run buffers one query pass may use (set by finish_index)
+    // tile tables of the cluster-major scans: per tile size, one {list, first, list begin, list length} entry per
+    // existing (list, tile); built on first use from the host copy of the offsets
+    std::vector<uint32_t> h_offsets;
+    std::mutex tt_mu;
+    std::map<uint32_t, std::unique_ptr<DevBuf<uint4>>> tile_tables;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -341,6 +348,29 @@ static void launch_rotate(const float *x, const float *P, float *out, uint64_t n
 // ------------------------------------------------------------------------------------------------
 // scan dispatch on W = dim / 64
 // ------------------------------------------------------------------------------------------------
+// The tile table of `tile` positions per block (see ScanArgs::use_table); nullptr on failure (the caller then uses the
+// plain grid).  Built once per (index, tile size).
+static const uint4 *get_tile_table(const rq_index *cidx, uint32_t tile, uint32_t *count) {
+    rq_index *idx = const_cast<rq_index *>(cidx);
+    std::lock_guard<std::mutex> lk(idx->tt_mu);
+    auto it = idx->tile_tables.find(tile);
+    if (it == idx->tile_tables.end()) {
+        std::vector<uint4> h;
+        h.reserve(idx->n / tile + idx->k + 1);
+        for (uint32_t c = 0; c < idx->k; ++c) {
+            const uint32_t b = idx->h_offsets[c], len = idx->h_offsets[c + 1] - b;
+            for (uint32_t f = 0; f < len; f += tile) h.push_back(make_uint4(c, f, b, len));
+        }
+        std::unique_ptr<DevBuf<uint4>> buf(new DevBuf<uint4>());
+        if (buf->alloc(h.size()) != RQ_OK) return nullptr;
+        if (!h.empty() && hipMemcpy(buf->p, h.data(), h.size() * sizeof(uint4), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        buf->count = h.size();
+        it = idx->tile_tables.emplace(tile, std::move(buf)).first;
+    }
+    *count = (uint32_t)it->second->count;
+    return it->second->p;
+}
+
 // A stage's grid is ngroups x tiles_per_group blocks.  Shapes whose grid exceeds the launch bound (few huge lists
 // x many pairs, ~1e9 vectors with skewed lists) are issued as several launches over (group, tile) sub-ranges; the
 // survivors of one stage are unordered until the run directory is sorted, so the split changes nothing.
@@ -361,7 +391,7 @@ static void launch_scan_chunks(const ScanArgs &a, F &&launch) {
         }
 }
 
-#define SCAN_ARGS p.codes, p.factors, p.offsets, p.grp_start, p.recs, p.surv, p.runs, p.surv_cnt, a
+#define SCAN_ARGS p.codes, p.factors, p.offsets, p.grp_start, p.recs, p.surv, p.runs, p.surv_cnt, p.tile_table, a
 static void launch_scan(const ScanPtrs &p, const ScanArgs &args, uint32_t W, hipStream_t st) {
     launch_scan_chunks(args, [&](const ScanArgs &a, dim3 g) {
         const dim3 b(256);
@@ -383,6 +413,7 @@ static void launch_scan(const ScanPtrs &p, const ScanArgs &args, uint32_t W, hip
 static std::atomic<int> g_scan_impl{0};
 static std::atomic<int> g_scan_dbg{0};
 static std::atomic<int> g_stage_growth{0};  // 0 = default schedule
+static std::atomic<int> g_scan_tile_table{1};  // 0 = plain (list x tile) grids everywhere (test / measurement hook)
 
 // matrix-core scan instantiations: W = dim/64, NT = 32-candidate sub-tiles per wave (resident operand registers
 // 6*W*NT), blocks per CU per scan_mfma_blocks_per_cu<W>()
@@ -398,7 +429,7 @@ static size_t scan_mfma_ring_bytes(uint32_t W) { return (W <= 2 ? 4ull : (W >= 1
 template <int W, int NT>
 static void launch_scan_mfma_t(const ScanPtrs &p, const ScanArgs &a, dim3 g, hipStream_t st) {
     scan_mfma_kernel<W, NT><<<g, dim3(256), scan_mfma_ring_bytes(W), st>>>(p.codes, p.factors, p.offsets, p.grp_start, p.grp_cnt,
-                                                                             p.recs, p.surv, p.runs, p.surv_cnt, p.stat, a);
+                                                                             p.recs, p.surv, p.runs, p.surv_cnt, p.stat, p.tile_table, a);
 }
 // callers check scan_has_mfma(W) first
 static void launch_scan_mfma(const ScanPtrs &p, const ScanArgs &args, uint32_t W, hipStream_t st) {
@@ -538,7 +569,7 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
     RQC(ws.win_count.ensure(nq));
     RQC(ws.arr_len.ensure(nq));
     RQC(ws.row_map.ensure(nq));
-    RQC(ws.big_list.ensure(nq + 2));  // [nq] = entries, [nq + 1] = blocks done
+    RQC(ws.big_list.ensure(nq + 3));  // [nq] = entries, [nq + 1] = blocks done, [nq + 2] = most entries of any stage of the pass
     if (qp.heuristic) RQC(ws.arr.ensure(nq * qp.hcap));
     return RQ_OK;
 }
@@ -557,6 +588,7 @@ static rq_status finish_pass(const rq_index *idx, Workspace &ws, PassResult *res
     res->precise = ws.h_totals[1];
     res->overflowed = ws.h_totals[2];
     res->max_need = ws.h_totals[4];
+    if (nq >= 256) const_cast<rq_index *>(idx)->big_dirs_hint.store((uint32_t)ws.h_totals[7]);
     if (pf.on && prof_acc) {
         float ms[PF_N] = {0};
         pf.collect(ms);
@@ -681,7 +713,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     // 4. ranker state (rerank.rs:70-77, :129-139) and per-query counters
     init_state_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(rs, ws.surv_cnt.p, nq);
     HIPC(hipMemsetAsync(ws.totals.p, 0, 8 * sizeof(unsigned long long), st));
-    HIPC(hipMemsetAsync(ws.big_list.p + nq, 0, 8, st));
+    HIPC(hipMemsetAsync(ws.big_list.p + nq, 0, 12, st));
     if (g_scan_dbg.load() & (128 | 256)) HIPC(hipMemsetAsync(ws.stat.p, 0, 256 * sizeof(unsigned long long), st));
     pf.end();
 
@@ -723,6 +755,9 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         }
     }
     ws.pend_matrix_ranges.clear();
+    // persistent blocks of the long-directory ordering: sized by how many such directories recent passes produced
+    const uint32_t big_hint = idx->big_dirs_hint.load();
+    const uint32_t mid_blocks = big_hint == 0 ? 64u : std::min(4096u, std::max(256u, big_hint / 4));
     const uint32_t tile = scan_tile(W);
     const uint64_t avg_len = std::max<uint64_t>(1, idx->n / std::max<uint32_t>(k, 1));
     for (const Stage &sg : stages) {
@@ -773,7 +808,20 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         sp.stat = ws.stat.p;  // 64 x {sub-tile steps, exact-path steps} of the matrix-core scan (dbg & 128)
         a.cap = qp.cap;
         a.dbg = (uint32_t)g_scan_dbg.load();
-        a.tiles_per_group = ceil_div(std::min<uint64_t>(idx->max_list_len, sg.s_hi), use_mfma ? scan_mfma_tile(W) : tile);
+        const uint32_t stage_tile = use_mfma ? scan_mfma_tile(W) : tile;
+        a.tiles_per_group = ceil_div(std::min<uint64_t>(idx->max_list_len, sg.s_hi), stage_tile);
+        sp.tile_table = nullptr;
+        const uint64_t grid_blocks = (uint64_t)k * a.tiles_per_group, real_tiles = idx->n / stage_tile + k;
+        const int tt_opt = g_scan_tile_table.load();  // 0 = never, 1 = when the plain grid is mostly empty blocks, 2 = always
+        if (cluster_major && scan_is_fused(W) && sg.s_hi >= idx->max_list_len &&
+            (tt_opt == 2 || (tt_opt == 1 && grid_blocks > 4 * real_tiles))) {
+            // the stage reaches every position of the lists and the lists are very unequal (one block per existing
+            // (list, tile) instead of k x the longest list's tiles; measured neutral-to-slower for moderately unequal
+            // lists, where the empty blocks of the plain grid cost less than the table's dependent load)
+            uint32_t count = 0;
+            sp.tile_table = get_tile_table(idx, stage_tile, &count);
+            if (sp.tile_table) a.use_table = 1u, a.ngroups = count, a.tiles_per_group = 1u;
+        }
         pf.begin(use_mfma ? PF_SCAN_MATRIX : PF_SCAN);
         if (use_mfma) launch_scan_mfma(sp, a, W, st);
         else launch_scan(sp, a, W, st);
@@ -802,7 +850,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             pf.begin(PF_SORT);
             sort_runs_kernel<<<nq, 64, 0, st>>>(ws.runs.p, ws.surv_cnt.p, qp.cap, ws.big_list.p, ws.big_list.p + nq);
             // queries with long run directories (loose thresholds): slot-bucketed ordering, persistent blocks walking the list
-            sort_runs_mid_kernel<<<512, 256, 0, st>>>(ws.runs.p, ws.runs_tmp.p, ws.surv_cnt.p, qp.cap, ws.big_list.p, ws.big_list.p + nq, nprobe);
+            sort_runs_mid_kernel<<<mid_blocks, 256, 0, st>>>(ws.runs.p, ws.runs_tmp.p, ws.surv_cnt.p, qp.cap, ws.big_list.p, ws.big_list.p + nq, nprobe);
             pf.end();
             pf.begin(PF_REPLAY);
             if (qp.heuristic)
@@ -828,7 +876,9 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         ws.totals.p);
     pf.end();
     if (pf.on) (void)hipEventRecord(pf.spans[total_span].b, st);
-    HIPC(hipMemcpyAsync(ws.h_totals, ws.totals.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPC(hipMemcpyAsync(ws.h_totals, ws.totals.p, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    ws.h_totals[7] = 0;
+    HIPC(hipMemcpyAsync(ws.h_totals + 7, ws.big_list.p + nq + 2, 4, hipMemcpyDeviceToHost, st));
     ws.pend_total_span = total_span;
     ws.pend_nq = nq;
     if (defer) return RQ_OK;  // the caller finishes the pass later (rq_query_batch_device_end)
@@ -1109,6 +1159,8 @@ static rq_status finish_index(rq_index *idx) {
     }
     HIPC(hipDeviceSynchronize());
     HIPC(hipGetLastError());
+    idx->h_offsets.resize((size_t)idx->k + 1);
+    HIPC(hipMemcpy(idx->h_offsets.data(), idx->offsets.p, ((size_t)idx->k + 1) * 4, hipMemcpyDeviceToHost));
     {
         size_t free_b = 0, total_b = 0;
         HIPC(hipMemGetInfo(&free_b, &total_b));
@@ -2406,6 +2458,11 @@ rq_status rq_set_option(const char *name, int value) {
                                                   // -1 = automatic (default), else MiB; the rest goes to pinned host memory
         if (value < -1) return fail(RQ_ERR_INVALID, "base_device_mb must be >= -1");
         g_base_device_mb = value;
+        return RQ_OK;
+    }
+    if (std::string(name) == "scan_tile_table") {  // full-list stages launch one block per existing (list, tile): 0 never, 1 auto, 2 always
+        if (value < 0 || value > 2) return fail(RQ_ERR_INVALID, "scan_tile_table must be 0 (never), 1 (auto) or 2 (always)");
+        g_scan_tile_table = value;
         return RQ_OK;
     }
     if (std::string(name) == "max_scan_blocks") {  // test hook: blocks per scan launch (0 = the hardware bound), forces chunked stages

@@ -550,8 +550,8 @@ def test_scan_implementations_match_oracle(rq, oracle, impl, n, d, k, nq):
 # A stage whose grid exceeds the launch bound is issued as several launches over (group, tile) sub-ranges
 # (launch_scan_chunks): lowered test-only bound, one artificially long list, both implementations, both work layouts.
 @pytest.mark.parametrize("impl", [1, 2])
-@pytest.mark.parametrize("max_blocks", [1, 5])
-def test_scan_grid_chunking_matches_oracle(rq, oracle, impl, max_blocks):
+@pytest.mark.parametrize("max_blocks,tile_table", [(1, 2), (5, 2), (5, 0), (0, 1)])
+def test_scan_grid_chunking_matches_oracle(rq, oracle, impl, max_blocks, tile_table):
     from rabitq_amd import index as ix
     n, d = 9000, 128
     rng = np.random.default_rng(77)
@@ -565,12 +565,14 @@ def test_scan_grid_chunking_matches_oracle(rq, oracle, impl, max_blocks):
     queries = (rng.standard_normal((70, d)) * 0.5).astype(np.float32)
     ix.set_option("scan_impl", impl)
     ix.set_option("max_scan_blocks", max_blocks)
+    ix.set_option("scan_tile_table", tile_table)   # full-list stages: one block per existing (list, tile) (2), plain grid (0), auto (1)
     try:
         _compare_with_oracle(rq, oracle, oidx, gidx, queries, 6, 10, False)      # cluster-major stages
         _compare_with_oracle(rq, oracle, oidx, gidx, queries[:3], 6, 10, False)  # pair-major stages
         _compare_with_oracle(rq, oracle, oidx, gidx, queries, 2, 30, True)
     finally:
         ix.set_option("max_scan_blocks", 0)
+        ix.set_option("scan_tile_table", 1)
         ix.set_option("scan_impl", 0)
     gidx.close()
     oidx.close()
