@@ -625,41 +625,6 @@ __global__ void group_count_kernel(const PairScalars *__restrict__ scal,
     if (pair_in_stage(scal[p], s_lo, s_hi)) atomicAdd(&grp_cnt[probe_cluster[p]], 1u);
 }
 
-// exclusive scan of cnt[0..k) into start[0..k]; single block, any k.  Also zeroes cnt for the
-// fill pass (cnt is reused as the per-list cursor, so it holds the counts again afterwards).
-// pad32: every group starts at a multiple of 32 records (the matrix-core scan's query tiles).
-__global__ __launch_bounds__(1024) void group_scan_kernel(uint32_t *__restrict__ cnt, uint32_t k,
-                                                          uint32_t *__restrict__ start, uint32_t pad32) {
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < k; base += 1024) {
-        uint32_t i = base + tid;
-        uint32_t v = i < k ? cnt[i] : 0;
-        if (pad32) v = (v + 31u) & ~31u;
-        uint32_t incl = v;
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t up = __shfl_up(incl, o, 64);
-            if ((int)lane >= o) incl += up;
-        }
-        if (lane == 63) wsum[wid] = incl;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (uint32_t w = 0; w < wid; ++w) woff += wsum[w];
-        uint32_t c0 = carry;
-        if (i < k) {
-            start[i] = c0 + woff + incl - v;
-            cnt[i] = 0;
-        }
-        __syncthreads();
-        if (tid == 1023) carry = c0 + woff + incl;
-        __syncthreads();
-    }
-    if (tid == 0) start[k] = carry;
-}
-
 // Per-stage work records.  Everything the scan needs about one (query, list) pair, contiguous, so
 // that the scan's inner loop is one pointer bump plus immediate-offset scalar loads:
 //   dwords [0, opdw)    query operand: 4-bit codes 8 per dword (fused kernel, 8W), the 4 bit planes (8W), or
@@ -681,6 +646,55 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(uint32_t *__restrict__
 #define RQ_REC_LIST_LEN 11
 #define RQ_REC_V0 12         // 8 dwords: per-query bf16 operand of the integer threshold S*(c,q) = sum_r u'_c[r] * v'_q[r]
 #define RQ_REC_TAIL 20
+
+// exclusive scan of cnt[0..k) into start[0..k]; single block, any k.  Also zeroes cnt for the
+// fill pass (cnt is reused as the per-list cursor, so it holds the counts again afterwards).
+// pad32: every group starts at a multiple of 32 records (the matrix-core scan's query tiles).
+// pad32 (matrix-core stages): the rows between a group's last record and its 32-row boundary are marked "no query"
+// right here (their threshold operand: constant term -inf, so the accumulator of such a row starts at -inf and is
+// never flagged): the scan then needs no per-tile masking.  recs / opdw: the stage's tile images.
+__global__ __launch_bounds__(1024) void group_scan_kernel(uint32_t *__restrict__ cnt, uint32_t k,
+                                                          uint32_t *__restrict__ start, uint32_t pad32,
+                                                          uint32_t *__restrict__ recs, uint32_t opdw) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < k; base += 1024) {
+        uint32_t i = base + tid;
+        uint32_t v = i < k ? cnt[i] : 0;
+        if (pad32) v = (v + 31u) & ~31u;
+        uint32_t incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t up = __shfl_up(incl, o, 64);
+            if ((int)lane >= o) incl += up;
+        }
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t w = 0; w < wid; ++w) woff += wsum[w];
+        uint32_t c0 = carry;
+        if (i < k) {
+            const uint32_t st0 = c0 + woff + incl - v;
+            start[i] = st0;
+            if (pad32 && recs) {
+                const uint32_t real = cnt[i];
+                const uint32_t opld = opdw + 2, img = 32 * opld + RQ_REC_TAIL * 32;
+                for (uint32_t at = st0 + real; at < st0 + v; ++at) {  // at most 31 rows
+                    uint32_t *tl = recs + (uint64_t)(at >> 5) * img + 32 * opld + (at & 31u) * RQ_REC_TAIL + RQ_REC_V0;
+                    *reinterpret_cast<uint4 *>(tl) = make_uint4(0u, 0u, 0u, 0x0000FF80u);  // slots 0..7: c0 = -inf
+                    *reinterpret_cast<uint4 *>(tl + 4) = make_uint4(0u, 0u, 0u, 0u);        // slots 8..15
+                }
+            }
+            cnt[i] = 0;
+        }
+        __syncthreads();
+        if (tid == 1023) carry = c0 + woff + incl;
+        __syncthreads();
+    }
+    if (tid == 0) start[k] = carry;
+}
 
 // f32 -> bf16 bits (round to nearest even) and back; finite inputs well inside the f32 range
 __device__ __forceinline__ uint32_t bf16_rne(float x) {
@@ -1220,6 +1234,9 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
     // as a scalar, together with the developer switch: the hot loop tests one SGPR instead of rebuilding the condition
     const uint32_t force_any = __builtin_amdgcn_readfirstlane(forcemask != 0ull ? 1u : 0u);
     const uint32_t exact_off = __builtin_amdgcn_readfirstlane((a.dbg & 64u) ? 1u : 0u);
+    // the hot test "some cell positive" as ONE compare against a wave-uniform bound: 1 normally (a positive float is an
+    // int32 >= 1), INT_MIN when some candidate of the wave is forced (always true), INT_MAX under the exact-off ablation
+    const int gate_min = (int)__builtin_amdgcn_readfirstlane(exact_off ? 0x7FFFFFFFu : (force_any ? 0x80000000u : 1u));
     if (h == 0) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) facL[lpos[t] - first] = fac0[t];
@@ -1321,7 +1338,6 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
         }
         const uint32_t *img = ring + slot * IMG;
         const uint32_t nvalid = cnt - 32 * qt;  // rows >= nvalid of the last tile are stale memory: masked here
-        const bool valid = j < nvalid;
 
         // A: query row j (= lane & 31), dims 64m + 32h .. +31 as fp6.  Rows >= nvalid hold stale bytes: harmless,
         // every fp6 pattern is a finite number and such a row's accumulator starts at -inf (below)
@@ -1358,12 +1374,8 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
             return bv;
         };
         // A operand of the threshold MFMA: slots 8h .. 8h+7 of query row j
-        v4i32 ua = *reinterpret_cast<const v4i32 *>(&img[IMG_OP + j * RQ_REC_TAIL + RQ_REC_V0 + 4 * h]);
-        if (nvalid < 32) {  // wave-uniform, last tile of a list only
-#pragma unroll
-            for (int e = 0; e < 4; ++e)  // a missing query: -S* = -inf (constant term hi = -inf, times 1), never flagged
-                ua[e] = valid ? ua[e] : ((h == 0 && e == 3) ? 0x0000FF80 : 0);
-        }
+        // (rows past the list's last query carry the "no query" operand written by group_scan_kernel: -S* = -inf)
+        const v4i32 ua = *reinterpret_cast<const v4i32 *>(&img[IMG_OP + j * RQ_REC_TAIL + RQ_REC_V0 + 4 * h]);
         auto tail = [&](uint32_t f, uint32_t row) { return img[IMG_OP + row * RQ_REC_TAIL + f]; };
 
         // accumulator tiles = -S*/2 (query row, candidate col) + s/2, all on the matrix pipe
@@ -1405,7 +1417,7 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
             for (int gq = 3; gq < 15; gq += 2) mxi = imax3(mxi, ai[gq], ai[gq + 1]);
             mxi = mxi > ai[15] ? mxi : ai[15];
             if (count_stat) ++n_steps;
-            if ((force_any | (__ballot(mxi > 0) != 0ull ? 1u : 0u)) & (exact_off ^ 1u)) {  // wave-uniform; everything below
+            if (__ballot(mxi >= gate_min) != 0ull) {  // wave-uniform; everything below
                 if (count_stat) ++n_flag;
                 // lives inside this branch so that the common path carries no state of it (not even a zeroed tile)
                 uint32_t gmask = force_any ? 0xFFFFu : 0u;  // accumulator registers with at least one flagged lane

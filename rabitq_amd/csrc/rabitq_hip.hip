@@ -701,7 +701,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     if (nq >= 256) {  // large batch: rerank queries of the same nearest list back to back (cache locality of the row gather)
         HIPC(hipMemsetAsync(ws.q_hist.p, 0, (size_t)(k + 2) * 4, st));
         order_count_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(probe_cluster, nprobe, nq, k, ws.q_hist.p);
-        group_scan_kernel<<<1, 1024, 0, st>>>(ws.q_hist.p, k + 1, ws.q_start.p, 0u);  // also zeroes the histogram: cursor
+        group_scan_kernel<<<1, 1024, 0, st>>>(ws.q_hist.p, k + 1, ws.q_start.p, 0u, nullptr, 0u);  // also zeroes the histogram: cursor
         order_scatter_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(probe_cluster, nprobe, nq, k, ws.q_start.p, ws.q_hist.p,
                                                                 ws.q_order.p);
         rerank_order = ws.q_order.p;
@@ -783,7 +783,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             HIPC(hipMemsetAsync(ws.grp_cnt.p, 0, (size_t)((k + 4) & ~3u) * 4, st));  // 16-byte multiple: one fill kernel
             group_count_kernel<<<ceil_div(stage_pairs, 256), 256, 0, st>>>(ws.scal.p, probe_cluster, stage_pairs, nprobe,
                                                                            slot_hi, sg.s_lo, sg.s_hi, ws.grp_cnt.p);
-            group_scan_kernel<<<1, 1024, 0, st>>>(ws.grp_cnt.p, k, ws.grp_start.p, use_mfma ? 1u : 0u);
+            group_scan_kernel<<<1, 1024, 0, st>>>(ws.grp_cnt.p, k, ws.grp_start.p, use_mfma ? 1u : 0u, ws.recs.p, 12 * W);
             a.ngroups = k;
         } else {
             a.ngroups = npairs;
@@ -1407,7 +1407,7 @@ static rq_status builder_order(rq_builder *b) {
     HIPC(hipMemset(cnt.p, 0, ((size_t)k + 1) * 4));
     const uint32_t g256 = (uint32_t)std::min<uint64_t>(ceil_div(std::max<uint64_t>(n, 1), 256), 1u << 22);
     if (n) label_hist_kernel<<<ceil_div(n, 256), 256>>>(b->label.p, n, cnt.p);
-    group_scan_kernel<<<1, 1024>>>(cnt.p, k, idx->offsets.p, 0u);  // also zeroes cnt -> cursor
+    group_scan_kernel<<<1, 1024>>>(cnt.p, k, idx->offsets.p, 0u, nullptr, 0u);  // also zeroes cnt -> cursor
     if (n) label_scatter_kernel<<<ceil_div(n, 256), 256>>>(b->label.p, b->mind.p, n, 0, idx->offsets.p, cnt.p, keys.p);
     list_sort_kernel<<<k, 1024>>>(keys.p, idx->offsets.p);
     HIPC(hipDeviceSynchronize());
