@@ -195,6 +195,8 @@ struct Workspace {
     uint32_t pend_nq = 0;
     std::vector<StreamRange> pend_matrix_ranges;  // stream ranges scanned on the matrix cores (profiling only)
     DevBuf<float> qpad, y, dist, probe_dist, thr, recent;
+    DevBuf<float> retry_q, retry_pd, retry_pc;  // overflow re-runs: the affected queries (and their probe lists)
+    DevBuf<uint32_t> retry_rows;
     DevBuf<uint32_t> q_hist, q_start, q_order;  // rerank order of a large batch (queries grouped by nearest list)
     DevBuf<uint32_t> probe_cluster, recs, grp_cnt, grp_start, heap_len, heap_id, precise, need,
         nsurv, win_count, arr_len, row_map, big_list;
@@ -962,9 +964,17 @@ static rq_status after_pass(rq_index *idx, Workspace *ws, const QueryParams &qp,
         // bound the retry workspace to ~4 GiB of survivor records
         uint32_t chunk = (uint32_t)std::max<uint64_t>(1, (4ull << 30) / ((uint64_t)(ncap + nhcap) * sizeof(SurvRec)));
         std::vector<uint32_t> still;
-        Workspace rws;
-        DevBuf<float> sub_q;
-        DevBuf<uint32_t> sub_rows;
+        // a pooled workspace (its buffers persist: a workload whose outliers overflow every batch must not pay
+        // hipMalloc / hipFree of gigabytes per batch)
+        Workspace *rwsp = ws_acquire(idx);
+        struct RelR {
+            rq_index *i;
+            Workspace *w;
+            ~RelR() { ws_release(i, w); }
+        } relr{idx, rwsp};
+        Workspace &rws = *rwsp;
+        DevBuf<float> &sub_q = rws.retry_q;
+        DevBuf<uint32_t> &sub_rows = rws.retry_rows;
         for (size_t o = 0; o < over_rows.size(); o += chunk) {
             uint32_t m = (uint32_t)std::min<size_t>(chunk, over_rows.size() - o);
             QueryParams rq{m, len, probe, topk, heuristic, ncap, nhcap};
@@ -976,7 +986,7 @@ static rq_status after_pass(rq_index *idx, Workspace *ws, const QueryParams &qp,
             PassResult rr;
             const uint32_t *sub_pc = nullptr;
             const float *sub_pd = nullptr;
-            DevBuf<float> sub_probe_d, sub_probe_c;
+            DevBuf<float> &sub_probe_d = rws.retry_pd, &sub_probe_c = rws.retry_pc;
             if (ext_cluster) {  // the caller's probe lists, restricted to the re-run queries
                 RQC(sub_probe_c.ensure((uint64_t)m * npb));
                 RQC(sub_probe_d.ensure((uint64_t)m * npb));
