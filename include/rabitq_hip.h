@@ -61,7 +61,7 @@ typedef struct {
     uint64_t n;            /* number of vectors */
     uint32_t max_list_len; /* longest IVF list */
     uint32_t reserved;
-    uint64_t n_hbm;        /* raw vectors resident in HBM; the other n - n_hbm are in pinned host memory */
+    uint64_t n_hbm;        /* raw vectors resident in HBM; the other n - n_hbm (list tails) are in pinned host memory */
 } rq_info_t;
 
 /* ---- library ------------------------------------------------------------------------------- */
@@ -90,8 +90,9 @@ rq_status rq_build_from_path(const char *base_fvecs, const char *centroid_fvecs,
  *   raw vectors to their cluster-order positions :244-247) -> rq_builder_finish.
  * Chunks are m x d row-major f32 in DEVICE memory covering rows [i0, i0 + m); any order, any sizes; each call returns
  * when the chunk buffer may be reused.  max_device_base_bytes: HBM budget of the raw vectors (0 = automatic: what is
- * free minus a reserve; UINT64_MAX = all in HBM); vectors beyond it are kept in pinned host memory and gathered over
- * the host link by the rerank (results identical).  rq_builder_finish consumes the builder (also on
+ * free minus a reserve; UINT64_MAX = all in HBM).  Beyond it the split is per list: the head of every list (the vectors
+ * nearest its centroid, which the re-ranker asks for most) stays in HBM, the tail goes to pinned host memory and is
+ * gathered over the host link by the rerank (results identical).  rq_builder_finish consumes the builder (also on
  * error); rq_builder_free abandons one. */
 typedef struct rq_builder rq_builder;
 typedef struct {
@@ -141,7 +142,8 @@ enum { RQ_ARR_BASE = 0, RQ_ARR_ORTHOGONAL, RQ_ARR_CENTROIDS, RQ_ARR_OFFSETS, RQ_
        RQ_ARR_CODES, RQ_ARR_FACTORS };
 rq_status rq_get_array(const rq_index *idx, int which, void *dst, uint64_t dst_bytes);
 /* Device pointer of one array (valid until rq_free); for zero-copy hand-over to a caller that
- * already lives on the GPU.  RQ_ARR_BASE gives the HBM tier (rows [0, n_hbm), all rows unless the index is tiered). */
+ * already lives on the GPU.  RQ_ARR_BASE gives the HBM tier: every row at its position when n_hbm == n; on a tiered
+ * index the list heads only, packed (use rq_get_array for the whole array). */
 rq_status rq_get_device_ptr(const rq_index *idx, int which, const void **out_ptr, uint64_t *out_bytes);
 
 /* ---- query: RaBitQ::query, src/rabitq.rs:268-333 --------------------------------------------- */

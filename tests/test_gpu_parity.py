@@ -341,9 +341,13 @@ def test_cli_harness_build_then_load(rq, oracle, tmp_path, capsys):
 
 # ---- properties at larger sizes (what the oracle cannot check in seconds) ---------------------------
 # (100M x 128, 4096 lists, nprobe 64) is BASELINE.json configs[2] at its full size.
-@pytest.mark.parametrize("n,d,k,probe", [(2_000_000, 128, 1024, 32), (200_000, 768, 256, 32), (100_000_000, 128, 4096, 64)])
-def test_large_index_properties(rq, n, d, k, probe):
+# (3M x 768 with a 4 GiB HBM budget) is configs[3]'s regime in small: raw vectors tiered per list between HBM and pinned
+# host memory, built through the streamed builder path, wide-vector scan kernels.
+@pytest.mark.parametrize("n,d,k,probe,hbm_mb", [(2_000_000, 128, 1024, 32, -1), (200_000, 768, 256, 32, -1),
+                                                (100_000_000, 128, 4096, 64, -1), (3_000_000, 768, 1024, 32, 4096)])
+def test_large_index_properties(rq, n, d, k, probe, hbm_mb):
     import torch
+    from rabitq_amd import index as ix
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)
     g.manual_seed(5)
@@ -359,8 +363,17 @@ def test_large_index_properties(rq, n, d, k, probe):
     uq = torch.randint(0, k, (nq,), generator=g, device=dev)
     q = (centres[uq] + 0.5 * torch.randn(nq, d, generator=g, device=dev)).contiguous()
     P = synth.random_orthogonal(d, seed=1)
-    idx = rq.RaBitQ.build_device(x.data_ptr(), n, d, centres.data_ptr(), k, orthogonal=P)
+    ix.set_option("base_device_mb", hbm_mb)
+    try:
+        idx = rq.RaBitQ.build_device(x.data_ptr(), n, d, centres.data_ptr(), k, orthogonal=P)
+    finally:
+        ix.set_option("base_device_mb", -1)
     off, ids = idx.offsets.astype(np.int64), idx.map_ids
+    if hbm_mb > 0:   # every list keeps floor(len * budget_rows / n) members in HBM, the rest is host-resident
+        budget_rows = (hbm_mb << 20) // (4 * idx.dim)
+        assert idx.n_hbm == int((np.diff(off) * budget_rows // n).sum()) and 0 < idx.n_hbm < n
+    else:
+        assert idx.n_hbm == n
     assert off[0] == 0 and off[-1] == n and np.all(np.diff(off) >= 0)
     assert np.array_equal(np.sort(ids), np.arange(n, dtype=np.uint32))              # a permutation
     assert np.array_equal(np.diff(off), counts.cpu().numpy())  # well separated mixture
