@@ -92,7 +92,6 @@ def main():
         os.dup2(2, 1)
         try:
             dist.init_process_group(args.backend, rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
-            dist.barrier()
         finally:
             sys.stdout.flush()
             os.dup2(keep, 1)

@@ -1950,7 +1950,7 @@ __global__ __launch_bounds__(1024) void stage_finish_kernel(SurvRec *__restrict_
                                                            const BaseView base,
                                                            const float *__restrict__ qpad, uint32_t dim, uint32_t topk,
                                                            ReplayState st, const uint32_t *__restrict__ probe_cluster,
-                                                           uint32_t nprobe) {
+                                                           uint32_t nprobe, uint32_t presorted) {
     __shared__ int32_t hkey[HEURISTIC ? 1 : RQ_MAX_TOPK];
     __shared__ uint32_t hid[HEURISTIC ? 1 : RQ_MAX_TOPK];
     extern __shared__ __attribute__((aligned(16))) float fin_q[];  // dim floats: the padded query
@@ -1974,7 +1974,9 @@ __global__ __launch_bounds__(1024) void stage_finish_kernel(SurvRec *__restrict_
         __syncthreads();
         accurate_rows(recs, n, base, fin_q, dim, threadIdx.x >> 1, blockDim.x >> 1, probe_cluster + (uint64_t)b * nprobe);  // 256 or 1024 threads per query
     }
-    sort_segment(runs + (uint64_t)b * cap, nruns);  // (B)
+    // (B): up to RQ_SORT_LDS_RECS descriptors in LDS; longer directories were already ordered by sort_runs_mid_kernel
+    // when the host launched it ahead of this kernel (presorted != 0), else (rare) bitonic in global memory
+    if (nruns <= RQ_SORT_LDS_RECS || !presorted) sort_segment(runs + (uint64_t)b * cap, nruns);
     __syncthreads();                                  // (A)'s stores and (B)'s order visible to wave 0
     if (threadIdx.x < 64)                             // (C)
         replay_wave<HEURISTIC>(recs, runs + (uint64_t)b * cap, nruns, topk, b, st, hkey, hid);
@@ -2026,13 +2028,17 @@ __global__ __launch_bounds__(256) void accurate_kernel(SurvRec *__restrict__ sur
 __global__ __launch_bounds__(64) void sort_runs_kernel(RunRec *__restrict__ runs,
                                                         const unsigned long long *__restrict__ surv_cnt,
                                                         uint32_t cap, uint32_t *__restrict__ big_list,
-                                                        uint32_t *__restrict__ big_count) {
+                                                        uint32_t *__restrict__ big_count, uint32_t list_above) {
     const uint32_t b = blockIdx.x;
     const unsigned long long c = surv_cnt[b];
     if ((uint32_t)c > cap) return;
     // early stages leave a few dozen runs per query, the stages around one list's worth a few hundred (more at dim 64,
     // where the estimates are noisier): 512 descriptors = 8 KiB of LDS per 64-thread block keep them out of global memory
     const uint32_t nruns = (uint32_t)(c >> 32);
+    if (list_above != 512u) {  // small-batch path: only list the directories stage_finish_kernel cannot sort in LDS
+        if (nruns > list_above && threadIdx.x == 0) big_list[atomicAdd(big_count, 1u)] = b;
+        return;
+    }
     if (nruns > 512) {  // a loose threshold: handed to sort_runs_mid_kernel (slot buckets + rank counting)
         if (threadIdx.x == 0) big_list[atomicAdd(big_count, 1u)] = b;
         return;

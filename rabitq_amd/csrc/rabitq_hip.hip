@@ -559,7 +559,7 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
     RQC(ws.thr.ensure(nq));
     RQC(ws.surv.ensure(nq * qp.cap));
     RQC(ws.runs.ensure(nq * qp.cap));
-    if (nq >= 256) RQC(ws.runs_tmp.ensure(nq * qp.cap));  // large batches order long run directories through it
+    if (nq >= 256 || qp.cap > RQ_DEFAULT_CAP) RQC(ws.runs_tmp.ensure(nq * qp.cap));  // long run directories are ordered through it
     RQC(ws.surv_cnt.ensure(nq));
     RQC(ws.heap_len.ensure(nq));
     RQC(ws.heap_key.ensure(nq * qp.topk));
@@ -836,12 +836,21 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         if (nq < 256) {  // small batch: one fused launch per stage (launch-bound regime)
             pf.begin(PF_RERANK);
             const uint32_t fin_threads = nq <= 16 ? 1024u : 256u;  // a handful of queries: more lanes on each one's rerank
+            // survivor buffers beyond the default mean this index / these queries leave long run directories (overflow
+            // re-runs, loose thresholds): those are ordered by the slot-bucketed kernel first; the fused kernel then sorts
+            // only what fits its LDS
+            const uint32_t presorted = qp.cap > RQ_DEFAULT_CAP && nprobe <= 1024 ? 1u : 0u;
+            if (presorted) {
+                sort_runs_kernel<<<nq, 64, 0, st>>>(ws.runs.p, ws.surv_cnt.p, qp.cap, ws.big_list.p, ws.big_list.p + nq, RQ_SORT_LDS_RECS);
+                sort_runs_mid_kernel<<<std::min(nq, 256u), 256, 0, st>>>(ws.runs.p, ws.runs_tmp.p, ws.surv_cnt.p, qp.cap, ws.big_list.p,
+                                                                         ws.big_list.p + nq, nprobe);
+            }
             if (qp.heuristic)
                 stage_finish_kernel<true><<<nq, fin_threads, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->view(),
-                                                              qpad, dim, topk, rs, probe_cluster, nprobe);
+                                                              qpad, dim, topk, rs, probe_cluster, nprobe, presorted);
             else
                 stage_finish_kernel<false><<<nq, fin_threads, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->view(),
-                                                               qpad, dim, topk, rs, probe_cluster, nprobe);
+                                                               qpad, dim, topk, rs, probe_cluster, nprobe, presorted);
             pf.end();
         } else {  // large batch: full-chip rerank, then run-directory sort, then one replay wave per query
             pf.begin(PF_RERANK);
@@ -850,7 +859,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                                                                                     rerank_order, probe_cluster, nprobe);
             pf.end();
             pf.begin(PF_SORT);
-            sort_runs_kernel<<<nq, 64, 0, st>>>(ws.runs.p, ws.surv_cnt.p, qp.cap, ws.big_list.p, ws.big_list.p + nq);
+            sort_runs_kernel<<<nq, 64, 0, st>>>(ws.runs.p, ws.surv_cnt.p, qp.cap, ws.big_list.p, ws.big_list.p + nq, 512u);
             // queries with long run directories (loose thresholds): slot-bucketed ordering, persistent blocks walking the list
             sort_runs_mid_kernel<<<mid_blocks, 256, 0, st>>>(ws.runs.p, ws.runs_tmp.p, ws.surv_cnt.p, qp.cap, ws.big_list.p, ws.big_list.p + nq, nprobe);
             pf.end();
