@@ -32,6 +32,11 @@ for it in range(rounds):
     dp = (d + 63) // 64 * 64
     P = synth.random_orthogonal(dp, seed=it) if rng.random() < 0.8 else np.eye(dp, dtype=np.float32)
     oidx = oracle.OracleIndex.build(x, centres, P)
+    # engine knobs that must never change a result: raw-vector tiers, chunked scan grids, tile tables
+    knobs = {"base_device_mb": int(rng.choice([-1, -1, 0, 1])), "max_scan_blocks": int(rng.choice([0, 0, 3, 40])),
+             "scan_tile_table": int(rng.choice([0, 1, 2]))}
+    for name, v in knobs.items():
+        ix.set_option(name, v)
     gidx = rq.RaBitQ.build(x, centres, P)
     queries, _, _ = synth.mixture(nq, d, k, sigma=sigma, seed=5000 + it, centre_scale=0.7)
     if nq > 2:
@@ -54,7 +59,8 @@ for it in range(rounds):
             if "reference panics" not in str(e):
                 raise
     ix.set_option("scan_impl", 0)
+    ix.set_option("base_device_mb", -1), ix.set_option("max_scan_blocks", 0), ix.set_option("scan_tile_table", 1)
     gidx.close()
     oidx.close()
-    print(f"[{it + 1}/{rounds}] n={n} d={d} k={k} nq={nq} impl={impl} cfgs={cfgs} ok  ({time.time() - t0:.0f}s)", flush=True)
+    print(f"[{it + 1}/{rounds}] n={n} d={d} k={k} nq={nq} impl={impl} knobs={list(knobs.values())} cfgs={cfgs} ok  ({time.time() - t0:.0f}s)", flush=True)
 print("fuzz parity: all rounds identical to the oracle")
