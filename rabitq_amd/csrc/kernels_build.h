@@ -228,33 +228,39 @@ __global__ __launch_bounds__(256) void assign_generic_kernel(const float *__rest
                                                              uint32_t k, uint32_t dim,
                                                              uint32_t *__restrict__ label,
                                                              float *__restrict__ dist) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];  // VT * dim
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [dim][VT]: one ds_read_b128 = 4 vectors at one dimension
     __shared__ unsigned long long red[VT][4];
+    static_assert(VT % 4 == 0, "vectors are processed in packed pairs, read four at a time");
     const uint64_t i0 = (uint64_t)blockIdx.x * VT;
     for (uint32_t t = threadIdx.x; t < VT * dim; t += 256) {
-        uint32_t v = t / dim, e = t - v * dim;
-        xs[t] = (i0 + v < n) ? xrot[(i0 + v) * dim + e] : 0.0f;
+        uint32_t v = t / dim, e = t - v * dim;  // coalesced reads of the rows, transposed into LDS
+        xs[e * VT + v] = (i0 + v < n) ? xrot[(i0 + v) * dim + e] : 0.0f;
     }
     __syncthreads();
     unsigned long long bestkey[VT];
 #pragma unroll
     for (int v = 0; v < VT; ++v) bestkey[v] = ((unsigned long long)ord32_biased(3.402823466e+38f) << 32);
     for (uint32_t j = threadIdx.x; j < k; j += 256) {
-        f32x2 acc2[VT / 2][8];  // vector pairs in packed f32
+        f32x2 acc2[VT / 2][8];  // [vector pair][AVX lane]: v_pk_add_f32 + v_pk_fma_f32, per-component rounding
 #pragma unroll
         for (int v = 0; v < VT / 2; ++v)
 #pragma unroll
             for (int l = 0; l < 8; ++l) acc2[v][l] = f32x2{0.0f, 0.0f};
+        const float *cp = cent_t + j;
         for (uint32_t c = 0; c < dim; c += 8) {
+            float ce[8];
+#pragma unroll
+            for (int l = 0; l < 8; ++l) ce[l] = cp[(uint64_t)(c + l) * k];  // 8 loads in flight
 #pragma unroll
             for (int l = 0; l < 8; ++l) {
-                float ce = cent_t[(uint64_t)(c + l) * k + j];
-                f32x2 ce2 = {ce, ce};
+                const f32x2 ce2 = {ce[l], ce[l]};
 #pragma unroll
-                for (int v = 0; v < VT / 2; ++v) {
-                    f32x2 xx = {xs[(2 * v) * dim + c + l], xs[(2 * v + 1) * dim + c + l]};
-                    f32x2 d = ce2 - xx;
-                    acc2[v][l] = __builtin_elementwise_fma(d, d, acc2[v][l]);
+                for (int v4 = 0; v4 < VT / 4; ++v4) {
+                    const float4 xq = *reinterpret_cast<const float4 *>(&xs[(c + l) * VT + 4 * v4]);
+                    const f32x2 x01 = {xq.x, xq.y}, x23 = {xq.z, xq.w};
+                    const f32x2 d01 = ce2 - x01, d23 = ce2 - x23;  // centroid - vector, as l2_squared_distance(c', x') does
+                    acc2[2 * v4][l] = __builtin_elementwise_fma(d01, d01, acc2[2 * v4][l]);
+                    acc2[2 * v4 + 1][l] = __builtin_elementwise_fma(d23, d23, acc2[2 * v4 + 1][l]);
                 }
             }
         }
