@@ -2057,8 +2057,8 @@ __global__ __launch_bounds__(256) void sort_runs_mid_kernel(RunRec *__restrict__
     const uint32_t total = big_count[0];
     for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
         const uint32_t b = big_list[i], n = (uint32_t)(surv_cnt[b] >> 32);
-        if (nslots <= 1024) sort_runs_by_slot<1024>(runs + (uint64_t)b * cap, runs_tmp + (uint64_t)b * cap, n, nslots);
-        else sort_segment<RunRec, 16>(runs + (uint64_t)b * cap, n);  // more than 1024 probe slots: plain bitonic sort (global memory)
+        if (nslots <= 1024 && runs_tmp) sort_runs_by_slot<1024>(runs + (uint64_t)b * cap, runs_tmp + (uint64_t)b * cap, n, nslots);
+        else sort_segment<RunRec, 16>(runs + (uint64_t)b * cap, n);  // more than 1024 probe slots, or no second buffer yet: bitonic sort in global memory
         __syncthreads();
     }
     __syncthreads();

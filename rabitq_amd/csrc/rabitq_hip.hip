@@ -208,6 +208,7 @@ struct Workspace {
     DevBuf<unsigned long long> rough_cnt, totals, surv_cnt, stat;
     DevBuf<SurvRec> surv, arr;
     DevBuf<RunRec> runs, runs_tmp;
+    bool use_runs_tmp = false;
     // multi-GPU step (rq_query_batch_sharded_device): this shard's results, the all-gathered keys, the merged keys
     DevBuf<float> sh_dist;
     DevBuf<uint32_t> sh_id, sh_n;
@@ -543,7 +544,7 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
     RQC(ws.probe_dist.ensure(npairs));
     RQC(ws.probe_cluster.ensure(npairs));
     RQC(ws.scal.ensure(npairs));
-    RQC(ws.planes.ensure(npairs * 4 * idx->W));
+    if (!scan_is_fused(idx->W)) RQC(ws.planes.ensure(npairs * 4 * idx->W));  // bit planes: only the generic-W scan reads them
     RQC(ws.qnib.ensure(npairs * 8 * idx->W));
     RQC(ws.qf6.ensure(npairs * 12 * idx->W));
     RQC(ws.rough_cnt.ensure(nq));
@@ -559,7 +560,10 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
     RQC(ws.thr.ensure(nq));
     RQC(ws.surv.ensure(nq * qp.cap));
     RQC(ws.runs.ensure(nq * qp.cap));
-    if (nq >= 256 || qp.cap > RQ_DEFAULT_CAP) RQC(ws.runs_tmp.ensure(nq * qp.cap));  // long run directories are ordered through it
+    // second run directory, through which long directories (> 512 runs) are ordered: only once the index has shown
+    // that it produces them (or with enlarged buffers); until then a stray long directory is bitonic-sorted in place
+    ws.use_runs_tmp = qp.cap > RQ_DEFAULT_CAP || idx->big_dirs_hint.load() > 0;
+    if (ws.use_runs_tmp) RQC(ws.runs_tmp.ensure(nq * qp.cap));
     RQC(ws.surv_cnt.ensure(nq));
     RQC(ws.heap_len.ensure(nq));
     RQC(ws.heap_key.ensure(nq * qp.topk));
@@ -842,7 +846,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             const uint32_t presorted = qp.cap > RQ_DEFAULT_CAP && nprobe <= 1024 ? 1u : 0u;
             if (presorted) {
                 sort_runs_kernel<<<nq, 64, 0, st>>>(ws.runs.p, ws.surv_cnt.p, qp.cap, ws.big_list.p, ws.big_list.p + nq, RQ_SORT_LDS_RECS);
-                sort_runs_mid_kernel<<<std::min(nq, 256u), 256, 0, st>>>(ws.runs.p, ws.runs_tmp.p, ws.surv_cnt.p, qp.cap, ws.big_list.p,
+                sort_runs_mid_kernel<<<std::min(nq, 256u), 256, 0, st>>>(ws.runs.p, ws.use_runs_tmp ? ws.runs_tmp.p : nullptr, ws.surv_cnt.p, qp.cap, ws.big_list.p,
                                                                          ws.big_list.p + nq, nprobe);
             }
             if (qp.heuristic)
@@ -861,7 +865,8 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             pf.begin(PF_SORT);
             sort_runs_kernel<<<nq, 64, 0, st>>>(ws.runs.p, ws.surv_cnt.p, qp.cap, ws.big_list.p, ws.big_list.p + nq, 512u);
             // queries with long run directories (loose thresholds): slot-bucketed ordering, persistent blocks walking the list
-            sort_runs_mid_kernel<<<mid_blocks, 256, 0, st>>>(ws.runs.p, ws.runs_tmp.p, ws.surv_cnt.p, qp.cap, ws.big_list.p, ws.big_list.p + nq, nprobe);
+            sort_runs_mid_kernel<<<mid_blocks, 256, 0, st>>>(ws.runs.p, ws.use_runs_tmp ? ws.runs_tmp.p : nullptr, ws.surv_cnt.p, qp.cap, ws.big_list.p,
+                                                         ws.big_list.p + nq, nprobe);
             pf.end();
             pf.begin(PF_REPLAY);
             if (qp.heuristic)
