@@ -1379,8 +1379,12 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
         auto tail = [&](uint32_t f, uint32_t row) { return img[IMG_OP + row * RQ_REC_TAIL + f]; };
 
         // accumulator tiles = -S*/2 (query row, candidate col) + s/2, all on the matrix pipe
-        f32x16 accs[STREAM_A ? NT : 1];
-        if constexpr (STREAM_A) {  // slab-outer: one fragment load feeds every sub-tile's accumulator
+        // Wide vectors: slab-outer, so that the NT accumulation chains interleave on the matrix pipe (a chain of dependent
+        // MFMAs alone issues at ~44 cycles per instruction instead of 32) and one fragment load (when A is streamed)
+        // feeds every sub-tile's accumulator
+        constexpr bool SLAB_OUTER = W > 4;
+        f32x16 accs[SLAB_OUTER ? NT : 1];
+        if constexpr (SLAB_OUTER) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const v4i32 ubv = {(int)ub[t][0], (int)ub[t][1], (int)ub[t][2], (int)ub[t][3]};
@@ -1389,7 +1393,7 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
             }
 #pragma unroll
             for (int m = 0; m < W; ++m) {
-                const v8i32 av = load_a(m);
+                const v8i32 av = get_a(m);
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
                     accs[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, get_b(t, m), accs[t], 2, 2, 0, 0, 0, 0);
@@ -1398,7 +1402,7 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             f32x16 acc;
-            if constexpr (STREAM_A) {
+            if constexpr (SLAB_OUTER) {
                 acc = accs[t];
             } else {
                 const v4i32 ubv = {(int)ub[t][0], (int)ub[t][1], (int)ub[t][2], (int)ub[t][3]};
