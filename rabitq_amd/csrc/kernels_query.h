@@ -1097,12 +1097,12 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) {
 // blocks per CU the register budget is cut for: the resident operands grow with W (6*W*NT dwords for the
 // candidates, 6*W for the query tile), so wide vectors run one block per CU with the full 512-register file
 template <int W>
-constexpr int scan_mfma_blocks_per_cu() { return W <= 2 ? 4 : (W <= 8 ? 2 : 1); }
+constexpr int scan_mfma_blocks_per_cu() { return W <= 2 ? 4 : (W <= 12 ? 2 : 1); }
 // Wide vectors (dim >= 384) do not keep the query tile's operand in registers: the candidates' expanded codes
 // (6*W*NT dwords) already fill most of the file, so the query fragments are streamed from the LDS image one
 // 64-dimension slab at a time (3 ds_read_b64 per slab, each feeding the MFMAs of all NT sub-tiles).
 template <int W>
-constexpr bool scan_mfma_stream_a() { return W > 4 && W <= 8; }  // one block per CU (W >= 12) has the registers to keep A resident
+constexpr bool scan_mfma_stream_a() { return W > 4 && W <= 8; }  // W = 12 (one sub-tile per wave) and W = 16 (one block per CU) keep A resident
 // Query tiles consumed per block barrier.  The four waves of a block sit on four SIMDs that each serve other
 // blocks as well, so a barrier per 32-query tile makes every wave advance at the pace of the slowest; narrow
 // vectors (small tile images) afford two tiles per barrier with a 4-slot ring.
@@ -1113,7 +1113,7 @@ constexpr uint32_t scan_mfma_ring_slots() {
     // one tile per barrier: slots - 1 tiles in flight.  The wide instantiations run one block per CU and wait on the
     // arrival of their (large) tile images, not on the matrix pipe: they take the LDS a second block would have used
     // for a deeper ring
-    return scan_mfma_tiles_per_barrier<W>() > 1 ? 2 * scan_mfma_tiles_per_barrier<W>() : (W >= 12 ? 5u : 3u);
+    return scan_mfma_tiles_per_barrier<W>() > 1 ? 2 * scan_mfma_tiles_per_barrier<W>() : (W >= 16 ? 5u : 3u);
 }
 
 template <int W, int NT>

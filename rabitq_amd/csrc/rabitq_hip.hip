@@ -426,9 +426,9 @@ static bool scan_has_mfma(uint32_t W) {
         default: return false;
     }
 }
-static uint32_t scan_mfma_nt(uint32_t W) { return W == 2 ? 3 : (W >= 4 ? 2 : 4); }
+static uint32_t scan_mfma_nt(uint32_t W) { return W == 2 ? 3 : (W == 12 ? 1 : (W >= 4 ? 2 : 4)); }
 static uint32_t scan_mfma_tile(uint32_t W) { return 128 * scan_mfma_nt(W); }
-static size_t scan_mfma_ring_bytes(uint32_t W) { return (W <= 2 ? 4ull : (W >= 12 ? 5ull : 3ull)) * (32 * (12 * W + 2) + RQ_REC_TAIL * 32) * 4; }  // scan_mfma_ring_slots<W>()
+static size_t scan_mfma_ring_bytes(uint32_t W) { return (W <= 2 ? 4ull : (W >= 16 ? 5ull : 3ull)) * (32 * (12 * W + 2) + RQ_REC_TAIL * 32) * 4; }  // scan_mfma_ring_slots<W>()
 template <int W, int NT>
 static void launch_scan_mfma_t(const ScanPtrs &p, const ScanArgs &a, dim3 g, hipStream_t st) {
     scan_mfma_kernel<W, NT><<<g, dim3(256), scan_mfma_ring_bytes(W), st>>>(p.codes, p.factors, p.offsets, p.grp_start, p.grp_cnt,
@@ -444,7 +444,7 @@ static void launch_scan_mfma(const ScanPtrs &p, const ScanArgs &args, uint32_t W
             case 4: launch_scan_mfma_t<4, 2>(p, a, g, st); break;
             case 6: launch_scan_mfma_t<6, 2>(p, a, g, st); break;
             case 8: launch_scan_mfma_t<8, 2>(p, a, g, st); break;
-            case 12: launch_scan_mfma_t<12, 2>(p, a, g, st); break;
+            case 12: launch_scan_mfma_t<12, 1>(p, a, g, st); break;
             case 16: launch_scan_mfma_t<16, 2>(p, a, g, st); break;
             default: break;
         }
@@ -511,7 +511,7 @@ static rq_status ensure_kernel_attributes() {
         chk(set_scan_mfma_attr<4, 2>(), "scan_mfma_kernel<4,2>");
         chk(set_scan_mfma_attr<6, 2>(), "scan_mfma_kernel<6,2>");
         chk(set_scan_mfma_attr<8, 2>(), "scan_mfma_kernel<8,2>");
-        chk(set_scan_mfma_attr<12, 2>(), "scan_mfma_kernel<12,2>");
+        chk(set_scan_mfma_attr<12, 1>(), "scan_mfma_kernel<12,1>");
         chk(set_scan_mfma_attr<16, 2>(), "scan_mfma_kernel<16,2>");
     });
     if (err != hipSuccess)
