@@ -63,10 +63,10 @@ def main():
     ap.add_argument("--sharded-path", action="store_true",
                     help="rehearsal on one GPU: run the multi-GPU step (sharded coarse ranking, probe-list merge, probed "
                          "query, top-k merge) with a world of 1, to see what the extra plumbing costs")
-    ap.add_argument("--two-in-flight", action="store_true",
-                    help="also measure the throughput with two batches in flight (rq_query_batch_device_begin/_end); off by "
-                         "default so that every launch of the default command runs alone and per-kernel times (HIP events, "
-                         "rocprofv3 --stats of the same command) stay comparable")
+    ap.add_argument("--two-in-flight", action=argparse.BooleanOptionalAction, default=True,
+                    help="after the timed region (whose steps run one batch at a time, so that every launch runs alone and "
+                         "per-kernel times from HIP events and rocprofv3 --stats stay comparable), also measure the throughput "
+                         "with two batches in flight (rq_query_batch_device_begin/_end) and report it as an extra field")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="batches kept in flight in the timed loop (rq_query_batch_device_begin/_end); 1 = one blocking "
                          "call per step (default: per-kernel times are then clean); see --two-in-flight")

@@ -28,7 +28,7 @@ shutil.copy(stats, os.path.join(OUT, f"{ROUND}_kernel_stats_full.csv"))
 ours = [r for r in rows if not any(t in r["Name"] for t in ("at::native", "Cijk_", "__amd_rocclr", "at::cuda", "rocprim", "hipcub"))]
 with open(os.path.join(OUT, f"{ROUND}_kernel_stats.csv"), "w") as f:
     bcfg = json.load(open(newest("bench_final.json")))["config"]
-    f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline\n")
+    f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-two-in-flight\n")
     f.write(f"# ({bcfg['workload']}: 2 warm-up + 3 timed + 1 breakdown query batches, every launch alone on the device,\n")
     f.write("#  small batches, 68 single queries, one streamed 100M build); engine kernels only, torch data-generation / ground-truth\n")
     f.write("#  kernels are in the _full file\n")
@@ -73,7 +73,7 @@ launches = [{"kernel": d["name"].split("(")[0].replace("void ", ""), "ms_under_p
 traffic = {
     "config": {"vectors": bench["config"]["n_per_gpu"], "dim": bench["config"]["dim"], "lists": bench["config"]["lists_total"] // bench["n_gpus"],
                "nprobe": bench["config"]["nprobe"], "batch": bench["config"]["batch"]},
-    "source": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --gt-queries 10 "
+    "source": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-two-in-flight --gt-queries 10 "
               f"--small-batch 0 ({bench['config']['workload']})",
     "correction": "gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM section) -> x2",
     "dominant_launch": {"kernel": launches[-1]["kernel"] + " (final stage: stream positions past the first list)",
