@@ -121,3 +121,27 @@ def test_load_json_rejects_malformed_text(L, tmp_path, text):
     assert L.rq_load_json(os.fsencode(str(f)), C.byref(h)) == -3, L.rq_last_error()
     assert not h.value
     assert L.rq_load_json(os.fsencode(str(tmp_path / "missing.json")), C.byref(h)) == -3
+
+
+def _build_c_host(tmp_path):
+    """gcc on tests/c_host/c_abi_host.c: a compiled host that sees only include/rabitq_hip.h and the shared library."""
+    import subprocess
+    from rabitq_amd import _lib
+    exe = str(tmp_path / "c_abi_host")
+    libdir = os.path.dirname(_lib.SO_PATH)
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_host", "c_abi_host.c"), "-o", exe, "-L", libdir, "-lrabitq_hip",
+                           f"-Wl,-rpath,{libdir}", "-lm"])
+    return exe
+
+
+def test_c_host_links_and_fails_loudly_without_device(L, tmp_path):
+    """The header is plain C (compiles with gcc -Wall -Werror), the library links without torch / Python, and without a
+    GPU the host gets RQ_ERR_NO_DEVICE -- not a CPU answer."""
+    import subprocess
+    import torch
+    exe = _build_c_host(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: tests/test_c_host_gpu.py runs the program")
+    p = subprocess.run([exe, str(tmp_path / "idx")], capture_output=True, text=True)
+    assert p.returncode == 2 and "no HIP device" in p.stderr, (p.returncode, p.stderr)
