@@ -738,7 +738,10 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         // small batches are launch-bound (coarser stages), large ones rerank-bound (tighter thresholds)
         const int gopt = g_stage_growth.load();
         const uint64_t growth = gopt >= 2 ? (uint64_t)gopt : (nq >= 256 ? 8 : 16);
-        uint64_t lo = 0, hi = std::max<uint32_t>(topk, 1);
+        // the first stage runs with threshold f32::MAX (everything survives) until the ranker's heap is full; in a large
+        // batch it also takes what would be the next stage (whose threshold -- the worst of the first topk -- lets most
+        // of it through anyway): one stage of launches less for ~1 % more exact distances
+        uint64_t lo = 0, hi = std::max<uint32_t>(topk, 1) * (nq >= 256 ? growth : 1);
         const uint64_t avg = std::max<uint64_t>(1, idx->n / std::max<uint32_t>(k, 1));
         // the threshold has settled once a query has seen its whole nearest list; with unbalanced lists (Zipf sizes) the
         // nearest list of many queries is one of the long ones, so the bar is the LONGEST list (capped: a single
