@@ -246,14 +246,32 @@ __global__ __launch_bounds__(256) void select_probe_wave_kernel(const float *__r
     const float *d = dist + (uint64_t)b * k;
     uint32_t key[KPL];
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    // register i of lane l holds list list_of(i) = 256 (i / 4) + 4 l + (i % 4): the row is read 16 bytes per lane, 1 KiB
+    // per wave instruction (rows are 16-byte aligned whenever k % 4 == 0; else element by element)
+    auto list_of = [&](int i) { return 256u * (uint32_t)(i >> 2) + 4u * lane + (uint32_t)(i & 3); };
+    const bool vec4 = (k & 3u) == 0u;
 #pragma unroll
-    for (int i = 0; i < KPL; ++i) {
-        const uint32_t j = lane + 64 * i;
-        key[i] = 0xFFFFFFFFu;  // "no list": above every real key (a NaN distance with all-ones payload is not supported)
-        if (j < k) {
-            key[i] = ord32_biased(d[j]);
-            kmin = key[i] < kmin ? key[i] : kmin;
-            kmax = key[i] > kmax ? key[i] : kmax;
+    for (int i4 = 0; i4 < KPL; i4 += 4) {
+        const uint32_t j0 = list_of(i4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vec4 && j0 < k) {
+            v = *reinterpret_cast<const float4 *>(d + j0);
+        } else if (!vec4) {
+            if (j0 < k) v.x = d[j0];
+            if (j0 + 1 < k) v.y = d[j0 + 1];
+            if (j0 + 2 < k) v.z = d[j0 + 2];
+            if (j0 + 3 < k) v.w = d[j0 + 3];
+        }
+        const float ve[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = i4 + e;
+            key[i] = 0xFFFFFFFFu;  // "no list": above every real key (a NaN distance with all-ones payload is not supported)
+            if (j0 + e < k) {
+                key[i] = ord32_biased(ve[e]);
+                kmin = key[i] < kmin ? key[i] : kmin;
+                kmax = key[i] > kmax ? key[i] : kmax;
+            }
         }
     }
 #pragma unroll
@@ -262,12 +280,12 @@ __global__ __launch_bounds__(256) void select_probe_wave_kernel(const float *__r
         kmin = a < kmin ? a : kmin;
         kmax = c > kmax ? c : kmax;
     }
+    // wave-wide count of keys <= t: one compare per register, the lane counts come out of the scalar unit
+    // (ballot + s_bcnt1), no cross-lane shuffles in the bisection loop
     auto count_le = [&](uint32_t t) {
         uint32_t c = 0;
 #pragma unroll
-        for (int i = 0; i < KPL; ++i) c += key[i] <= t ? 1u : 0u;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+        for (int i = 0; i < KPL; ++i) c += (uint32_t)__popcll(__ballot(key[i] <= t));
         return c;
     };
     // smallest T with count(key <= T) >= nprobe (nprobe <= k, so T <= kmax)
@@ -296,7 +314,7 @@ __global__ __launch_bounds__(256) void select_probe_wave_kernel(const float *__r
                 const uint32_t jm = jl + ((jh - jl) >> 1);
                 uint32_t c = 0;
 #pragma unroll
-                for (int i = 0; i < KPL; ++i) c += (key[i] == T && lane + 64 * i <= jm) ? 1u : 0u;
+                for (int i = 0; i < KPL; ++i) c += (key[i] == T && list_of(i) <= jm) ? 1u : 0u;
 #pragma unroll
                 for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
                 if (c >= need) jh = jm;
@@ -309,7 +327,7 @@ __global__ __launch_bounds__(256) void select_probe_wave_kernel(const float *__r
     uint32_t base = 0;
 #pragma unroll
     for (int i = 0; i < KPL; ++i) {
-        const uint32_t j = lane + 64 * i;
+        const uint32_t j = list_of(i);
         const bool take = key[i] < T || (key[i] == T && j <= J && j < k);
         const uint64_t m = __ballot(take);
         if (m) {  // wave-uniform
