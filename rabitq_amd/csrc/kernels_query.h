@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ y,
 // shuffle steps, and the operand images come out of one neighbour exchange each: a lane's four 4-bit codes
 // are half a qnib dword, its four fp6 fields 24 bits of the 6-dword image of its 32-dimension block.
 // Writes the fused scan's operands only (no bit planes); arithmetic identical to prep_kernel.
-template <int LP, int R>
+template <int LP, int R, int PP>
 __global__ __launch_bounds__(256) void prep_small_kernel(const float *__restrict__ y,
                                                          const float *__restrict__ centroids,
                                                          const uint32_t *__restrict__ offsets,
@@ -510,88 +510,114 @@ __global__ __launch_bounds__(256) void prep_small_kernel(const float *__restrict
                                                          uint32_t *__restrict__ qnib, uint32_t *__restrict__ qf6,
                                                          uint32_t nlists, uint32_t skip_empty) {
     // dim = 4 * LP * R: LP lanes per pair, each owning 4 consecutive dimensions in each of R rounds of 4*LP
-    // dimensions (R > 1 only with LP = 64: dim 512, 768, 1024)
+    // dimensions (R > 1 only with LP = 64: dim 512, 768, 1024).  Every lane group handles PP pairs: the kernel is a
+    // chain of dependent gathers (probe list -> centroid row, list bounds), so the loads of all PP pairs are issued
+    // before any of them is consumed.
     static_assert(R == 1 || LP == 64, "several rounds only with a full wave per pair");
     constexpr uint32_t DIM = 4 * LP * R, W = DIM / 64, PPW = 64 / LP;
     const uint32_t lane = threadIdx.x & 63, sub = lane % LP;
-    const uint32_t p = (blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW + lane / LP;
-    if (p >= npairs) return;  // uniform over the pair's LP lanes
-    const uint32_t row = p / pairs_per_row;
-    const uint32_t c = pair_cluster[p];
-    const uint32_t len_c = c < nlists ? offsets[c + 1] - offsets[c] : 0u;
-    if (len_c == 0 && skip_empty) {  // nothing to scan for this pair (e.g. a list another shard owns)
-        if (sub == 0) {
-            PairScalars s;
-            s.lower = 0.0f, s.delta = 0.0f, s.sumq = 0.0f, s.ycd = pair_ycd[p], s.ycd_sqrt = 0.0f;
-            s.row = row, s.list_begin = 0, s.list_len = 0, s.stream_begin = 0, s.pad = 0;
-            scal[p] = s;
-        }
-        return;
+    const uint32_t p0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (PPW * PP) + lane / LP;  // pairs p0, p0 + PPW, ...
+    uint32_t cl[PP], lb[PP], ll[PP];
+    float ycd_in[PP];
+    bool live[PP];
+#pragma unroll
+    for (int pp = 0; pp < PP; ++pp) {
+        const uint32_t p = p0 + pp * PPW;
+        live[pp] = p < npairs;  // uniform over the pair's LP lanes
+        cl[pp] = live[pp] ? pair_cluster[p] : 0xFFFFFFFFu;
+        ycd_in[pp] = live[pp] ? pair_ycd[p] : 0.0f;
     }
-    float r[R][4];
-    float mn = 3.402823466e+38f, mx = -3.402823466e+38f;
+    float4 cv[PP][R], yv[PP][R];
 #pragma unroll
-    for (int rd = 0; rd < R; ++rd) {
-        const float4 yv = *reinterpret_cast<const float4 *>(y + (uint64_t)row * DIM + 4 * LP * rd + 4 * sub);
-        const float4 cv = *reinterpret_cast<const float4 *>(centroids + (uint64_t)c * DIM + 4 * LP * rd + 4 * sub);
-        r[rd][0] = yv.x - cv.x, r[rd][1] = yv.y - cv.y, r[rd][2] = yv.z - cv.z, r[rd][3] = yv.w - cv.w;
+    for (int pp = 0; pp < PP; ++pp) {
+        const uint32_t p = p0 + pp * PPW, c = cl[pp];
+        const bool in = live[pp] && c < nlists;
+        lb[pp] = in ? offsets[c] : 0u;
+        ll[pp] = in ? offsets[c + 1] - lb[pp] : 0u;
+        const uint32_t row = live[pp] ? p / pairs_per_row : 0u;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            mn = r[rd][e] < mn ? r[rd][e] : mn;
-            mx = r[rd][e] > mx ? r[rd][e] : mx;
+        for (int rd = 0; rd < R; ++rd) {
+            yv[pp][rd] = *reinterpret_cast<const float4 *>(y + (uint64_t)row * DIM + 4 * LP * rd + 4 * sub);
+            cv[pp][rd] = *reinterpret_cast<const float4 *>(centroids + (uint64_t)(in ? c : 0u) * DIM + 4 * LP * rd + 4 * sub);
         }
     }
 #pragma unroll
-    for (int o = LP / 2; o >= 1; o >>= 1) {
-        const float a = __shfl_xor(mn, o, LP), bb = __shfl_xor(mx, o, LP);
-        mn = a < mn ? a : mn;
-        mx = bb > mx ? bb : mx;
-    }
-    const float scalar = 1.0f / 15.0f;          // consts.rs:10
-    const float delta = (mx - mn) * scalar;     // rabitq.rs:307
-    const float one_over_delta = 1.0f / delta;  // :308 f32::recip
-    uint32_t sum = 0;
-#pragma unroll
-    for (int rd = 0; rd < R; ++rd) {
-        uint32_t nib16 = 0, f24 = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int32_t q = cvtps_epi32((r[rd][e] - mn) * one_over_delta);
-            sum += (uint32_t)q;
-            const uint32_t v = (uint32_t)q & 15u;
-            nib16 |= v << (4 * e);
-            f24 |= (v < 4 ? 4 * v : (v < 8 ? 8 + 2 * v : 16 + v)) << (6 * e);  // q/2 as fp6 e2m3
+    for (int pp = 0; pp < PP; ++pp) {
+        const uint32_t p = p0 + pp * PPW;
+        if (!live[pp]) continue;
+        const uint32_t row = p / pairs_per_row;
+        if (ll[pp] == 0 && skip_empty) {  // nothing to scan for this pair (e.g. a list another shard owns)
+            if (sub == 0) {
+                PairScalars s;
+                s.lower = 0.0f, s.delta = 0.0f, s.sumq = 0.0f, s.ycd = ycd_in[pp], s.ycd_sqrt = 0.0f;
+                s.row = row, s.list_begin = 0, s.list_len = 0, s.stream_begin = 0, s.pad = 0;
+                scal[p] = s;
+            }
+            continue;
         }
-        const uint32_t dsub = LP * rd + sub;  // this lane's 4-dimension group among the dim/4 of the vector
-        {  // qnib: dword m <-> dims 8m..8m+7 = groups 2m (low half), 2m+1 (high half)
-            const uint32_t other = __shfl_xor(nib16, 1, LP);
-            if (qnib && (sub & 1) == 0) qnib[(uint64_t)p * 8 * W + (dsub >> 1)] = nib16 | (other << 16);
-        }
-        {  // qf6: group t = dsub % 8 of a 32-dimension block holds stream bits [24t, 24t+24) of its 6 dwords
-            const uint32_t nxt = __shfl_down(f24, 1, LP);
-            const uint32_t t = dsub & 7, sh = 8 * (t & 3);
-            if (qf6 && (t & 3) != 3) {
-                const uint32_t w = dsub >> 4, h = (dsub >> 3) & 1;
-                qf6[(uint64_t)p * 12 * W + h * 6 * W + 6 * w + 3 * (t >> 2) + (t & 3)] = (f24 >> sh) | (nxt << (24 - sh));
+        float r[R][4];
+        float mn = 3.402823466e+38f, mx = -3.402823466e+38f;
+#pragma unroll
+        for (int rd = 0; rd < R; ++rd) {
+            r[rd][0] = yv[pp][rd].x - cv[pp][rd].x, r[rd][1] = yv[pp][rd].y - cv[pp][rd].y;
+            r[rd][2] = yv[pp][rd].z - cv[pp][rd].z, r[rd][3] = yv[pp][rd].w - cv[pp][rd].w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                mn = r[rd][e] < mn ? r[rd][e] : mn;
+                mx = r[rd][e] > mx ? r[rd][e] : mx;
             }
         }
-    }
 #pragma unroll
-    for (int o = LP / 2; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, LP);
-    if (sub == 0) {
-        PairScalars s;
-        const float ycd = pair_ycd[p];
-        s.lower = mn;
-        s.delta = delta;
-        s.sumq = (float)sum;  // rabitq.rs:322 `scalar_sum as f32`
-        s.ycd = ycd;
-        s.ycd_sqrt = sqrtf(ycd);  // :346
-        s.row = row;
-        s.list_begin = offsets[c];
-        s.list_len = offsets[c + 1] - offsets[c];
-        s.stream_begin = 0;  // filled by pair_prefix_kernel
-        s.pad = 0;
-        scal[p] = s;
+        for (int o = LP / 2; o >= 1; o >>= 1) {
+            const float a = __shfl_xor(mn, o, LP), bb = __shfl_xor(mx, o, LP);
+            mn = a < mn ? a : mn;
+            mx = bb > mx ? bb : mx;
+        }
+        const float scalar = 1.0f / 15.0f;          // consts.rs:10
+        const float delta = (mx - mn) * scalar;     // rabitq.rs:307
+        const float one_over_delta = 1.0f / delta;  // :308 f32::recip
+        uint32_t sum = 0;
+#pragma unroll
+        for (int rd = 0; rd < R; ++rd) {
+            uint32_t nib16 = 0, f24 = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int32_t q = cvtps_epi32((r[rd][e] - mn) * one_over_delta);
+                sum += (uint32_t)q;
+                const uint32_t v = (uint32_t)q & 15u;
+                nib16 |= v << (4 * e);
+                f24 |= (v < 4 ? 4 * v : (v < 8 ? 8 + 2 * v : 16 + v)) << (6 * e);  // q/2 as fp6 e2m3
+            }
+            const uint32_t dsub = LP * rd + sub;  // this lane's 4-dimension group among the dim/4 of the vector
+            {  // qnib: dword m <-> dims 8m..8m+7 = groups 2m (low half), 2m+1 (high half)
+                const uint32_t other = __shfl_xor(nib16, 1, LP);
+                if (qnib && (sub & 1) == 0) qnib[(uint64_t)p * 8 * W + (dsub >> 1)] = nib16 | (other << 16);
+            }
+            {  // qf6: group t = dsub % 8 of a 32-dimension block holds stream bits [24t, 24t+24) of its 6 dwords
+                const uint32_t nxt = __shfl_down(f24, 1, LP);
+                const uint32_t t = dsub & 7, sh = 8 * (t & 3);
+                if (qf6 && (t & 3) != 3) {
+                    const uint32_t w = dsub >> 4, h = (dsub >> 3) & 1;
+                    qf6[(uint64_t)p * 12 * W + h * 6 * W + 6 * w + 3 * (t >> 2) + (t & 3)] = (f24 >> sh) | (nxt << (24 - sh));
+                }
+            }
+        }
+#pragma unroll
+        for (int o = LP / 2; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, LP);
+        if (sub == 0) {
+            PairScalars s;
+            s.lower = mn;
+            s.delta = delta;
+            s.sumq = (float)sum;  // rabitq.rs:322 `scalar_sum as f32`
+            s.ycd = ycd_in[pp];
+            s.ycd_sqrt = sqrtf(ycd_in[pp]);  // :346
+            s.row = row;
+            s.list_begin = lb[pp];
+            s.list_len = ll[pp];
+            s.stream_begin = 0;  // filled by pair_prefix_kernel
+            s.pad = 0;
+            scal[p] = s;
+        }
     }
 }
 

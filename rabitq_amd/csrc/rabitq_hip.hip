@@ -686,15 +686,15 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     {
         uint32_t *qn = scan_is_fused(W) ? ws.qnib.p : nullptr;
         uint32_t *q6 = scan_has_mfma(W) && impl != 1 ? ws.qf6.p : nullptr;
-#define RQ_PREP_SMALL(LP, R, PPB)                                                                                  \
-    prep_small_kernel<LP, R><<<ceil_div(npairs, PPB), 256, 0, st>>>(ws.y.p, idx->centroids.p, idx->offsets.p, probe_cluster, \
+#define RQ_PREP_SMALL(LP, R, PPB, PP)                                                                              \
+    prep_small_kernel<LP, R, PP><<<ceil_div(npairs, (PPB) * (PP)), 256, 0, st>>>(ws.y.p, idx->centroids.p, idx->offsets.p, probe_cluster, \
                                                                     probe_dist, npairs, nprobe, ws.scal.p, qn, q6, k, 1u)
-        if (dim == 128) RQ_PREP_SMALL(32, 1, 8);  // 32 lanes per pair, two pairs per wave
-        else if (dim == 64) RQ_PREP_SMALL(16, 1, 16);
-        else if (dim == 256) RQ_PREP_SMALL(64, 1, 4);
-        else if (dim == 512) RQ_PREP_SMALL(64, 2, 4);
-        else if (dim == 768) RQ_PREP_SMALL(64, 3, 4);
-        else if (dim == 1024) RQ_PREP_SMALL(64, 4, 4);
+        if (dim == 128) RQ_PREP_SMALL(32, 1, 8, 4);  // 32 lanes per pair, two pairs per wave, four rounds of pairs per lane group
+        else if (dim == 64) RQ_PREP_SMALL(16, 1, 16, 4);
+        else if (dim == 256) RQ_PREP_SMALL(64, 1, 4, 4);
+        else if (dim == 512) RQ_PREP_SMALL(64, 2, 4, 2);
+        else if (dim == 768) RQ_PREP_SMALL(64, 3, 4, 2);
+        else if (dim == 1024) RQ_PREP_SMALL(64, 4, 4, 2);
 #undef RQ_PREP_SMALL
         else
             prep_kernel<<<ceil_div(npairs, 4), 256, 0, st>>>(ws.y.p, idx->centroids.p, idx->offsets.p, probe_cluster, probe_dist,
