@@ -423,6 +423,8 @@ def main():
             "rough_per_query": m["rough"] / max(m["query"], 1), "precise_per_query": m["precise"] / max(m["query"], 1),
             "kernel_ms_per_step": breakdown, "scan_ms_per_step_timed": round(prof["ms_scan"] / args.steps, 3),
             "rerank_candidates_per_query": prof["rerank_candidates"] / (B * args.steps),
+            # of those: rejected on the fp16 shadow row alone (2*dim bytes read instead of 4*dim; results identical)
+            "rerank_shadow_rejects_per_query": prof["rerank_shadow_rejects"] / (B * args.steps),
             "matrix_exact_path_rate": None if exact_rate is None else round(exact_rate, 5),
             "retries": int(prof["retries"]), "roofline": roofline, "roofline_scan_all_launches": scan_all,
             "roofline_rotation": rotation,

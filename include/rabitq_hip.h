@@ -276,6 +276,9 @@ typedef struct {
     /* only with rq_set_option("scan_debug", 128) (a measurement hook; results unchanged): 32x32 (query x candidate)
      * sub-tile steps of the matrix-core scan, and how many of them were flagged and took the exact f32 path */
     uint64_t matrix_subtile_steps, matrix_exact_steps;
+    /* of rerank_candidates: survivors the fp16 shadow rows proved to be at or above their stage's threshold, whose
+     * 4*dim-byte row was therefore never fetched (option "rerank_shadow"; large batches) */
+    uint64_t rerank_shadow_rejects;
 } rq_profile_t;
 /* level: 0 = off; 1 = every kernel group bracketed (each event costs a few microseconds of stream
  * time); 2 = only the scan launches and the whole pass (ms_scan, ms_total; the other fields stay 0). */
@@ -285,6 +288,11 @@ rq_status rq_set_profiling(int level);
  * settings return identical results; the option exists for tests and measurements.
  * "base_device_mb": HBM budget (MiB) of the raw vectors of indexes built / loaded from now on (-1 = automatic, the
  * default); vectors beyond it live in pinned host memory.  Results never depend on it.
+ * "rerank_shadow": 1 (default) = indexes built / loaded from now on whose raw vectors are all in HBM also keep an fp16
+ * shadow of them (2*dim bytes per vector, when that still leaves the query workspaces their room): the re-ranker of
+ * large batches reads the shadow row first and fetches the f32 row only when the shadow cannot prove that the exact
+ * distance is at or above the stage's threshold (then the reference rejects it whatever its value).  0 = never.
+ * Results are bit-identical either way.
  * "max_scan_blocks": test hook, blocks per scan launch (0 = hardware bound).
  * Developer knobs: "stage_growth" (geometric growth of the early stages, 0 = default; results are
  * identical for every value), "scan_debug" (bit 128: count sub-tile / exact-path steps into rq_profile_t, results unchanged;

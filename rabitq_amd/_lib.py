@@ -54,7 +54,8 @@ class ProfileT(C.Structure):
         ("scan_bytes", C.c_uint64), ("scan_candidates", C.c_uint64), ("rerank_candidates", C.c_uint64),
         ("scan_launches", C.c_uint32), ("retries", C.c_uint32),
         ("ms_scan_matrix", C.c_float), ("matrix_launches", C.c_uint32), ("matrix_pairs", C.c_uint64),
-        ("matrix_subtile_steps", C.c_uint64), ("matrix_exact_steps", C.c_uint64)]
+        ("matrix_subtile_steps", C.c_uint64), ("matrix_exact_steps", C.c_uint64),
+        ("rerank_shadow_rejects", C.c_uint64)]
 
 
 def build(force: bool = False) -> str:

@@ -1780,6 +1780,7 @@ struct ReplayState {
     uint32_t *precise;       // nq   (rerank.rs:91 / :153)
     uint32_t *need;          // nq   max survivor count seen (overflow detection)
     uint32_t *nsurv;         // nq   survivors replayed (= accurate distances computed)
+    uint32_t *nshadow;       // nq   of those: rejected by the fp16 shadow rows, f32 row never read
     // heuristic ranker
     float *recent_max;       // nq
     uint32_t *win_count;     // nq
@@ -2050,6 +2051,143 @@ __global__ void order_scatter_kernel(const uint32_t *__restrict__ probe_cluster,
     order[start[g] + atomicAdd(&cursor[g], 1u)] = b;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Rerank pre-filter: an fp16 shadow of the raw vectors (derived state, half the bytes of a row).
+//
+// The re-ranker's exact distance only matters when it can pass `accurate < threshold` (src/rerank.rs:91): a
+// survivor whose exact distance PROVABLY is >= the threshold its stage started with (the threshold only falls)
+// is rejected by the reference whatever the exact value is.  For such a survivor the 4*dim-byte row is never
+// fetched: the 2*dim-byte shadow row x~ gives
+//     ||x - q||  >=  ||x~ - q|| - ||x - x~||,      ||x - x~|| <= 2^-11 ||x|| + sqrt(dim) 2^-25
+// (fp16 round-to-nearest: relative 2^-11 per normal element, absolute 2^-25 per subnormal one; an element beyond
+// the fp16 range becomes inf and disables the test), and the reference's f32 evaluation of ||x - q||^2
+// (src/simd.rs:14-73: dim/8 fused multiply-adds per AVX lane + 3 adds, non-negative terms) is at least
+// (1 - (dim/8 + 5) 2^-24) of the real value.  Every quantity below is rounded against the test (factors
+// 1 -/+ eps with eps = (dim/4 + 64) 2^-24), so the bound can only be lower than the exact f32 result: a rejected
+// survivor gets accurate = +inf, which fails `accurate < threshold` exactly as its exact value would.  Everything
+// else goes through the exact path unchanged; results are bit-identical with and without the shadow.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 rq_half8 __attribute__((ext_vector_type(8)));
+
+// 8 consecutive elements per thread; total = n * dim (a multiple of 64)
+__global__ __launch_bounds__(256) void half_rows_kernel(const float *__restrict__ base, uint64_t total,
+                                                        _Float16 *__restrict__ out) {
+    for (uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < total; i += (uint64_t)gridDim.x * 2048) {
+        const float4 a = *reinterpret_cast<const float4 *>(base + i), b = *reinterpret_cast<const float4 *>(base + i + 4);
+        rq_half8 h;
+        h[0] = (_Float16)a.x, h[1] = (_Float16)a.y, h[2] = (_Float16)a.z, h[3] = (_Float16)a.w;
+        h[4] = (_Float16)b.x, h[5] = (_Float16)b.y, h[6] = (_Float16)b.z, h[7] = (_Float16)b.w;
+        *reinterpret_cast<rq_half8 *>(out + i) = h;
+    }
+}
+
+// exact f32 L2 of one row against the query in LDS by a PAIR of lanes (see accurate_rows); x already offset by 4*hf
+__device__ __forceinline__ float exact_l2_pair(const float *__restrict__ x, const float *q_lds, uint32_t dim, uint32_t hf) {
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    for (uint32_t c = 0; c < dim; c += 64) {
+        float4 xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xv[u] = *reinterpret_cast<const float4 *>(x + c + 8 * u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 qv = *reinterpret_cast<const float4 *>(q_lds + c + 8 * u + 4 * hf);
+            const float d0 = xv[u].x - qv.x, d1 = xv[u].y - qv.y, d2 = xv[u].z - qv.z, d3 = xv[u].w - qv.w;
+            a0 = fmaf(d0, d0, a0), a1 = fmaf(d1, d1, a1), a2 = fmaf(d2, d2, a2), a3 = fmaf(d3, d3, a3);
+        }
+    }
+    const float c0 = a0 + __shfl_xor(a0, 1, 2), c1 = a1 + __shfl_xor(a1, 1, 2);
+    const float c2 = a2 + __shfl_xor(a2, 1, 2), c3 = a3 + __shfl_xor(a3, 1, 2);
+    return (c0 + c1) + (c2 + c3);
+}
+
+// grid (gx, nq), block 256 = 128 survivors per round, two lanes each.  Round: shadow-row test of 128 survivors; the
+// ones it cannot reject queue up in LDS and are re-ranked exactly 128 at a time, so both phases keep every lane busy.
+__global__ __launch_bounds__(256) void accurate_filtered_kernel(SurvRec *__restrict__ surv,
+                                                                const unsigned long long *__restrict__ surv_cnt,
+                                                                uint32_t cap, const float *__restrict__ base,
+                                                                const _Float16 *__restrict__ base_h,
+                                                                const float *__restrict__ qpad, uint32_t dim,
+                                                                const uint32_t *__restrict__ order,
+                                                                const float *__restrict__ thr_start,
+                                                                uint32_t *__restrict__ nshadow) {
+    extern __shared__ __attribute__((aligned(16))) float acc_q[];  // dim floats (the padded query)
+    __shared__ uint32_t queue[256];
+    __shared__ uint32_t qn;
+    const uint32_t b = order ? order[blockIdx.y] : blockIdx.y;
+    const uint32_t n = (uint32_t)surv_cnt[b];
+    if (n > cap || n == 0) return;  // overflowed: this query is re-run with a larger buffer
+    for (uint32_t c = threadIdx.x * 4; c < dim; c += 1024)
+        *reinterpret_cast<float4 *>(acc_q + c) = *reinterpret_cast<const float4 *>(qpad + (uint64_t)b * dim + c);
+    if (threadIdx.x == 0) qn = 0;
+    __syncthreads();
+    SurvRec *recs = surv + (uint64_t)b * cap;
+    const uint32_t hf = threadIdx.x & 1, pair = threadIdx.x >> 1;
+    const float thr = thr_start[b];
+    const bool test = thr > 1e-30f && thr < 3.0e38f;  // a finite, normal threshold (false for NaN / inf: everything is exact)
+    const float eps = (float)(dim / 4 + 64) * 5.9604645e-8f, down = 1.0f - eps, up = 1.0f + eps;
+    const float abs_err = sqrtf((float)dim) * 3.0e-8f;  // sqrt(dim) * 2^-25, rounded up
+    uint32_t rejected = 0;
+    for (uint32_t i0 = blockIdx.x * 128; i0 < n; i0 += gridDim.x * 128) {
+        const uint32_t i = i0 + pair;
+        bool exact = i < n;
+        if (exact && test) {
+            const _Float16 *x = base_h + (uint64_t)recs[i].pos * dim + 8 * hf;
+            float d0 = 0.0f, d1 = 0.0f, n0 = 0.0f, n1 = 0.0f;
+            for (uint32_t c = 0; c < dim; c += 128) {  // 256 bytes of the row: 8 x 16 bytes per lane in flight
+                rq_half8 xv[8];
+                const bool full = dim - c >= 128;  // dim is a multiple of 64: the last chunk may be a half one
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (u < 4 || full) xv[u] = *reinterpret_cast<const rq_half8 *>(x + c + 16 * u);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (!(u < 4 || full)) continue;
+                    const float4 qa = *reinterpret_cast<const float4 *>(acc_q + c + 16 * u + 8 * hf);
+                    const float4 qb = *reinterpret_cast<const float4 *>(acc_q + c + 16 * u + 8 * hf + 4);
+                    const float x0 = (float)xv[u][0], x1 = (float)xv[u][1], x2 = (float)xv[u][2], x3 = (float)xv[u][3];
+                    const float x4 = (float)xv[u][4], x5 = (float)xv[u][5], x6 = (float)xv[u][6], x7 = (float)xv[u][7];
+                    const float e0 = x0 - qa.x, e1 = x1 - qa.y, e2 = x2 - qa.z, e3 = x3 - qa.w;
+                    const float e4 = x4 - qb.x, e5 = x5 - qb.y, e6 = x6 - qb.z, e7 = x7 - qb.w;
+                    d0 = fmaf(e0, e0, d0), d1 = fmaf(e1, e1, d1), d0 = fmaf(e2, e2, d0), d1 = fmaf(e3, e3, d1);
+                    d0 = fmaf(e4, e4, d0), d1 = fmaf(e5, e5, d1), d0 = fmaf(e6, e6, d0), d1 = fmaf(e7, e7, d1);
+                    n0 = fmaf(x0, x0, n0), n1 = fmaf(x1, x1, n1), n0 = fmaf(x2, x2, n0), n1 = fmaf(x3, x3, n1);
+                    n0 = fmaf(x4, x4, n0), n1 = fmaf(x5, x5, n1), n0 = fmaf(x6, x6, n0), n1 = fmaf(x7, x7, n1);
+                }
+            }
+            float dt = d0 + d1, nx = n0 + n1;
+            dt += __shfl_xor(dt, 1, 2), nx += __shfl_xor(nx, 1, 2);
+            const float err = (sqrtf(nx) * up) * 4.8877e-4f + abs_err;  // >= 2^-11 (1 + 2^-10) ||x~|| + sqrt(dim) 2^-25 >= ||x - x~||
+            const float t = sqrtf(dt * down) * down - err * up;
+            if (t > 0.0f && (t * t) * (down * down) > thr) {  // false for NaN
+                exact = false;
+                if (hf == 0) recs[i].accurate = __builtin_inff();
+                ++rejected;
+            }
+        }
+        if (exact && hf == 0) queue[atomicAdd(&qn, 1u)] = i;  // at most 127 waiting + 128 new
+        __syncthreads();
+        const uint32_t waiting = qn;  // the same value in every thread: nobody touches qn before the next barrier
+        __syncthreads();
+        if (waiting >= 128) {
+            const uint32_t j = queue[waiting - 128 + pair];
+            const float r = exact_l2_pair(base + (uint64_t)recs[j].pos * dim + 4 * hf, acc_q, dim, hf);
+            if (hf == 0) recs[j].accurate = r;
+            if (threadIdx.x == 0) qn = waiting - 128;
+            __syncthreads();  // the queue's top 128 entries are free again, qn is set
+        }
+    }
+    const uint32_t waiting = qn;
+    if (pair < waiting) {
+        const uint32_t j = queue[pair];
+        const float r = exact_l2_pair(base + (uint64_t)recs[j].pos * dim + 4 * hf, acc_q, dim, hf);
+        if (hf == 0) recs[j].accurate = r;
+    }
+    uint32_t rj = hf == 0 ? rejected : 0u;  // per-query counter (one address per query: no hot spot)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) rj += __shfl_xor(rj, o, 64);
+    if ((threadIdx.x & 63) == 0 && rj) atomicAdd(&nshadow[b], rj);
+}
+
 // ---- the same three phases as separate launches: better for large batches, where all queries'
 // survivors are reranked with full-chip parallelism before the (latency-bound) replay --------------
 // grid (gx, nq); block 256
@@ -2148,7 +2286,7 @@ __global__ void init_state_kernel(ReplayState st, unsigned long long *__restrict
     if (b >= nq) return;
     st.thr[b] = 3.402823466e+38f;          // f32::MAX
     st.recent_max[b] = -3.402823466e+38f;  // f32::MIN
-    st.heap_len[b] = 0, st.precise[b] = 0, st.need[b] = 0, st.nsurv[b] = 0, st.win_count[b] = 0, st.arr_len[b] = 0;
+    st.heap_len[b] = 0, st.precise[b] = 0, st.need[b] = 0, st.nsurv[b] = 0, st.nshadow[b] = 0, st.win_count[b] = 0, st.arr_len[b] = 0;
     surv_cnt[b] = 0;
 }
 
@@ -2197,19 +2335,21 @@ __global__ __launch_bounds__(256) void metrics_sum_kernel(const unsigned long lo
                                                           const uint32_t *__restrict__ precise,
                                                           const uint32_t *__restrict__ need,
                                                           const uint32_t *__restrict__ arr_len,
-                                                          const uint32_t *__restrict__ nsurv, uint32_t nq,
+                                                          const uint32_t *__restrict__ nsurv,
+                                                          const uint32_t *__restrict__ nshadow, uint32_t nq,
                                                           uint32_t cap, uint32_t hcap,
                                                           unsigned long long *__restrict__ out4) {
-    __shared__ unsigned long long s[5];
-    if (threadIdx.x < 5) s[threadIdx.x] = 0;
+    __shared__ unsigned long long s[6];
+    if (threadIdx.x < 6) s[threadIdx.x] = 0;
     __syncthreads();
-    unsigned long long r = 0, p = 0, o = 0, a = 0, mx = 0;
+    unsigned long long r = 0, p = 0, o = 0, a = 0, mx = 0, sh = 0;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) {
         const bool ok = need[i] <= cap && (!arr_len || arr_len[i] <= hcap);
         r += rough[i];
         p += ok ? precise[i] : 0;
         o += ok ? 0 : 1;
         a += nsurv[i];
+        sh += nshadow[i];
         const unsigned long long al = arr_len ? arr_len[i] : 0ull;
         unsigned long long nd = need[i] > al ? (unsigned long long)need[i] : al;
         mx = nd > mx ? nd : mx;
@@ -2219,7 +2359,9 @@ __global__ __launch_bounds__(256) void metrics_sum_kernel(const unsigned long lo
     atomicAdd(&s[2], o);
     atomicAdd(&s[3], a);
     atomicMax(&s[4], mx);
+    atomicAdd(&s[5], sh);
     __syncthreads();
     if (threadIdx.x < 4) atomicAdd(&out4[threadIdx.x], s[threadIdx.x]);
+    if (threadIdx.x == 5) atomicAdd(&out4[5], s[5]);
     if (threadIdx.x == 4) atomicMax(&out4[4], s[4]);
 }

@@ -199,7 +199,7 @@ struct Workspace {
     DevBuf<uint32_t> retry_rows;
     DevBuf<uint32_t> q_hist, q_start, q_order;  // rerank order of a large batch (queries grouped by nearest list)
     DevBuf<uint32_t> probe_cluster, recs, grp_cnt, grp_start, heap_len, heap_id, precise, need,
-        nsurv, win_count, arr_len, row_map, big_list;
+        nsurv, nshadow, win_count, arr_len, row_map, big_list;
     DevBuf<int32_t> heap_key;
     DevBuf<PairScalars> scal;
     DevBuf<uint64_t> planes;
@@ -238,6 +238,7 @@ struct rq_index {
         if (base_host) (void)hipHostFree(base_host);
     }
     DevBuf<float> base, P, centroids, cent_t;
+    DevBuf<_Float16> base_h;  // fp16 shadow of `base` (rerank pre-filter, derived; untiered indexes with HBM to spare)
     DevBuf<uint32_t> offsets, map_ids;
     DevBuf<uint64_t> codes;
     DevBuf<float4> factors;
@@ -571,6 +572,7 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
     RQC(ws.precise.ensure(nq));
     RQC(ws.need.ensure(nq));
     RQC(ws.nsurv.ensure(nq));
+    RQC(ws.nshadow.ensure(nq));
     RQC(ws.recent.ensure(nq));
     RQC(ws.win_count.ensure(nq));
     RQC(ws.arr_len.ensure(nq));
@@ -615,6 +617,7 @@ static rq_status finish_pass(const rq_index *idx, Workspace &ws, PassResult *res
         prof_acc->scan_candidates += res->rough;
         prof_acc->scan_bytes += res->rough * (uint64_t)(dim / 8 + 16);
         prof_acc->rerank_candidates += ws.h_totals[3];
+        prof_acc->rerank_shadow_rejects += ws.h_totals[5];
         if (g_scan_dbg.load() & 256) {  // developer hook: where the matrix-core scan's waves spend their cycles
             unsigned long long ht[8];
             HIPC(hipMemcpy(ht, ws.stat.p + 128, sizeof ht, hipMemcpyDeviceToHost));
@@ -714,7 +717,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     }
     ReplayState rs;
     rs.thr = ws.thr.p, rs.heap_len = ws.heap_len.p, rs.heap_key = ws.heap_key.p, rs.heap_id = ws.heap_id.p;
-    rs.precise = ws.precise.p, rs.need = ws.need.p, rs.nsurv = ws.nsurv.p, rs.recent_max = ws.recent.p, rs.win_count = ws.win_count.p;
+    rs.precise = ws.precise.p, rs.need = ws.need.p, rs.nsurv = ws.nsurv.p, rs.nshadow = ws.nshadow.p, rs.recent_max = ws.recent.p, rs.win_count = ws.win_count.p;
     rs.arr_len = ws.arr_len.p, rs.arr = ws.arr.p, rs.hcap = qp.hcap;
     // 4. ranker state (rerank.rs:70-77, :129-139) and per-query counters
     init_state_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(rs, ws.surv_cnt.p, nq);
@@ -769,7 +772,9 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     const uint32_t mid_blocks = big_hint == 0 ? 64u : std::min(4096u, std::max(256u, big_hint / 4));
     const uint32_t tile = scan_tile(W);
     const uint64_t avg_len = std::max<uint64_t>(1, idx->n / std::max<uint32_t>(k, 1));
+    uint32_t stage_no = ~0u;
     for (const Stage &sg : stages) {
+        ++stage_no;
         const uint64_t span = (uint64_t)std::min<uint64_t>(sg.s_hi, (uint64_t)nprobe * idx->max_list_len) - sg.s_lo;
         const uint64_t est_pairs = (uint64_t)nq * std::min<uint64_t>(nprobe, span / avg_len + 2);
         // matrix cores pay once many queries share each list AND survivors are rare, i.e. past the nearest list
@@ -862,8 +867,14 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         } else {  // large batch: full-chip rerank, then run-directory sort, then one replay wave per query
             pf.begin(PF_RERANK);
             const uint32_t gx = std::max(1u, std::min(16u, 4096u / std::max(nq, 1u)));
-            accurate_kernel<<<dim3(gx, nq), 256, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.surv_cnt.p, qp.cap, idx->view(), qpad, dim,
-                                                                                    rerank_order, probe_cluster, nprobe);
+            // past the first stage the thresholds are finite: survivors go through the fp16 shadow rows first
+            if (idx->base_h.p && stage_no > 0 && !(g_scan_dbg & 512))
+                accurate_filtered_kernel<<<dim3(gx, nq), 256, (size_t)dim * sizeof(float), st>>>(
+                    ws.surv.p, ws.surv_cnt.p, qp.cap, idx->base.p, idx->base_h.p, qpad, dim, rerank_order, ws.thr.p,
+                    ws.nshadow.p);
+            else
+                accurate_kernel<<<dim3(gx, nq), 256, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.surv_cnt.p, qp.cap, idx->view(), qpad, dim,
+                                                                                        rerank_order, probe_cluster, nprobe);
             pf.end();
             pf.begin(PF_SORT);
             sort_runs_kernel<<<nq, 64, 0, st>>>(ws.runs.p, ws.surv_cnt.p, qp.cap, ws.big_list.p, ws.big_list.p + nq, 512u);
@@ -891,7 +902,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                                                                                   d_out_id, d_out_n);
     }
     metrics_sum_kernel<<<std::min(256u, ceil_div(nq, 256)), 256, 0, st>>>(
-        ws.rough_cnt.p, ws.precise.p, ws.need.p, qp.heuristic ? ws.arr_len.p : nullptr, ws.nsurv.p, nq, qp.cap, qp.hcap,
+        ws.rough_cnt.p, ws.precise.p, ws.need.p, qp.heuristic ? ws.arr_len.p : nullptr, ws.nsurv.p, ws.nshadow.p, nq, qp.cap, qp.hcap,
         ws.totals.p);
     pf.end();
     if (pf.on) (void)hipEventRecord(pf.spans[total_span].b, st);
@@ -1159,6 +1170,11 @@ static rq_status query_device_end(rq_ticket *tk) {
 // ------------------------------------------------------------------------------------------------
 // index construction helpers
 // ------------------------------------------------------------------------------------------------
+// fp16 shadow of the raw vectors (kernels_query.h: rerank pre-filter).  Only for untiered indexes, and only when the
+// 2*dim bytes per vector still leave the query workspaces their room; it costs one streaming pass over `base`.
+#define RQ_SHADOW_MIN_ROWS 1ull
+static std::atomic<int> g_rerank_shadow{1};  // fp16 shadow rows for the rerank pre-filter: 0 never, 1 when they fit
+static rq_status derive_shadow_rows(rq_index *idx);
 static rq_status finish_index(rq_index *idx) {
     // derived state: transposed centroids, longest list
     idx->W = idx->dim / 64;
@@ -1186,6 +1202,7 @@ static rq_status finish_index(rq_index *idx) {
     }
     HIPC(hipDeviceSynchronize());
     HIPC(hipGetLastError());
+    RQC(derive_shadow_rows(idx));
     idx->h_offsets.resize((size_t)idx->k + 1);
     HIPC(hipMemcpy(idx->h_offsets.data(), idx->offsets.p, ((size_t)idx->k + 1) * 4, hipMemcpyDeviceToHost));
     {
@@ -1193,6 +1210,23 @@ static rq_status finish_index(rq_index *idx) {
         HIPC(hipMemGetInfo(&free_b, &total_b));
         idx->pass_budget = std::min<uint64_t>(std::max<uint64_t>(free_b / 3, 4ull << 30), 96ull << 30);
     }
+    return RQ_OK;
+}
+
+static rq_status derive_shadow_rows(rq_index *idx) {
+    idx->base_h.release();
+    if (!g_rerank_shadow.load() || idx->base_host != nullptr || idx->n < RQ_SHADOW_MIN_ROWS) return RQ_OK;
+    const uint64_t total = idx->n * idx->dim, bytes = total * 2;
+    size_t free_b = 0, total_b = 0;
+    HIPC(hipMemGetInfo(&free_b, &total_b));
+    if (free_b < bytes + (48ull << 30) && bytes > (1ull << 30)) return RQ_OK;  // keep the survivor buffers their share
+    if (idx->base_h.alloc(total) != RQ_OK) {
+        (void)hipGetLastError();
+        return RQ_OK;  // no room: queries run without the pre-filter
+    }
+    half_rows_kernel<<<(uint32_t)std::min<uint64_t>(ceil_div(total, 2048), 1u << 20), 256>>>(idx->base.p, total, idx->base_h.p);
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipGetLastError());
     return RQ_OK;
 }
 
@@ -2495,6 +2529,11 @@ rq_status rq_set_option(const char *name, int value) {
     if (std::string(name) == "max_scan_blocks") {  // test hook: blocks per scan launch (0 = the hardware bound), forces chunked stages
         if (value < 0) return fail(RQ_ERR_INVALID, "max_scan_blocks must be >= 0");
         g_max_scan_blocks = value == 0 ? RQ_MAX_BLOCKS_256 : std::min<uint32_t>((uint32_t)value, RQ_MAX_BLOCKS_256);
+        return RQ_OK;
+    }
+    if (std::string(name) == "rerank_shadow") {  // fp16 shadow rows (rerank pre-filter) for indexes built / loaded from now on
+        if (value < 0 || value > 1) return fail(RQ_ERR_INVALID, "rerank_shadow must be 0 (never) or 1 (when they fit)");
+        g_rerank_shadow = value;
         return RQ_OK;
     }
     if (std::string(name) == "scan_debug") {  // developer ablations of the matrix-core scan (results are WRONG when != 0)

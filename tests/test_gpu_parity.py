@@ -958,6 +958,57 @@ def test_long_run_directories_large_batch(rq, oracle):
     oidx.close()
 
 
+@pytest.mark.parametrize("d,kind", [(128, "gauss"), (192, "gauss"), (128, "beyond_fp16"), (128, "fp16_subnormal"),
+                                    (128, "small_ints"), (64, "near_ties")])
+def test_rerank_shadow_rows_keep_results_exact(rq, oracle, d, kind):
+    """Large batches re-rank through the fp16 shadow rows (accurate_filtered_kernel): a survivor is dropped without its
+    f32 row being read only when the shadow PROVES accurate >= the stage's threshold.  Data the shadow represents badly
+    (elements beyond the fp16 range -> inf, fp16 subnormals, near-equal distances around the threshold) must still give
+    the oracle's ids and distances bit for bit; on ordinary data the test must actually reject rows."""
+    from rabitq_amd import index as ix
+    n, k, nq = 40_000, 8, 300
+    rng = np.random.default_rng(d + len(kind))
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.7, seed=3 + d, centre_scale=0.6)
+    queries, _, _ = synth.mixture(nq, d, k, sigma=0.7, seed=4 + d, centre_scale=0.6)
+    if kind == "beyond_fp16":      # a fifth of the rows carry elements the shadow can only store as inf
+        big = rng.random(n) < 0.2
+        x[big, rng.integers(0, d, int(big.sum()))] *= 1.0e5
+        x *= 40.0
+        centres, queries = centres * 40.0, queries * 40.0
+    elif kind == "fp16_subnormal":
+        x, centres, queries = x * 1e-6, centres * 1e-6, queries * 1e-6
+    elif kind == "small_ints":     # SIFT-like
+        x, centres, queries = np.rint(x * 40 + 128).clip(0, 255), np.rint(centres * 40 + 128), np.rint(queries * 40 + 128).clip(0, 255)
+    elif kind == "near_ties":      # thousands of rows within 1e-4 of each other: distances crowd around every threshold
+        x[: n // 2] = x[:20].repeat(n // 40, axis=0) + 1e-4 * rng.standard_normal((n // 2, d))
+        queries[:150] = x[rng.integers(0, n // 2, 150)] + 1e-4 * rng.standard_normal((150, d))
+    x, centres, queries = (np.ascontiguousarray(a, np.float32) for a in (x, centres, queries))
+    P = synth.random_orthogonal(d, seed=d)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    gidx = rq.RaBitQ.build(x, centres, P)
+    ix.set_profiling(1)
+    try:
+        for probe, topk, heur in [(8, 10, False), (3, 50, False), (8, 10, True)]:
+            _compare_with_oracle(rq, oracle, oidx, gidx, queries, probe, topk, heur)
+            pr = ix.last_profile()
+            assert pr["rerank_shadow_rejects"] <= pr["rerank_candidates"]
+            if kind in ("gauss", "small_ints") and not heur:
+                assert pr["rerank_shadow_rejects"] > pr["rerank_candidates"] // 4, (pr["rerank_shadow_rejects"], pr["rerank_candidates"])
+        ix.set_option("rerank_shadow", 0)      # the same index without shadow rows: the plain exact re-ranker
+        plain = rq.RaBitQ.build(x, centres, P)
+        ix.set_option("rerank_shadow", 1)
+        a, b = gidx.query_batch(queries, 8, 10, False), plain.query_batch(queries, 8, 10, False)
+        assert ix.last_profile()["rerank_shadow_rejects"] == 0
+        for u, v in zip(a, b):
+            assert_bits_equal(u, v, "with / without shadow rows")
+        plain.close()
+    finally:
+        ix.set_profiling(0)
+        ix.set_option("rerank_shadow", 1)
+    gidx.close()
+    oidx.close()
+
+
 def test_json_persistence_round_trip(rq, oracle, tmp_path):
     """dump_to_json / load_from_json (src/rabitq.rs:72-81): the serde_json image of the struct (faer Mats as
     {"nrows","ncols","data": row-major}, base dim x n, centroids dim x k); every f32 survives the text bit for bit."""
