@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--sharded-path", action="store_true",
                     help="rehearsal on one GPU: run the multi-GPU step (sharded coarse ranking, probe-list merge, probed "
                          "query, top-k merge) with a world of 1, to see what the extra plumbing costs")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="engine option for this run (rq_set_option; e.g. stage_growth=16, rerank_shadow=0): experiments only, "
+                         "recorded in the output line")
     ap.add_argument("--two-in-flight", action=argparse.BooleanOptionalAction, default=True,
                     help="after the timed region (whose steps run one batch at a time, so that every launch runs alone and "
                          "per-kernel times from HIP events and rocprofv3 --stats stay comparable), also measure the throughput "
@@ -104,6 +107,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     _lib.check(_lib.lib().rq_init(local_rank))
+    from rabitq_amd import index as _ix
+    for ov in args.option:
+        name, _, val = ov.partition("=")
+        _ix.set_option(name, int(val))
 
     n, d, k_local, nprobe, topk, B = args.vectors, args.dim, args.lists, args.nprobe, args.topk, args.batch
     k = k_local * world                      # global list count; every rank knows all centroids
@@ -410,6 +417,7 @@ def main():
             "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "exact integer dot (fp6 MFMA, v_dot8_u32_u4) + f32", "data": "synthetic",
+            "engine_options": args.option,
             "config": {"workload": f"{n // 1_000_000}Mx{d} synthetic mixture per GPU, {k_local} lists per GPU, "
                                    f"nprobe={nprobe}, topk={topk}, batch={B}" +
                                    (" (BASELINE.json configs[2])" if (n, d, k_local, nprobe) == (100_000_000, 128, 4096, 64) else ""),

@@ -294,6 +294,8 @@ rq_status rq_set_profiling(int level);
  * distance is at or above the stage's threshold (then the reference rejects it whatever its value).  0 = never.
  * Results are bit-identical either way.
  * "max_scan_blocks": test hook, blocks per scan launch (0 = hardware bound).
+ * "group_rank": test hook, placement of a cluster-major stage's (query, list) pairs: 0 = one atomic per pair,
+ * 1 = automatic (default: per-block LDS histograms for big stages), 2 = histograms whenever they fit.
  * Developer knobs: "stage_growth" (geometric growth of the early stages, 0 = default; results are
  * identical for every value), "scan_debug" (bit 128: count sub-tile / exact-path steps into rq_profile_t, results unchanged;
  * the other bits are timing ablations of the matrix-core scan: results are WRONG while they are set). */

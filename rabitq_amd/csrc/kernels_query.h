@@ -669,6 +669,39 @@ __global__ void group_count_kernel(const PairScalars *__restrict__ scal,
     if (pair_in_stage(scal[p], s_lo, s_hi)) atomicAdd(&grp_cnt[probe_cluster[p]], 1u);
 }
 
+// The same count for big stages, with the place of every pair inside its list's group decided on the way
+// (cluster-major stages of large batches: ~16 pairs per list and block).  A block owns RQ_RANK_ITEMS consecutive work
+// items and a histogram of the lists in LDS: an item's rank inside (block, list) comes from the LDS atomic, the
+// block's base inside the list from ONE global atomic per (block, list) -- instead of one contended global atomic
+// per pair here and a second one in stage_fill_kernel (4.2 M each at batch 65 536, on 4096 addresses).
+//   rank[i]           place of item i among its block's pairs of the same list (~0u: not in the stage)
+//   blk_base[blk][c]  first place of block blk's pairs in list c's group
+// Dynamic LDS: k counters.
+#define RQ_RANK_ITEMS 32768u
+__global__ __launch_bounds__(1024) void group_rank_kernel(const PairScalars *__restrict__ scal,
+                                                          const uint32_t *__restrict__ probe_cluster, uint32_t count,
+                                                          uint32_t nprobe, uint32_t slot_hi, uint32_t s_lo, uint32_t s_hi,
+                                                          uint32_t k, uint32_t *__restrict__ grp_cnt,
+                                                          uint32_t *__restrict__ rank, uint32_t *__restrict__ blk_base) {
+    extern __shared__ uint32_t rank_hist[];
+    for (uint32_t c = threadIdx.x; c < k; c += 1024) rank_hist[c] = 0;
+    __syncthreads();
+    const uint32_t first = blockIdx.x * RQ_RANK_ITEMS;
+    for (uint32_t j = threadIdx.x; j < RQ_RANK_ITEMS; j += 1024) {
+        const uint32_t i = first + j;
+        if (i >= count) break;
+        const uint32_t b = i / slot_hi, p = b * nprobe + (i - b * slot_hi);
+        uint32_t r = ~0u;
+        if (pair_in_stage(scal[p], s_lo, s_hi)) r = atomicAdd(&rank_hist[probe_cluster[p]], 1u);
+        rank[i] = r;
+    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < k; c += 1024) {
+        const uint32_t h = rank_hist[c];
+        blk_base[(uint64_t)blockIdx.x * k + c] = h ? atomicAdd(&grp_cnt[c], h) : 0u;
+    }
+}
+
 // Per-stage work records.  Everything the scan needs about one (query, list) pair, contiguous, so
 // that the scan's inner loop is one pointer bump plus immediate-offset scalar loads:
 //   dwords [0, opdw)    query operand: 4-bit codes 8 per dword (fused kernel, 8W), the 4 bit planes (8W), or
@@ -693,7 +726,7 @@ __global__ void group_count_kernel(const PairScalars *__restrict__ scal,
 
 // exclusive scan of cnt[0..k) into start[0..k]; single block, any k.  Also zeroes cnt for the
 // fill pass (cnt is reused as the per-list cursor, so it holds the counts again afterwards).
-// pad32: every group starts at a multiple of 32 records (the matrix-core scan's query tiles).
+// pad32 bit 0: every group starts at a multiple of 32 records (the matrix-core scan's query tiles).
 // pad32 (matrix-core stages): the rows between a group's last record and its 32-row boundary are marked "no query"
 // right here (their threshold operand: constant term -inf, so the accumulator of such a row starts at -inf and is
 // never flagged): the scan then needs no per-tile masking.  recs / opdw: the stage's tile images.
@@ -708,7 +741,7 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(uint32_t *__restrict__
     for (uint32_t base = 0; base < k; base += 1024) {
         uint32_t i = base + tid;
         uint32_t v = i < k ? cnt[i] : 0;
-        if (pad32) v = (v + 31u) & ~31u;
+        if (pad32 & 1u) v = (v + 31u) & ~31u;
         uint32_t incl = v;
         for (int o = 1; o < 64; o <<= 1) {
             uint32_t up = __shfl_up(incl, o, 64);
@@ -722,7 +755,7 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(uint32_t *__restrict__
         if (i < k) {
             const uint32_t st0 = c0 + woff + incl - v;
             start[i] = st0;
-            if (pad32 && recs) {
+            if ((pad32 & 1u) && recs) {
                 const uint32_t real = cnt[i];
                 const uint32_t opld = opdw + 2, img = 32 * opld + RQ_REC_TAIL * 32;
                 for (uint32_t at = st0 + real; at < st0 + v; ++at) {  // at most 31 rows
@@ -731,7 +764,7 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(uint32_t *__restrict__
                     *reinterpret_cast<uint4 *>(tl + 4) = make_uint4(0u, 0u, 0u, 0u);        // slots 8..15
                 }
             }
-            cnt[i] = 0;
+            if (!(pad32 & 2u)) cnt[i] = 0;  // bit 1: the places are already known (group_rank_kernel), cnt stays the count
         }
         __syncthreads();
         if (tid == 1023) carry = c0 + woff + incl;
@@ -758,7 +791,9 @@ __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__re
                                                          const uint32_t *__restrict__ grp_start,
                                                          uint32_t *__restrict__ grp_cursor,
                                                          uint32_t *__restrict__ recs, const FactorStats fs,
-                                                         uint32_t tile_images) {
+                                                         uint32_t tile_images,
+                                                         const uint32_t *__restrict__ rank /* group_rank_kernel, or null */,
+                                                         const uint32_t *__restrict__ blk_base, uint32_t k) {
     const uint32_t sub = threadIdx.x & 15;                       // 16 lanes per pair
     const uint32_t wi = blockIdx.x * 16 + (threadIdx.x >> 4);  // work item: (query, slot < slot_hi)
     if (wi >= count) return;
@@ -769,9 +804,13 @@ __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__re
     uint32_t at = p;
     if (cluster_major) {
         const uint32_t c = probe_cluster[p];
-        uint32_t a = 0;
-        if (sub == 0) a = atomicAdd(&grp_cursor[c], 1u);
-        at = grp_start[c] + __shfl(a, 0, 16);
+        if (rank) {  // places were handed out by group_rank_kernel
+            at = grp_start[c] + blk_base[(uint64_t)(wi / RQ_RANK_ITEMS) * k + c] + rank[wi];
+        } else {
+            uint32_t a = 0;
+            if (sub == 0) a = atomicAdd(&grp_cursor[c], 1u);
+            at = grp_start[c] + __shfl(a, 0, 16);
+        }
     }
     // record-major: record `at` = opdw operand dwords + RQ_REC_TAIL tail dwords.  tile images (matrix-core
     // scan): records in tiles of 32, each tile stored as the exact LDS image the kernel copies in with

@@ -198,6 +198,7 @@ struct Workspace {
     DevBuf<float> retry_q, retry_pd, retry_pc;  // overflow re-runs: the affected queries (and their probe lists)
     DevBuf<uint32_t> retry_rows;
     DevBuf<uint32_t> q_hist, q_start, q_order;  // rerank order of a large batch (queries grouped by nearest list)
+    DevBuf<uint32_t> pair_rank, rank_base;      // group_rank_kernel: places of a big stage's pairs inside their groups
     DevBuf<uint32_t> probe_cluster, recs, grp_cnt, grp_start, heap_len, heap_id, precise, need,
         nsurv, nshadow, win_count, arr_len, row_map, big_list;
     DevBuf<int32_t> heap_key;
@@ -418,6 +419,7 @@ static std::atomic<int> g_scan_impl{0};
 static std::atomic<int> g_scan_dbg{0};
 static std::atomic<int> g_stage_growth{0};  // 0 = default schedule
 static std::atomic<int> g_scan_tile_table{1};  // 0 = plain (list x tile) grids everywhere (test / measurement hook)
+static std::atomic<int> g_group_rank{1};  // group_rank_kernel for cluster-major stages: 0 never, 1 big stages, 2 always
 
 // matrix-core scan instantiations: W = dim/64, NT = 32-candidate sub-tiles per wave (resident operand registers
 // 6*W*NT), blocks per CU per scan_mfma_blocks_per_cu<W>()
@@ -793,11 +795,23 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         if (cluster_major && idx->min_list_len > 0 && !ext_cluster && sg.s_hi != 0xFFFFFFFFu)
             slot_hi = (uint32_t)std::min<uint64_t>(nprobe, (uint64_t)(sg.s_hi - 1) / idx->min_list_len + 1);
         const uint32_t stage_pairs = nq * slot_hi;
+        bool ranked = false;
         if (cluster_major) {
             HIPC(hipMemsetAsync(ws.grp_cnt.p, 0, (size_t)((k + 4) & ~3u) * 4, st));  // 16-byte multiple: one fill kernel
-            group_count_kernel<<<ceil_div(stage_pairs, 256), 256, 0, st>>>(ws.scal.p, probe_cluster, stage_pairs, nprobe,
-                                                                           slot_hi, sg.s_lo, sg.s_hi, ws.grp_cnt.p);
-            group_scan_kernel<<<1, 1024, 0, st>>>(ws.grp_cnt.p, k, ws.grp_start.p, use_mfma ? 1u : 0u, ws.recs.p, 12 * W);
+            // big stages: places inside the groups come out of the counting pass (LDS histogram per block)
+            const int rank_opt = g_group_rank.load();  // 0 never, 1 auto, 2 whenever the histogram fits LDS (tests)
+            ranked = k <= 12288 && (rank_opt == 2 || (rank_opt == 1 && stage_pairs >= 16 * RQ_RANK_ITEMS &&
+                                                      stage_pairs / RQ_RANK_ITEMS >= k / 256));
+            if (ranked) {
+                const uint32_t nblk = ceil_div(stage_pairs, RQ_RANK_ITEMS);
+                RQC(ws.pair_rank.ensure(stage_pairs));
+                RQC(ws.rank_base.ensure((size_t)nblk * k));
+                group_rank_kernel<<<nblk, 1024, (size_t)k * 4, st>>>(ws.scal.p, probe_cluster, stage_pairs, nprobe, slot_hi, sg.s_lo,
+                                                                    sg.s_hi, k, ws.grp_cnt.p, ws.pair_rank.p, ws.rank_base.p);
+            } else
+                group_count_kernel<<<ceil_div(stage_pairs, 256), 256, 0, st>>>(ws.scal.p, probe_cluster, stage_pairs, nprobe,
+                                                                               slot_hi, sg.s_lo, sg.s_hi, ws.grp_cnt.p);
+            group_scan_kernel<<<1, 1024, 0, st>>>(ws.grp_cnt.p, k, ws.grp_start.p, (use_mfma ? 1u : 0u) | (ranked ? 2u : 0u), ws.recs.p, 12 * W);
             a.ngroups = k;
         } else {
             a.ngroups = npairs;
@@ -808,7 +822,8 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         stage_fill_kernel<<<ceil_div(stage_pairs, 16), 256, 0, st>>>(ws.scal.p, probe_cluster, operand, ws.thr.p, stage_pairs,
                                                                 nprobe, slot_hi, use_mfma ? 12 * W : 8 * W, sg.s_lo, sg.s_hi,
                                                                 a.cluster_major, ws.grp_start.p, ws.grp_cnt.p, ws.recs.p,
-                                                                idx->fstats, use_mfma ? 1u : 0u);
+                                                                idx->fstats, use_mfma ? 1u : 0u, ranked ? ws.pair_rank.p : nullptr,
+                                                                ws.rank_base.p, k);
         pf.end();
         sp.codes = reinterpret_cast<const uint32_t *>(idx->codes.p);
         sp.factors = idx->factors.p;
@@ -2529,6 +2544,11 @@ rq_status rq_set_option(const char *name, int value) {
     if (std::string(name) == "max_scan_blocks") {  // test hook: blocks per scan launch (0 = the hardware bound), forces chunked stages
         if (value < 0) return fail(RQ_ERR_INVALID, "max_scan_blocks must be >= 0");
         g_max_scan_blocks = value == 0 ? RQ_MAX_BLOCKS_256 : std::min<uint32_t>((uint32_t)value, RQ_MAX_BLOCKS_256);
+        return RQ_OK;
+    }
+    if (std::string(name) == "group_rank") {  // test hook: how a cluster-major stage places its pairs (0 atomics per pair, 1 auto, 2 ranked)
+        if (value < 0 || value > 2) return fail(RQ_ERR_INVALID, "group_rank must be 0, 1 or 2");
+        g_group_rank = value;
         return RQ_OK;
     }
     if (std::string(name) == "rerank_shadow") {  // fp16 shadow rows (rerank pre-filter) for indexes built / loaded from now on

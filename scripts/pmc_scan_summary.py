@@ -1,10 +1,13 @@
-"""Summarise gpurun_out/pmc_mfma*/ (scripts/pmc_scan.sh): per-launch SQ counters of scan_mfma_kernel."""
+"""Summarise gpurun_out/pmc_mfma*/ (scripts/pmc_scan.sh): per-launch SQ counters of scan_mfma_kernel (or of the kernel
+whose name contains argv[1]); the launch with the largest grid is reported."""
 import collections
 import csv
 import glob
 import os
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL = sys.argv[1] if len(sys.argv) > 1 else "scan_mfma_kernel"  # e.g. "scan_kernel<" for the VALU scan stages
 csv.field_size_limit(10**9)
 tot = {}
 for d in ("pmc_mfma", "pmc_mfma2"):
@@ -13,7 +16,7 @@ for d in ("pmc_mfma", "pmc_mfma2"):
         print(d, "missing")
         continue
     fs.sort(key=os.path.getmtime)
-    rows = [r for r in csv.DictReader(open(fs[-1])) if "scan_mfma_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(fs[-1])) if KERNEL in r["Kernel_Name"]]
     byd = collections.defaultdict(dict)
     grid = {}
     for r in rows:

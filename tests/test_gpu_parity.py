@@ -591,6 +591,39 @@ def test_scan_grid_chunking_matches_oracle(rq, oracle, impl, max_blocks, tile_ta
     oidx.close()
 
 
+@pytest.mark.parametrize("impl", [1, 2])
+def test_ranked_group_placement_matches_oracle(rq, oracle, impl):
+    """Cluster-major stages place their (query, list) pairs either with one atomic per pair or through per-block
+    LDS histograms (group_rank_kernel, what big stages use).  Forced on a small batch (several shapes of stage, empty
+    lists, padding rows of the matrix-core tiles), then reached the automatic way: 9000 queries x 64 probes is a stage
+    of more than 16 blocks of pairs."""
+    from rabitq_amd import index as ix
+    n, d, k = 30_000, 128, 96
+    x, centres, _ = synth.mixture(n, d, k - 6, sigma=0.8, seed=91, centre_scale=0.6)
+    centres = np.concatenate([centres, 50.0 + np.arange(6 * d, dtype=np.float32).reshape(6, d)])   # six lists stay empty
+    P = synth.random_orthogonal(d, seed=92)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    gidx = rq.RaBitQ.build(x, centres, P)
+    queries, _, _ = synth.mixture(9000, d, k - 6, sigma=0.8, seed=93, centre_scale=0.6)
+    ix.set_option("scan_impl", impl)
+    try:
+        ix.set_option("group_rank", 2)
+        _compare_with_oracle(rq, oracle, oidx, gidx, queries[:300], 20, 10, False)
+        _compare_with_oracle(rq, oracle, oidx, gidx, queries[:77], 96, 5, True)
+        ix.set_option("group_rank", 1)
+        _compare_with_oracle(rq, oracle, oidx, gidx, queries, 64, 10, False)
+        a = gidx.query_batch(queries, 64, 10, False)
+        ix.set_option("group_rank", 0)
+        b = gidx.query_batch(queries, 64, 10, False)
+        for u, v in zip(a, b):
+            assert_bits_equal(u, v, "ranked / per-pair placement")
+    finally:
+        ix.set_option("group_rank", 1)
+        ix.set_option("scan_impl", 0)
+    gidx.close()
+    oidx.close()
+
+
 def test_wide_vectors_dim_3072(rq, oracle):
     # dim in (2048, 4096]: assign_generic_kernel<8> needs > 64 KiB of dynamic LDS, so the attribute must be in
     # place before the FIRST build / quantize of a process (ensure_kernel_attributes); generic-W scan (W = 48)
