@@ -294,6 +294,8 @@ rq_status rq_set_profiling(int level);
  * distance is at or above the stage's threshold (then the reference rejects it whatever its value).  0 = never.
  * Results are bit-identical either way.
  * "max_scan_blocks": test hook, blocks per scan launch (0 = hardware bound).
+ * "coarse_impl": test hook, coarse-distance kernel: 0 = automatic (default), 1 = query rows through LDS, 2 = query
+ * rows in scalar registers (what large batches use).
  * "group_rank": test hook, placement of a cluster-major stage's (query, list) pairs: 0 = one atomic per pair,
  * 1 = automatic (default: per-block LDS histograms for big stages), 2 = histograms whenever they fit.
  * Developer knobs: "stage_growth" (geometric growth of the early stages, 0 = default; results are

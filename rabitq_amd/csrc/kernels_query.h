@@ -53,6 +53,65 @@ __global__ __launch_bounds__(256) void rotate_valu_kernel(const float *__restric
 // lane <-> centroid j over the TRANSPOSED rotated centroids cent_t[dim][k] (coalesced; this is also
 // the reference's on-disk centroids.fvecs layout), QT queries per thread held in LDS (broadcast).
 // ------------------------------------------------------------------------------------------------
+// Large batches: the same distances with the QUERY side in scalar registers.  A lane still owns one list; the block's
+// QT queries are read through the scalar unit (their rows are wave-uniform), 16 dimensions of one query per
+// s_load_dwordx16, and enter the packed ops as SGPR pairs: two neighbouring dimensions (= two neighbouring AVX
+// lanes of src/simd.rs:14-73, each with its own accumulator and per-component rounding) per v_pk_add_f32 /
+// v_pk_fma_f32.  No LDS: the LDS-broadcast form above spends as many LDS cycles as VALU cycles per element and
+// stalls at half the packed-f32 rate.  QT queries per centroid element loaded (8: 86 VGPRs, five waves per SIMD; 16 was
+// measured slower, three waves per SIMD do not cover the scalar loads).
+template <int QT>
+__global__ __launch_bounds__(256) void coarse_dist_sreg_kernel(const float *__restrict__ cent_t,
+                                                               const float *__restrict__ y, float *__restrict__ dist,
+                                                               uint32_t k, uint32_t dim, uint32_t nq, uint32_t kstride) {
+    const uint32_t q0 = blockIdx.x * QT;
+    const uint32_t j = blockIdx.y * 256 + threadIdx.x;
+    const bool live = j < k;
+    const float *cp = cent_t + (live ? j : 0);
+    f32x2 acc[QT][4];  // [query][pair of AVX lanes]
+#pragma unroll
+    for (int v = 0; v < QT; ++v)
+#pragma unroll
+        for (int l = 0; l < 4; ++l) acc[v][l] = f32x2{0.0f, 0.0f};
+    static_assert(QT % 4 == 0, "queries are fetched four at a time");
+    for (uint32_t c = 0; c < dim; c += 16) {  // dim is a multiple of 64
+        float ce[16];
+#pragma unroll
+        for (int l = 0; l < 16; ++l) ce[l] = cp[(uint64_t)(c + l) * kstride];  // 16 loads in flight
+#pragma unroll
+        for (int v0 = 0; v0 < QT; v0 += 4) {
+            float yv[4][16];  // four queries x 16 dimensions: four s_load_dwordx16 issued together
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const uint32_t q = q0 + v0 + v < nq ? q0 + v0 + v : nq - 1;  // uniform; rows past the batch are computed and dropped
+                const float *yq = y + (uint64_t)q * dim + c;
+#pragma unroll
+                for (int l = 0; l < 16; ++l) yv[v][l] = yq[l];
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)  // the two 8-dimension steps of the chunk, in order (one accumulator chain per AVX lane)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) {
+                        const f32x2 c2 = {ce[8 * h + 2 * l], ce[8 * h + 2 * l + 1]};
+                        const f32x2 y2 = {yv[v][8 * h + 2 * l], yv[v][8 * h + 2 * l + 1]};
+                        const f32x2 d2 = c2 - y2;
+                        acc[v0 + v][l] = __builtin_elementwise_fma(d2, d2, acc[v0 + v][l]);
+                    }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int v = 0; v < QT; ++v) {
+            float a[8];
+#pragma unroll
+            for (int l = 0; l < 4; ++l) a[2 * l] = acc[v][l].x, a[2 * l + 1] = acc[v][l].y;
+            if (q0 + v < nq) dist[(uint64_t)(q0 + v) * k + j] = reduce8_regs(a);
+        }
+    }
+}
+
 template <int QT>
 __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restrict__ cent_t,
                                                           const float *__restrict__ y,

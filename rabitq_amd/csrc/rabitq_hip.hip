@@ -324,6 +324,21 @@ __global__ void unpack_topk_keys_kernel(const unsigned long long *__restrict__ k
     cnt[b] = c;
 }
 
+// coarse ranking distances (src/rabitq.rs:283-287), every query against the lists [first, first + k) of cent_t
+static std::atomic<int> g_coarse_impl{0};  // 0 auto, 1 LDS-broadcast kernels, 2 scalar-register kernel (test hook)
+static void launch_coarse(const float *cent_t, const float *y, float *dist, uint32_t k, uint32_t dim, uint32_t nq,
+                          uint32_t kstride, hipStream_t st) {
+    const int impl = g_coarse_impl.load();
+    if ((impl == 2 || (impl == 0 && nq >= 2048)) && nq > 0)  // many queries per list: query side in SGPRs
+        coarse_dist_sreg_kernel<8><<<dim3(ceil_div(nq, 8), ceil_div(k, 256)), 256, 0, st>>>(cent_t, y, dist, k, dim, nq, kstride);
+    else if (nq >= 64 && dim <= 2048)  // 8 queries per thread: 8 packed VALU ops per centroid element loaded
+        coarse_dist_kernel<8><<<dim3(ceil_div(nq, 8), ceil_div(k, 256)), 256, 8 * dim * sizeof(float), st>>>(cent_t, y, dist, k, dim, nq,
+                                                                                                    kstride);
+    else
+        coarse_dist_kernel<4><<<dim3(ceil_div(nq, 4), ceil_div(k, 256)), 256, 4 * dim * sizeof(float), st>>>(cent_t, y, dist, k, dim, nq,
+                                                                                                    kstride);
+}
+
 // ------------------------------------------------------------------------------------------------
 // rotation launcher (MFMA kernel for bulk, VALU kernel for a handful of rows; bit-identical)
 // ------------------------------------------------------------------------------------------------
@@ -673,12 +688,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         probe_dist = ext_dist;
     } else {
         pf.begin(PF_COARSE);
-        if (nq >= 64 && dim <= 2048)  // 8 queries per thread: 8 packed VALU ops per centroid element loaded
-            coarse_dist_kernel<8><<<dim3(ceil_div(nq, 8), ceil_div(k, 256)), 256, 8 * dim * sizeof(float), st>>>(
-                idx->cent_t.p, ws.y.p, ws.dist.p, k, dim, nq, k);
-        else
-            coarse_dist_kernel<4><<<dim3(ceil_div(nq, 4), ceil_div(k, 256)), 256, 4 * dim * sizeof(float), st>>>(
-                idx->cent_t.p, ws.y.p, ws.dist.p, k, dim, nq, k);
+        launch_coarse(idx->cent_t.p, ws.y.p, ws.dist.p, k, dim, nq, k, st);
         pf.end();
         pf.begin(PF_SELECT);
         launch_select(ws.dist.p, k, nprobe, ws.probe_cluster.p, ws.probe_dist.p, 0, nprobe, nq, st);
@@ -2226,12 +2236,7 @@ rq_status rq_coarse_topk_device(const rq_index *idx, const float *d_queries, uin
         qp = ws->qpad.p;
     }
     launch_rotate(qp, idx->P.p, ws->y.p, nq, dim, nq >= 32, st);
-    if (nq >= 64 && dim <= 2048)
-        coarse_dist_kernel<8><<<dim3(ceil_div(nq, 8), ceil_div(kc, 256)), 256, 8 * dim * sizeof(float), st>>>(
-            idx->cent_t.p + list_lo, ws->y.p, ws->dist.p, kc, dim, nq, idx->k);
-    else
-        coarse_dist_kernel<4><<<dim3(ceil_div(nq, 4), ceil_div(kc, 256)), 256, 4 * dim * sizeof(float), st>>>(
-            idx->cent_t.p + list_lo, ws->y.p, ws->dist.p, kc, dim, nq, idx->k);
+    launch_coarse(idx->cent_t.p + list_lo, ws->y.p, ws->dist.p, kc, dim, nq, idx->k, st);
     launch_select(ws->dist.p, kc, np, d_out_cluster, d_out_dist, list_lo, probe, nq, st);
     HIPC(hipStreamSynchronize(st));
     HIPC(hipGetLastError());
@@ -2544,6 +2549,11 @@ rq_status rq_set_option(const char *name, int value) {
     if (std::string(name) == "max_scan_blocks") {  // test hook: blocks per scan launch (0 = the hardware bound), forces chunked stages
         if (value < 0) return fail(RQ_ERR_INVALID, "max_scan_blocks must be >= 0");
         g_max_scan_blocks = value == 0 ? RQ_MAX_BLOCKS_256 : std::min<uint32_t>((uint32_t)value, RQ_MAX_BLOCKS_256);
+        return RQ_OK;
+    }
+    if (std::string(name) == "coarse_impl") {  // test hook: coarse-distance kernel (0 auto, 1 LDS broadcast, 2 scalar registers)
+        if (value < 0 || value > 2) return fail(RQ_ERR_INVALID, "coarse_impl must be 0, 1 or 2");
+        g_coarse_impl = value;
         return RQ_OK;
     }
     if (std::string(name) == "group_rank") {  // test hook: how a cluster-major stage places its pairs (0 atomics per pair, 1 auto, 2 ranked)

@@ -794,6 +794,31 @@ def test_many_lists_probe_selection_matches_oracle(rq, oracle, k):
     oidx.close()
 
 
+@pytest.mark.parametrize("d,k,nq", [(128, 300, 50), (64, 1000, 37), (192, 77, 19), (768, 40, 21)])
+def test_coarse_distance_kernels_agree_bitwise(rq, oracle, d, k, nq):
+    """The coarse ranking (src/rabitq.rs:283-297) has two distance kernels: query rows broadcast through LDS (small
+    batches) and query rows in scalar registers (large batches).  Both reproduce l2_squared_distance's lane order, so
+    forcing either one must give the oracle's probe lists and distances bit for bit (ragged sizes: nq not a multiple of
+    16, k not a multiple of 256)."""
+    from rabitq_amd import index as ix
+    n = 6000
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.9, seed=d + k, centre_scale=0.8)
+    centres[5] = centres[2]
+    P = synth.random_orthogonal(d, seed=21)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    gidx = rq.RaBitQ.build(x, centres, P)
+    queries, _, _ = synth.mixture(nq, d, k, sigma=0.9, seed=d + k + 1, centre_scale=0.8)
+    try:
+        for impl in (1, 2):
+            ix.set_option("coarse_impl", impl)
+            _compare_with_oracle(rq, oracle, oidx, gidx, queries, min(k, 40), 10, False)
+            _compare_with_oracle(rq, oracle, oidx, gidx, queries[:3], 7, 5, False)
+    finally:
+        ix.set_option("coarse_impl", 0)
+    gidx.close()
+    oidx.close()
+
+
 def test_wide_probe_and_deep_topk_match_oracle(rq, oracle):
     # nprobe > 64 (block-wide probe selection, many pairs per query) together with a deep top-k, on a batch large
     # enough for the matrix-core final stage and the rerank-order grouping (nq >= 256)
