@@ -1091,15 +1091,16 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
         fac[c] = factors[pos[c]];
     }
 
-    for (uint32_t i = pb; i < pe; ++i, rec += STRIDE) {
-        const uint32_t *qn = rec;
-        const uint32_t *t = rec + 8 * W;
+    // one (query, list) pair of the group against this block's candidates; qn = the query's 8W operand dwords,
+    // t = the record's tail (both wave-uniform: a pointer the compiler turns into scalar loads, or SGPR tuples)
+    auto score_pair = [&](const auto &qn, const auto &t) {
         // positions of this list that belong to the stage: [lo_p, hi_p) (wave-uniform)
         const uint32_t lo_p = t[RQ_REC_LO], hi_p = t[RQ_REC_HI];
-        if (hi_p <= first || lo_p >= first + 256 * CPL) continue;
-        const float lower = __builtin_bit_cast(float, t[RQ_REC_LOWER]), delta = __builtin_bit_cast(float, t[RQ_REC_DELTA]),
-                    sumq = __builtin_bit_cast(float, t[RQ_REC_SUMQ]), ycd = __builtin_bit_cast(float, t[RQ_REC_YCD]),
-                    ycd_sqrt = __builtin_bit_cast(float, t[RQ_REC_YCD_SQRT]), thr = __builtin_bit_cast(float, t[RQ_REC_THR]);
+        if (hi_p <= first || lo_p >= first + 256 * CPL) return;
+        // (through a by-value parameter: __builtin_bit_cast applied directly to an element of an SGPR tuple reads element 0)
+        auto f32_of = [](uint32_t v) { return __builtin_bit_cast(float, v); };
+        const float lower = f32_of(t[RQ_REC_LOWER]), delta = f32_of(t[RQ_REC_DELTA]), sumq = f32_of(t[RQ_REC_SUMQ]),
+                    ycd = f32_of(t[RQ_REC_YCD]), ycd_sqrt = f32_of(t[RQ_REC_YCD_SQRT]), thr = f32_of(t[RQ_REC_THR]);
         float rough[CPL];
         uint32_t sdot[CPL];
 #pragma unroll
@@ -1145,6 +1146,7 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
                 total += (uint32_t)__popcll(m[c]);
             }
         }
+        if (a.dbg & 1024u) total = 0;  // timing ablation: no survivor is recorded (results are wrong)
         if (total) {  // wave-uniform: one 64-bit atomic reserves the records and the run descriptors
             const uint32_t b = t[RQ_REC_ROW], slot = t[RQ_REC_SLOT];
             uint32_t nruns = 0;
@@ -1181,6 +1183,44 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
                 rbase += cntc ? 1u : 0u;
             }
         }
+    };
+    if constexpr (W <= 2) {
+        // Scalar loads issued by hand, one record ahead: the wait for record i is followed by the load of record
+        // i + 1, which then has the whole scoring of record i (~50 VALU instructions) to arrive.  Left to the
+        // compiler every iteration was load -> wait -> compute (two dependent round trips: first the stage range, then
+        // the operands), and the stage ran at 58 % VALU occupancy with 5-7 waves per SIMD.
+        typedef uint32_t qv_t __attribute__((ext_vector_type(8 * W)));
+        typedef uint32_t tv_t __attribute__((ext_vector_type(16)));  // 12 of the RQ_REC_TAIL = 20 tail dwords are used here
+        qv_t qa, qb;
+        tv_t ta, tb;
+#define RQ_SLOAD(Q, T, PTR)                                                                                   \
+    do {                                                                                                      \
+        if constexpr (W == 1) asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(Q) : "s"(PTR));               \
+        else asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(Q) : "s"(PTR));                                \
+        asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(T) : "s"(PTR), "i"(8 * W * 4));                      \
+    } while (0)
+#define RQ_SWAIT(Q, T) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(Q), "+s"(T))
+        RQ_SLOAD(qa, ta, rec);
+        uint32_t i = pb;
+        while (true) {
+            const uint32_t *nx = i + 1 < pe ? rec + STRIDE : rec;  // the last prefetch re-reads the last record
+            RQ_SWAIT(qa, ta);
+            RQ_SLOAD(qb, tb, nx);
+            score_pair(qa, ta);
+            if (++i >= pe) break;
+            rec = nx;
+            nx = i + 1 < pe ? rec + STRIDE : rec;
+            RQ_SWAIT(qb, tb);
+            RQ_SLOAD(qa, ta, nx);
+            score_pair(qb, tb);
+            if (++i >= pe) break;
+            rec = nx;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the trailing prefetch has landed before the registers are reused
+#undef RQ_SLOAD
+#undef RQ_SWAIT
+    } else {
+        for (uint32_t i = pb; i < pe; ++i, rec += STRIDE) score_pair(rec, rec + 8 * W);
     }
 }
 
