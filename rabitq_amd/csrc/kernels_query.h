@@ -883,8 +883,12 @@ __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__re
         r = base + (at & 31u) * opld;
         tdst = base + 32 * opld + (at & 31u) * RQ_REC_TAIL;
     }
-    for (uint32_t i = sub; i < opdw; i += 16) r[i] = operand[(uint64_t)p * opdw + i];
-    if (sub == 0) {
+    {  // operand rows are 8-byte aligned in both layouts (opdw, the record stride and the image row stride are even)
+        const uint2 *src = reinterpret_cast<const uint2 *>(operand + (uint64_t)p * opdw);
+        uint2 *dst = reinterpret_cast<uint2 *>(r);
+        for (uint32_t i = sub; i < opdw / 2; i += 16) dst[i] = src[i];
+    }
+    {  // the tail: computed by every lane of the pair (they would idle otherwise), stored 16 bytes per lane by lanes 0..4
         uint32_t t[RQ_REC_TAIL];
         uint32_t lo = 0, hi = 0;
         if (in) {
@@ -952,9 +956,12 @@ __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__re
         t[RQ_REC_V0 + 5] = vl[2] | (vh[3] << 16);
         t[RQ_REC_V0 + 6] = vh[3] | (vl[3] << 16);
         t[RQ_REC_V0 + 7] = c2;
+        static_assert(RQ_REC_TAIL == 20, "five 16-byte pieces");
+        uint4 piece = make_uint4(t[0], t[1], t[2], t[3]);  // 16-byte aligned in both layouts
 #pragma unroll
-        for (int i = 0; i < RQ_REC_TAIL; i += 4)  // 16-byte aligned in both layouts
-            *reinterpret_cast<uint4 *>(tdst + i) = make_uint4(t[i], t[i + 1], t[i + 2], t[i + 3]);
+        for (int i = 1; i < 5; ++i)
+            if (sub == (uint32_t)i) piece = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
+        if (sub < 5) *reinterpret_cast<uint4 *>(tdst + 4 * sub) = piece;
     }
 }
 
