@@ -1681,6 +1681,207 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Dense scan on the matrix cores: the EARLY cluster-major stages of a large batch (positions inside a query's nearest
+// list or two).  There a list meets only ~16 queries and thresholds are still loose (several per cent of the
+// candidates pass), so the kernel above is the wrong tool twice over: its 32-query tiles stay half empty and nearly
+// every sub-tile takes its (per-register, rare-event) exact path; the VALU kernel spends 32 of its ~64 instructions
+// per (wave, query) on v_dot8 and runs issue-bound.  Here the dot products come from v_mfma_f32_16x16x128_f8f6f4 and
+// EVERY cell is then evaluated exactly:
+//   rows    = 16 candidates (A: code bits as fp6, expanded once per block and resident),
+//   columns = 16 queries (B: their fp6 images straight from the stage records),
+//   D lane map: column j = lane & 15 is ONE query per lane (its six scalars live in registers), rows 4g .. 4g+3
+//   (g = lane >> 4) are four candidates per sub-tile whose factors are resident as packed pairs, so the reference's
+//   expression runs as v_pk_* ops on whole registers with no per-row operand fetch.
+// A wave owns 64 consecutive list positions: lane group g owns positions 16g .. 16g+15 (row 4g+r of sub-tile t holds
+// position 16g + 4t + r: a lane's 16 pass bits are then in position order and a survivor's rank among its query's
+// survivors is popcounts over four bit fields).  One reservation atomic and one run descriptor per (query, wave) with
+// survivors, issued by 16 lanes at once.  Results are those of scan_kernel (same expression, same order).
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int W>
+__global__ __launch_bounds__(256) void scan_dense_kernel(SCAN_PARAMS) {
+    static_assert(W % 2 == 0 && W <= 4, "one 16x16x128 MFMA covers two code words; operands resident in registers");
+    constexpr int KB = W / 2;  // 128-dimension blocks
+    constexpr uint32_t OPDW = 12 * W, STRIDE = OPDW + RQ_REC_TAIL;
+    __shared__ __attribute__((aligned(16))) uint2 lut[256];
+    const uint32_t gl = blockIdx.x / a.tiles_per_group;
+    const uint32_t g = a.group_base + gl;
+    const uint32_t first = (a.tile_base + (blockIdx.x - gl * a.tiles_per_group)) * 256;
+    const uint32_t list_begin = offsets[g], list_len = offsets[g + 1] - list_begin;
+    const uint32_t pb = grp_start[g], pe = grp_start[g + 1];
+    if (pb >= pe || first >= list_len) return;  // block-uniform
+    const uint32_t tid = threadIdx.x, lane = tid & 63, j = lane & 15, kb = lane >> 4;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {  // byte -> 8 fp6 fields (bit e -> 1.0 = 0b001000 at bits 6e .. 6e+5)
+        uint64_t f = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f |= (uint64_t)((tid >> e) & 1u) << (6 * e + 3);
+        lut[tid] = make_uint2((uint32_t)f, (uint32_t)(f >> 32));
+    }
+    const uint32_t wfirst = first + 64 * wave;  // this wave's 64 positions
+    // A rows: row i of sub-tile t = position 16 (i >> 2) + 4 t + (i & 3); this lane holds row j, dimensions 32 kb .. +31
+    // of every 128-dimension block
+    uint32_t craw[4][KB];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const uint32_t lp = wfirst + 16 * (j >> 2) + 4 * t + (j & 3);
+        const uint32_t *cp = codes + (uint64_t)(list_begin + (lp < list_len ? lp : 0)) * (2 * W);
+#pragma unroll
+        for (int m = 0; m < KB; ++m) craw[t][m] = cp[4 * m + kb];
+    }
+    // factors of this lane's rows (positions 16 kb + 4 t + r), as packed pairs (r = 0,1 | 2,3)
+    f32x2 cds2[4][2], ppc2[4][2], fip2[4][2], eb2[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+            const uint32_t lp = wfirst + 16 * kb + 4 * t + 2 * hp;
+            const float4 f0 = factors[list_begin + (lp < list_len ? lp : 0)];
+            const float4 f1 = factors[list_begin + (lp + 1 < list_len ? lp + 1 : 0)];
+            fip2[t][hp] = f32x2{f0.x, f1.x}, ppc2[t][hp] = f32x2{f0.y, f1.y};
+            eb2[t][hp] = f32x2{f0.z, f1.z}, cds2[t][hp] = f32x2{f0.w, f1.w};
+        }
+    __syncthreads();  // table visible
+    if (wfirst >= list_len) return;  // wave-uniform: nothing to score (after the barrier)
+    uint32_t aexp[4][KB][6];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int m = 0; m < KB; ++m) {
+            const uint32_t c = craw[t][m];
+            const uint2 p0 = lut[c & 0xFFu], p1 = lut[(c >> 8) & 0xFFu], p2 = lut[(c >> 16) & 0xFFu], p3 = lut[c >> 24];
+            aexp[t][m][0] = p0.x;
+            aexp[t][m][1] = p0.y | (p1.x << 16);
+            aexp[t][m][2] = (p1.x >> 16) | (p1.y << 16);
+            aexp[t][m][3] = p2.x;
+            aexp[t][m][4] = p2.y | (p3.x << 16);
+            aexp[t][m][5] = (p3.x >> 16) | (p3.y << 16);
+        }
+    // positions of this lane's 16 cells relative to the wave: 16 kb + b (b = 4 t + r)
+    const uint32_t lbase = wfirst + 16 * kb;
+
+    // one query tile: this lane's query (column j) -- operand fragments of its K block and the record tail
+    struct QTile {
+        uint32_t b[KB][6];
+        uint4 ta, tb, tc;  // lower delta sumq ycd | ycd_sqrt thr lo hi | row slot list_begin list_len
+    };
+    const uint32_t npairs = pe - pb, ntiles = (npairs + 15) / 16;
+    auto load_tile = [&](uint32_t qt, QTile &q) {
+        const uint32_t r = 16 * qt + j;
+        const uint32_t *rec = recs + (uint64_t)(pb + (r < npairs ? r : npairs - 1)) * STRIDE;
+#pragma unroll
+        for (int m = 0; m < KB; ++m) {
+            // dimensions 128 m + 32 kb .. +31 = slab 2m + (kb >> 1), half kb & 1 of the record's fp6 image
+            const uint32_t *src = rec + 6 * W * (kb & 1) + 6 * (2 * m + (kb >> 1));
+#pragma unroll
+            for (int e = 0; e < 6; e += 2) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(src + e);
+                q.b[m][e] = v.x, q.b[m][e + 1] = v.y;
+            }
+        }
+        q.ta = *reinterpret_cast<const uint4 *>(rec + OPDW);
+        q.tb = *reinterpret_cast<const uint4 *>(rec + OPDW + 4);
+        q.tc = *reinterpret_cast<const uint4 *>(rec + OPDW + 8);
+    };
+    auto f32_of = [](uint32_t v) { return __builtin_bit_cast(float, v); };
+    QTile cur, nxt;
+    load_tile(0, cur);
+    for (uint32_t qt = 0; qt < ntiles; ++qt) {
+        if (qt + 1 < ntiles) load_tile(qt + 1, nxt);  // in flight while this tile is scored
+        const bool qvalid = 16 * qt + j < npairs;
+        const float lower = f32_of(cur.ta.x), delta = f32_of(cur.ta.y), sumq = f32_of(cur.ta.z), ycd = f32_of(cur.ta.w);
+        const float ycd_sqrt = f32_of(cur.tb.x), thr = f32_of(cur.tb.y);
+        const uint32_t lo_p = cur.tb.z, hi_p = cur.tb.w;
+        // does this query's stage range touch the wave at all?  (wave-uniform skip when no query's does)
+        const bool touches = qvalid && hi_p > wfirst && lo_p < wfirst + 64;
+        if (__ballot(touches) == 0ull) {
+            cur = nxt;
+            continue;
+        }
+        const bool whole = lo_p <= wfirst && wfirst + 64 <= hi_p;  // every cell of this query is inside the stage
+        const bool ranged = __ballot(touches && !whole) != 0ull;   // wave-uniform: some query needs per-cell range tests
+        float rough[16];
+        uint32_t pbits = 0;  // bit b = 4 t + r: cell (position lbase + b, this query) passes the gate
+#pragma unroll
+        for (int t = 3; t >= 0; --t) {  // high bits first: pbits = 2 pbits + pass
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int m = 0; m < KB; ++m) {
+                const v8i32 av = {(int)aexp[t][m][0], (int)aexp[t][m][1], (int)aexp[t][m][2], (int)aexp[t][m][3],
+                                  (int)aexp[t][m][4], (int)aexp[t][m][5], 0, 0};
+                const v8i32 bv = {(int)cur.b[m][0], (int)cur.b[m][1], (int)cur.b[m][2], (int)cur.b[m][3],
+                                  (int)cur.b[m][4], (int)cur.b[m][5], 0, 0};
+                acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, acc, 2 /*A e2m3*/, 2 /*B e2m3*/, 0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int hp = 1; hp >= 0; --hp) {
+                // acc = s/2 exactly (q/2 in e2m3 times 0/1, f32 accumulate), so s as a float is acc + acc; then the
+                // reference's expression left to right, one rounding per op, both cells of the pair at once
+                const f32x2 half_s = {acc[2 * hp], acc[2 * hp + 1]};
+                const f32x2 sf = half_s + half_s;
+                f32x2 tt = cds2[t][hp] + ycd;
+                tt = tt + lower * ppc2[t][hp];
+                const f32x2 u = (2.0f * sf - sumq) * fip2[t][hp];
+                tt = tt + u * delta;
+                const f32x2 rg = tt - eb2[t][hp] * ycd_sqrt;
+                rough[4 * t + 2 * hp] = rg.x, rough[4 * t + 2 * hp + 1] = rg.y;
+                pbits = pbits + pbits + (rg.y < thr ? 1u : 0u);  // src/rerank.rs:84 gate
+                pbits = pbits + pbits + (rg.x < thr ? 1u : 0u);
+            }
+        }
+        if (!touches) pbits = 0;
+        if (ranged && !whole) {  // per-cell stage range (boundary tiles only)
+            uint32_t inr = 0;
+#pragma unroll
+            for (int b = 15; b >= 0; --b) inr = inr + inr + ((lbase + b >= lo_p && lbase + b < hi_p) ? 1u : 0u);
+            pbits &= inr;
+        }
+        if (a.dbg & 1024u) pbits = 0;  // timing ablation: no survivor is recorded (results are wrong)
+        if (__ballot(pbits != 0u) != 0ull) {
+            // the four lane groups' fields of this lane's query, in position order g = 0..3
+            const uint32_t p0 = (uint32_t)__shfl((int)pbits, (int)j, 64), p1 = (uint32_t)__shfl((int)pbits, (int)j + 16, 64);
+            const uint32_t p2 = (uint32_t)__shfl((int)pbits, (int)j + 32, 64), p3 = (uint32_t)__shfl((int)pbits, (int)j + 48, 64);
+            const uint32_t c0 = (uint32_t)__popc(p0), c1 = (uint32_t)__popc(p1), c2 = (uint32_t)__popc(p2), c3 = (uint32_t)__popc(p3);
+            const uint32_t total = c0 + c1 + c2 + c3;
+            const uint32_t before = (kb > 0 ? c0 : 0u) + (kb > 1 ? c1 : 0u) + (kb > 2 ? c2 : 0u);
+            const uint32_t row = cur.tc.x, slot = cur.tc.y;
+            // one reservation per query with survivors: 16 lanes (kb = 0) at once, one run of this wave's 64 positions each
+            unsigned long long old = 0;
+            if (kb == 0 && total) old = atomicAdd(surv_cnt + row, (1ull << 32) | total);
+            const uint32_t base = (uint32_t)__shfl((int)(uint32_t)old, (int)j, 64);
+            if (kb == 0 && total) {
+                const uint32_t rbase = (uint32_t)(old >> 32);
+                if (rbase < a.cap) {
+                    RunRec rr;
+                    rr.pos = list_begin + wfirst;
+                    rr.slot = slot;
+                    rr.base = (uint32_t)old;
+                    rr.cnt = total;
+                    runs[(uint64_t)row * a.cap + rbase] = rr;
+                }
+            }
+            SurvRec *out = surv + (uint64_t)row * a.cap;
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                if ((pbits >> b) & 1u) {
+                    const uint32_t at = base + before + (uint32_t)__popc(pbits & ((1u << b) - 1u));
+                    if (at < a.cap) {
+                        SurvRec r;
+                        r.pos = list_begin + lbase + b;
+                        r.slot = slot;
+                        r.rough = rough[b];
+                        r.accurate = 0.0f;
+                        out[at] = r;
+                    }
+                }
+            }
+        }
+        cur = nxt;
+    }
+}
+
 // generic-W fallback (dim/64 not in the templated set): code words re-read per query (L1-resident)
 __global__ __launch_bounds__(256) void scan_generic_kernel(SCAN_PARAMS, uint32_t W) {
     const uint32_t STRIDE = 8 * W + RQ_REC_TAIL;

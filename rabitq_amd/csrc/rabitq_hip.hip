@@ -428,6 +428,16 @@ static void launch_scan(const ScanPtrs &p, const ScanArgs &args, uint32_t W, hip
         }
     });
 }
+// dense matrix-core scan of the early cluster-major stages (scan_dense_kernel): dims 128 and 256
+static bool scan_has_dense(uint32_t W) { return W == 2 || W == 4; }
+static void launch_scan_dense(const ScanPtrs &p, const ScanArgs &args, uint32_t W, hipStream_t st) {
+    launch_scan_chunks(args, [&](const ScanArgs &a, dim3 g) {
+        const dim3 b(256);
+        if (W == 2) scan_dense_kernel<2><<<g, b, 0, st>>>(SCAN_ARGS);
+        else if (W == 4) scan_dense_kernel<4><<<g, b, 0, st>>>(SCAN_ARGS);
+    });
+}
+static std::atomic<int> g_scan_dense{1};  // 0 never, 1 auto (>= 8 queries per list on average), 2 every cluster-major VALU stage
 // scan implementation: 0 = auto (matrix cores when many queries share each list, VALU otherwise),
 // 1 = VALU (v_dot8_u32_u4) only, 2 = matrix cores wherever the kernel exists (test hook)
 static std::atomic<int> g_scan_impl{0};
@@ -794,6 +804,12 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         // kernel wins, measured at any batch size)
         const bool use_mfma = scan_has_mfma(W) && impl != 1 && (impl == 2 || (est_pairs >= 8ull * k && sg.s_lo >= avg_len));
         const bool cluster_major = use_mfma || (est_pairs >= k / 2 && est_pairs > 64);
+        // early stages of a large batch: a list meets ~16 queries and several per cent of its candidates pass, so
+        // every cell is evaluated exactly, with the dot products from 16x16x128 MFMAs (scan_dense_kernel)
+        const int dense_opt = g_scan_dense.load();
+        const bool use_dense = !use_mfma && cluster_major && scan_has_dense(W) && impl != 1 &&
+                               (dense_opt == 2 || (dense_opt == 1 && est_pairs >= 8ull * k));
+        const bool fp6_records = use_mfma || use_dense;
         pf.begin(PF_GROUP);
         ScanArgs a{};
         ScanPtrs sp{};
@@ -827,10 +843,10 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             a.ngroups = npairs;
         }
         // pack the stage's work records (query operand + scalars + current threshold + local range)
-        const uint32_t *operand = use_mfma ? ws.qf6.p
-                                           : (scan_is_fused(W) ? ws.qnib.p : reinterpret_cast<const uint32_t *>(ws.planes.p));
+        const uint32_t *operand = fp6_records ? ws.qf6.p
+                                              : (scan_is_fused(W) ? ws.qnib.p : reinterpret_cast<const uint32_t *>(ws.planes.p));
         stage_fill_kernel<<<ceil_div(stage_pairs, 16), 256, 0, st>>>(ws.scal.p, probe_cluster, operand, ws.thr.p, stage_pairs,
-                                                                nprobe, slot_hi, use_mfma ? 12 * W : 8 * W, sg.s_lo, sg.s_hi,
+                                                                nprobe, slot_hi, fp6_records ? 12 * W : 8 * W, sg.s_lo, sg.s_hi,
                                                                 a.cluster_major, ws.grp_start.p, ws.grp_cnt.p, ws.recs.p,
                                                                 idx->fstats, use_mfma ? 1u : 0u, ranked ? ws.pair_rank.p : nullptr,
                                                                 ws.rank_base.p, k);
@@ -847,12 +863,12 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         sp.stat = ws.stat.p;  // 64 x {sub-tile steps, exact-path steps} of the matrix-core scan (dbg & 128)
         a.cap = qp.cap;
         a.dbg = (uint32_t)g_scan_dbg.load();
-        const uint32_t stage_tile = use_mfma ? scan_mfma_tile(W) : tile;
+        const uint32_t stage_tile = use_mfma ? scan_mfma_tile(W) : (use_dense ? 256u : tile);
         a.tiles_per_group = ceil_div(std::min<uint64_t>(idx->max_list_len, sg.s_hi), stage_tile);
         sp.tile_table = nullptr;
         const uint64_t grid_blocks = (uint64_t)k * a.tiles_per_group, real_tiles = idx->n / stage_tile + k;
         const int tt_opt = g_scan_tile_table.load();  // 0 = never, 1 = when the plain grid is mostly empty blocks, 2 = always
-        if (cluster_major && scan_is_fused(W) && sg.s_hi >= idx->max_list_len &&
+        if (cluster_major && !use_dense && scan_is_fused(W) && sg.s_hi >= idx->max_list_len &&
             (tt_opt == 2 || (tt_opt == 1 && grid_blocks > 4 * real_tiles))) {
             // the stage reaches every position of the lists and the lists are very unequal (one block per existing
             // (list, tile) instead of k x the longest list's tiles; measured neutral-to-slower for moderately unequal
@@ -863,6 +879,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         }
         pf.begin(use_mfma ? PF_SCAN_MATRIX : PF_SCAN);
         if (use_mfma) launch_scan_mfma(sp, a, W, st);
+        else if (use_dense) launch_scan_dense(sp, a, W, st);
         else launch_scan(sp, a, W, st);
         pf.end();
         if (prof_acc) prof_acc->scan_launches++;
@@ -2554,6 +2571,11 @@ rq_status rq_set_option(const char *name, int value) {
     if (std::string(name) == "coarse_impl") {  // test hook: coarse-distance kernel (0 auto, 1 LDS broadcast, 2 scalar registers)
         if (value < 0 || value > 2) return fail(RQ_ERR_INVALID, "coarse_impl must be 0, 1 or 2");
         g_coarse_impl = value;
+        return RQ_OK;
+    }
+    if (std::string(name) == "scan_dense") {  // dense matrix-core scan of early cluster-major stages: 0 never, 1 auto, 2 always
+        if (value < 0 || value > 2) return fail(RQ_ERR_INVALID, "scan_dense must be 0, 1 or 2");
+        g_scan_dense = value;
         return RQ_OK;
     }
     if (std::string(name) == "group_rank") {  // test hook: how a cluster-major stage places its pairs (0 atomics per pair, 1 auto, 2 ranked)

@@ -624,6 +624,35 @@ def test_ranked_group_placement_matches_oracle(rq, oracle, impl):
     oidx.close()
 
 
+@pytest.mark.parametrize("d,n,k,nq", [(128, 30_000, 12, 300), (128, 9_000, 40, 70), (256, 12_000, 9, 131), (100, 5_000, 3, 33)])
+def test_dense_matrix_scan_matches_oracle(rq, oracle, d, n, k, nq):
+    """scan_dense_kernel (16x16x128 MFMA dot products, every cell evaluated exactly) is what the early cluster-major
+    stages of large batches use at dim 128 / 256.  Forced here for every cluster-major VALU stage: ragged list lengths
+    (not multiples of 16 / 64 / 256), query counts that are not multiples of 16, stage boundaries inside a wave's 64
+    positions, empty lists, both rankers, deep top-k (loose thresholds: most cells pass)."""
+    from rabitq_amd import index as ix
+    x, centres, _ = synth.mixture(n, d, k - 1, sigma=0.8, seed=d + n, centre_scale=0.6)
+    centres = np.concatenate([centres, np.full((1, d), 40.0, np.float32)])   # one list stays empty
+    P = synth.random_orthogonal((d + 63) // 64 * 64, seed=d + 1)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    gidx = rq.RaBitQ.build(x, centres, P)
+    queries, _, _ = synth.mixture(nq, d, k - 1, sigma=0.8, seed=d + n + 1, centre_scale=0.6)
+    queries[1] = x[5]
+    try:
+        ix.set_option("scan_dense", 2)
+        for probe, topk, heur in [(min(k, 8), 10, False), (k, 100, False), (2, 3, False), (min(k, 5), 10, True)]:
+            _compare_with_oracle(rq, oracle, oidx, gidx, queries, probe, topk, heur)
+        a = gidx.query_batch(queries, min(k, 8), 10, False)
+        ix.set_option("scan_dense", 0)
+        b = gidx.query_batch(queries, min(k, 8), 10, False)
+        for u, v in zip(a, b):
+            assert_bits_equal(u, v, "dense / VALU early stages")
+    finally:
+        ix.set_option("scan_dense", 1)
+    gidx.close()
+    oidx.close()
+
+
 def test_wide_vectors_dim_3072(rq, oracle):
     # dim in (2048, 4096]: assign_generic_kernel<8> needs > 64 KiB of dynamic LDS, so the attribute must be in
     # place before the FIRST build / quantize of a process (ensure_kernel_attributes); generic-W scan (W = 48)
