@@ -294,6 +294,9 @@ rq_status rq_set_profiling(int level);
  * distance is at or above the stage's threshold (then the reference rejects it whatever its value).  0 = never.
  * Results are bit-identical either way.
  * "max_scan_blocks": test hook, blocks per scan launch (0 = hardware bound).
+ * "scan_dense": 0 (default) / 1 / 2: use the dense matrix-core kernel (16x16x128 MFMA, every cell evaluated exactly) for
+ * the early cluster-major stages at dim 128 / 256: never / when a list meets >= 8 queries / always.  Identical results;
+ * off by default because it measured slower than the VALU kernel.
  * "coarse_impl": test hook, coarse-distance kernel: 0 = automatic (default), 1 = query rows through LDS, 2 = query
  * rows in scalar registers (what large batches use).
  * "group_rank": test hook, placement of a cluster-major stage's (query, list) pairs: 0 = one atomic per pair,

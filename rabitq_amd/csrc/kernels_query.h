@@ -1699,6 +1699,7 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
 // survivors, issued by 16 lanes at once.  Results are those of scan_kernel (same expression, same order).
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define RQ_DENSE_TILE 1024u  // list positions per block: each of the four waves streams 256 of them, 16 at a time
 
 template <int W>
 __global__ __launch_bounds__(256) void scan_dense_kernel(SCAN_PARAMS) {
@@ -1706,9 +1707,12 @@ __global__ __launch_bounds__(256) void scan_dense_kernel(SCAN_PARAMS) {
     constexpr int KB = W / 2;  // 128-dimension blocks
     constexpr uint32_t OPDW = 12 * W, STRIDE = OPDW + RQ_REC_TAIL;
     __shared__ __attribute__((aligned(16))) uint2 lut[256];
+    // each wave's 256 candidates, staged once by LDS-DMA: code words and factors
+    __shared__ __attribute__((aligned(16))) uint32_t codesL[4][256][2 * W];
+    __shared__ __attribute__((aligned(16))) float4 facL[4][256];
     const uint32_t gl = blockIdx.x / a.tiles_per_group;
     const uint32_t g = a.group_base + gl;
-    const uint32_t first = (a.tile_base + (blockIdx.x - gl * a.tiles_per_group)) * 256;
+    const uint32_t first = (a.tile_base + (blockIdx.x - gl * a.tiles_per_group)) * RQ_DENSE_TILE;
     const uint32_t list_begin = offsets[g], list_len = offsets[g + 1] - list_begin;
     const uint32_t pb = grp_start[g], pe = grp_start[g + 1];
     if (pb >= pe || first >= list_len) return;  // block-uniform
@@ -1720,57 +1724,38 @@ __global__ __launch_bounds__(256) void scan_dense_kernel(SCAN_PARAMS) {
         for (int e = 0; e < 8; ++e) f |= (uint64_t)((tid >> e) & 1u) << (6 * e + 3);
         lut[tid] = make_uint2((uint32_t)f, (uint32_t)(f >> 32));
     }
-    const uint32_t wfirst = first + 64 * wave;  // this wave's 64 positions
-    // A rows: row i of sub-tile t = position 16 (i >> 2) + 4 t + (i & 3); this lane holds row j, dimensions 32 kb .. +31
-    // of every 128-dimension block
-    uint32_t craw[4][KB];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const uint32_t lp = wfirst + 16 * (j >> 2) + 4 * t + (j & 3);
-        const uint32_t *cp = codes + (uint64_t)(list_begin + (lp < list_len ? lp : 0)) * (2 * W);
-#pragma unroll
-        for (int m = 0; m < KB; ++m) craw[t][m] = cp[4 * m + kb];
-    }
-    // factors of this lane's rows (positions 16 kb + 4 t + r), as packed pairs (r = 0,1 | 2,3)
-    f32x2 cds2[4][2], ppc2[4][2], fip2[4][2], eb2[4][2];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int hp = 0; hp < 2; ++hp) {
-            const uint32_t lp = wfirst + 16 * kb + 4 * t + 2 * hp;
-            const float4 f0 = factors[list_begin + (lp < list_len ? lp : 0)];
-            const float4 f1 = factors[list_begin + (lp + 1 < list_len ? lp + 1 : 0)];
-            fip2[t][hp] = f32x2{f0.x, f1.x}, ppc2[t][hp] = f32x2{f0.y, f1.y};
-            eb2[t][hp] = f32x2{f0.z, f1.z}, cds2[t][hp] = f32x2{f0.w, f1.w};
-        }
     __syncthreads();  // table visible
-    if (wfirst >= list_len) return;  // wave-uniform: nothing to score (after the barrier)
-    uint32_t aexp[4][KB][6];
+    const uint32_t wfirst = first + 256 * wave;  // this wave's 256 positions
+    if (wfirst >= list_len) return;              // wave-uniform (after the barrier)
+    const uint32_t wend = wfirst + 256 < list_len ? wfirst + 256 : list_len;
+    {  // stage the wave's candidates (positions past the list's end re-read its first member: never in a stage range)
+        constexpr uint32_t PPP = (2 * W) / 4;  // 16-byte pieces per code
+        const uint32_t cbase = lds_addr(&codesL[wave][0][0]), fbase = lds_addr(&facL[wave][0]);
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int m = 0; m < KB; ++m) {
-            const uint32_t c = craw[t][m];
-            const uint2 p0 = lut[c & 0xFFu], p1 = lut[(c >> 8) & 0xFFu], p2 = lut[(c >> 16) & 0xFFu], p3 = lut[c >> 24];
-            aexp[t][m][0] = p0.x;
-            aexp[t][m][1] = p0.y | (p1.x << 16);
-            aexp[t][m][2] = (p1.x >> 16) | (p1.y << 16);
-            aexp[t][m][3] = p2.x;
-            aexp[t][m][4] = p2.y | (p3.x << 16);
-            aexp[t][m][5] = (p3.x >> 16) | (p3.y << 16);
+        for (uint32_t i = 0; i < 4 * PPP; ++i) {
+            const uint32_t piece = i * 64 + lane, lp = wfirst + piece / PPP;
+            glds16(codes + (uint64_t)(list_begin + (lp < list_len ? lp : 0)) * (2 * W) + 4 * (piece % PPP), cbase + i * 1024);
         }
-    // positions of this lane's 16 cells relative to the wave: 16 kb + b (b = 4 t + r)
-    const uint32_t lbase = wfirst + 16 * kb;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) {
+            const uint32_t lp = wfirst + i * 64 + lane;
+            glds16(factors + list_begin + (lp < list_len ? lp : 0), fbase + i * 1024);
+        }
+    }
 
-    // one query tile: this lane's query (column j) -- operand fragments of its K block and the record tail
+    // ---- the queries (columns): two tiles of 16 resident per pass ----
     struct QTile {
-        uint32_t b[KB][6];
-        uint4 ta, tb, tc;  // lower delta sumq ycd | ycd_sqrt thr lo hi | row slot list_begin list_len
+        uint32_t b[KB][6];  // fp6 fragments of this lane's query (column j), K block kb
+        float lower, delta, sumq, ycd, ycd_sqrt, thr;
+        uint32_t lo, hi, row, slot;
+        bool valid;
     };
-    const uint32_t npairs = pe - pb, ntiles = (npairs + 15) / 16;
+    const uint32_t npairs = pe - pb;
+    auto f32_of = [](uint32_t v) { return __builtin_bit_cast(float, v); };
     auto load_tile = [&](uint32_t qt, QTile &q) {
         const uint32_t r = 16 * qt + j;
-        const uint32_t *rec = recs + (uint64_t)(pb + (r < npairs ? r : npairs - 1)) * STRIDE;
+        q.valid = r < npairs;
+        const uint32_t *rec = recs + (uint64_t)(pb + (q.valid ? r : npairs - 1)) * STRIDE;
 #pragma unroll
         for (int m = 0; m < KB; ++m) {
             // dimensions 128 m + 32 kb .. +31 = slab 2m + (kb >> 1), half kb & 1 of the record's fp6 image
@@ -1781,104 +1766,160 @@ __global__ __launch_bounds__(256) void scan_dense_kernel(SCAN_PARAMS) {
                 q.b[m][e] = v.x, q.b[m][e + 1] = v.y;
             }
         }
-        q.ta = *reinterpret_cast<const uint4 *>(rec + OPDW);
-        q.tb = *reinterpret_cast<const uint4 *>(rec + OPDW + 4);
-        q.tc = *reinterpret_cast<const uint4 *>(rec + OPDW + 8);
+        const uint4 ta = *reinterpret_cast<const uint4 *>(rec + OPDW);      // lower delta sumq ycd
+        const uint4 tb = *reinterpret_cast<const uint4 *>(rec + OPDW + 4);  // ycd_sqrt thr lo hi
+        const uint2 tc = *reinterpret_cast<const uint2 *>(rec + OPDW + 8);  // row slot
+        q.lower = f32_of(ta.x), q.delta = f32_of(ta.y), q.sumq = f32_of(ta.z), q.ycd = f32_of(ta.w);
+        q.ycd_sqrt = f32_of(tb.x), q.thr = f32_of(tb.y), q.lo = tb.z, q.hi = tb.w;
+        q.row = tc.x, q.slot = tc.y;
+        if (!q.valid) q.lo = 0, q.hi = 0;
     };
-    auto f32_of = [](uint32_t v) { return __builtin_bit_cast(float, v); };
-    QTile cur, nxt;
-    load_tile(0, cur);
-    for (uint32_t qt = 0; qt < ntiles; ++qt) {
-        if (qt + 1 < ntiles) load_tile(qt + 1, nxt);  // in flight while this tile is scored
-        const bool qvalid = 16 * qt + j < npairs;
-        const float lower = f32_of(cur.ta.x), delta = f32_of(cur.ta.y), sumq = f32_of(cur.ta.z), ycd = f32_of(cur.ta.w);
-        const float ycd_sqrt = f32_of(cur.tb.x), thr = f32_of(cur.tb.y);
-        const uint32_t lo_p = cur.tb.z, hi_p = cur.tb.w;
-        // does this query's stage range touch the wave at all?  (wave-uniform skip when no query's does)
-        const bool touches = qvalid && hi_p > wfirst && lo_p < wfirst + 64;
-        if (__ballot(touches) == 0ull) {
-            cur = nxt;
-            continue;
+    // ---- the candidates (rows), streamed 16 at a time: row 4g + r of sub-tile (grp, t) = position
+    //      wfirst + 64 grp + 16 g + 4 t + r.  A lane fetches, as an A-operand lane (row j), one code dword per K block,
+    //      and as an output lane (group kb) the factors of its four rows.
+    struct Sub {
+        uint32_t craw[KB];
+        float4 f[4];
+    };
+    auto load_sub = [&](uint32_t u, Sub &sd) {  // u = 4 grp + t, from the staged copy
+        const uint32_t base = 64 * (u >> 2) + 4 * (u & 3);
+#pragma unroll
+        for (int m = 0; m < KB; ++m) sd.craw[m] = codesL[wave][base + 16 * (j >> 2) + (j & 3)][4 * m + kb];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sd.f[r] = facL[wave][base + 16 * kb + r];
+    };
+    const uint32_t ngroups = (wend - wfirst + 63) / 64;  // groups of 64 positions in this wave's range
+    const uint32_t ntiles = (npairs + 15) / 16;
+
+    for (uint32_t qt0 = 0; qt0 < ntiles; qt0 += 2) {
+        QTile qa, qb;
+        load_tile(qt0, qa);
+        load_tile(qt0 + 1 < ntiles ? qt0 + 1 : qt0, qb);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged candidates (and these tiles) have landed
+        if (qt0 + 1 >= ntiles) qb.valid = false, qb.lo = 0, qb.hi = 0;
+        // groups of this wave some query of the pass reaches: [g_lo, g_hi) (wave-uniform)
+        uint32_t mn = qa.lo < qb.lo || qb.hi == 0 ? qa.lo : qb.lo, mx = qa.hi > qb.hi ? qa.hi : qb.hi;
+        if (qa.hi == 0) mn = qb.lo;
+        if (mx == 0) mn = 0xFFFFFFFFu;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const uint32_t omn = (uint32_t)__shfl_xor((int)mn, o, 64), omx = (uint32_t)__shfl_xor((int)mx, o, 64);
+            mn = omn < mn ? omn : mn, mx = omx > mx ? omx : mx;
         }
-        const bool whole = lo_p <= wfirst && wfirst + 64 <= hi_p;  // every cell of this query is inside the stage
-        const bool ranged = __ballot(touches && !whole) != 0ull;   // wave-uniform: some query needs per-cell range tests
-        float rough[16];
-        uint32_t pbits = 0;  // bit b = 4 t + r: cell (position lbase + b, this query) passes the gate
+        mn = __builtin_amdgcn_readfirstlane(mn), mx = __builtin_amdgcn_readfirstlane(mx);
+        if (mx <= wfirst || mn >= wend) continue;
+        const uint32_t g_lo = mn > wfirst ? (mn - wfirst) / 64 : 0u;
+        const uint32_t g_hi = mx < wend ? (mx - wfirst + 63) / 64 : ngroups;
+        for (uint32_t grp = g_lo; grp < g_hi; ++grp) {
+            const uint32_t gp = wfirst + 64 * grp;  // first position of the group
+            const uint32_t lbase = gp + 16 * kb;    // this lane's 16 cells: positions lbase + b, b = 4 t + r
+            float rough_a[16], rough_b[16];
+            uint32_t pa = 0, pbb = 0;  // pass bits of the two tiles
 #pragma unroll
-        for (int t = 3; t >= 0; --t) {  // high bits first: pbits = 2 pbits + pass
-            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int t = 0; t < 4; ++t) {
+                Sub cur;
+                load_sub(4 * grp + t, cur);
+                uint32_t aexp[KB][6];
 #pragma unroll
-            for (int m = 0; m < KB; ++m) {
-                const v8i32 av = {(int)aexp[t][m][0], (int)aexp[t][m][1], (int)aexp[t][m][2], (int)aexp[t][m][3],
-                                  (int)aexp[t][m][4], (int)aexp[t][m][5], 0, 0};
-                const v8i32 bv = {(int)cur.b[m][0], (int)cur.b[m][1], (int)cur.b[m][2], (int)cur.b[m][3],
-                                  (int)cur.b[m][4], (int)cur.b[m][5], 0, 0};
-                acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, acc, 2 /*A e2m3*/, 2 /*B e2m3*/, 0, 0, 0, 0);
-            }
-#pragma unroll
-            for (int hp = 1; hp >= 0; --hp) {
-                // acc = s/2 exactly (q/2 in e2m3 times 0/1, f32 accumulate), so s as a float is acc + acc; then the
-                // reference's expression left to right, one rounding per op, both cells of the pair at once
-                const f32x2 half_s = {acc[2 * hp], acc[2 * hp + 1]};
-                const f32x2 sf = half_s + half_s;
-                f32x2 tt = cds2[t][hp] + ycd;
-                tt = tt + lower * ppc2[t][hp];
-                const f32x2 u = (2.0f * sf - sumq) * fip2[t][hp];
-                tt = tt + u * delta;
-                const f32x2 rg = tt - eb2[t][hp] * ycd_sqrt;
-                rough[4 * t + 2 * hp] = rg.x, rough[4 * t + 2 * hp + 1] = rg.y;
-                pbits = pbits + pbits + (rg.y < thr ? 1u : 0u);  // src/rerank.rs:84 gate
-                pbits = pbits + pbits + (rg.x < thr ? 1u : 0u);
-            }
-        }
-        if (!touches) pbits = 0;
-        if (ranged && !whole) {  // per-cell stage range (boundary tiles only)
-            uint32_t inr = 0;
-#pragma unroll
-            for (int b = 15; b >= 0; --b) inr = inr + inr + ((lbase + b >= lo_p && lbase + b < hi_p) ? 1u : 0u);
-            pbits &= inr;
-        }
-        if (a.dbg & 1024u) pbits = 0;  // timing ablation: no survivor is recorded (results are wrong)
-        if (__ballot(pbits != 0u) != 0ull) {
-            // the four lane groups' fields of this lane's query, in position order g = 0..3
-            const uint32_t p0 = (uint32_t)__shfl((int)pbits, (int)j, 64), p1 = (uint32_t)__shfl((int)pbits, (int)j + 16, 64);
-            const uint32_t p2 = (uint32_t)__shfl((int)pbits, (int)j + 32, 64), p3 = (uint32_t)__shfl((int)pbits, (int)j + 48, 64);
-            const uint32_t c0 = (uint32_t)__popc(p0), c1 = (uint32_t)__popc(p1), c2 = (uint32_t)__popc(p2), c3 = (uint32_t)__popc(p3);
-            const uint32_t total = c0 + c1 + c2 + c3;
-            const uint32_t before = (kb > 0 ? c0 : 0u) + (kb > 1 ? c1 : 0u) + (kb > 2 ? c2 : 0u);
-            const uint32_t row = cur.tc.x, slot = cur.tc.y;
-            // one reservation per query with survivors: 16 lanes (kb = 0) at once, one run of this wave's 64 positions each
-            unsigned long long old = 0;
-            if (kb == 0 && total) old = atomicAdd(surv_cnt + row, (1ull << 32) | total);
-            const uint32_t base = (uint32_t)__shfl((int)(uint32_t)old, (int)j, 64);
-            if (kb == 0 && total) {
-                const uint32_t rbase = (uint32_t)(old >> 32);
-                if (rbase < a.cap) {
-                    RunRec rr;
-                    rr.pos = list_begin + wfirst;
-                    rr.slot = slot;
-                    rr.base = (uint32_t)old;
-                    rr.cnt = total;
-                    runs[(uint64_t)row * a.cap + rbase] = rr;
+                for (int m = 0; m < KB; ++m) {
+                    const uint32_t c = cur.craw[m];
+                    const uint2 p0 = lut[c & 0xFFu], p1 = lut[(c >> 8) & 0xFFu], p2 = lut[(c >> 16) & 0xFFu], p3 = lut[c >> 24];
+                    aexp[m][0] = p0.x;
+                    aexp[m][1] = p0.y | (p1.x << 16);
+                    aexp[m][2] = (p1.x >> 16) | (p1.y << 16);
+                    aexp[m][3] = p2.x;
+                    aexp[m][4] = p2.y | (p3.x << 16);
+                    aexp[m][5] = (p3.x >> 16) | (p3.y << 16);
                 }
-            }
-            SurvRec *out = surv + (uint64_t)row * a.cap;
+                const f32x2 fip01 = {cur.f[0].x, cur.f[1].x}, fip23 = {cur.f[2].x, cur.f[3].x};
+                const f32x2 ppc01 = {cur.f[0].y, cur.f[1].y}, ppc23 = {cur.f[2].y, cur.f[3].y};
+                const f32x2 eb01 = {cur.f[0].z, cur.f[1].z}, eb23 = {cur.f[2].z, cur.f[3].z};
+                const f32x2 cds01 = {cur.f[0].w, cur.f[1].w}, cds23 = {cur.f[2].w, cur.f[3].w};
+                auto score = [&](const QTile &q, float *rough, uint32_t &pbits) {
+                    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                if ((pbits >> b) & 1u) {
-                    const uint32_t at = base + before + (uint32_t)__popc(pbits & ((1u << b) - 1u));
-                    if (at < a.cap) {
-                        SurvRec r;
-                        r.pos = list_begin + lbase + b;
-                        r.slot = slot;
-                        r.rough = rough[b];
-                        r.accurate = 0.0f;
-                        out[at] = r;
+                    for (int m = 0; m < KB; ++m) {
+                        const v8i32 av = {(int)aexp[m][0], (int)aexp[m][1], (int)aexp[m][2], (int)aexp[m][3],
+                                          (int)aexp[m][4], (int)aexp[m][5], 0, 0};
+                        const v8i32 bv = {(int)q.b[m][0], (int)q.b[m][1], (int)q.b[m][2], (int)q.b[m][3],
+                                          (int)q.b[m][4], (int)q.b[m][5], 0, 0};
+                        acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, acc, 2 /*A e2m3*/, 2 /*B e2m3*/, 0, 0, 0, 0);
+                    }
+                    // acc = s/2 exactly (q/2 in e2m3 times 0/1, f32 accumulate), so s as a float is acc + acc; then the
+                    // reference's expression left to right, one rounding per op, two cells per packed instruction
+                    const f32x2 h01 = {acc[0], acc[1]}, h23 = {acc[2], acc[3]};
+                    const f32x2 s01 = h01 + h01, s23 = h23 + h23;
+                    f32x2 t01 = cds01 + q.ycd, t23 = cds23 + q.ycd;
+                    t01 = t01 + q.lower * ppc01, t23 = t23 + q.lower * ppc23;
+                    const f32x2 u01 = (2.0f * s01 - q.sumq) * fip01, u23 = (2.0f * s23 - q.sumq) * fip23;
+                    t01 = t01 + u01 * q.delta, t23 = t23 + u23 * q.delta;
+                    const f32x2 r01 = t01 - eb01 * q.ycd_sqrt, r23 = t23 - eb23 * q.ycd_sqrt;
+                    rough[4 * t] = r01.x, rough[4 * t + 1] = r01.y, rough[4 * t + 2] = r23.x, rough[4 * t + 3] = r23.y;
+                    uint32_t n = r23.y < q.thr ? 1u : 0u;  // src/rerank.rs:84 gate, bits r = 3..0
+                    n = n + n + (r23.x < q.thr ? 1u : 0u);
+                    n = n + n + (r01.y < q.thr ? 1u : 0u);
+                    n = n + n + (r01.x < q.thr ? 1u : 0u);
+                    pbits |= n << (4 * t);
+                };
+                score(qa, rough_a, pa);
+                score(qb, rough_b, pbb);
+            }
+            // stage ranges: a cell counts only if its position is inside its query's [lo, hi)
+            auto clip = [&](const QTile &q, uint32_t &pbits) {
+                if (q.hi <= gp || q.lo >= gp + 64) {
+                    pbits = 0;
+                } else if (!(q.lo <= gp && gp + 64 <= q.hi)) {  // boundary group of this query
+                    uint32_t inr = 0;
+#pragma unroll
+                    for (int b = 15; b >= 0; --b) inr = inr + inr + ((lbase + b >= q.lo && lbase + b < q.hi) ? 1u : 0u);
+                    pbits &= inr;
+                }
+            };
+            clip(qa, pa);
+            clip(qb, pbb);
+            if (a.dbg & 1024u) pa = 0, pbb = 0;  // timing ablation: no survivor is recorded (results are wrong)
+            auto emit = [&](const QTile &q, const float *rough, uint32_t pbits) {
+                if (__ballot(pbits != 0u) == 0ull) return;
+                // the four lane groups' fields of this lane's query, in position order g = 0..3
+                const uint32_t p0 = (uint32_t)__shfl((int)pbits, (int)j, 64), p1 = (uint32_t)__shfl((int)pbits, (int)j + 16, 64);
+                const uint32_t p2 = (uint32_t)__shfl((int)pbits, (int)j + 32, 64), p3 = (uint32_t)__shfl((int)pbits, (int)j + 48, 64);
+                const uint32_t c0 = (uint32_t)__popc(p0), c1 = (uint32_t)__popc(p1), c2 = (uint32_t)__popc(p2), c3 = (uint32_t)__popc(p3);
+                const uint32_t total = c0 + c1 + c2 + c3;
+                const uint32_t before = (kb > 0 ? c0 : 0u) + (kb > 1 ? c1 : 0u) + (kb > 2 ? c2 : 0u);
+                // one reservation per query with survivors: 16 lanes (kb = 0) at once, one run of this group's 64 positions each
+                unsigned long long old = 0;
+                if (kb == 0 && total) old = atomicAdd(surv_cnt + q.row, (1ull << 32) | total);
+                const uint32_t base = (uint32_t)__shfl((int)(uint32_t)old, (int)j, 64);
+                if (kb == 0 && total) {
+                    const uint32_t rbase = (uint32_t)(old >> 32);
+                    if (rbase < a.cap) {
+                        RunRec rr;
+                        rr.pos = list_begin + gp;
+                        rr.slot = q.slot;
+                        rr.base = (uint32_t)old;
+                        rr.cnt = total;
+                        runs[(uint64_t)q.row * a.cap + rbase] = rr;
                     }
                 }
-            }
+                SurvRec *out = surv + (uint64_t)q.row * a.cap;
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    if ((pbits >> b) & 1u) {
+                        const uint32_t at = base + before + (uint32_t)__popc(pbits & ((1u << b) - 1u));
+                        if (at < a.cap) {
+                            SurvRec r;
+                            r.pos = list_begin + lbase + b;
+                            r.slot = q.slot;
+                            r.rough = rough[b];
+                            r.accurate = 0.0f;
+                            out[at] = r;
+                        }
+                    }
+                }
+            };
+            emit(qa, rough_a, pa);
+            emit(qb, rough_b, pbb);
         }
-        cur = nxt;
     }
 }
 

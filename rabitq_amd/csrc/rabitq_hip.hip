@@ -437,7 +437,9 @@ static void launch_scan_dense(const ScanPtrs &p, const ScanArgs &args, uint32_t 
         else if (W == 4) scan_dense_kernel<4><<<g, b, 0, st>>>(SCAN_ARGS);
     });
 }
-static std::atomic<int> g_scan_dense{1};  // 0 never, 1 auto (>= 8 queries per list on average), 2 every cluster-major VALU stage
+// 0 never (default: measured slower than the VALU kernel), 1 when a list meets >= 8 queries on
+// average, 2 every cluster-major VALU stage (tests)
+static std::atomic<int> g_scan_dense{0};
 // scan implementation: 0 = auto (matrix cores when many queries share each list, VALU otherwise),
 // 1 = VALU (v_dot8_u32_u4) only, 2 = matrix cores wherever the kernel exists (test hook)
 static std::atomic<int> g_scan_impl{0};
@@ -863,7 +865,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         sp.stat = ws.stat.p;  // 64 x {sub-tile steps, exact-path steps} of the matrix-core scan (dbg & 128)
         a.cap = qp.cap;
         a.dbg = (uint32_t)g_scan_dbg.load();
-        const uint32_t stage_tile = use_mfma ? scan_mfma_tile(W) : (use_dense ? 256u : tile);
+        const uint32_t stage_tile = use_mfma ? scan_mfma_tile(W) : (use_dense ? RQ_DENSE_TILE : tile);
         a.tiles_per_group = ceil_div(std::min<uint64_t>(idx->max_list_len, sg.s_hi), stage_tile);
         sp.tile_table = nullptr;
         const uint64_t grid_blocks = (uint64_t)k * a.tiles_per_group, real_tiles = idx->n / stage_tile + k;

@@ -62,7 +62,7 @@ for it in range(rounds):
                 raise
     ix.set_option("scan_impl", 0)
     ix.set_option("base_device_mb", -1), ix.set_option("max_scan_blocks", 0), ix.set_option("scan_tile_table", 1)
-    ix.set_option("group_rank", 1), ix.set_option("rerank_shadow", 1), ix.set_option("coarse_impl", 0), ix.set_option("scan_dense", 1)
+    ix.set_option("group_rank", 1), ix.set_option("rerank_shadow", 1), ix.set_option("coarse_impl", 0), ix.set_option("scan_dense", 0)
     gidx.close()
     oidx.close()
     print(f"[{it + 1}/{rounds}] n={n} d={d} k={k} nq={nq} impl={impl} knobs={list(knobs.values())} cfgs={cfgs} ok  ({time.time() - t0:.0f}s)", flush=True)

@@ -626,8 +626,9 @@ def test_ranked_group_placement_matches_oracle(rq, oracle, impl):
 
 @pytest.mark.parametrize("d,n,k,nq", [(128, 30_000, 12, 300), (128, 9_000, 40, 70), (256, 12_000, 9, 131), (100, 5_000, 3, 33)])
 def test_dense_matrix_scan_matches_oracle(rq, oracle, d, n, k, nq):
-    """scan_dense_kernel (16x16x128 MFMA dot products, every cell evaluated exactly) is what the early cluster-major
-    stages of large batches use at dim 128 / 256.  Forced here for every cluster-major VALU stage: ragged list lengths
+    """scan_dense_kernel (16x16x128 MFMA dot products, every cell evaluated exactly): an alternative to the VALU kernel
+    for the early cluster-major stages at dim 128 / 256 (off by default: measured slower).  Forced
+    here for every cluster-major VALU stage: ragged list lengths
     (not multiples of 16 / 64 / 256), query counts that are not multiples of 16, stage boundaries inside a wave's 64
     positions, empty lists, both rankers, deep top-k (loose thresholds: most cells pass)."""
     from rabitq_amd import index as ix
@@ -648,7 +649,7 @@ def test_dense_matrix_scan_matches_oracle(rq, oracle, d, n, k, nq):
         for u, v in zip(a, b):
             assert_bits_equal(u, v, "dense / VALU early stages")
     finally:
-        ix.set_option("scan_dense", 1)
+        ix.set_option("scan_dense", 0)
     gidx.close()
     oidx.close()
 
