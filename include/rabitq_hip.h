@@ -299,6 +299,8 @@ rq_status rq_set_profiling(int level);
  * off by default because it measured slower than the VALU kernel.
  * "coarse_impl": test hook, coarse-distance kernel: 0 = automatic (default), 1 = query rows through LDS, 2 = query
  * rows in scalar registers (what large batches use).
+ * "dense_dir": test hook, 1 (default) = the VALU stages of large batches write their survivor runs into a directory
+ * indexed by stream position (nothing to sort), 0 = runs are appended and the directory is sorted.
  * "group_rank": test hook, placement of a cluster-major stage's (query, list) pairs: 0 = one atomic per pair,
  * 1 = automatic (default: per-block LDS histograms for big stages), 2 = histograms whenever they fit.
  * Developer knobs: "stage_growth" (geometric growth of the early stages, 0 = default; results are

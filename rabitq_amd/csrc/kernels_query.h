@@ -781,6 +781,7 @@ __global__ __launch_bounds__(1024) void group_rank_kernel(const PairScalars *__r
 #define RQ_REC_LIST_BEGIN 10
 #define RQ_REC_LIST_LEN 11
 #define RQ_REC_V0 12         // 8 dwords: per-query bf16 operand of the integer threshold S*(c,q) = sum_r u'_c[r] * v'_q[r]
+#define RQ_REC_CELL0 12      // record-major (VALU) records only: directory cell of this pair's list position 0 (dense directories)
 #define RQ_REC_TAIL 20
 
 // exclusive scan of cnt[0..k) into start[0..k]; single block, any k.  Also zeroes cnt for the
@@ -956,6 +957,11 @@ __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__re
         t[RQ_REC_V0 + 5] = vl[2] | (vh[3] << 16);
         t[RQ_REC_V0 + 6] = vh[3] | (vl[3] << 16);
         t[RQ_REC_V0 + 7] = c2;
+        // Dense run directory of a VALU stage: list position p of this pair lives in cell CELL0 + p / 64.  Cells follow
+        // the stream: floor(stream_begin / 64) + 2 slot + 1 - floor(s_lo / 64) leaves every list its own cells (the two
+        // spare cells per slot absorb the roundings of stream_begin and of the list's length) and never goes negative
+        // for a position inside the stage.
+        if (!tile_images) t[RQ_REC_CELL0] = (ps.stream_begin >> 6) + 2u * (p - ps.row * nprobe) + 1u - (s_lo >> 6);
         static_assert(RQ_REC_TAIL == 20, "five 16-byte pieces");
         uint4 piece = make_uint4(t[0], t[1], t[2], t[3]);  // 16-byte aligned in both layouts
 #pragma unroll
@@ -990,6 +996,10 @@ struct ScanArgs {   // scalars only; pointers are explicit __restrict__ kernel p
     // unbalanced lists launch no empty blocks, and the list's bounds arrive with the entry instead of a second
     // dependent load); ngroups then counts table entries and tiles_per_group is 1
     uint32_t use_table;
+    // dense_dir: the stage's run descriptors go to a directory indexed by stream position (cell = the record's
+    // RQ_REC_CELL0 + list position / 64: already in the reference's visiting order, nothing to sort) instead of being
+    // appended in completion order
+    uint32_t dense_dir;
 };
 struct ScanPtrs {   // host-side bundle only
     const uint32_t *codes;        // n * 2W dwords (x_binary_vec, src/rabitq.rs:66)
@@ -1178,13 +1188,15 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
                         out[at] = r;
                     }
                 }
-                if (cntc && lane == 0 && rbase < a.cap) {
+                // the run's descriptor: appended (sorted later), or straight into its cell of the dense directory
+                const uint32_t dcell = a.dense_dir ? t[RQ_REC_CELL0] + ((first + c * 256 + (threadIdx.x & ~63u)) >> 6) : rbase;
+                if (cntc && lane == 0 && dcell < a.cap) {
                     RunRec rr;
                     rr.pos = list_begin + first + c * 256 + (threadIdx.x & ~63u);
                     rr.slot = slot;
                     rr.base = base;
                     rr.cnt = cntc;
-                    runs[(uint64_t)b * a.cap + rbase] = rr;
+                    runs[(uint64_t)b * a.cap + dcell] = rr;
                 }
                 base += cntc;
                 rbase += cntc ? 1u : 0u;
@@ -2648,7 +2660,7 @@ __global__ __launch_bounds__(256) void sort_runs_mid_kernel(RunRec *__restrict__
 template <bool HEURISTIC>
 __global__ __launch_bounds__(64) void replay_kernel(const SurvRec *__restrict__ surv, const RunRec *__restrict__ runs,
                                                     unsigned long long *__restrict__ surv_cnt, uint32_t cap, uint32_t topk,
-                                                    ReplayState st) {
+                                                    ReplayState st, uint32_t dense_cells) {
     extern __shared__ __attribute__((aligned(16))) unsigned char replay_smem[];  // topk * 8 bytes (heap ranker)
     int32_t *hkey = reinterpret_cast<int32_t *>(replay_smem);
     uint32_t *hid = reinterpret_cast<uint32_t *>(replay_smem) + topk;
@@ -2657,7 +2669,8 @@ __global__ __launch_bounds__(64) void replay_kernel(const SurvRec *__restrict__ 
     const uint32_t cnt = (uint32_t)cnt64;
     const bool overflow = cnt > cap;
     const uint32_t n = overflow ? 0 : cnt;
-    const uint32_t nruns = overflow ? 0 : (uint32_t)(cnt64 >> 32);
+    // dense directory: every cell of the stage is a descriptor (count 0 where nothing survived), already in order
+    const uint32_t nruns = overflow ? 0 : (dense_cells ? dense_cells : (uint32_t)(cnt64 >> 32));
     if (threadIdx.x == 0) {
         if (cnt > st.need[b]) st.need[b] = cnt;
         st.nsurv[b] += n;
@@ -2665,6 +2678,16 @@ __global__ __launch_bounds__(64) void replay_kernel(const SurvRec *__restrict__ 
     }
     if (n == 0) return;
     replay_wave<HEURISTIC>(surv + (uint64_t)b * cap, runs + (uint64_t)b * cap, nruns, topk, b, st, hkey, hid);
+}
+
+// dense run directory of a stage: cells [0, ncells) of every query start empty
+__global__ void clear_dir_kernel(RunRec *__restrict__ runs, uint32_t nq, uint32_t cap, uint32_t ncells) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)nq * ncells) return;
+    const uint32_t b = (uint32_t)(i / ncells), c = (uint32_t)(i - (uint64_t)b * ncells);
+    RunRec z;
+    z.pos = 0, z.slot = 0, z.base = 0, z.cnt = 0;
+    runs[(uint64_t)b * cap + c] = z;
 }
 
 // ranker state of a fresh query (src/rerank.rs:70-77, :129-139) + per-query counters, one launch

@@ -447,6 +447,7 @@ static std::atomic<int> g_scan_dbg{0};
 static std::atomic<int> g_stage_growth{0};  // 0 = default schedule
 static std::atomic<int> g_scan_tile_table{1};  // 0 = plain (list x tile) grids everywhere (test / measurement hook)
 static std::atomic<int> g_group_rank{1};  // group_rank_kernel for cluster-major stages: 0 never, 1 big stages, 2 always
+static std::atomic<int> g_dense_dir{1};  // dense run directories for the VALU stages of large batches (0 = always append + sort: test hook)
 
 // matrix-core scan instantiations: W = dim/64, NT = 32-candidate sub-tiles per wave (resident operand registers
 // 6*W*NT), blocks per CU per scan_mfma_blocks_per_cu<W>()
@@ -879,6 +880,19 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             sp.tile_table = get_tile_table(idx, stage_tile, &count);
             if (sp.tile_table) a.use_table = 1u, a.ngroups = count, a.tiles_per_group = 1u;
         }
+        // large batches, VALU-kernel stages: the run descriptors go into a dense directory indexed by stream position
+        // (stage_fill_kernel: RQ_REC_CELL0), so the stage needs no sort of its run directory
+        uint32_t dense_cells = 0;
+        if (nq >= 256 && !use_mfma && !use_dense && scan_is_fused(W) && g_dense_dir.load() && sg.s_hi != 0xFFFFFFFFu) {
+            const uint64_t cells = (uint64_t)((sg.s_hi - 1) >> 6) - (sg.s_lo >> 6) + 2ull * slot_hi + 2;
+            if (cells <= qp.cap) dense_cells = (uint32_t)cells;
+        }
+        a.dense_dir = dense_cells ? 1u : 0u;
+        if (dense_cells) {
+            pf.begin(PF_SORT);
+            clear_dir_kernel<<<ceil_div((uint64_t)nq * dense_cells, 256), 256, 0, st>>>(ws.runs.p, nq, qp.cap, dense_cells);
+            pf.end();
+        }
         pf.begin(use_mfma ? PF_SCAN_MATRIX : PF_SCAN);
         if (use_mfma) launch_scan_mfma(sp, a, W, st);
         else if (use_dense) launch_scan_dense(sp, a, W, st);
@@ -920,17 +934,19 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                 accurate_kernel<<<dim3(gx, nq), 256, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.surv_cnt.p, qp.cap, idx->view(), qpad, dim,
                                                                                         rerank_order, probe_cluster, nprobe);
             pf.end();
-            pf.begin(PF_SORT);
-            sort_runs_kernel<<<nq, 64, 0, st>>>(ws.runs.p, ws.surv_cnt.p, qp.cap, ws.big_list.p, ws.big_list.p + nq, 512u);
-            // queries with long run directories (loose thresholds): slot-bucketed ordering, persistent blocks walking the list
-            sort_runs_mid_kernel<<<mid_blocks, 256, 0, st>>>(ws.runs.p, ws.use_runs_tmp ? ws.runs_tmp.p : nullptr, ws.surv_cnt.p, qp.cap, ws.big_list.p,
-                                                         ws.big_list.p + nq, nprobe);
-            pf.end();
+            if (!dense_cells) {
+                pf.begin(PF_SORT);
+                sort_runs_kernel<<<nq, 64, 0, st>>>(ws.runs.p, ws.surv_cnt.p, qp.cap, ws.big_list.p, ws.big_list.p + nq, 512u);
+                // queries with long run directories (loose thresholds): slot-bucketed ordering, persistent blocks walking the list
+                sort_runs_mid_kernel<<<mid_blocks, 256, 0, st>>>(ws.runs.p, ws.use_runs_tmp ? ws.runs_tmp.p : nullptr, ws.surv_cnt.p, qp.cap, ws.big_list.p,
+                                                             ws.big_list.p + nq, nprobe);
+                pf.end();
+            }
             pf.begin(PF_REPLAY);
             if (qp.heuristic)
-                replay_kernel<true><<<nq, 64, 16, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, topk, rs);
+                replay_kernel<true><<<nq, 64, 16, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, topk, rs, dense_cells);
             else
-                replay_kernel<false><<<nq, 64, (size_t)topk * 8, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, topk, rs);
+                replay_kernel<false><<<nq, 64, (size_t)topk * 8, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, topk, rs, dense_cells);
             pf.end();
         }
     }
@@ -2578,6 +2594,11 @@ rq_status rq_set_option(const char *name, int value) {
     if (std::string(name) == "scan_dense") {  // dense matrix-core scan of early cluster-major stages: 0 never, 1 auto, 2 always
         if (value < 0 || value > 2) return fail(RQ_ERR_INVALID, "scan_dense must be 0, 1 or 2");
         g_scan_dense = value;
+        return RQ_OK;
+    }
+    if (std::string(name) == "dense_dir") {  // test hook: 0 = run descriptors always appended and sorted, 1 = dense directories where they fit
+        if (value < 0 || value > 1) return fail(RQ_ERR_INVALID, "dense_dir must be 0 or 1");
+        g_dense_dir = value;
         return RQ_OK;
     }
     if (std::string(name) == "group_rank") {  // test hook: how a cluster-major stage places its pairs (0 atomics per pair, 1 auto, 2 ranked)

@@ -1021,10 +1021,14 @@ def test_streamed_builder_equals_one_shot_build(rq, oracle, d, budget):
     oidx.close()
 
 
-def test_long_run_directories_large_batch(rq, oracle):
-    """Loose thresholds (deep top-k, one long list) leave more than 512 survivor runs per query in a large batch:
-    the directories are ordered by the slot-bucketed rank sort (sort_runs_mid_kernel), several stages in a row."""
+@pytest.mark.parametrize("dense_dir", [0, 1])
+def test_long_run_directories_large_batch(rq, oracle, dense_dir):
+    """Loose thresholds (deep top-k, one long list) leave more than 512 survivor runs per query in a large batch.
+    dense_dir = 0: runs are appended and the directories ordered by the slot-bucketed rank sort (sort_runs_mid_kernel),
+    several stages in a row; dense_dir = 1 (default): the VALU stages write their runs into directories indexed by
+    stream position (stage_fill_kernel: RQ_REC_CELL0) and nothing is sorted."""
     from rabitq_amd import index as ix
+    ix.set_option("dense_dir", dense_dir)
     n, d, k = 200_000, 64, 2
     rng = np.random.default_rng(15)
     centres = np.stack([np.zeros(d, np.float32), np.full(d, 5.0, np.float32)])
@@ -1042,6 +1046,7 @@ def test_long_run_directories_large_batch(rq, oracle):
     assert pr["retries"] == 0 and pr["rerank_candidates"] / 260 > 4096, (pr["retries"], pr["rerank_candidates"] / 260)
     _compare_with_oracle(rq, oracle, oidx, gidx, queries, 1, 100, False)
     _compare_with_oracle(rq, oracle, oidx, gidx, queries, 2, 50, True)
+    ix.set_option("dense_dir", 1)
     gidx.close()
     oidx.close()
 
