@@ -2191,7 +2191,7 @@ struct ReplayState {
 #define RQ_MAX_TOPK 2048
 
 // One wave replays a query's survivors (run directory `dir`, records `recs`) through the ranker.
-template <bool HEURISTIC>
+template <bool HEURISTIC, bool REGHEAP = false>
 __device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, const RunRec *__restrict__ dir,
                                             uint32_t nruns, uint32_t topk,
                                             uint32_t b, const ReplayState &st, int32_t *hkey, uint32_t *hid) {
@@ -2200,11 +2200,37 @@ __device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, co
     uint32_t precise = 0;
     uint32_t hlen = 0, wcount = 0, alen = 0;
     float recent = 0.0f;
+    // REGHEAP (topk <= 64): the heap lives in one register pair, element i in lane i, read and written with
+    // v_readlane / a lane-select at wave-uniform indices: a sift step is a few scalar instructions instead of a chain of
+    // dependent LDS round trips (the replay of a stage was bound by exactly that latency)
+    int32_t rk = 0;
+    uint32_t ri = 0;
+    auto HK = [&](uint32_t idx) -> int32_t {
+        if constexpr (REGHEAP) return __builtin_amdgcn_readlane(rk, (int)idx);
+        else return hkey[idx];
+    };
+    auto HI = [&](uint32_t idx) -> uint32_t {
+        if constexpr (REGHEAP) return (uint32_t)__builtin_amdgcn_readlane((int)ri, (int)idx);
+        else return hid[idx];
+    };
+    auto SETH = [&](uint32_t idx, int32_t k, uint32_t i) {
+        if constexpr (REGHEAP) {
+            rk = lane == idx ? k : rk;  // (no writelane builtin in this toolchain: a compare and two selects)
+            ri = lane == idx ? i : ri;
+        } else {
+            hkey[idx] = k, hid[idx] = i;
+        }
+    };
     if constexpr (!HEURISTIC) {
         hlen = st.heap_len[b];
-        for (uint32_t i = lane; i < hlen; i += 64) {
-            hkey[i] = st.heap_key[(uint64_t)b * topk + i];
-            hid[i] = st.heap_id[(uint64_t)b * topk + i];
+        if constexpr (REGHEAP) {
+            hlen = __builtin_amdgcn_readfirstlane(hlen);
+            if (lane < hlen) rk = st.heap_key[(uint64_t)b * topk + lane], ri = st.heap_id[(uint64_t)b * topk + lane];
+        } else {
+            for (uint32_t i = lane; i < hlen; i += 64) {
+                hkey[i] = st.heap_key[(uint64_t)b * topk + i];
+                hid[i] = st.heap_id[(uint64_t)b * topk + i];
+            }
         }
     } else {
         recent = st.recent_max[b];
@@ -2268,50 +2294,55 @@ __device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, co
             if constexpr (!HEURISTIC) {
                 // push: append + sift_up(0, old_len)
                 int32_t key = ord32_from_f32(acc);
+                uint32_t idv = id;
+                if constexpr (REGHEAP) {  // every lane holds the same values: keep them (and the control flow) scalar
+                    key = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)key);
+                    idv = __builtin_amdgcn_readfirstlane(idv);
+                }
                 uint32_t p = hlen++;
                 while (p > 0) {
                     uint32_t parent = (p - 1) >> 1;
-                    int32_t pk = hkey[parent];
+                    int32_t pk = HK(parent);
                     if (key <= pk) break;
-                    uint32_t pid = hid[parent];
-                    hkey[p] = pk, hid[p] = pid;
+                    uint32_t pid = HI(parent);
+                    SETH(p, pk, pid);
                     p = parent;
                 }
-                hkey[p] = key, hid[p] = id;
+                SETH(p, key, idv);
                 if (hlen > topk) {  // pop: last -> root, sift_down_to_bottom(0), sift_up
                     --hlen;
-                    int32_t hk = hkey[hlen];
-                    uint32_t hi = hid[hlen];
+                    int32_t hk = HK(hlen);
+                    uint32_t hi = HI(hlen);
                     if (hlen > 0) {
                         const uint32_t end = hlen;
                         uint32_t q = 0, child = 1;
                         while (child + 1 < end) {
-                            int32_t kl = hkey[child], kr = hkey[child + 1];
+                            int32_t kl = HK(child), kr = HK(child + 1);
                             if (kl <= kr) child += 1;
-                            int32_t ck = hkey[child];
-                            uint32_t ci = hid[child];
-                            hkey[q] = ck, hid[q] = ci;
+                            int32_t ck = HK(child);
+                            uint32_t ci = HI(child);
+                            SETH(q, ck, ci);
                             q = child;
                             child = 2 * q + 1;
                         }
                         if (child == end - 1) {
-                            int32_t ck = hkey[child];
-                            uint32_t ci = hid[child];
-                            hkey[q] = ck, hid[q] = ci;
+                            int32_t ck = HK(child);
+                            uint32_t ci = HI(child);
+                            SETH(q, ck, ci);
                             q = child;
                         }
                         while (q > 0) {  // sift_up(0, q) of the hole element
                             uint32_t parent = (q - 1) >> 1;
-                            int32_t pk = hkey[parent];
+                            int32_t pk = HK(parent);
                             if (hk <= pk) break;
-                            uint32_t pid = hid[parent];
-                            hkey[q] = pk, hid[q] = pid;
+                            uint32_t pid = HI(parent);
+                            SETH(q, pk, pid);
                             q = parent;
                         }
-                        hkey[q] = hk, hid[q] = hi;
+                        SETH(q, hk, hi);
                     }
                 }
-                if (hlen == topk) thr = ord32_to_f32(hkey[0]);  // rerank.rs:98-100
+                if (hlen == topk) thr = ord32_to_f32(HK(0));  // rerank.rs:98-100
             } else {
                 if (alen < st.hcap && lane == 0) {
                     SurvRec e;
@@ -2335,9 +2366,13 @@ __device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, co
         }
     }
     if constexpr (!HEURISTIC) {
-        for (uint32_t i = lane; i < hlen; i += 64) {
-            st.heap_key[(uint64_t)b * topk + i] = hkey[i];
-            st.heap_id[(uint64_t)b * topk + i] = hid[i];
+        if constexpr (REGHEAP) {
+            if (lane < hlen) st.heap_key[(uint64_t)b * topk + lane] = rk, st.heap_id[(uint64_t)b * topk + lane] = ri;
+        } else {
+            for (uint32_t i = lane; i < hlen; i += 64) {
+                st.heap_key[(uint64_t)b * topk + i] = hkey[i];
+                st.heap_id[(uint64_t)b * topk + i] = hid[i];
+            }
         }
         if (lane == 0) st.heap_len[b] = hlen;
     } else if (lane == 0) {
@@ -2657,7 +2692,7 @@ __global__ __launch_bounds__(256) void sort_runs_mid_kernel(RunRec *__restrict__
     }
 }
 
-template <bool HEURISTIC>
+template <bool HEURISTIC, bool REGHEAP = false>
 __global__ __launch_bounds__(64) void replay_kernel(const SurvRec *__restrict__ surv, const RunRec *__restrict__ runs,
                                                     unsigned long long *__restrict__ surv_cnt, uint32_t cap, uint32_t topk,
                                                     ReplayState st, uint32_t dense_cells) {
@@ -2677,7 +2712,7 @@ __global__ __launch_bounds__(64) void replay_kernel(const SurvRec *__restrict__ 
         surv_cnt[b] = 0;  // ready for the next stage
     }
     if (n == 0) return;
-    replay_wave<HEURISTIC>(surv + (uint64_t)b * cap, runs + (uint64_t)b * cap, nruns, topk, b, st, hkey, hid);
+    replay_wave<HEURISTIC, REGHEAP>(surv + (uint64_t)b * cap, runs + (uint64_t)b * cap, nruns, topk, b, st, hkey, hid);
 }
 
 // dense run directory of a stage: cells [0, ncells) of every query start empty
