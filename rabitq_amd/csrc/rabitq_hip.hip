@@ -903,7 +903,10 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             prof_acc->matrix_launches++;
             ws.pend_matrix_ranges.push_back({sg.s_lo, sg.s_hi});
         }
-        if (nq < 256) {  // small batch: one fused launch per stage (launch-bound regime)
+        // small batch: one fused launch per stage (launch-bound regime) -- unless the survivor buffers are large (queries
+        // re-run after an overflow: tens of thousands of survivors each): one block per query would rerank and order
+        // those alone, the large-batch kernels spread them over the chip
+        if (nq < 256 && qp.cap <= 4 * RQ_DEFAULT_CAP) {
             pf.begin(PF_RERANK);
             const uint32_t fin_threads = nq <= 16 ? 1024u : 256u;  // a handful of queries: more lanes on each one's rerank
             // survivor buffers beyond the default mean this index / these queries leave long run directories (overflow
