@@ -198,6 +198,17 @@ rq_status rq_query_batch_device_probed(const rq_index *idx, const float *d_queri
                                        uint32_t topk, int heuristic_rank, float *d_out_dist, uint32_t *d_out_id,
                                        uint32_t *d_out_n);
 
+/* The same with a per-query INITIAL threshold (device, nq floats; f32::MAX = none): a candidate is re-ranked only if
+ * rough < threshold and kept only if accurate < threshold, from the first candidate on -- the multi-GPU step seeds every
+ * shard with the k-th best distance the owner of the query's nearest list found there (one all-reduce(min)), so that
+ * a shard which does not hold a query's neighbourhood stops re-ranking its far candidates (per-shard
+ * thresholds).  The whole candidate stream runs as one stage.  A query may return fewer than topk results: everything
+ * left out is at or above its initial threshold.  No reference counterpart (single process). */
+rq_status rq_query_batch_device_seeded(const rq_index *idx, const float *d_queries, uint32_t nq, uint32_t len,
+                                       const uint32_t *d_probe_cluster, const float *d_probe_dist, uint32_t probe,
+                                       uint32_t topk, int heuristic_rank, const float *d_thr_init, float *d_out_dist,
+                                       uint32_t *d_out_id, uint32_t *d_out_n);
+
 /* List partitioner: whole IVF lists to `world` shards, greedy by list length (longest first,
  * each to the least-loaded shard; deterministic).  out_owner[c] = shard of list c (k entries, host);
  * out_load (world entries, host, may be NULL) = vectors per shard.  The reference has no counterpart (single process). */

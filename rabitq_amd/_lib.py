@@ -22,7 +22,7 @@ STATUS_NAMES = {0: "RQ_OK", -1: "RQ_ERR_INVALID", -2: "RQ_ERR_DIM_MISMATCH", -3:
 EXPORTS = [
     "rq_version", "rq_last_error", "rq_init", "rq_build", "rq_build_device", "rq_build_from_path", "rq_kmeans_device", "rq_builder_create", "rq_builder_assign_chunk", "rq_builder_order", "rq_builder_place_chunk", "rq_builder_finish", "rq_builder_free", "rq_builder_stats", "rq_load_dir",
     "rq_dump_dir", "rq_load_json", "rq_dump_json", "rq_free", "rq_from_arrays", "rq_info", "rq_get_array", "rq_get_device_ptr", "rq_query",
-    "rq_query_batch", "rq_query_batch_device", "rq_query_batch_device_begin", "rq_query_batch_device_end", "rq_coarse_topk_device", "rq_merge_smallest_u64_device", "rq_query_batch_device_probed", "rq_partition_lists", "rq_shard_index", "rq_query_batch_sharded_device", "rq_metrics", "rq_metrics_reset", "rq_rotate", "rq_rotate_device",
+    "rq_query_batch", "rq_query_batch_device", "rq_query_batch_device_begin", "rq_query_batch_device_end", "rq_coarse_topk_device", "rq_merge_smallest_u64_device", "rq_query_batch_device_probed", "rq_query_batch_device_seeded", "rq_partition_lists", "rq_shard_index", "rq_query_batch_sharded_device", "rq_metrics", "rq_metrics_reset", "rq_rotate", "rq_rotate_device",
     "rq_quantize_pack",
     "rq_coarse_rank", "rq_query_prep", "rq_scan", "rq_rerank", "rq_set_profiling", "rq_set_option", "rq_last_profile",
 ]
@@ -74,6 +74,16 @@ def lib():
         return _lib
     if not os.path.exists(SO_PATH):
         raise RabitqError(-5, f"{SO_PATH} not built (run `make -C rabitq_amd/csrc`); there is no CPU fallback")
+    # A process that also uses PyTorch must load torch's bundled ROCm runtime BEFORE this library pulls in the system
+    # one: the other way round torch later reports "No HIP GPUs are available" (measured on this image).  The library
+    # itself does not need torch; the import only fixes the load order when torch is installed.
+    import importlib.util
+    import sys
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(SO_PATH)
     vp, f32p, u32p, u64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p  # raw addresses (host or device)
     u32, u64, i32, flt = C.c_uint32, C.c_uint64, C.c_int32, C.c_float
@@ -110,6 +120,7 @@ def lib():
         "rq_coarse_topk_device": (i32, [vp, f32p, u32, u32, u32, u32, u32, u32p, f32p]),
         "rq_merge_smallest_u64_device": (i32, [vp, u32, u32, u32, u32, vp]),
         "rq_query_batch_device_probed": (i32, [vp, f32p, u32, u32, u32p, f32p, u32, u32, C.c_int, f32p, u32p, u32p]),
+        "rq_query_batch_device_seeded": (i32, [vp, f32p, u32, u32, u32p, f32p, u32, u32, C.c_int, f32p, f32p, u32p, u32p]),
         "rq_partition_lists": (i32, [vp, u32, u32p, u64p]),
         "rq_shard_index": (i32, [vp, u32p, u32, pp]),
         "rq_query_batch_sharded_device": (i32, [vp, vp, u32, u32, f32p, u32, u32, u32, u32, C.c_int, f32p, u32p, u32p]),

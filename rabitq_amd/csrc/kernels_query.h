@@ -2726,10 +2726,12 @@ __global__ void clear_dir_kernel(RunRec *__restrict__ runs, uint32_t nq, uint32_
 }
 
 // ranker state of a fresh query (src/rerank.rs:70-77, :129-139) + per-query counters, one launch
-__global__ void init_state_kernel(ReplayState st, unsigned long long *__restrict__ surv_cnt, uint32_t nq) {
+// thr_init (seeded passes): the threshold a query starts with instead of f32::MAX, row_map: pass row -> row of thr_init
+__global__ void init_state_kernel(ReplayState st, unsigned long long *__restrict__ surv_cnt, uint32_t nq,
+                                  const float *__restrict__ thr_init, const uint32_t *__restrict__ row_map) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nq) return;
-    st.thr[b] = 3.402823466e+38f;          // f32::MAX
+    st.thr[b] = thr_init ? thr_init[row_map ? row_map[b] : b] : 3.402823466e+38f;  // f32::MAX
     st.recent_max[b] = -3.402823466e+38f;  // f32::MIN
     st.heap_len[b] = 0, st.precise[b] = 0, st.need[b] = 0, st.nsurv[b] = 0, st.nshadow[b] = 0, st.win_count[b] = 0, st.arr_len[b] = 0;
     surv_cnt[b] = 0;

@@ -557,6 +557,9 @@ struct QueryParams {
     uint32_t nq, len, probe, topk;
     bool heuristic;
     uint32_t cap, hcap;  // survivor / heuristic-array capacity per query (powers of two)
+    // Seeded pass (rq_query_batch_device_seeded): per-query initial thresholds (device; f32::MAX = none).  A first pass
+    // runs the whole stream as ONE stage under them; an overflow re-run (row map given) starts from them and stages as usual.
+    const float *thr_init = nullptr;
 };
 
 #define RQ_DEFAULT_CAP 4096u
@@ -745,7 +748,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     rs.precise = ws.precise.p, rs.need = ws.need.p, rs.nsurv = ws.nsurv.p, rs.nshadow = ws.nshadow.p, rs.recent_max = ws.recent.p, rs.win_count = ws.win_count.p;
     rs.arr_len = ws.arr_len.p, rs.arr = ws.arr.p, rs.hcap = qp.hcap;
     // 4. ranker state (rerank.rs:70-77, :129-139) and per-query counters
-    init_state_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(rs, ws.surv_cnt.p, nq);
+    init_state_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(rs, ws.surv_cnt.p, nq, qp.thr_init, d_row_map);
     HIPC(hipMemsetAsync(ws.totals.p, 0, 8 * sizeof(unsigned long long), st));
     HIPC(hipMemsetAsync(ws.big_list.p + nq, 0, 12, st));
     if (g_scan_dbg.load() & (128 | 256)) HIPC(hipMemsetAsync(ws.stat.p, 0, 256 * sizeof(unsigned long long), st));
@@ -761,7 +764,10 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         uint32_t s_lo, s_hi;
     };
     std::vector<Stage> stages;
-    {
+    const bool one_stage = qp.thr_init != nullptr && d_row_map == nullptr;  // thresholds are already tight: nothing to learn in early stages
+    if (one_stage) {
+        stages.push_back({0u, 0xFFFFFFFFu});
+    } else {
         const uint64_t total_max = std::min<uint64_t>((uint64_t)nprobe * idx->max_list_len, idx->n);
         // small batches are launch-bound (coarser stages), large ones rerank-bound (tighter thresholds)
         const int gopt = g_stage_growth.load();
@@ -805,7 +811,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         // matrix cores pay once many queries share each list AND survivors are rare, i.e. past the nearest list
         // (stages inside it leave hundreds of survivors per query: the exact path dominates there and the VALU
         // kernel wins, measured at any batch size)
-        const bool use_mfma = scan_has_mfma(W) && impl != 1 && (impl == 2 || (est_pairs >= 8ull * k && sg.s_lo >= avg_len));
+        const bool use_mfma = scan_has_mfma(W) && impl != 1 && (impl == 2 || (est_pairs >= 8ull * k && (sg.s_lo >= avg_len || one_stage)));
         const bool cluster_major = use_mfma || (est_pairs >= k / 2 && est_pairs > 64);
         // early stages of a large batch: a list meets ~16 queries and several per cent of its candidates pass, so
         // every cell is evaluated exactly, with the dot products from 16x16x128 MFMAs (scan_dense_kernel)
@@ -929,7 +935,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             pf.begin(PF_RERANK);
             const uint32_t gx = std::max(1u, std::min(16u, 4096u / std::max(nq, 1u)));
             // past the first stage the thresholds are finite: survivors go through the fp16 shadow rows first
-            if (idx->base_h.p && stage_no > 0 && !(g_scan_dbg & 512))
+            if (idx->base_h.p && (stage_no > 0 || qp.thr_init) && !(g_scan_dbg & 512))
                 accurate_filtered_kernel<<<dim3(gx, nq), 256, (size_t)dim * sizeof(float), st>>>(
                     ws.surv.p, ws.surv_cnt.p, qp.cap, idx->base.p, idx->base_h.p, qpad, dim, rerank_order, ws.thr.p,
                     ws.nshadow.p);
@@ -1071,6 +1077,7 @@ static rq_status after_pass(rq_index *idx, Workspace *ws, const QueryParams &qp,
         for (size_t o = 0; o < over_rows.size(); o += chunk) {
             uint32_t m = (uint32_t)std::min<size_t>(chunk, over_rows.size() - o);
             QueryParams rq{m, len, probe, topk, heuristic, ncap, nhcap};
+            rq.thr_init = qp.thr_init;  // indexed through the row map
             RQC(ws_prepare(idx, rws, rq));
             RQC(sub_q.ensure((uint64_t)m * len));
             RQC(sub_rows.ensure(m));
@@ -1132,7 +1139,7 @@ static rq_status conclude_query(uint32_t nq, bool heuristic, const uint32_t *d_o
 static rq_status query_device(rq_index *idx, const float *d_q, uint32_t nq, uint32_t len, uint32_t probe,
                               uint32_t topk, bool heuristic, float *d_out_dist, uint32_t *d_out_id,
                               uint32_t *d_out_n, const uint32_t *ext_cluster = nullptr,
-                              const float *ext_dist = nullptr, Workspace *use_ws = nullptr) {
+                              const float *ext_dist = nullptr, Workspace *use_ws = nullptr, const float *ext_thr = nullptr) {
     RQC(validate_query(idx, d_q, len, probe, topk, d_out_dist, d_out_id, d_out_n));
     if (nq == 0) return RQ_OK;
     rq_profile_t prof;
@@ -1151,6 +1158,7 @@ static rq_status query_device(rq_index *idx, const float *d_q, uint32_t nq, uint
         const uint32_t cap0 = std::max(RQ_DEFAULT_CAP, idx->cap_hint.load());
         step_nq = pass_queries(idx, nq - q0, probe, cap0);
         QueryParams qp{step_nq, len, probe, topk, heuristic, cap0, cap0};
+        qp.thr_init = ext_thr ? ext_thr + q0 : nullptr;
         RQC(ws_prepare(idx, *ws, qp));
         PassResult pr;
         const float *q_at = d_q + (uint64_t)q0 * len;
@@ -2307,6 +2315,16 @@ rq_status rq_query_batch_device_probed(const rq_index *idx, const float *d_queri
     if (idx && probe > idx->k) return fail(RQ_ERR_INVALID, "probe lists must have min(probe, k) columns: pass probe <= k");
     return query_device(const_cast<rq_index *>(idx), d_queries, nq, len, probe, topk, heuristic_rank != 0, d_out_dist,
                         d_out_id, d_out_n, d_probe_cluster, d_probe_dist);
+}
+
+rq_status rq_query_batch_device_seeded(const rq_index *idx, const float *d_queries, uint32_t nq, uint32_t len,
+                                       const uint32_t *d_probe_cluster, const float *d_probe_dist, uint32_t probe,
+                                       uint32_t topk, int heuristic_rank, const float *d_thr_init, float *d_out_dist,
+                                       uint32_t *d_out_id, uint32_t *d_out_n) {
+    if (!d_probe_cluster || !d_probe_dist || !d_thr_init) return fail(RQ_ERR_INVALID, "null probe lists / thresholds");
+    if (idx && probe > idx->k) return fail(RQ_ERR_INVALID, "probe lists must have min(probe, k) columns: pass probe <= k");
+    return query_device(const_cast<rq_index *>(idx), d_queries, nq, len, probe, topk, heuristic_rank != 0, d_out_dist,
+                        d_out_id, d_out_n, d_probe_cluster, d_probe_dist, nullptr, d_thr_init);
 }
 
 rq_status rq_query_batch_device(const rq_index *idx, const float *d_queries, uint32_t nq, uint32_t len,

@@ -225,6 +225,15 @@ class RaBitQ:
                                                  C.c_void_p(out_dist_ptr), C.c_void_p(out_id_ptr), C.c_void_p(out_n_ptr)))
 
 
+    def query_batch_device_seeded(self, q_ptr: int, nq: int, length: int, probe_cluster_ptr: int, probe_dist_ptr: int,
+                                  probe: int, topk: int, thr_init_ptr: int, out_dist_ptr: int, out_id_ptr: int,
+                                  out_n_ptr: int, heuristic_rank: bool = False) -> None:
+        """query_batch_device_probed with per-query initial thresholds (nq floats on the device, f32 max = none)."""
+        check(lib().rq_query_batch_device_seeded(self._h, C.c_void_p(q_ptr), nq, length, C.c_void_p(probe_cluster_ptr),
+                                                 C.c_void_p(probe_dist_ptr), probe, topk, int(heuristic_rank),
+                                                 C.c_void_p(thr_init_ptr), C.c_void_p(out_dist_ptr),
+                                                 C.c_void_p(out_id_ptr), C.c_void_p(out_n_ptr)))
+
     def partition_lists(self, world: int):
         """Greedy-by-length assignment of whole lists to `world` shards -> (owner u32[k], load u64[world])."""
         owner = np.zeros(self.k, dtype=np.uint32)

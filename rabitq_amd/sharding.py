@@ -117,3 +117,64 @@ def merge_probe_lists(cluster: torch.Tensor, dist_t: torch.Tensor, nprobe: int, 
     out_ids = (key & 0xFFFFFFFF).to(torch.int32)      # wraps to the u32 bit pattern
     out_dist = (key >> 32).to(torch.int32).view(torch.float32)
     return out_ids.contiguous(), out_dist.contiguous()
+
+
+class SeededShardQuery:
+    """The per-shard part of a multi-GPU query step with SHARED thresholds ("per-shard thresholds are
+    looser"): a shard that does not hold a query's neighbourhood never fills its ranker with near candidates, so on its
+    own it would re-rank (and, in the matrix-core scan, re-evaluate exactly) most of what it scans.  Two engine calls:
+      A  the query's NEAREST list alone (only its owner finds candidates there): the usual staged pass;
+      -  threshold = the k-th best exact distance of A where A is full (an actual k-th best of a subset, hence an upper
+         bound of the final k-th distance), f32 max elsewhere; ONE all-reduce(min) of nq floats gives it to every shard;
+      B  the other probed lists, seeded with that threshold (rq_query_batch_device_seeded): one stage, no learning.
+    The caller merges A and B of all shards (payload(): (nq, 2 topk, 2) for merge_shard_topk).  The work is the same
+    candidates as one probed call; what changes is that B prunes with the best threshold any shard knows."""
+
+    def __init__(self, nq: int, topk: int, device):
+        f32, i32 = torch.float32, torch.int32
+        self.nq, self.topk = nq, topk
+        self.a = (torch.empty((nq, topk), device=device, dtype=f32), torch.zeros((nq, topk), device=device, dtype=i32),
+                  torch.zeros((nq,), device=device, dtype=i32))
+        self.b = (torch.empty((nq, topk), device=device, dtype=f32), torch.zeros((nq, topk), device=device, dtype=i32),
+                  torch.zeros((nq,), device=device, dtype=i32))
+        self.profile_a = None
+
+    def run(self, idx, q_ptr: int, length: int, pc: torch.Tensor, pdist: torch.Tensor, group=None,
+            cpu_collectives: bool = False):
+        """pc / pdist: the merged probe lists (nq, nprobe) on the device, visiting order.  Runs A, the all-reduce and B;
+        results stay in self.a / self.b (dist, local id, count)."""
+        from . import index as _ix
+        nq, topk = self.nq, self.topk
+        nprobe = pc.shape[1]
+        ad, ai, an = self.a
+        bd, bi, bn = self.b
+        pc_a, pd_a = pc[:, :1].contiguous(), pdist[:, :1].contiguous()
+        torch.cuda.current_stream().synchronize()   # the engine runs on its own streams
+        idx.query_batch_device_probed(q_ptr, nq, length, pc_a.data_ptr(), pd_a.data_ptr(), 1, topk, ad.data_ptr(),
+                                      ai.data_ptr(), an.data_ptr())
+        self.profile_a = _ix.last_profile()
+        fmax = torch.finfo(torch.float32).max
+        valid = torch.arange(topk, device=ad.device)[None, :] < an.to(torch.int64)[:, None]
+        kth = torch.where(valid, ad, torch.full_like(ad, -fmax)).max(dim=1).values
+        thr = torch.where(an == topk, kth, torch.full_like(kth, fmax)).contiguous()
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            if cpu_collectives:
+                t = thr.cpu()
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+                thr = t.to(ad.device)
+            else:
+                dist.all_reduce(thr, op=dist.ReduceOp.MIN, group=group)
+        self.thr = thr
+        if nprobe > 1:
+            pc_b, pd_b = pc[:, 1:].contiguous(), pdist[:, 1:].contiguous()
+            torch.cuda.current_stream().synchronize()
+            idx.query_batch_device_seeded(q_ptr, nq, length, pc_b.data_ptr(), pd_b.data_ptr(), nprobe - 1, topk,
+                                          thr.data_ptr(), bd.data_ptr(), bi.data_ptr(), bn.data_ptr())
+        else:
+            bn.zero_()
+
+    def payload(self, id_offset: int) -> torch.Tensor:
+        """(nq, 2 topk, 2) merge payload of A and B (merge_shard_topk keeps the topk smallest over all shards)."""
+        pa = pack_topk(self.a[0], self.a[1].to(torch.int64) & 0xFFFFFFFF, self.a[2], id_offset)
+        pb = pack_topk(self.b[0], self.b[1].to(torch.int64) & 0xFFFFFFFF, self.b[2], id_offset)
+        return torch.cat([pa, pb], dim=1)

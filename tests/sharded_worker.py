@@ -6,7 +6,9 @@ batch two ways:
   A  arbitrary partition (rq_partition_lists, greedy by list length), replicated coarse ranking: the shard runs the
      ordinary pipeline (lists it does not own are empty), ONE all-gather of per-shard top-k, merge;
   B  contiguous partition, sharded coarse ranking: rq_coarse_topk_device over the rank's own lists -> all-gather ->
-     merged probe lists -> rq_query_batch_device_probed -> all-gather of per-shard top-k, merge.
+     merged probe lists -> rq_query_batch_device_probed -> all-gather of per-shard top-k, merge;
+  C  as B, with the thresholds shared between the shards (sharding.SeededShardQuery: nearest list first, one
+     all-reduce(min) of the k-th best distances, the other lists seeded with it).
 Rank 0 writes the merged results to argv[1] (npz)."""
 import os
 import sys
@@ -73,10 +75,17 @@ def main():
     torch.cuda.synchronize()
     shb.query_batch_device_probed(q.data_ptr(), nq, d, mc_d.data_ptr(), md_d.data_ptr(), probe, topk, od.data_ptr(),
                                   oi.data_ptr(), on.data_ptr())
+    b_rerank = rabitq_amd.index.last_profile()["rerank_candidates"]
     pay = sharding.pack_topk(od, oi.to(torch.int64) & 0xFFFFFFFF, on, 0).cpu()
     bd, bi, bn = sharding.merge_shard_topk(pay, topk, id_bound=n)
     res.update(b_dist=bd.numpy(), b_ids=bi.numpy(), b_cnt=bn.numpy(), b_probe=mc.numpy().view(np.uint32),
-               b_probe_dist=mdist.numpy())
+               b_probe_dist=mdist.numpy(), b_local_rerank=np.array([b_rerank]))
+    # ---- C: the same partition and probe lists, thresholds shared between the shards (two engine calls) --------
+    sq = sharding.SeededShardQuery(nq, topk, dev)
+    sq.run(shb, q.data_ptr(), d, mc_d, md_d, cpu_collectives=True)
+    cd, ci, cn = sharding.merge_shard_topk(sq.payload(0).cpu(), topk, id_bound=n)
+    res.update(c_dist=cd.numpy(), c_ids=ci.numpy(), c_cnt=cn.numpy(), c_thr=sq.thr.cpu().numpy(),
+               c_local_rerank=np.array([sq.profile_a["rerank_candidates"] + rabitq_amd.index.last_profile()["rerank_candidates"]]))
     shb.close()
     full.close()
     dist.barrier()

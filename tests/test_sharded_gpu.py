@@ -67,7 +67,7 @@ def test_two_rank_hip_sharded_step(rq, tmp_path):
     wd, wi, wn = full.query_batch(queries, probe, topk)
     gt = synth.brute_force_topk(x, queries, topk)
     report = {"n": n, "lists": k, "queries": nq, "probe": probe, "topk": topk, "world": 2}
-    for tag in ("a", "b"):
+    for tag in ("a", "b", "c"):
         ids, cnt = got[f"{tag}_ids"], got[f"{tag}_cnt"]
         assert np.array_equal(cnt, wn.astype(np.int64))
         qdiff = idiff = worse = 0
@@ -86,14 +86,20 @@ def test_two_rank_hip_sharded_step(rq, tmp_path):
                 worse += 1
         rec_sh = np.mean([len(set(ids[b, :topk].tolist()) & set(gt[b].tolist())) / topk for b in range(nq)])
         rec_one = np.mean([len(set(wi[b, :topk].tolist()) & set(gt[b].tolist())) / topk for b in range(nq)])
-        report[tag] = {"partition": "greedy by list length, replicated coarse ranking" if tag == "a"
-                       else "contiguous halves, sharded coarse ranking + probe-list all-gather",
+        report[tag] = {"partition": {"a": "greedy by list length, replicated coarse ranking",
+                                     "b": "contiguous halves, sharded coarse ranking + probe-list all-gather",
+                                     "c": "as b, thresholds shared between the shards (nearest list first, all-reduce(min) of "
+                                          "the k-th best distances, the other lists seeded with it)"}[tag],
                        "queries_with_different_id_set": int(qdiff), "query_mismatch_rate": qdiff / nq,
                        "ids_different": int(idiff), "id_mismatch_rate": idiff / (nq * topk),
                        "queries_where_sharded_kth_distance_is_larger": int(worse),
                        "recall_sharded": float(rec_sh), "recall_single_index": float(rec_one)}
         assert rec_sh >= rec_one - 0.005           # looser per-shard thresholds: the merged set is at least as good
         assert idiff / (nq * topk) <= 0.02, report
+    # what sharing the thresholds is for: rank 0's exact-distance count of the same batch, own thresholds vs shared ones
+    report["rank0_rerank_candidates"] = {"own_thresholds": int(got["b_local_rerank"][0]),
+                                         "shared_thresholds": int(got["c_local_rerank"][0])}
+    assert got["c_local_rerank"][0] < got["b_local_rerank"][0]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(report, open(os.path.join(ROOT, "gpurun_out", "sharded_mismatch.json"), "w"), indent=1)
     print(json.dumps(report))
@@ -105,6 +111,7 @@ def test_sharded_entry_through_rccl_world1(rq):
     dlsym binding, the pack -> ncclAllGather -> merge -> unpack chain on the engine's stream; and without a
     communicator.  Results: the single index's top-k, ascending."""
     import torch
+    torch.zeros(1, device="cuda:0")   # a live HIP context in this process before RCCL is initialised
     path = os.environ.get("RABITQ_RCCL_LIB") or "librccl.so"
     try:
         nccl = C.CDLL(path, mode=C.RTLD_GLOBAL)
