@@ -236,6 +236,8 @@ def main():
 
     pc_local = torch.zeros((B, nprobe), device=dev, dtype=torch.int32)
     pd_local = torch.zeros((B, nprobe), device=dev, dtype=torch.float32)
+    seeded = sharding.SeededShardQuery(B, topk, dev) if sharded else None
+    extra_prof = []   # profiles of the first engine call of a multi-GPU step (the second one is last_profile())
 
     def step():
         if sharded:
@@ -245,16 +247,16 @@ def main():
             pcl, pdl = (pc_local.cpu(), pd_local.cpu()) if args.backend == "gloo" else (pc_local, pd_local)
             pc, pdist = sharding.merge_probe_lists(pcl, pdl, nprobe)
             pc, pdist = pc.to(dev), pdist.to(dev)
-            # the engine runs on its own (non-blocking) HIP streams: torch's merge kernels must have finished
-            # before it reads their output
-            torch.cuda.current_stream().synchronize()
-            idx.query_batch_device_probed(queries.data_ptr(), B, d, pc.data_ptr(), pdist.data_ptr(), nprobe, topk,
-                                          out_d.data_ptr(), out_i.data_ptr(), out_n.data_ptr())
+            # thresholds shared between the shards (sharding.SeededShardQuery): the nearest list alone, one
+            # all-reduce(min) of the k-th best distances found there, then the other lists seeded with it -- a shard that
+            # does not hold a query's neighbourhood would otherwise re-rank most of what it scans
+            seeded.run(idx, queries.data_ptr(), d, pc, pdist, cpu_collectives=args.backend == "gloo")
+            extra_prof.append(seeded.profile_a)
         else:
             idx.query_batch_device(queries.data_ptr(), B, d, nprobe, topk, out_d.data_ptr(), out_i.data_ptr(),
                                    out_n.data_ptr())
         if sharded:
-            pay = sharding.pack_topk(out_d, out_i.to(torch.int64) & 0xFFFFFFFF, out_n, rank * n)
+            pay = seeded.payload(rank * n)
             if args.backend == "gloo":
                 pay = pay.cpu()
             return sharding.merge_shard_topk(pay, topk, id_bound=world * n)
@@ -273,10 +275,12 @@ def main():
         res = None
         if depth == 1:
             for _ in range(count):
+                extra_prof.clear()
                 res = step()
                 if record:
-                    for key, v in rqi.last_profile().items():
-                        prof[key] = prof.get(key, 0) + v
+                    for pr in [rqi.last_profile()] + extra_prof:
+                        for key, v in pr.items():
+                            prof[key] = prof.get(key, 0) + v
             return res
         pending = []
         for i in range(count + depth - 1):
@@ -317,9 +321,14 @@ def main():
                            "`value` and the roofline figures are taken with one batch at a time"}
     # per-kernel-group breakdown from ONE extra, untimed step (an event pair per group costs ~10 us of stream time each)
     rqi.set_profiling(1)
+    extra_prof.clear()
     step()
     fence()
-    breakdown = {key[3:]: round(v, 3) for key, v in rqi.last_profile().items() if key.startswith("ms_")}
+    breakdown = {}
+    for pr in [rqi.last_profile()] + extra_prof:   # a multi-GPU step is two engine calls
+        for key, v in pr.items():
+            if key.startswith("ms_"):
+                breakdown[key[3:]] = round(breakdown.get(key[3:], 0.0) + v, 3)
     # share of the matrix-core scan's 32x32 sub-tile steps that were flagged by the integer gate and took the exact f32 path
     # (one more untimed step with the counting hook on; results are unchanged by it)
     rqi.set_option("scan_debug", 128)

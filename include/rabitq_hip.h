@@ -310,6 +310,9 @@ rq_status rq_set_profiling(int level);
  * off by default because it measured slower than the VALU kernel.
  * "coarse_impl": test hook, coarse-distance kernel: 0 = automatic (default), 1 = query rows through LDS, 2 = query
  * rows in scalar registers (what large batches use).
+ * "shared_thresholds": rq_query_batch_sharded_device: 1 (default) = with more than one shard the step runs the nearest
+ * list first, all-reduces (min) the k-th best distances and seeds the rest of the probe list with them (see
+ * rq_query_batch_device_seeded); 0 = every shard prunes with its own thresholds only; 2 = also with one shard (tests).
  * "dense_dir": test hook, 1 (default) = the VALU stages of large batches write their survivor runs into a directory
  * indexed by stream position (nothing to sort), 0 = runs are appended and the directory is sorted.
  * "group_rank": test hook, placement of a cluster-major stage's (query, list) pairs: 0 = one atomic per pair,

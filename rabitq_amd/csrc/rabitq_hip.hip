@@ -214,6 +214,8 @@ struct Workspace {
     DevBuf<float> sh_dist;
     DevBuf<uint32_t> sh_id, sh_n;
     DevBuf<unsigned long long> sh_packed, sh_gathered, sh_merged;
+    DevBuf<uint32_t> sh_pc, sh_id_b, sh_n_b;  // shared-threshold step: probe lists (whole | nearest | rest), second call's results
+    DevBuf<float> sh_pd, sh_thr, sh_dist_b;
     unsigned long long *h_totals = nullptr;  // pinned, 8
     Prof prof;
     ~Workspace() {
@@ -308,6 +310,38 @@ __global__ void pack_topk_keys_kernel(const float *__restrict__ dist, const uint
     if (i >= nq * topk) return;
     const uint32_t b = i / topk, e = i - b * topk;
     keys[i] = e < cnt[b] ? (((unsigned long long)ord32_biased(dist[i]) << 32) | (uint32_t)(id[i] + id_offset)) : ~0ull;
+}
+// shared-threshold multi-GPU step: the merged probe lists split into the nearest list and the rest
+__global__ void split_probe_kernel(const uint32_t *__restrict__ pc, const float *__restrict__ pd, uint32_t nq, uint32_t npb,
+                                   uint32_t *__restrict__ pc_a, float *__restrict__ pd_a, uint32_t *__restrict__ pc_b,
+                                   float *__restrict__ pd_b) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)nq * npb) return;
+    const uint32_t b = (uint32_t)(i / npb), c = (uint32_t)(i - (uint64_t)b * npb);
+    if (c == 0) pc_a[b] = pc[i], pd_a[b] = pd[i];
+    else pc_b[(uint64_t)b * (npb - 1) + c - 1] = pc[i], pd_b[(uint64_t)b * (npb - 1) + c - 1] = pd[i];
+}
+// a query's seed threshold: the k-th best distance its nearest list gave, if the list gave k; f32::MAX otherwise
+__global__ void kth_threshold_kernel(const float *__restrict__ dist, const uint32_t *__restrict__ cnt, uint32_t nq, uint32_t topk,
+                                     float *__restrict__ thr) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nq) return;
+    float m = 3.402823466e+38f;
+    if (cnt[b] == topk) {
+        m = dist[(uint64_t)b * topk];
+        for (uint32_t e = 1; e < topk; ++e) m = dist[(uint64_t)b * topk + e] > m ? dist[(uint64_t)b * topk + e] : m;
+    }
+    thr[b] = m;
+}
+// per-shard top-k -> merge keys, written at columns [col0, col0 + topk) of rows of `width` keys
+__global__ void pack_topk_keys_at_kernel(const float *__restrict__ dist, const uint32_t *__restrict__ id, const uint32_t *__restrict__ cnt,
+                                         uint32_t nq, uint32_t topk, uint32_t id_offset, uint32_t width, uint32_t col0,
+                                         unsigned long long *__restrict__ keys) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq * topk) return;
+    const uint32_t b = i / topk, e = i - b * topk;
+    keys[(uint64_t)b * width + col0 + e] =
+        e < cnt[b] ? (((unsigned long long)ord32_biased(dist[i]) << 32) | (uint32_t)(id[i] + id_offset)) : ~0ull;
 }
 __global__ void unpack_topk_keys_kernel(const unsigned long long *__restrict__ keys, uint32_t nq, uint32_t topk,
                                         float *__restrict__ dist, uint32_t *__restrict__ id, uint32_t *__restrict__ cnt) {
@@ -447,6 +481,7 @@ static std::atomic<int> g_scan_dbg{0};
 static std::atomic<int> g_stage_growth{0};  // 0 = default schedule
 static std::atomic<int> g_scan_tile_table{1};  // 0 = plain (list x tile) grids everywhere (test / measurement hook)
 static std::atomic<int> g_group_rank{1};  // group_rank_kernel for cluster-major stages: 0 never, 1 big stages, 2 always
+static std::atomic<int> g_shared_thr{1};  // rq_query_batch_sharded_device: thresholds shared between the shards (0 never, 1 world > 1, 2 always)
 static std::atomic<int> g_dense_dir{1};  // dense run directories for the VALU stages of large batches (0 = always append + sort: test hook)
 
 // matrix-core scan instantiations: W = dim/64, NT = 32-candidate sub-tiles per wave (resident operand registers
@@ -2491,6 +2526,7 @@ rq_status rq_shard_index(const rq_index *idx, const uint32_t *owner, uint32_t ra
 // the communicator handle and the collective come from the same library.
 struct RcclApi {
     int (*all_gather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*all_reduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     const char *(*error_string)(int) = nullptr;
     std::string err;
 };
@@ -2514,12 +2550,77 @@ static RcclApi *rccl_api() {
             return;
         }
         api.all_gather = reinterpret_cast<decltype(api.all_gather)>(sym);
+        api.all_reduce = reinterpret_cast<decltype(api.all_reduce)>(h ? dlsym(h, "ncclAllReduce") : dlsym(RTLD_DEFAULT, "ncclAllReduce"));
         void *es = h ? dlsym(h, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString");
         api.error_string = reinterpret_cast<decltype(api.error_string)>(es);
     });
     return &api;
 }
 #define RQ_NCCL_UINT64 5  // ncclUint64 (rccl.h: ncclDataType_t)
+#define RQ_NCCL_FLOAT32 7  // ncclFloat32
+#define RQ_NCCL_MIN 3      // ncclMin (rccl.h: ncclRedOp_t)
+
+// The multi-GPU step with thresholds shared between the shards (a shard's own threshold is looser than
+// the reference's; a shard that does not hold a query's neighbourhood would re-rank most of what it scans):
+//   every rank ranks all (replicated) centroids -> the same probe lists everywhere;
+//   A  the nearest list alone (only its owner finds candidates): the usual staged pass;
+//      seed = the k-th best distance of A where A is full, one ncclAllReduce(min) of nq floats;
+//   B  the other probed lists, seeded (one stage);
+//   one all-gather of the 2 x topk keys of A and B, k-way merge on every rank.
+static rq_status sharded_step_shared_thresholds(rq_index *mi, void *nccl_comm, uint32_t world, uint32_t id_offset,
+                                                const float *d_queries, uint32_t nq, uint32_t len, uint32_t probe, uint32_t topk,
+                                                bool heuristic, float *d_out_dist, uint32_t *d_out_id, uint32_t *d_out_n) {
+    RcclApi *api = rccl_api();
+    if (!api->all_gather || !api->all_reduce) return fail(RQ_ERR_UNSUPPORTED, api->err.empty() ? "ncclAllReduce not found" : api->err);
+    const uint32_t npb = std::min(probe, mi->k);
+    Workspace *ws = ws_acquire(mi);
+    struct Rel {
+        rq_index *i;
+        Workspace *w;
+        ~Rel() { ws_release(i, w); }
+    } rel{mi, ws};
+    if (!ws->stream) HIPC(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
+    hipStream_t st = ws->stream;
+    const uint64_t cells = (uint64_t)nq * topk;
+    RQC(ws->sh_dist.ensure(cells));
+    RQC(ws->sh_id.ensure(cells));
+    RQC(ws->sh_n.ensure(nq));
+    RQC(ws->sh_dist_b.ensure(cells));
+    RQC(ws->sh_id_b.ensure(cells));
+    RQC(ws->sh_n_b.ensure(nq));
+    RQC(ws->sh_packed.ensure(2 * cells));
+    RQC(ws->sh_gathered.ensure(2 * cells * world));
+    RQC(ws->sh_merged.ensure(cells));
+    RQC(ws->sh_pc.ensure(2ull * nq * npb));
+    RQC(ws->sh_pd.ensure(2ull * nq * npb));
+    RQC(ws->sh_thr.ensure(nq));
+    uint32_t *pc = ws->sh_pc.p, *pc_a = pc + (uint64_t)nq * npb, *pc_b = pc_a + nq;
+    float *pd = ws->sh_pd.p, *pd_a = pd + (uint64_t)nq * npb, *pd_b = pd_a + nq;
+    RQC(rq_coarse_topk_device(mi, d_queries, nq, len, 0, mi->k, npb, pc, pd));  // synchronous, on a pooled workspace
+    split_probe_kernel<<<ceil_div((uint64_t)nq * npb, 256), 256, 0, st>>>(pc, pd, nq, npb, pc_a, pd_a, pc_b, pd_b);
+    HIPC(hipStreamSynchronize(st));
+    rq_status qs = query_device(mi, d_queries, nq, len, 1, topk, heuristic, ws->sh_dist.p, ws->sh_id.p, ws->sh_n.p, pc_a, pd_a, ws);
+    if (qs != RQ_OK && qs != RQ_ERR_EMPTY) return qs;
+    kth_threshold_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(ws->sh_dist.p, ws->sh_n.p, nq, topk, ws->sh_thr.p);
+    int rc = api->all_reduce(ws->sh_thr.p, ws->sh_thr.p, nq, RQ_NCCL_FLOAT32, RQ_NCCL_MIN, nccl_comm, st);
+    if (rc != 0) return fail(RQ_ERR_HIP, std::string("ncclAllReduce: ") + (api->error_string ? api->error_string(rc) : "error"));
+    HIPC(hipStreamSynchronize(st));
+    qs = query_device(mi, d_queries, nq, len, npb - 1, topk, heuristic, ws->sh_dist_b.p, ws->sh_id_b.p, ws->sh_n_b.p, pc_b, pd_b, ws,
+                      ws->sh_thr.p);
+    if (qs != RQ_OK && qs != RQ_ERR_EMPTY) return qs;
+    pack_topk_keys_at_kernel<<<ceil_div(cells, 256), 256, 0, st>>>(ws->sh_dist.p, ws->sh_id.p, ws->sh_n.p, nq, topk, id_offset, 2 * topk, 0,
+                                                                   ws->sh_packed.p);
+    pack_topk_keys_at_kernel<<<ceil_div(cells, 256), 256, 0, st>>>(ws->sh_dist_b.p, ws->sh_id_b.p, ws->sh_n_b.p, nq, topk, id_offset, 2 * topk,
+                                                                   topk, ws->sh_packed.p);
+    rc = api->all_gather(ws->sh_packed.p, ws->sh_gathered.p, 2 * cells, RQ_NCCL_UINT64, nccl_comm, st);
+    if (rc != 0) return fail(RQ_ERR_HIP, std::string("ncclAllGather: ") + (api->error_string ? api->error_string(rc) : "error"));
+    merge_smallest_u64_kernel<<<nq, 256, (size_t)pow2_ceil(world * 2 * topk) * 8, st>>>(ws->sh_gathered.p, world, nq, 2 * topk, topk,
+                                                                                        ws->sh_merged.p);
+    unpack_topk_keys_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(ws->sh_merged.p, nq, topk, d_out_dist, d_out_id, d_out_n);
+    HIPC(hipStreamSynchronize(st));
+    HIPC(hipGetLastError());
+    return RQ_OK;
+}
 
 rq_status rq_query_batch_sharded_device(const rq_index *shard, void *nccl_comm, uint32_t world, uint32_t id_offset,
                                         const float *d_queries, uint32_t nq, uint32_t len, uint32_t probe, uint32_t topk,
@@ -2529,9 +2630,13 @@ rq_status rq_query_batch_sharded_device(const rq_index *shard, void *nccl_comm, 
     if (!shard || !d_queries || !d_out_dist || !d_out_id || !d_out_n || world == 0)
         return fail(RQ_ERR_INVALID, "null argument");
     if (world > 1 && !nccl_comm) return fail(RQ_ERR_INVALID, "world > 1 needs an RCCL communicator");
-    if (topk == 0 || (uint64_t)world * topk > 16384) return fail(RQ_ERR_UNSUPPORTED, "world * topk must be in [1, 16384]");
+    if (topk == 0 || (uint64_t)world * topk > 8192) return fail(RQ_ERR_UNSUPPORTED, "world * topk must be in [1, 8192]");
     if (nq == 0) return RQ_OK;
     rq_index *mi = const_cast<rq_index *>(shard);
+    const int shared_opt = g_shared_thr.load();  // 0 never, 1 when there are other shards (default), 2 always (tests: one-rank communicator)
+    if (nccl_comm && (shared_opt == 2 || (shared_opt == 1 && world > 1)) && std::min(probe, shard->k) > 1 && validate_query(mi, d_queries, len, probe, topk, d_out_dist, d_out_id, d_out_n) == RQ_OK)
+        return sharded_step_shared_thresholds(mi, nccl_comm, world, id_offset, d_queries, nq, len, probe, topk, heuristic_rank != 0,
+                                              d_out_dist, d_out_id, d_out_n);
     Workspace *ws = ws_acquire(mi);  // one workspace for the whole step: the local query, then the collective on its stream
     struct Rel {
         rq_index *i;
@@ -2622,6 +2727,11 @@ rq_status rq_set_option(const char *name, int value) {
     if (std::string(name) == "dense_dir") {  // test hook: 0 = run descriptors always appended and sorted, 1 = dense directories where they fit
         if (value < 0 || value > 1) return fail(RQ_ERR_INVALID, "dense_dir must be 0 or 1");
         g_dense_dir = value;
+        return RQ_OK;
+    }
+    if (std::string(name) == "shared_thresholds") {  // rq_query_batch_sharded_device: 0 = every shard on its own thresholds, 1 = shared when world > 1, 2 = always
+        if (value < 0 || value > 2) return fail(RQ_ERR_INVALID, "shared_thresholds must be 0, 1 or 2");
+        g_shared_thr = value;
         return RQ_OK;
     }
     if (std::string(name) == "group_rank") {  // test hook: how a cluster-major stage places its pairs (0 atomics per pair, 1 auto, 2 ranked)

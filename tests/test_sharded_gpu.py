@@ -131,7 +131,12 @@ def test_sharded_entry_through_rccl_world1(rq):
     full = rq.RaBitQ.build(x, centres, P)
     wd, wi, wn = full.query_batch(queries, probe, topk)
     q = torch.from_numpy(queries).to(dev)
-    for c in (comm.value, 0):
+    from rabitq_amd import index as ix
+    # (communicator, shared_thresholds): the plain step with and without a communicator, then the shared-threshold step
+    # (nearest list -> ncclAllReduce(min) of the k-th best distances -> seeded rest -> all-gather of 2 x topk keys) forced
+    # onto the one-rank communicator -- all a single GPU can run of it
+    for c, shared in ((comm.value, 1), (0, 1), (comm.value, 2)):
+        ix.set_option("shared_thresholds", shared)
         od = torch.full((nq, topk), -1.0, device=dev)
         oi = torch.zeros((nq, topk), device=dev, dtype=torch.int32)
         on = torch.zeros(nq, device=dev, dtype=torch.int32)
@@ -142,6 +147,7 @@ def test_sharded_entry_through_rccl_world1(rq):
             order = np.lexsort((wi[b, :wn[b]], wd[b, :wn[b]]))
             assert np.array_equal(gi[b, :wn[b]], wi[b, :wn[b]][order] + 1000)
             assert np.array_equal(gd[b, :wn[b]].view(np.uint32), wd[b, :wn[b]][order].view(np.uint32))
+    ix.set_option("shared_thresholds", 1)
     nccl.ncclCommDestroy.argtypes = [C.c_void_p]
     nccl.ncclCommDestroy(comm)
     full.close()
