@@ -33,7 +33,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2,
+                    help="untimed steps; two by default: the first one learns the survivor-buffer capacity of the workload, the "
+                         "second one runs with it and re-allocates the workspace once (tens of GB on the hard distribution: "
+                         "0.5-2 s that would otherwise land in the first timed step)")
     # workload (defaults = BASELINE.json configs[2], the configuration the metric is quoted on)
     ap.add_argument("--vectors", type=int, default=100_000_000, help="vectors per GPU")
     ap.add_argument("--dim", type=int, default=128)
@@ -276,7 +279,11 @@ def main():
         if depth == 1:
             for _ in range(count):
                 extra_prof.clear()
+                ts = time.perf_counter()
                 res = step()
+                if os.environ.get("RQ_BENCH_STEP_TIMES"):   # diagnostics: wall time of every step (the engine call is synchronous)
+                    log(f"step {'timed' if record else 'warm-up'}: {(time.perf_counter() - ts) * 1e3:.1f} ms, "
+                        f"retries so far {rqi.last_profile()['retries']}")
                 if record:
                     for pr in [rqi.last_profile()] + extra_prof:
                         for key, v in pr.items():
