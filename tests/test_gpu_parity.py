@@ -737,6 +737,61 @@ def test_sharded_coarse_and_probed_query_equal_single(rq):
     idx.close()
 
 
+@pytest.mark.parametrize("nq", [40, 300])
+def test_seeded_probed_query(rq, nq):
+    """rq_query_batch_device_seeded (the multi-GPU step's second call): the ranker starts from a per-query threshold and
+    the whole stream runs as one stage.  (i) seeds of f32::MAX: nothing is pruned by them -- the single stage lets every
+    candidate through, the survivor buffers overflow, the re-run stages as usual (thresholds through the row map) -- and the
+    result is the plain probed query's, bit for bit; (ii) seeds just above each query's final k-th distance: the same
+    top-k, far fewer exact distances; (iii) seeds below a query's best distance: nothing is returned for it."""
+    import torch
+    from rabitq_amd import index as ix
+    dev = torch.device("cuda", 0)
+    n, d, k, probe, topk = 30_000, 128, 24, 8, 10
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.8, seed=81, centre_scale=0.6)
+    idx = rq.RaBitQ.build(x, centres, synth.random_orthogonal(d, seed=82))
+    queries, _, _ = synth.mixture(nq, d, k, sigma=0.8, seed=83, centre_scale=0.6)
+    wd, wi, wn = idx.query_batch(queries, probe, topk)
+    plain_rerank = ix.last_profile()["rerank_candidates"]
+    assert (wn == topk).all()
+    _, cl, cd = rq.ops.coarse_rank(idx, queries, probe)
+    q = torch.from_numpy(queries).to(dev)
+    pc = torch.from_numpy(cl.view(np.int32)).to(dev)
+    pdd = torch.from_numpy(cd).to(dev)
+    od = torch.empty((nq, topk), device=dev)
+    oi = torch.zeros((nq, topk), device=dev, dtype=torch.int32)
+    on = torch.zeros(nq, device=dev, dtype=torch.int32)
+
+    def run(thr):
+        t = torch.from_numpy(np.ascontiguousarray(thr, np.float32)).to(dev)
+        torch.cuda.synchronize()
+        idx.query_batch_device_seeded(q.data_ptr(), nq, d, pc.data_ptr(), pdd.data_ptr(), probe, topk, t.data_ptr(),
+                                      od.data_ptr(), oi.data_ptr(), on.data_ptr())
+        return od.cpu().numpy(), oi.cpu().numpy().view(np.uint32), on.cpu().numpy().view(np.uint32), ix.last_profile()
+
+    fmax = np.finfo(np.float32).max
+    gd, gi, gn, pr = run(np.full(nq, fmax))                                   # (i)
+    assert pr["retries"] > 0, "f32::MAX seeds should overflow the single stage"
+    assert np.array_equal(gn, wn) and np.array_equal(gi, wi) and np.array_equal(gd.view(np.uint32), wd.view(np.uint32))
+    kth = wd.max(axis=1)
+    gd, gi, gn, pr = run(np.nextafter(kth, np.float32(np.inf)) * np.float32(1.0001))   # (ii)
+    assert pr["retries"] == 0 and pr["rerank_candidates"] < plain_rerank
+    # every returned entry is one of the plain top-k with the same distance; a plain neighbour can be missing only where its
+    # ESTIMATE (rough) is not below the seed although its exact distance is (the plain run met it under a looser threshold)
+    missing = 0
+    for b in range(nq):
+        plain = {int(i): wd[b, e].tobytes() for e, i in enumerate(wi[b, :topk])}
+        for e in range(gn[b]):
+            assert int(gi[b, e]) in plain and gd[b, e].tobytes() == plain[int(gi[b, e])], (b, e)
+        missing += topk - int(gn[b])
+    assert missing <= nq * topk // 50, missing
+    seeds = kth.copy()
+    seeds[::2] = wd.min(axis=1)[::2]                                          # (iii) every other query: nothing is below its best
+    gd, gi, gn, pr = run(seeds)
+    assert (gn[::2] == 0).all() and (gn[1::2] <= topk - 1).all() and (gn[1::2] >= topk - 3).all()   # strict "<": the k-th itself is cut too
+    idx.close()
+
+
 # ---- batches in flight: begin / end halves of the device batch call -----------------------------------
 def test_begin_end_batches_overlap_and_match_sync(rq):
     import torch
