@@ -2200,7 +2200,7 @@ __device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, co
     uint32_t precise = 0;
     uint32_t hlen = 0, wcount = 0, alen = 0;
     float recent = 0.0f;
-    // REGHEAP (topk <= 64): the heap lives in one register pair, element i in lane i, read and written with
+    // REGHEAP (topk < 64: BinaryHeap::push before pop holds topk + 1 elements): the heap lives in one register pair, element i in lane i, read and written with
     // v_readlane / a lane-select at wave-uniform indices: a sift step is a few scalar instructions instead of a chain of
     // dependent LDS round trips (the replay of a stage was bound by exactly that latency)
     int32_t rk = 0;

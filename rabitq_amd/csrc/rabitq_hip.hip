@@ -989,7 +989,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             pf.begin(PF_REPLAY);
             if (qp.heuristic)
                 replay_kernel<true><<<nq, 64, 16, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, topk, rs, dense_cells);
-            else if (topk <= 64)  // the heap in registers, one element per lane
+            else if (topk < 64)  // the heap in registers, one element per lane (a push before a pop holds topk + 1 elements)
                 replay_kernel<false, true><<<nq, 64, 16, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, topk, rs, dense_cells);
             else
                 replay_kernel<false><<<nq, 64, (size_t)topk * 8, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, topk, rs, dense_cells);

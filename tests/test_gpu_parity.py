@@ -904,6 +904,23 @@ def test_coarse_distance_kernels_agree_bitwise(rq, oracle, d, k, nq):
     oidx.close()
 
 
+@pytest.mark.parametrize("topk", [63, 64, 65])
+def test_large_batch_heap_sizes_around_a_wave(rq, oracle, topk):
+    """Large batches keep the ranker's heap in registers (one element per lane) while it fits: a push before a pop holds
+    topk + 1 elements, so 63 is the last register-resident size and 64 / 65 use the LDS heap (a fuzz run caught 64 being
+    sent to the register path: the 65th element was dropped)."""
+    n, d, k, nq = 18_000, 128, 2, 260
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.8, seed=1003, centre_scale=1.5)
+    P = synth.random_orthogonal(d, seed=3)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    gidx = rq.RaBitQ.build(x, centres, P)
+    queries, _, _ = synth.mixture(nq, d, k, sigma=0.8, seed=5003, centre_scale=0.7)
+    _compare_with_oracle(rq, oracle, oidx, gidx, queries, 1, topk, False)
+    _compare_with_oracle(rq, oracle, oidx, gidx, queries, 2, topk, False)
+    gidx.close()
+    oidx.close()
+
+
 def test_wide_probe_and_deep_topk_match_oracle(rq, oracle):
     # nprobe > 64 (block-wide probe selection, many pairs per query) together with a deep top-k, on a batch large
     # enough for the matrix-core final stage and the rerank-order grouping (nq >= 256)
