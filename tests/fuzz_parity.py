@@ -23,7 +23,7 @@ for it in range(rounds):
     k = int(rng.choice([1, 2, 5, 16, 40, 120, 300]))
     nmax = int(os.environ.get("N_MAX", 12000))
     n = int(rng.integers(max(k, 200), nmax if d <= 256 else max(4000, nmax // 4)))
-    nq = int(rng.choice([1, 3, 9, 33, 70, 260, 300]))
+    nq = int(rng.choice([1, 3, 9, 33, 70, 260, 300, 700]))
     sigma = float(rng.choice([0.4, 0.8, 1.2]))
     x, centres, _ = synth.mixture(n, d, k, sigma=sigma, seed=1000 + it, centre_scale=float(rng.choice([0.3, 0.7, 1.5])))
     if rng.random() < 0.3:   # duplicates and exact centroid copies
@@ -48,7 +48,7 @@ for it in range(rounds):
     cfgs = []
     for _ in range(2):
         probe = int(rng.choice([1, 2, max(1, k // 2), k, k + 3, 70]))
-        topk = int(rng.choice([1, 5, 10, 64, 200]))
+        topk = int(rng.choice([1, 5, 10, 63, 64, 65, 200]))
         cfgs.append((probe, topk, bool(rng.random() < 0.3)))
     ok = True
     for probe, topk, heur in cfgs:
