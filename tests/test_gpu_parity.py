@@ -1174,6 +1174,24 @@ def test_rerank_shadow_rows_keep_results_exact(rq, oracle, d, kind):
     oidx.close()
 
 
+def test_dense_directory_falls_back_when_a_stage_has_more_cells_than_capacity(rq, oracle):
+    """One list of 600 000 vectors, a large batch: the geometric stage [40 960, 327 680) spans 4 480 directory cells, more
+    than the default survivor capacity (4 096), so that stage appends and sorts its runs while its neighbours use dense
+    directories -- both forms inside one query pass."""
+    n, d, nq = 600_000, 64, 260
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    centres = np.zeros((1, d), np.float32)
+    P = synth.random_orthogonal(d, seed=22)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    gidx = rq.RaBitQ.build(x, centres, P)
+    queries = (x[rng.integers(0, n, nq)] + 0.3 * rng.standard_normal((nq, d))).astype(np.float32)
+    _compare_with_oracle(rq, oracle, oidx, gidx, queries, 1, 10, False)
+    _compare_with_oracle(rq, oracle, oidx, gidx, queries, 1, 10, True)
+    gidx.close()
+    oidx.close()
+
+
 def test_json_persistence_round_trip(rq, oracle, tmp_path):
     """dump_to_json / load_from_json (src/rabitq.rs:72-81): the serde_json image of the struct (faer Mats as
     {"nrows","ncols","data": row-major}, base dim x n, centroids dim x k); every f32 survives the text bit for bit."""
