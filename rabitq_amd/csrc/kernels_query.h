@@ -1641,15 +1641,20 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
                     gmask &= gmask - 1;
                     const uint32_t row = (gq & 3) + 8 * (gq >> 2) + 4 * h;
                     const float sf = 2.0f * sc[gq];  // wave-uniform register index
+                    // the row's scalars in two 16-byte LDS reads: lower delta sumq ycd | ycd_sqrt thr lo hi
+                    const uint4 ta = *reinterpret_cast<const uint4 *>(&img[IMG_OP + row * RQ_REC_TAIL]);
+                    const uint4 tb = *reinterpret_cast<const uint4 *>(&img[IMG_OP + row * RQ_REC_TAIL + 4]);
+                    static_assert(RQ_REC_LOWER == 0 && RQ_REC_DELTA == 1 && RQ_REC_SUMQ == 2 && RQ_REC_YCD == 3 && RQ_REC_YCD_SQRT == 4 &&
+                                      RQ_REC_THR == 5 && RQ_REC_LO == 6 && RQ_REC_HI == 7, "tail layout read as two uint4");
                     // the reference's expression, left to right (src/rabitq.rs:352-363)
-                    float tt = fc.w + __builtin_bit_cast(float, tail(RQ_REC_YCD, row));
-                    tt = tt + __builtin_bit_cast(float, tail(RQ_REC_LOWER, row)) * fc.y;
-                    const float u = (2.0f * sf - __builtin_bit_cast(float, tail(RQ_REC_SUMQ, row))) * fc.x;
-                    tt = tt + u * __builtin_bit_cast(float, tail(RQ_REC_DELTA, row));
-                    const float rg = tt - fc.z * __builtin_bit_cast(float, tail(RQ_REC_YCD_SQRT, row));
-                    bool pass = rg < __builtin_bit_cast(float, tail(RQ_REC_THR, row));  // src/rerank.rs:84
+                    float tt = fc.w + __builtin_bit_cast(float, ta.w);
+                    tt = tt + __builtin_bit_cast(float, ta.x) * fc.y;
+                    const float u = (2.0f * sf - __builtin_bit_cast(float, ta.z)) * fc.x;
+                    tt = tt + u * __builtin_bit_cast(float, ta.y);
+                    const float rg = tt - fc.z * __builtin_bit_cast(float, tb.x);
+                    bool pass = rg < __builtin_bit_cast(float, tb.y);  // src/rerank.rs:84
                     // a real query, and a list position inside its stage range
-                    pass = pass && row < nvalid && lpos[t] >= tail(RQ_REC_LO, row) && lpos[t] < tail(RQ_REC_HI, row);
+                    pass = pass && row < nvalid && lpos[t] >= tb.z && lpos[t] < tb.w;
                     const uint64_t m = __ballot(pass);
                     if (m == 0) continue;
                     if (nE + 64 > QE || nR + 2 > QR) flush();
