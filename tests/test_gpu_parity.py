@@ -1125,7 +1125,7 @@ def test_long_run_directories_large_batch(rq, oracle, dense_dir):
 
 @pytest.mark.parametrize("d,kind", [(128, "gauss"), (192, "gauss"), (128, "beyond_fp16"), (128, "fp16_subnormal"),
                                     (128, "small_ints"), (64, "near_ties")])
-def test_rerank_shadow_rows_keep_results_exact(rq, oracle, d, kind):
+def test_rerank_shadow_rows_keep_results_exact(rq, oracle, d, kind, tmp_path):
     """Large batches re-rank through the fp16 shadow rows (accurate_filtered_kernel): a survivor is dropped without its
     f32 row being read only when the shadow PROVES accurate >= the stage's threshold.  Data the shadow represents badly
     (elements beyond the fp16 range -> inf, fp16 subnormals, near-equal distances around the threshold) must still give
@@ -1167,6 +1167,20 @@ def test_rerank_shadow_rows_keep_results_exact(rq, oracle, d, kind):
         for u, v in zip(a, b):
             assert_bits_equal(u, v, "with / without shadow rows")
         plain.close()
+        if kind == "gauss" and d == 128:   # the shadow is derived state: a loaded index and a carved shard rebuild it
+            gidx.dump_to_dir(str(tmp_path / "idx"))
+            loaded = rq.RaBitQ.load_from_dir(str(tmp_path / "idx"))
+            c = loaded.query_batch(queries, 8, 10, False)
+            assert ix.last_profile()["rerank_shadow_rejects"] > 0
+            owner, _ = gidx.partition_lists(1)
+            shard = gidx.shard(owner, 0)
+            e = shard.query_batch(queries, 8, 10, False)
+            assert ix.last_profile()["rerank_shadow_rejects"] > 0
+            for u, v, w in zip(a, c, e):
+                assert_bits_equal(u, v, "loaded index")
+                assert_bits_equal(u, w, "shard of everything")
+            loaded.close()
+            shard.close()
     finally:
         ix.set_profiling(0)
         ix.set_option("rerank_shadow", 1)
