@@ -293,12 +293,119 @@ __global__ __launch_bounds__(256) void select_probe_kernel(const float *__restri
 // ~20 steps, stopping as soon as a threshold selects exactly nprobe), ties at the threshold are broken
 // by list id (a second bisection, rare), the winners are compacted by ballot and sorted across the 64
 // lanes with a shuffle bitonic network.  No LDS atomics, no block barriers.
-template <int KPL>
+// ------------------------------------------------------------------------------------------------
+// Coarse ranking of a large batch through the matrix cores, WITHOUT giving up the exact distances.
+//   1. coarse_approx_kernel: a[q][i] = (|c_i|^2 + |y_q|^2) - 2 <c_i, y_q> with the inner products from
+//      v_mfma_f32_32x32x2_f32 (plain f32 FMAs, 64 per 32 x 32 tile at dim 128): 1/3 of the time of the exact-order
+//      VALU kernel.  Against the reference's f32 value e[q][i] (src/simd.rs:14-73 order)
+//          |a - e| <= m_q = (9 dim/8 + 16) 1.05 2^-24 (Cmax + |y_q|)^2
+//      (dim roundings each in the two norms and the product, two in the final ops, dim/8 + 5 in the reference's own
+//      chain; Cmax = the largest centroid norm of the index).
+//   2. select_probe_wave_kernel (refine): T = an upper bound of the nprobe-th smallest a (the 64th smallest of the
+//      lanes' two smallest values each: 128 actual entries of the row).  Every list of the exact top-nprobe has
+//      a <= T + 2 m_q: at least nprobe lists have e <= T + m_q, so the nprobe-th smallest e is <= T + m_q, and a list
+//      at or below it has a <= e + m_q.  Those candidates (~80 of 4096) get their EXACT distance, computed in the
+//      reference's lane order by one lane each; everything else is dropped; the selection then runs on exact values
+//      only, as before.  The result is the exact ranking, bit for bit (ties included: tied lists are all candidates).
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// squared norms of n rows of `dim` floats (sequential f32 chain per row) and, optionally, their maximum (as u32 bits:
+// non-negative floats order like their bit patterns)
+__global__ void row_sqnorm_kernel(const float *__restrict__ rows, uint32_t n, uint32_t dim, float *__restrict__ out,
+                                  uint32_t *__restrict__ max_bits) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const float4 *p = reinterpret_cast<const float4 *>(rows + (uint64_t)r * dim);
+    float s = 0.0f;
+    for (uint32_t c = 0; c < dim / 4; ++c) {
+        const float4 v = p[c];
+        s = fmaf(v.x, v.x, s), s = fmaf(v.y, v.y, s), s = fmaf(v.z, v.z, s), s = fmaf(v.w, v.w, s);
+    }
+    out[r] = s;
+    if (max_bits) atomicMax(max_bits, __builtin_bit_cast(uint32_t, s));  // NaN / inf bit patterns sort above every finite norm
+}
+
+// one wave = 32 queries (MFMA rows, their dim values resident: dim/2 VGPRs) against every 32-list tile (MFMA columns,
+// read from the transposed centroids, coalesced); block = 4 waves = 128 queries.  DIM <= 256.
+template <int DIM>
+__global__ __launch_bounds__(256) void coarse_approx_kernel(const float *__restrict__ y, const float *__restrict__ cent_t,
+                                                            const float *__restrict__ cnorm, const float *__restrict__ ynorm,
+                                                            float *__restrict__ dist, uint32_t k, uint32_t nq, uint32_t kstride) {
+    constexpr int NM = DIM / 2;  // MFMAs per tile (K = 2 each)
+    const uint32_t lane = threadIdx.x & 63, li = lane & 31, kk = lane >> 5;
+    const uint32_t q0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
+    if (q0 >= nq) return;
+    const uint32_t qa = q0 + li < nq ? q0 + li : nq - 1;
+    float a[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) a[m] = y[(uint64_t)qa * DIM + 2 * m + kk];
+    float yn[16];  // |y|^2 of this lane's 16 output rows
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const uint32_t q = q0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        yn[r] = ynorm[q < nq ? q : nq - 1];
+    }
+    const uint32_t ntile = (k + 31) / 32;
+    float bc[NM], bn[NM];
+    auto load_b = [&](uint32_t t, float (&b)[NM], float &cn) {
+        const uint32_t i = 32 * t + li < k ? 32 * t + li : k - 1;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) b[m] = cent_t[(uint64_t)(2 * m + kk) * kstride + i];
+        cn = cnorm[i];
+    };
+    float cn_c, cn_n = 0.0f;
+    load_b(0, bc, cn_c);
+    for (uint32_t t = 0; t < ntile; ++t) {
+        if (t + 1 < ntile) load_b(t + 1, bn, cn_n);  // in flight while this tile's MFMAs run
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int m = 0; m < NM; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bc[m], acc, 0, 0, 0);
+        const uint32_t i = 32 * t + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t q = q0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            if (q < nq && i < k) dist[(uint64_t)q * k + i] = (cn_c + yn[r]) - 2.0f * acc[r];
+        }
+#pragma unroll
+        for (int m = 0; m < NM; ++m) bc[m] = bn[m];
+        cn_c = cn_n;
+    }
+}
+
+// the reference's l2_squared_distance(centroid, y) by ONE lane (src/simd.rs:14-73: 8 lanes of fused multiply-adds, folded
+// pairwise); y in LDS.  (Force-inlined: as a real call -- __noinline__ -- it returned wrong keys on this toolchain.)
+__device__ __forceinline__ uint32_t refine_exact_key(const float *__restrict__ c, const float *yq, uint32_t dim) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (uint32_t e = 0; e < dim; e += 8) {
+        const float4 c0 = *reinterpret_cast<const float4 *>(c + e), c1 = *reinterpret_cast<const float4 *>(c + e + 4);
+        const float4 y0 = *reinterpret_cast<const float4 *>(yq + e), y1 = *reinterpret_cast<const float4 *>(yq + e + 4);
+        const float d0 = c0.x - y0.x, d1 = c0.y - y0.y, d2 = c0.z - y0.z, d3 = c0.w - y0.w;
+        const float d4 = c1.x - y1.x, d5 = c1.y - y1.y, d6 = c1.z - y1.z, d7 = c1.w - y1.w;
+        acc[0] = fmaf(d0, d0, acc[0]), acc[1] = fmaf(d1, d1, acc[1]), acc[2] = fmaf(d2, d2, acc[2]), acc[3] = fmaf(d3, d3, acc[3]);
+        acc[4] = fmaf(d4, d4, acc[4]), acc[5] = fmaf(d5, d5, acc[5]), acc[6] = fmaf(d6, d6, acc[6]), acc[7] = fmaf(d7, d7, acc[7]);
+    }
+    return ord32_biased(reduce8_regs(acc));
+}
+#define RQ_REFINE_CAP 1024u      // candidate lists per query handled through the balanced path
+#define RQ_REFINE_MAX_DIM 256u   // the approximate product keeps a query's dim/2 operand registers resident
+// what the refining probe selection needs besides the approximate row (cent == nullptr: the row is exact already)
+struct RefineArgs {
+    const float *cent;   // the ranked lists' centroids, row-major (row i = list i of the row)
+    const float *y;      // rotated queries, nq x dim
+    const float *ynorm;  // |y|^2
+    float err_coef;      // (9 dim/8 + 16) 1.05 2^-24
+    float cmax;          // largest centroid norm (finite)
+    uint32_t dim;
+};
+
+template <int KPL, bool REFINE = false>
 __global__ __launch_bounds__(256) void select_probe_wave_kernel(const float *__restrict__ dist, uint32_t k,
                                                                 uint32_t nprobe, uint32_t *__restrict__ out_cluster,
                                                                 float *__restrict__ out_dist, uint32_t id_offset,
-                                                                uint32_t out_stride, uint32_t nq) {
+                                                                uint32_t out_stride, uint32_t nq, const RefineArgs rf) {
     __shared__ unsigned long long win[4][64];
+    __shared__ uint32_t cand[REFINE ? 4 : 1][REFINE ? RQ_REFINE_CAP : 1];                         // refine: candidate lists, then their exact keys
+    __shared__ __attribute__((aligned(16))) float yq[REFINE ? 4 : 1][REFINE ? RQ_REFINE_MAX_DIM : 4];  // refine: the wave's query
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x * 4 + wave;
     if (b >= nq) return;
@@ -332,6 +439,72 @@ __global__ __launch_bounds__(256) void select_probe_wave_kernel(const float *__r
                 kmax = key[i] > kmax ? key[i] : kmax;
             }
         }
+    }
+    if constexpr (REFINE) {  // the row is approximate: exact distances for everything that can be among the nprobe nearest
+        // T: the 64th smallest of the lanes' two smallest keys (128 entries of the row, so at least 64 >= nprobe lists lie at
+        // or below it)
+        uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) {
+            const uint32_t x = key[i];
+            m2 = x < m1 ? m1 : (x < m2 ? x : m2);
+            m1 = x < m1 ? x : m1;
+        }
+        uint32_t lo = 0, hi = 0xFFFFFFFFu;  // smallest T with #(m1, m2 <= T) >= 64
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            const uint32_t c = (uint32_t)__popcll(__ballot(m1 <= mid)) + (uint32_t)__popcll(__ballot(m2 <= mid));
+            if (c >= 64) hi = mid;
+            else lo = mid + 1;
+        }
+        // candidates: a <= T + 2 m_q, evaluated in floats and rounded up; anything not finite -> every list is a candidate
+        const float yn = rf.ynorm[b];
+        const float rad = rf.cmax + sqrtf(yn) * 1.000001f;
+        const float mq = rf.err_coef * (rad * rad) * 1.000001f;
+        const float tf = ord32_unbias(lo) + 2.0f * mq;
+        uint32_t tkey = 0xFFFFFFFEu;
+        if (lo != 0xFFFFFFFFu && tf == tf && fabsf(tf) < 3.0e38f) {
+            const float up = tf + fabsf(tf) * 1.0e-6f + 1.0e-30f;
+            tkey = ord32_biased(up);
+            if (tkey < lo) tkey = lo;
+        }
+        for (uint32_t c = lane * 4; c < rf.dim; c += 256)
+            *reinterpret_cast<float4 *>(&yq[wave][c]) = *reinterpret_cast<const float4 *>(rf.y + (uint64_t)b * rf.dim + c);
+        // 16 registers (<= 1024 entries = RQ_REFINE_CAP) at a time: compact the candidates' list ids into LDS, one exact
+        // distance per lane and round (so the work is balanced whatever lanes the candidates sit in), read the keys back
+        static_assert(KPL % 16 == 0 && RQ_REFINE_CAP == 1024, "a group of 16 registers always fits the candidate buffer");
+#pragma unroll
+        for (int g0 = 0; g0 < KPL; g0 += 16) {
+            uint32_t nc = 0;  // wave-uniform
+#pragma unroll
+            for (int i = g0; i < g0 + 16; ++i) {
+                const bool is_c = key[i] <= tkey && key[i] != 0xFFFFFFFFu;
+                const uint64_t m = __ballot(is_c);
+                if (is_c) cand[wave][nc + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = list_of(i);
+                nc += (uint32_t)__popcll(m);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            for (uint32_t jx = lane; jx < nc; jx += 64)
+                cand[wave][jx] = refine_exact_key(rf.cent + (uint64_t)cand[wave][jx] * rf.dim, &yq[wave][0], rf.dim);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            uint32_t at0 = 0;
+#pragma unroll
+            for (int i = g0; i < g0 + 16; ++i) {
+                const bool is_c = key[i] <= tkey && key[i] != 0xFFFFFFFFu;
+                const uint64_t m = __ballot(is_c);
+                const uint32_t got = is_c ? cand[wave][at0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] : 0xFFFFFFFFu;
+                key[i] = got;
+                at0 += (uint32_t)__popcll(m);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the buffer is reused by the next group
+        }
+        kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i)
+            if (key[i] != 0xFFFFFFFFu) {
+                kmin = key[i] < kmin ? key[i] : kmin;
+                kmax = key[i] > kmax ? key[i] : kmax;
+            }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {

@@ -35,7 +35,7 @@ for it in range(rounds):
     # engine knobs that must never change a result: raw-vector tiers, chunked scan grids, tile tables
     knobs = {"base_device_mb": int(rng.choice([-1, -1, 0, 1])), "max_scan_blocks": int(rng.choice([0, 0, 3, 40])),
              "scan_tile_table": int(rng.choice([0, 1, 2])), "group_rank": int(rng.choice([0, 1, 2])),
-             "rerank_shadow": int(rng.choice([0, 1, 1])), "coarse_impl": int(rng.choice([0, 1, 2])),
+             "rerank_shadow": int(rng.choice([0, 1, 1])), "coarse_impl": int(rng.choice([0, 1, 2, 3, 3])),
              "scan_dense": int(rng.choice([0, 1, 2, 2])), "dense_dir": int(rng.choice([0, 1, 1]))}
     for name, v in knobs.items():
         ix.set_option(name, v)

@@ -859,8 +859,9 @@ def test_begin_end_overflow_retry_matches_sync(rq):
     assert np.array_equal(res[0][0], res[1][0])
 
 
+@pytest.mark.parametrize("coarse_impl", [0, 3])
 @pytest.mark.parametrize("k", [2000, 5000])
-def test_many_lists_probe_selection_matches_oracle(rq, oracle, k):
+def test_many_lists_probe_selection_matches_oracle(rq, oracle, k, coarse_impl):
     # the register-resident probe selection is instantiated per list-count bracket (<= 1024, <= 4096, <= 8192):
     # exercise the two larger ones (and many tiny / empty lists) against the oracle
     n, d, nq = 30000, 64, 24
@@ -873,18 +874,24 @@ def test_many_lists_probe_selection_matches_oracle(rq, oracle, k):
     gidx = rq.RaBitQ.build(x, centres, P)
     assert np.array_equal(gidx.offsets, oidx.offsets)
     queries = (x[rng.choice(n, nq, replace=False)] + 0.05).astype(np.float32)
-    for probe, topk in ((64, 10), (33, 5), (1, 3)):
-        _compare_with_oracle(rq, oracle, oidx, gidx, queries, probe, topk, False)
+    from rabitq_amd import index as ix
+    ix.set_option("coarse_impl", coarse_impl)
+    try:
+        for probe, topk in ((64, 10), (33, 5), (1, 3)):
+            _compare_with_oracle(rq, oracle, oidx, gidx, queries, probe, topk, False)
+    finally:
+        ix.set_option("coarse_impl", 0)
     gidx.close()
     oidx.close()
 
 
-@pytest.mark.parametrize("d,k,nq", [(128, 300, 50), (64, 1000, 37), (192, 77, 19), (768, 40, 21)])
+@pytest.mark.parametrize("d,k,nq", [(128, 300, 50), (64, 1000, 37), (192, 77, 19), (768, 40, 21), (256, 401, 45), (128, 4100, 33)])
 def test_coarse_distance_kernels_agree_bitwise(rq, oracle, d, k, nq):
-    """The coarse ranking (src/rabitq.rs:283-297) has two distance kernels: query rows broadcast through LDS (small
-    batches) and query rows in scalar registers (large batches).  Both reproduce l2_squared_distance's lane order, so
-    forcing either one must give the oracle's probe lists and distances bit for bit (ragged sizes: nq not a multiple of
-    16, k not a multiple of 256)."""
+    """The coarse ranking (src/rabitq.rs:283-297) has two exact distance kernels -- query rows broadcast through LDS (small
+    batches), query rows in scalar registers (large batches) -- and a pre-filtered form (approximate f32 matrix-core
+    product, then the exact lane-order distance of every list that can still be among the nprobe nearest).  Forcing any
+    of them must give the oracle's probe lists and distances bit for bit (ragged sizes: nq not a multiple of 16 / 32, k
+    not a multiple of 32 / 256; duplicate centroids: ties at the selection threshold)."""
     from rabitq_amd import index as ix
     n = 6000
     x, centres, _ = synth.mixture(n, d, k, sigma=0.9, seed=d + k, centre_scale=0.8)
@@ -894,7 +901,7 @@ def test_coarse_distance_kernels_agree_bitwise(rq, oracle, d, k, nq):
     gidx = rq.RaBitQ.build(x, centres, P)
     queries, _, _ = synth.mixture(nq, d, k, sigma=0.9, seed=d + k + 1, centre_scale=0.8)
     try:
-        for impl in (1, 2):
+        for impl in (1, 2, 3):    # 3: approximate matrix-core product + exact refinement of the candidates (dim 64/128/256, k >= 256)
             ix.set_option("coarse_impl", impl)
             _compare_with_oracle(rq, oracle, oidx, gidx, queries, min(k, 40), 10, False)
             _compare_with_oracle(rq, oracle, oidx, gidx, queries[:3], 7, 5, False)
