@@ -346,29 +346,39 @@ __global__ __launch_bounds__(256) void coarse_approx_kernel(const float *__restr
         yn[r] = ynorm[q < nq ? q : nq - 1];
     }
     const uint32_t ntile = (k + 31) / 32;
-    float bc[NM], bn[NM];
-    auto load_b = [&](uint32_t t, float (&b)[NM], float &cn) {
+    float b0[NM], b1[NM];  // two operand sets, used alternately: the next tile's loads fly during this tile's MFMAs, no copies
+    auto load_b = [&](uint32_t t, float (&bb)[NM], float &cn) {
         const uint32_t i = 32 * t + li < k ? 32 * t + li : k - 1;
 #pragma unroll
-        for (int m = 0; m < NM; ++m) b[m] = cent_t[(uint64_t)(2 * m + kk) * kstride + i];
+        for (int m = 0; m < NM; ++m) bb[m] = cent_t[(uint64_t)(2 * m + kk) * kstride + i];
         cn = cnorm[i];
     };
-    float cn_c, cn_n = 0.0f;
-    load_b(0, bc, cn_c);
-    for (uint32_t t = 0; t < ntile; ++t) {
-        if (t + 1 < ntile) load_b(t + 1, bn, cn_n);  // in flight while this tile's MFMAs run
+    const bool rows_full = q0 + 32 <= nq;
+    auto tile = [&](uint32_t t, const float (&bb)[NM], float cn) {
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int m = 0; m < NM; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bc[m], acc, 0, 0, 0);
+        for (int m = 0; m < NM; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bb[m], acc, 0, 0, 0);
         const uint32_t i = 32 * t + li;
+        float *out = dist + (uint64_t)(q0 + 4 * kk) * k + i;
+        if (rows_full && 32 * t + 32 <= k) {  // wave-uniform: sixteen plain stores
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const uint32_t q = q0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-            if (q < nq && i < k) dist[(uint64_t)q * k + i] = (cn_c + yn[r]) - 2.0f * acc[r];
+            for (int r = 0; r < 16; ++r) out[(uint64_t)((r & 3) + 8 * (r >> 2)) * k] = (cn + yn[r]) - 2.0f * acc[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t q = q0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (q < nq && i < k) out[(uint64_t)((r & 3) + 8 * (r >> 2)) * k] = (cn + yn[r]) - 2.0f * acc[r];
+            }
         }
-#pragma unroll
-        for (int m = 0; m < NM; ++m) bc[m] = bn[m];
-        cn_c = cn_n;
+    };
+    float cn0 = 0.0f, cn1 = 0.0f;
+    load_b(0, b0, cn0);
+    for (uint32_t t = 0; t < ntile; t += 2) {
+        if (t + 1 < ntile) load_b(t + 1, b1, cn1);
+        tile(t, b0, cn0);
+        if (t + 1 >= ntile) break;
+        if (t + 2 < ntile) load_b(t + 2, b0, cn0);
+        tile(t + 1, b1, cn1);
     }
 }
 
@@ -386,7 +396,6 @@ __device__ __forceinline__ uint32_t refine_exact_key(const float *__restrict__ c
     }
     return ord32_biased(reduce8_regs(acc));
 }
-#define RQ_REFINE_CAP 1024u      // candidate lists per query handled through the balanced path
 #define RQ_REFINE_MAX_DIM 256u   // the approximate product keeps a query's dim/2 operand registers resident
 // what the refining probe selection needs besides the approximate row (cent == nullptr: the row is exact already)
 struct RefineArgs {
@@ -398,16 +407,45 @@ struct RefineArgs {
     uint32_t dim;
 };
 
+// refine phase of select_probe_wave_kernel: registers [G0, G1) of the wave's row
+template <int KPL, int G0, int G1>
+__device__ __forceinline__ void refine_registers(uint32_t (&key)[KPL], uint32_t tkey, uint32_t *cand_w, const float *yq_w,
+                                                 const RefineArgs &rf, uint32_t lane) {
+    uint32_t nc = 0;  // wave-uniform
+#pragma unroll
+    for (int i = G0; i < G1; ++i) {
+        const bool is_c = key[i] <= tkey && key[i] != 0xFFFFFFFFu;
+        const uint64_t m = __ballot(is_c);
+        if (m) {
+            if (is_c) cand_w[nc + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = 256u * (uint32_t)(i >> 2) + 4u * lane + (uint32_t)(i & 3);
+            nc += (uint32_t)__popcll(m);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    for (uint32_t jx = lane; jx < nc; jx += 64) cand_w[jx] = refine_exact_key(rf.cent + (uint64_t)cand_w[jx] * rf.dim, yq_w, rf.dim);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    uint32_t at0 = 0;
+#pragma unroll
+    for (int i = G0; i < G1; ++i) {
+        const bool is_c = key[i] <= tkey && key[i] != 0xFFFFFFFFu;
+        const uint64_t m = __ballot(is_c);
+        key[i] = is_c ? cand_w[at0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] : 0xFFFFFFFFu;
+        at0 += (uint32_t)__popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the buffer may be reused
+}
 template <int KPL, bool REFINE = false>
 __global__ __launch_bounds__(256) void select_probe_wave_kernel(const float *__restrict__ dist, uint32_t k,
                                                                 uint32_t nprobe, uint32_t *__restrict__ out_cluster,
                                                                 float *__restrict__ out_dist, uint32_t id_offset,
                                                                 uint32_t out_stride, uint32_t nq, const RefineArgs rf) {
-    __shared__ unsigned long long win[4][64];
-    __shared__ uint32_t cand[REFINE ? 4 : 1][REFINE ? RQ_REFINE_CAP : 1];                         // refine: candidate lists, then their exact keys
-    __shared__ __attribute__((aligned(16))) float yq[REFINE ? 4 : 1][REFINE ? RQ_REFINE_MAX_DIM : 4];  // refine: the wave's query
+    // waves per block: 4, or what the refine buffers (a whole row of list ids per wave) leave room for
+    constexpr uint32_t WPB = REFINE ? (KPL <= 16 ? 4u : (KPL <= 64 ? 2u : 1u)) : 4u;
+    __shared__ unsigned long long win[WPB][64];
+    __shared__ uint32_t cand[REFINE ? WPB : 1][REFINE ? 64 * KPL : 1];                             // refine: candidate lists, then their exact keys
+    __shared__ __attribute__((aligned(16))) float yq[REFINE ? WPB : 1][REFINE ? RQ_REFINE_MAX_DIM : 4];  // refine: the wave's query
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t b = blockIdx.x * 4 + wave;
+    const uint32_t b = blockIdx.x * WPB + wave;
     if (b >= nq) return;
     const float *d = dist + (uint64_t)b * k;
     uint32_t key[KPL];
@@ -470,34 +508,10 @@ __global__ __launch_bounds__(256) void select_probe_wave_kernel(const float *__r
         }
         for (uint32_t c = lane * 4; c < rf.dim; c += 256)
             *reinterpret_cast<float4 *>(&yq[wave][c]) = *reinterpret_cast<const float4 *>(rf.y + (uint64_t)b * rf.dim + c);
-        // 16 registers (<= 1024 entries = RQ_REFINE_CAP) at a time: compact the candidates' list ids into LDS, one exact
-        // distance per lane and round (so the work is balanced whatever lanes the candidates sit in), read the keys back
-        static_assert(KPL % 16 == 0 && RQ_REFINE_CAP == 1024, "a group of 16 registers always fits the candidate buffer");
-#pragma unroll
-        for (int g0 = 0; g0 < KPL; g0 += 16) {
-            uint32_t nc = 0;  // wave-uniform
-#pragma unroll
-            for (int i = g0; i < g0 + 16; ++i) {
-                const bool is_c = key[i] <= tkey && key[i] != 0xFFFFFFFFu;
-                const uint64_t m = __ballot(is_c);
-                if (is_c) cand[wave][nc + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = list_of(i);
-                nc += (uint32_t)__popcll(m);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            for (uint32_t jx = lane; jx < nc; jx += 64)
-                cand[wave][jx] = refine_exact_key(rf.cent + (uint64_t)cand[wave][jx] * rf.dim, &yq[wave][0], rf.dim);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            uint32_t at0 = 0;
-#pragma unroll
-            for (int i = g0; i < g0 + 16; ++i) {
-                const bool is_c = key[i] <= tkey && key[i] != 0xFFFFFFFFu;
-                const uint64_t m = __ballot(is_c);
-                const uint32_t got = is_c ? cand[wave][at0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] : 0xFFFFFFFFu;
-                key[i] = got;
-                at0 += (uint32_t)__popcll(m);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the buffer is reused by the next group
-        }
+        // compact the candidates' list ids into LDS (the buffer holds a whole row: the margin decides how many there are,
+        // usually ~80), one exact distance per lane and round -- balanced whatever lanes the candidates sit in --, read the
+        // keys back
+        refine_registers<KPL, 0, KPL>(key, tkey, cand[wave], yq[wave], rf, lane);
         kmin = 0xFFFFFFFFu, kmax = 0u;
 #pragma unroll
         for (int i = 0; i < KPL; ++i)

@@ -564,9 +564,9 @@ static void launch_select(const float *dist, uint32_t k, uint32_t nprobe, uint32
     if (select_is_wave(k, nprobe, nq)) {
         const dim3 g(ceil_div(nq, 4)), b(256);
         if (rf.cent) {  // approximate row: the refining instantiations
-            if (k <= 1024) select_probe_wave_kernel<16, true><<<g, b, 0, st>>>(dist, k, nprobe, out_cluster, out_dist, id_offset, out_stride, nq, rf);
-            else if (k <= 4096) select_probe_wave_kernel<64, true><<<g, b, 0, st>>>(dist, k, nprobe, out_cluster, out_dist, id_offset, out_stride, nq, rf);
-            else select_probe_wave_kernel<128, true><<<g, b, 0, st>>>(dist, k, nprobe, out_cluster, out_dist, id_offset, out_stride, nq, rf);
+            if (k <= 1024) select_probe_wave_kernel<16, true><<<ceil_div(nq, 4), 256, 0, st>>>(dist, k, nprobe, out_cluster, out_dist, id_offset, out_stride, nq, rf);
+            else if (k <= 4096) select_probe_wave_kernel<64, true><<<ceil_div(nq, 2), 128, 0, st>>>(dist, k, nprobe, out_cluster, out_dist, id_offset, out_stride, nq, rf);
+            else select_probe_wave_kernel<128, true><<<nq, 64, 0, st>>>(dist, k, nprobe, out_cluster, out_dist, id_offset, out_stride, nq, rf);
             return;
         }
         if (k <= 1024) select_probe_wave_kernel<16><<<g, b, 0, st>>>(dist, k, nprobe, out_cluster, out_dist, id_offset, out_stride, nq, rf);
