@@ -55,16 +55,25 @@ typedef struct {
     uint64_t rough, precise, query, miss;
 } rq_metrics_t;
 
+/* Out-structs (rq_info_t, rq_build_stats_t, rq_profile_t) are versioned by size: the caller sets `struct_size` to
+ * sizeof(the struct it was compiled against) before the call and the library writes at most that many bytes, so a
+ * host built against an older header is never written past its struct when fields are appended (fields are only ever
+ * appended).  struct_size == 0 (an unset field) is refused with RQ_ERR_INVALID. */
 typedef struct {
+    uint32_t struct_size;  /* in: sizeof(rq_info_t) of the caller */
     uint32_t dim;          /* padded dimension */
     uint32_t k;            /* number of clusters */
-    uint64_t n;            /* number of vectors */
     uint32_t max_list_len; /* longest IVF list */
-    uint32_t reserved;
+    uint64_t n;            /* number of vectors */
     uint64_t n_hbm;        /* raw vectors resident in HBM; the other n - n_hbm (list tails) are in pinned host memory */
 } rq_info_t;
 
 /* ---- library ------------------------------------------------------------------------------- */
+/* ABI revision of this header: bumped whenever a struct layout or the meaning of an entry point changes (3: sized
+ * out-structs, rq_get_device_ptr refuses RQ_ARR_BASE on tiered indexes).  A host checks rq_abi_version() ==
+ * RQ_ABI_VERSION once after loading the library. */
+#define RQ_ABI_VERSION 3
+uint32_t rq_abi_version(void);
 const char *rq_version(void);
 const char *rq_last_error(void);              /* thread-local message of the last failure        */
 rq_status rq_init(int device);                /* select the HIP device for this process          */
@@ -88,7 +97,9 @@ rq_status rq_build_from_path(const char *base_fvecs, const char *centroid_fvecs,
  *   rq_builder_create -> rq_builder_assign_chunk (every row once: rotate src/rabitq.rs:188, nearest list :203, sign-pack +
  *   factors :205-229) -> rq_builder_order (cluster ordering :232-243) -> rq_builder_place_chunk (every row once more:
  *   raw vectors to their cluster-order positions :244-247) -> rq_builder_finish.
- * Chunks are m x d row-major f32 in DEVICE memory covering rows [i0, i0 + m); any order, any sizes; each call returns
+ * Chunks are m x d row-major f32 in DEVICE memory covering rows [i0, i0 + m); any order, any sizes, but every row exactly
+ * once per pass: a chunk that overlaps rows already fed to the same pass is refused (RQ_ERR_INVALID), and
+ * rq_builder_order / rq_builder_finish refuse to run while rows are missing.  Each call returns
  * when the chunk buffer may be reused.  max_device_base_bytes: HBM budget of the raw vectors (0 = automatic: what is
  * free minus a reserve; UINT64_MAX = all in HBM).  Beyond it the split is per list: the head of every list (the vectors
  * nearest its centroid, which the re-ranker asks for most) stays in HBM, the tail goes to pinned host memory and is
@@ -96,8 +107,8 @@ rq_status rq_build_from_path(const char *base_fvecs, const char *centroid_fvecs,
  * error); rq_builder_free abandons one. */
 typedef struct rq_builder rq_builder;
 typedef struct {
+    uint32_t struct_size;                      /* in: sizeof(rq_build_stats_t) of the caller */
     float ms_rotate, ms_assign, ms_quantize;   /* device time of the three pass-1 kernels, HIP events, summed over chunks */
-    uint32_t reserved;
     uint64_t rows_assigned;                    /* rotation flops so far = 2 * rows_assigned * dim^2 */
     uint64_t rows_in_hbm, rows_in_host_memory; /* base tiers (known after rq_builder_order) */
 } rq_build_stats_t;
@@ -142,8 +153,9 @@ enum { RQ_ARR_BASE = 0, RQ_ARR_ORTHOGONAL, RQ_ARR_CENTROIDS, RQ_ARR_OFFSETS, RQ_
        RQ_ARR_CODES, RQ_ARR_FACTORS };
 rq_status rq_get_array(const rq_index *idx, int which, void *dst, uint64_t dst_bytes);
 /* Device pointer of one array (valid until rq_free); for zero-copy hand-over to a caller that
- * already lives on the GPU.  RQ_ARR_BASE gives the HBM tier: every row at its position when n_hbm == n; on a tiered
- * index the list heads only, packed (use rq_get_array for the whole array). */
+ * already lives on the GPU.  RQ_ARR_BASE: every row at its position -- only when n_hbm == n; on a tiered index (list
+ * tails in pinned host memory) there is no single device array and the call returns RQ_ERR_UNSUPPORTED (use
+ * rq_get_array for a host copy of the whole array). */
 rq_status rq_get_device_ptr(const rq_index *idx, int which, const void **out_ptr, uint64_t *out_bytes);
 
 /* ---- query: RaBitQ::query, src/rabitq.rs:268-333 --------------------------------------------- */
@@ -273,6 +285,8 @@ rq_status rq_rerank(const rq_index *idx, const float *query_padded, const uint32
  * "rerank", "sort", "replay", "total".  Also the algorithmic bytes the scan launches covered
  * (sum over probed lists of len * (dim/8 + 16)) and the number of scan launches. */
 typedef struct {
+    uint32_t struct_size;      /* in: sizeof(rq_profile_t) of the caller */
+    uint32_t reserved;
     float ms_rotate, ms_coarse, ms_select, ms_prep, ms_group, ms_scan, ms_rerank, ms_sort, ms_replay,
         ms_total;
     uint64_t scan_bytes;       /* algorithmic bytes over all scan launches of the call */

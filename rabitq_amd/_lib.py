@@ -20,7 +20,7 @@ STATUS_NAMES = {0: "RQ_OK", -1: "RQ_ERR_INVALID", -2: "RQ_ERR_DIM_MISMATCH", -3:
 
 # every symbol include/rabitq_hip.h declares (checked by tests/test_abi.py against the header)
 EXPORTS = [
-    "rq_version", "rq_last_error", "rq_init", "rq_build", "rq_build_device", "rq_build_from_path", "rq_kmeans_device", "rq_builder_create", "rq_builder_assign_chunk", "rq_builder_order", "rq_builder_place_chunk", "rq_builder_finish", "rq_builder_free", "rq_builder_stats", "rq_load_dir",
+    "rq_version", "rq_abi_version", "rq_last_error", "rq_init", "rq_build", "rq_build_device", "rq_build_from_path", "rq_kmeans_device", "rq_builder_create", "rq_builder_assign_chunk", "rq_builder_order", "rq_builder_place_chunk", "rq_builder_finish", "rq_builder_free", "rq_builder_stats", "rq_load_dir",
     "rq_dump_dir", "rq_load_json", "rq_dump_json", "rq_free", "rq_from_arrays", "rq_info", "rq_get_array", "rq_get_device_ptr", "rq_query",
     "rq_query_batch", "rq_query_batch_device", "rq_query_batch_device_begin", "rq_query_batch_device_end", "rq_coarse_topk_device", "rq_merge_smallest_u64_device", "rq_query_batch_device_probed", "rq_query_batch_device_seeded", "rq_partition_lists", "rq_shard_index", "rq_query_batch_sharded_device", "rq_metrics", "rq_metrics_reset", "rq_rotate", "rq_rotate_device",
     "rq_quantize_pack",
@@ -34,22 +34,33 @@ class RabitqError(RuntimeError):
         self.status = status
 
 
-class Info(C.Structure):
-    _fields_ = [("dim", C.c_uint32), ("k", C.c_uint32), ("n", C.c_uint64), ("max_list_len", C.c_uint32),
-                ("reserved", C.c_uint32), ("n_hbm", C.c_uint64)]
+ABI_VERSION = 3   # RQ_ABI_VERSION of include/rabitq_hip.h this mirror was written against
+
+
+class _Sized(C.Structure):
+    """Out-struct versioned by size: `struct_size` is set to the mirror's sizeof before every call."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = C.sizeof(type(self))
+
+
+class Info(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("dim", C.c_uint32), ("k", C.c_uint32), ("max_list_len", C.c_uint32),
+                ("n", C.c_uint64), ("n_hbm", C.c_uint64)]
 
 
 class MetricsT(C.Structure):
     _fields_ = [("rough", C.c_uint64), ("precise", C.c_uint64), ("query", C.c_uint64), ("miss", C.c_uint64)]
 
 
-class BuildStatsT(C.Structure):
-    _fields_ = [("ms_rotate", C.c_float), ("ms_assign", C.c_float), ("ms_quantize", C.c_float), ("reserved", C.c_uint32),
+class BuildStatsT(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("ms_rotate", C.c_float), ("ms_assign", C.c_float), ("ms_quantize", C.c_float),
                 ("rows_assigned", C.c_uint64), ("rows_in_hbm", C.c_uint64), ("rows_in_host_memory", C.c_uint64)]
 
 
-class ProfileT(C.Structure):
-    _fields_ = [(n, C.c_float) for n in ("ms_rotate", "ms_coarse", "ms_select", "ms_prep", "ms_group", "ms_scan",
+class ProfileT(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_uint32)] + [(n, C.c_float) for n in ("ms_rotate", "ms_coarse", "ms_select", "ms_prep", "ms_group", "ms_scan",
                                          "ms_rerank", "ms_sort", "ms_replay", "ms_total")] + [
         ("scan_bytes", C.c_uint64), ("scan_candidates", C.c_uint64), ("rerank_candidates", C.c_uint64),
         ("scan_launches", C.c_uint32), ("retries", C.c_uint32),
@@ -76,10 +87,12 @@ def lib():
         raise RabitqError(-5, f"{SO_PATH} not built (run `make -C rabitq_amd/csrc`); there is no CPU fallback")
     # A process that also uses PyTorch must load torch's bundled ROCm runtime BEFORE this library pulls in the system
     # one: the other way round torch later reports "No HIP GPUs are available" (measured on this image).  The library
-    # itself does not need torch; the import only fixes the load order when torch is installed.
+    # itself does not need torch; the import only fixes the load order when torch is installed.  Hosts that never use
+    # torch set RABITQ_NO_TORCH_PRELOAD=1 and skip the (heavy) import ("Loading order").
     import importlib.util
     import sys
-    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+    if (not os.environ.get("RABITQ_NO_TORCH_PRELOAD") and "torch" not in sys.modules
+            and importlib.util.find_spec("torch") is not None):
         try:
             import torch  # noqa: F401
         except Exception:
@@ -90,6 +103,7 @@ def lib():
     pp = C.POINTER(C.c_void_p)
     sig = {
         "rq_version": (C.c_char_p, []),
+        "rq_abi_version": (C.c_uint32, []),
         "rq_last_error": (C.c_char_p, []),
         "rq_init": (i32, [C.c_int]),
         "rq_build": (i32, [f32p, u64, u32, f32p, u32, f32p, u64, pp]),
@@ -141,6 +155,9 @@ def lib():
         fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if L.rq_abi_version() != ABI_VERSION:
+        raise RabitqError(-6, f"{SO_PATH} has ABI revision {L.rq_abi_version()}, this mirror expects {ABI_VERSION}: rebuild "
+                              "(make -C rabitq_amd/csrc)")
     _lib = L
     return L
 

@@ -87,6 +87,16 @@ struct DevBuf {
     rq_status ensure(size_t n) { return n <= count && p ? RQ_OK : alloc(n); }
 };
 
+// Sized out-structs (include/rabitq_hip.h): write at most the bytes the caller's struct has.
+template <typename T>
+static rq_status copy_out_sized(T *out, T full) {
+    const uint32_t sz = out->struct_size;
+    if (sz < 8) return fail(RQ_ERR_INVALID, "struct_size is not set (set it to sizeof(the struct) before the call)");
+    const uint32_t w = std::min<uint32_t>(sz, (uint32_t)sizeof(T));
+    full.struct_size = w;
+    memcpy(out, &full, w);
+    return RQ_OK;
+}
 static inline uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 static inline uint32_t pow2_ceil(uint32_t v) {
     uint32_t p = 1;
@@ -309,9 +319,9 @@ __global__ __launch_bounds__(256) void shard_gather_kernel(const uint32_t *__res
 // per-shard top-k -> merge keys (Ord32 image << 32 | global id); entries past the valid count sort last
 __global__ void pack_topk_keys_kernel(const float *__restrict__ dist, const uint32_t *__restrict__ id, const uint32_t *__restrict__ cnt,
                                       uint32_t nq, uint32_t topk, uint32_t id_offset, unsigned long long *__restrict__ keys) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq * topk) return;
-    const uint32_t b = i / topk, e = i - b * topk;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)nq * topk) return;
+    const uint32_t b = (uint32_t)(i / topk), e = (uint32_t)(i - (uint64_t)b * topk);
     keys[i] = e < cnt[b] ? (((unsigned long long)ord32_biased(dist[i]) << 32) | (uint32_t)(id[i] + id_offset)) : ~0ull;
 }
 // shared-threshold multi-GPU step: the merged probe lists split into the nearest list and the rest
@@ -340,9 +350,9 @@ __global__ void kth_threshold_kernel(const float *__restrict__ dist, const uint3
 __global__ void pack_topk_keys_at_kernel(const float *__restrict__ dist, const uint32_t *__restrict__ id, const uint32_t *__restrict__ cnt,
                                          uint32_t nq, uint32_t topk, uint32_t id_offset, uint32_t width, uint32_t col0,
                                          unsigned long long *__restrict__ keys) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq * topk) return;
-    const uint32_t b = i / topk, e = i - b * topk;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)nq * topk) return;
+    const uint32_t b = (uint32_t)(i / topk), e = (uint32_t)(i - (uint64_t)b * topk);
     keys[(uint64_t)b * width + col0 + e] =
         e < cnt[b] ? (((unsigned long long)ord32_biased(dist[i]) << 32) | (uint32_t)(id[i] + id_offset)) : ~0ull;
 }
@@ -1514,6 +1524,35 @@ struct rq_builder {
     DevBuf<uint64_t> codes_tmp;
     DevBuf<float4> factors_tmp;
     uint64_t assigned = 0, placed = 0;
+    // Rows each pass has seen, as disjoint [begin, end) intervals: chunks may come in any order and size, but every row
+    // exactly once per pass.  A duplicated chunk would leave other rows with uninitialised labels / codes (and then
+    // index the list histogram with garbage), so overlap is refused here and gaps by the row counts in order / finish.
+    struct Coverage {
+        std::map<uint64_t, uint64_t> iv;  // begin -> end
+        bool add(uint64_t i0, uint64_t m) {
+            if (m == 0) return true;
+            const uint64_t i1 = i0 + m;
+            auto nx = iv.lower_bound(i0);  // first interval starting at or after i0
+            if (nx != iv.end() && nx->first < i1) return false;
+            if (nx != iv.begin()) {
+                auto pv = std::prev(nx);
+                if (pv->second > i0) return false;
+                if (pv->second == i0) {  // extend the neighbour on the left (and swallow the one on the right if it touches)
+                    pv->second = i1;
+                    if (nx != iv.end() && nx->first == i1) pv->second = nx->second, iv.erase(nx);
+                    return true;
+                }
+            }
+            if (nx != iv.end() && nx->first == i1) {
+                const uint64_t e = nx->second;
+                iv.erase(nx);
+                iv[i0] = e;
+            } else {
+                iv[i0] = i1;
+            }
+            return true;
+        }
+    } cov_assign, cov_place;
     bool ordered = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     rq_build_stats_t stats{};
@@ -1577,6 +1616,7 @@ static rq_status builder_assign(rq_builder *b, const float *d_rows, uint64_t i0,
     if (b->ordered) return fail(RQ_ERR_INVALID, "rq_builder_assign_chunk after rq_builder_order");
     rq_index *idx = b->idx.get();
     if (i0 > idx->n || m > idx->n - i0) return fail(RQ_ERR_INVALID, "chunk outside [0, n)");
+    if (!b->cov_assign.add(i0, m)) return fail(RQ_ERR_INVALID, "rq_builder_assign_chunk: rows [" + std::to_string(i0) + ", " + std::to_string(i0 + m) + ") overlap rows already assigned");
     const uint32_t d = b->d, dim = idx->dim;
     for (uint64_t c0 = 0; c0 < m; c0 += RQ_BUILD_CHUNK) {
         const uint64_t mm = std::min<uint64_t>(RQ_BUILD_CHUNK, m - c0), at = i0 + c0;
@@ -1657,6 +1697,7 @@ static rq_status builder_place(rq_builder *b, const float *d_rows, uint64_t i0, 
     if (!b->ordered) return fail(RQ_ERR_INVALID, "rq_builder_place_chunk before rq_builder_order");
     rq_index *idx = b->idx.get();
     if (i0 > idx->n || m > idx->n - i0) return fail(RQ_ERR_INVALID, "chunk outside [0, n)");
+    if (!b->cov_place.add(i0, m)) return fail(RQ_ERR_INVALID, "rq_builder_place_chunk: rows [" + std::to_string(i0) + ", " + std::to_string(i0 + m) + ") overlap rows already placed");
     if (m) {
         place_rows_kernel<<<(uint32_t)std::min<uint64_t>(ceil_div(m, 4), 1u << 20), 256>>>(d_rows, i0, m, b->d, idx->dim,
                                                                                           b->pos_of_id.p, idx->view());
@@ -1954,7 +1995,8 @@ static rq_status copy_base_rows(const rq_index *idx, uint64_t i0, uint64_t m, fl
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-const char *rq_version(void) { return "rabitq_hip 0.1.0 (gfx950)"; }
+const char *rq_version(void) { return "rabitq_hip 0.3.0 (gfx950, abi 3)"; }
+uint32_t rq_abi_version(void) { return RQ_ABI_VERSION; }
 const char *rq_last_error(void) { return g_err.c_str(); }
 
 rq_status rq_init(int device) {
@@ -2024,8 +2066,7 @@ rq_status rq_builder_finish(rq_builder *b, rq_index **out) { return builder_fini
 void rq_builder_free(rq_builder *b) { delete b; }
 rq_status rq_builder_stats(const rq_builder *b, rq_build_stats_t *out) {
     if (!b || !out) return fail(RQ_ERR_INVALID, "null argument");
-    *out = b->stats;
-    return RQ_OK;
+    return copy_out_sized(out, b->stats);
 }
 
 rq_status rq_build(const float *base, uint64_t n, uint32_t d, const float *centroids, uint32_t k,
@@ -2304,15 +2345,19 @@ void rq_free(rq_index *idx) { delete idx; }
 
 rq_status rq_info(const rq_index *idx, rq_info_t *out) {
     if (!idx || !out) return fail(RQ_ERR_INVALID, "null argument");
-    out->dim = idx->dim, out->k = idx->k, out->n = idx->n, out->max_list_len = idx->max_list_len, out->reserved = 0;
-    out->n_hbm = idx->n_dev;
-    return RQ_OK;
+    rq_info_t full{};
+    full.dim = idx->dim, full.k = idx->k, full.n = idx->n, full.max_list_len = idx->max_list_len, full.n_hbm = idx->n_dev;
+    return copy_out_sized(out, full);
 }
 
 rq_status rq_get_device_ptr(const rq_index *idx, int which, const void **out_ptr, uint64_t *out_bytes) {
     if (!idx || !out_ptr || !out_bytes) return fail(RQ_ERR_INVALID, "null argument");
     switch (which) {
-        case RQ_ARR_BASE: *out_ptr = idx->base.p, *out_bytes = idx->n_dev * idx->dim * 4; break;  // the HBM tier (every row, at its position, unless tiered)
+        case RQ_ARR_BASE:
+            if (idx->n_dev < idx->n)  // tiered: the HBM tier holds packed list heads, not rows at their positions
+                return fail(RQ_ERR_UNSUPPORTED, "the raw vectors of this index are tiered (HBM + pinned host memory): no single device array; use rq_get_array");
+            *out_ptr = idx->base.p, *out_bytes = idx->n_dev * idx->dim * 4;
+            break;
         case RQ_ARR_ORTHOGONAL: *out_ptr = idx->P.p, *out_bytes = (uint64_t)idx->dim * idx->dim * 4; break;
         case RQ_ARR_CENTROIDS: *out_ptr = idx->centroids.p, *out_bytes = (uint64_t)idx->k * idx->dim * 4; break;
         case RQ_ARR_OFFSETS: *out_ptr = idx->offsets.p, *out_bytes = ((uint64_t)idx->k + 1) * 4; break;
@@ -2808,8 +2853,7 @@ rq_status rq_set_profiling(int level) {
 }
 rq_status rq_last_profile(rq_profile_t *out) {
     if (!out) return fail(RQ_ERR_INVALID, "null argument");
-    *out = g_profile;
-    return RQ_OK;
+    return copy_out_sized(out, g_profile);
 }
 
 // ---- per-stage entry points --------------------------------------------------------------------

@@ -279,7 +279,7 @@ class Builder:
     def stats(self) -> dict:
         st = BuildStatsT()
         check(lib().rq_builder_stats(self._b, C.byref(st)))
-        return {name: getattr(st, name) for name, _ in BuildStatsT._fields_ if name != "reserved"}
+        return {name: getattr(st, name) for name, _ in BuildStatsT._fields_ if name != "struct_size"}
 
     def finish(self) -> RaBitQ:
         h = C.c_void_p()
@@ -325,7 +325,7 @@ def set_option(name: str, value: int) -> None:
 def last_profile() -> dict:
     p = ProfileT()
     check(lib().rq_last_profile(C.byref(p)))
-    return {name: getattr(p, name) for name, _ in ProfileT._fields_}
+    return {name: getattr(p, name) for name, _ in ProfileT._fields_ if name not in ("struct_size", "reserved")}
 
 
 def calculate_recall(truth, res, topk: int) -> float:

@@ -39,7 +39,8 @@ def main():
     n, d, k = args.vectors, args.dim, args.lists
     x, centres = synth.device_mixture(n, d, k, args.sigma, dev)
     bmax = max(int(b) for b in args.batches.split(","))
-    queries = synth.device_queries(centres, max(bmax, 64), args.sigma, dev)
+    # (reps + 3 warm-up calls) x the largest batch: every call, warm-up included, sees queries (and so lists) of its own
+    queries = synth.device_queries(centres, (args.reps + 3) * bmax, args.sigma, dev)
     idx = rabitq_amd.RaBitQ.build_device(x.data_ptr(), n, d, centres.data_ptr(), k, orthogonal=synth.random_orthogonal(d, 99))
     del x
     torch.cuda.empty_cache()
@@ -54,10 +55,10 @@ def main():
             idx.query_batch_device(queries[q0:q0 + b].data_ptr(), b, d, args.nprobe, args.topk, out_d.data_ptr(),
                                    out_i.data_ptr(), out_n.data_ptr())
         for w in range(3):
-            call(0)
+            call(w * b)
         acc = {}
         for r in range(args.reps):
-            call((r * b) % max(1, queries.shape[0] - b + 1))     # different queries per call: no list stays cache-warm by design
+            call((3 + r) * b)     # different queries per call: no list stays cache-warm by design
             for key, v in rqi.last_profile().items():
                 acc[key] = acc.get(key, 0) + v
         res["regimes"].append({

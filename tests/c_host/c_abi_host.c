@@ -37,7 +37,12 @@ int main(int argc, char **argv) {
     CHECK(rq_init(0));
     rq_index *idx = NULL, *idx2 = NULL;
     CHECK(rq_build(base, n, d, cent, k, NULL /* seeded Gaussian-QR rotation */, 12345, &idx));
+    if (rq_abi_version() != RQ_ABI_VERSION) {
+        fprintf(stderr, "library ABI %u, header ABI %u\n", rq_abi_version(), (unsigned)RQ_ABI_VERSION);
+        return 3;
+    }
     rq_info_t info;
+    info.struct_size = sizeof info; /* sized out-struct: the library writes at most this many bytes */
     CHECK(rq_info(idx, &info));
     if (info.dim != 128 || info.k != k || info.n != n || info.n_hbm != n) {
         fprintf(stderr, "unexpected rq_info\n");

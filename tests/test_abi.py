@@ -31,9 +31,55 @@ def test_struct_layouts_match_reference():
     from rabitq_amd import _lib
     import ctypes as C
     assert C.sizeof(_lib.MetricsT) == 32            # 4 x u64, src/metrics.rs:7-18
-    assert C.sizeof(_lib.Info) == 32            # rq_info_t: dim, k, n, max_list_len, reserved, n_hbm
+    assert C.sizeof(_lib.Info) == 32            # rq_info_t: struct_size, dim, k, max_list_len, n, n_hbm
     # Factor is repr(C) 4 x f32 (src/rabitq.rs:21-32): (n, 4) f32 arrays are passed as rq_factor_t*
     assert np.dtype(np.float32).itemsize * 4 == 16
+
+
+def test_ctypes_mirror_matches_the_compiled_header(tmp_path):
+    """sizeof / offsetof of the sized out-structs as gcc lays them out from include/rabitq_hip.h == the ctypes mirror."""
+    import ctypes as C
+    import subprocess
+    from rabitq_amd import _lib
+    src = tmp_path / "layout.c"
+    src.write_text('''#include <stdio.h>
+#include <stddef.h>
+#include "rabitq_hip.h"
+int main(void) {
+    printf("%zu %zu %zu %zu\\n", sizeof(rq_info_t), offsetof(rq_info_t, n), offsetof(rq_info_t, n_hbm), offsetof(rq_info_t, max_list_len));
+    printf("%zu %zu %zu\\n", sizeof(rq_build_stats_t), offsetof(rq_build_stats_t, rows_assigned), offsetof(rq_build_stats_t, rows_in_host_memory));
+    printf("%zu %zu %zu %zu\\n", sizeof(rq_profile_t), offsetof(rq_profile_t, ms_rotate), offsetof(rq_profile_t, scan_bytes), offsetof(rq_profile_t, rerank_shadow_rejects));
+    printf("%d\\n", RQ_ABI_VERSION);
+    return 0;
+}''')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    rows = [[int(v) for v in ln.split()] for ln in subprocess.check_output([str(exe)]).decode().splitlines()]
+    I, B, P = _lib.Info, _lib.BuildStatsT, _lib.ProfileT
+    assert rows[0] == [C.sizeof(I), I.n.offset, I.n_hbm.offset, I.max_list_len.offset]
+    assert rows[1] == [C.sizeof(B), B.rows_assigned.offset, B.rows_in_host_memory.offset]
+    assert rows[2] == [C.sizeof(P), P.ms_rotate.offset, P.scan_bytes.offset, P.rerank_shadow_rejects.offset]
+    assert rows[3] == [_lib.ABI_VERSION]
+
+
+def test_sized_out_structs_are_never_overrun(L):
+    """A host compiled against an older, shorter struct passes its own sizeof: nothing is written beyond it; an unset
+    struct_size is refused (ADVICE r2: rq_info_t / rq_profile_t grew without a version)."""
+    import ctypes as C
+    from rabitq_amd import _lib
+    assert L.rq_abi_version() == _lib.ABI_VERSION and b"abi 3" in L.rq_version()
+    buf = (C.c_uint8 * 256)(*([0xAB] * 256))
+    C.cast(buf, C.POINTER(C.c_uint32))[0] = 24                      # an "old" rq_profile_t of 24 bytes
+    assert L.rq_last_profile(C.cast(buf, C.POINTER(_lib.ProfileT))) == 0
+    assert bytes(buf[24:]) == b"\xab" * (256 - 24)
+    assert C.cast(buf, C.POINTER(C.c_uint32))[0] == 24
+    C.cast(buf, C.POINTER(C.c_uint32))[0] = 0
+    assert L.rq_last_profile(C.cast(buf, C.POINTER(_lib.ProfileT))) == -1
+    big = (C.c_uint8 * 1024)(*([0xCD] * 1024))
+    C.cast(big, C.POINTER(C.c_uint32))[0] = 1024                    # a "newer" host: only the known bytes are written
+    assert L.rq_last_profile(C.cast(big, C.POINTER(_lib.ProfileT))) == 0
+    assert C.cast(big, C.POINTER(C.c_uint32))[0] == C.sizeof(_lib.ProfileT)
+    assert bytes(big[C.sizeof(_lib.ProfileT):]) == b"\xcd" * (1024 - C.sizeof(_lib.ProfileT))
 
 
 def test_no_cpu_fallback_without_device(L):

@@ -1096,6 +1096,35 @@ def test_streamed_builder_equals_one_shot_build(rq, oracle, d, budget):
     with pytest.raises(rq.RabitqError):
         b2.order()
     del b2
+    # a duplicated chunk whose sizes still sum to n is refused (the uncovered rows would keep uninitialised labels and
+    # codes), in both passes; touching and out-of-order chunks are fine
+    h = n // 2
+    b3 = rq.RaBitQ.builder(n, d, cd.data_ptr(), k, orthogonal=P)
+    b3.assign_chunk(xd.data_ptr(), 0, h)
+    for bad in ((0, h), (h - 1, 5), (10, 1)):
+        with pytest.raises(rq.RabitqError) as e:
+            b3.assign_chunk(xd[bad[0]:].data_ptr(), bad[0], bad[1])
+        assert e.value.status == -1 and "overlap" in str(e.value)
+    with pytest.raises(rq.RabitqError):
+        b3.order()                                   # rows [h, n) are still missing
+    b3.assign_chunk(xd[h + 100:].data_ptr(), h + 100, n - h - 100)
+    b3.assign_chunk(xd[h:].data_ptr(), h, 100)       # fills the gap between two covered stretches
+    b3.order()
+    b3.place_chunk(xd[h:].data_ptr(), h, n - h)
+    with pytest.raises(rq.RabitqError) as e:
+        b3.place_chunk(xd[h:].data_ptr(), h, n - h)  # the same half again instead of the first one
+    assert e.value.status == -1
+    b3.place_chunk(xd.data_ptr(), 0, h)
+    g3 = b3.finish()
+    for name in ("base", "map_ids", "codes", "factors"):
+        assert_bits_equal(getattr(g3, name), getattr(oidx, name), name + " (builder with refused duplicates)")
+    g3.close()
+    if st["rows_in_host_memory"]:
+        with pytest.raises(rq.RabitqError) as e:     # tiered: no single device array of the raw vectors
+            gidx.device_ptr(0)
+        assert e.value.status == -6
+    else:
+        assert gidx.device_ptr(0)[1] == n * gidx.dim * 4
     gidx.close()
     oidx.close()
 
