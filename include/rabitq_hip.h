@@ -229,15 +229,40 @@ rq_status rq_partition_lists(const rq_index *idx, uint32_t world, uint32_t *out_
  * holds only the lists with owner[c] == rank (the others are empty); map_ids keep the ORIGINAL ids, so per-shard
  * results are global.  The source index is unchanged; free both with rq_free. */
 rq_status rq_shard_index(const rq_index *idx, const uint32_t *owner, uint32_t rank, rq_index **out);
-/* The whole multi-GPU step behind the C ABI, for hosts without torch: answer the batch against this rank's shard
- * (all ranks rank the same replicated centroids, so they walk the same probe list), all-gather the per-shard top-k
- * as u64 keys with ONE ncclAllGather on `nccl_comm` (an ncclComm_t of `world` ranks created by the caller with
- * ncclCommInitRank; may be NULL when world == 1) and merge: every rank receives the same global top-k, ascending
- * by (distance, id); ids are shard-local map_ids + id_offset (u32).  RCCL is resolved at first use from the
- * host process (or RABITQ_RCCL_LIB), so the library itself does not link against it. */
+/* The whole multi-GPU step behind the C ABI, for hosts without torch.  Every rank holds all (replicated) rotated centroids
+ * and a subset of the lists.  `nccl_comm` is an ncclComm_t of `world` ranks created by the caller with ncclCommInitRank
+ * (may be NULL when world == 1).  The step, all on one HIP stream of the engine:
+ *   handshake  one ncclAllReduce(max) of three int32 (a hash of the call's parameters and an error flag);
+ *   coarse     rank r ranks lists [r k / world, (r+1) k / world) only, one ncclAllGather of the nq x probe
+ *              (distance, list) keys + merge: the same global probe list on every rank;
+ *   answer     the shard's own lists of that probe list, with thresholds shared between the shards (option
+ *              "shared_thresholds": the nearest list first, one ncclAllReduce(min) of the k-th best distances found
+ *              there, the rest seeded with it; see rq_query_batch_device_seeded) or on the shard's own thresholds;
+ *   merge      ONE ncclAllGather of the per-shard top-k as u64 keys (+ a status word per rank), k-way merge.
+ * Every rank receives the same global top-k, ascending by (distance, id); ids are shard-local map_ids + id_offset (u32).
+ * COLLECTIVE CONTRACT: all ranks of the communicator call this entry with the same nq, len, probe, topk, world,
+ * heuristic_rank and the same "shared_thresholds" option, in the same order.  The handshake detects a violation (and a
+ * rank that failed validation or allocation) and makes every rank return an error before any data collective; after
+ * it a rank that fails locally keeps taking part in every collective and reports through its status word, so no peer is
+ * left blocked and all ranks return an error for that step.  Limits: world * topk <= 8192, nq * topk < 2^32.
+ * RCCL is resolved at first use from the host process (or RABITQ_RCCL_LIB), so the library itself does not link against it.
+ * rq_last_profile() afterwards holds the sum over the step's engine passes. */
 rq_status rq_query_batch_sharded_device(const rq_index *shard, void *nccl_comm, uint32_t world, uint32_t id_offset,
                                         const float *d_queries, uint32_t nq, uint32_t len, uint32_t probe, uint32_t topk,
                                         int heuristic_rank, float *d_out_dist, uint32_t *d_out_id, uint32_t *d_out_n);
+/* The collectives rq_query_batch_sharded_device calls, for hosts with another transport than RCCL (or a test harness):
+ * same signatures and semantics as ncclAllGather / ncclAllReduce / ncclCommUserRank (device buffers, enqueued on
+ * `hip_stream` or completed before returning; dtype / op are the ncclDataType_t / ncclRedOp_t values: int32 = 2,
+ * uint64 = 5, float32 = 7; max = 2, min = 3; return 0 on success).  `comm` is passed through untouched.  NULL = back to
+ * RCCL (the default).  Process-wide; set it before the first sharded call. */
+typedef struct {
+    uint32_t struct_size; /* in: sizeof(rq_collectives_t) */
+    uint32_t reserved;
+    int (*all_gather)(const void *send, void *recv, size_t send_count, int dtype, void *comm, void *hip_stream);
+    int (*all_reduce)(const void *send, void *recv, size_t count, int dtype, int op, void *comm, void *hip_stream);
+    int (*comm_user_rank)(void *comm, int *rank);
+} rq_collectives_t;
+rq_status rq_set_collectives(const rq_collectives_t *collectives);
 
 /* ---- metrics: METRICS, src/metrics.rs:65 ------------------------------------------------------ */
 rq_status rq_metrics(rq_metrics_t *out);

@@ -22,7 +22,7 @@ STATUS_NAMES = {0: "RQ_OK", -1: "RQ_ERR_INVALID", -2: "RQ_ERR_DIM_MISMATCH", -3:
 EXPORTS = [
     "rq_version", "rq_abi_version", "rq_last_error", "rq_init", "rq_build", "rq_build_device", "rq_build_from_path", "rq_kmeans_device", "rq_builder_create", "rq_builder_assign_chunk", "rq_builder_order", "rq_builder_place_chunk", "rq_builder_finish", "rq_builder_free", "rq_builder_stats", "rq_load_dir",
     "rq_dump_dir", "rq_load_json", "rq_dump_json", "rq_free", "rq_from_arrays", "rq_info", "rq_get_array", "rq_get_device_ptr", "rq_query",
-    "rq_query_batch", "rq_query_batch_device", "rq_query_batch_device_begin", "rq_query_batch_device_end", "rq_coarse_topk_device", "rq_merge_smallest_u64_device", "rq_query_batch_device_probed", "rq_query_batch_device_seeded", "rq_partition_lists", "rq_shard_index", "rq_query_batch_sharded_device", "rq_metrics", "rq_metrics_reset", "rq_rotate", "rq_rotate_device",
+    "rq_query_batch", "rq_query_batch_device", "rq_query_batch_device_begin", "rq_query_batch_device_end", "rq_coarse_topk_device", "rq_merge_smallest_u64_device", "rq_query_batch_device_probed", "rq_query_batch_device_seeded", "rq_partition_lists", "rq_shard_index", "rq_query_batch_sharded_device", "rq_set_collectives", "rq_metrics", "rq_metrics_reset", "rq_rotate", "rq_rotate_device",
     "rq_quantize_pack",
     "rq_coarse_rank", "rq_query_prep", "rq_scan", "rq_rerank", "rq_set_profiling", "rq_set_option", "rq_last_profile",
 ]
@@ -138,6 +138,7 @@ def lib():
         "rq_partition_lists": (i32, [vp, u32, u32p, u64p]),
         "rq_shard_index": (i32, [vp, u32p, u32, pp]),
         "rq_query_batch_sharded_device": (i32, [vp, vp, u32, u32, f32p, u32, u32, u32, u32, C.c_int, f32p, u32p, u32p]),
+        "rq_set_collectives": (i32, [vp]),
         "rq_metrics": (i32, [C.POINTER(MetricsT)]),
         "rq_metrics_reset": (i32, []),
         "rq_rotate": (i32, [f32p, u64, u32, f32p, C.c_int, f32p]),

@@ -611,15 +611,16 @@ __global__ __launch_bounds__(256) void select_probe_wave_kernel(const float *__r
 // (key = distance bits << 32 | list id) and for the per-shard top-k (key = Ord32 image << 32 | global id).
 // One block per query, LDS bitonic sort; dynamic LDS: pow2_ceil(world * width) * 8 bytes.
 // ------------------------------------------------------------------------------------------------
+// rank_stride: keys between the blocks of consecutive ranks (nq * width, or more when a rank's block carries trailing words).
 __global__ __launch_bounds__(256) void merge_smallest_u64_kernel(const unsigned long long *__restrict__ in, uint32_t world,
                                                                  uint32_t nq, uint32_t width, uint32_t m_out,
-                                                                 unsigned long long *__restrict__ out) {
+                                                                 unsigned long long *__restrict__ out, uint64_t rank_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char merge_smem[];
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(merge_smem);
     const uint32_t b = blockIdx.x, m = world * width;
     for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
         const uint32_t w = i / width, e = i - w * width;
-        keys[i] = in[((uint64_t)w * nq + b) * width + e];
+        keys[i] = in[(uint64_t)w * rank_stride + (uint64_t)b * width + e];
     }
     __syncthreads();
     bitonic_sort_block(keys, m, [](unsigned long long v) { return v; });

@@ -178,3 +178,134 @@ class SeededShardQuery:
         pa = pack_topk(self.a[0], self.a[1].to(torch.int64) & 0xFFFFFFFF, self.a[2], id_offset)
         pb = pack_topk(self.b[0], self.b[1].to(torch.int64) & 0xFFFFFFFF, self.b[2], id_offset)
         return torch.cat([pa, pb], dim=1)
+
+
+# ---- the C-ABI multi-GPU step (rq_query_batch_sharded_device) from Python: communicators and transports --------------
+class _UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]   # ncclUniqueId (rccl.h)
+
+
+def _rccl_lib():
+    """The RCCL this process already carries (torch's bundled copy), so that the communicator handle and the
+    collectives the engine resolves with dlsym come from the same library (RABITQ_RCCL_LIB overrides)."""
+    import os
+    path = os.environ.get("RABITQ_RCCL_LIB")
+    cands = [path] if path else []
+    cands += [os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "librccl.so.1", "librccl.so"]
+    last = None
+    for c in cands:
+        try:
+            return C.CDLL(c, mode=C.RTLD_GLOBAL)
+        except OSError as e:       # noqa: PERF203
+            last = e
+    raise OSError(f"RCCL not found: {last}")
+
+
+class RcclComm:
+    """An ncclComm_t of torch.distributed's world, created with ncclGetUniqueId (rank 0) / ncclCommInitRank; the 128-byte
+    id travels through the already initialised process group (any backend).  `.handle` is what
+    rq_query_batch_sharded_device takes.  One HIP device per rank (RCCL refuses two ranks on one device)."""
+
+    def __init__(self, rank: int, world: int, group=None):
+        self.lib = _rccl_lib()
+        uid = _UniqueId()
+        if rank == 0:
+            rc = self.lib.ncclGetUniqueId(C.byref(uid))
+            if rc != 0:
+                raise RuntimeError(f"ncclGetUniqueId failed ({rc})")
+        box = [bytes(uid.internal)] if rank == 0 else [None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        C.memmove(C.byref(uid), box[0], 128)
+        self.comm = C.c_void_p()
+        self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
+        rc = self.lib.ncclCommInitRank(C.byref(self.comm), world, uid, rank)
+        if rc != 0:
+            raise RuntimeError(f"ncclCommInitRank failed ({rc})")
+        self.handle = self.comm.value
+
+    def close(self):
+        if getattr(self, "comm", None) and self.comm.value:
+            self.lib.ncclCommDestroy.argtypes = [C.c_void_p]
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = C.c_void_p()
+
+
+class HostCollectives:
+    """rq_set_collectives with torch.distributed on HOST buffers as the transport (gloo): the device buffers are copied
+    to the host, exchanged, and copied back.  For rehearsals and tests on one GPU -- several rank processes share the
+    device, which RCCL refuses -- where every kernel and the whole step logic are the engine's and only the transport
+    differs.  Keep the object alive while it is installed."""
+    _SIZES = {2: 4, 5: 8, 7: 4}
+    _DTYPES = {2: torch.int32, 5: torch.int64, 7: torch.float32}
+
+    class _Table(C.Structure):
+        _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_uint32), ("all_gather", C.c_void_p),
+                    ("all_reduce", C.c_void_p), ("comm_user_rank", C.c_void_p)]
+
+    def __init__(self, group=None):
+        import os
+        self.group = group
+        self.hip = None
+        for name in (None, os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"), "libamdhip64.so"):
+            try:
+                lib_ = C.CDLL(name)
+                lib_.hipMemcpy, lib_.hipStreamSynchronize    # noqa: B018
+                self.hip = lib_
+                break
+            except (OSError, AttributeError):
+                continue
+        if self.hip is None:
+            raise OSError("libamdhip64 not found")
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p)
+        AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+        UR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int))
+        self._ag, self._ar, self._ur = AG(self._all_gather), AR(self._all_reduce), UR(self._user_rank)
+        self.calls = []     # (name, count) of every collective issued, for tests
+        self.table = self._Table(C.sizeof(self._Table), 0, C.cast(self._ag, C.c_void_p), C.cast(self._ar, C.c_void_p),
+                                 C.cast(self._ur, C.c_void_p))
+
+    def install(self):
+        from ._lib import check, lib
+        check(lib().rq_set_collectives(C.byref(self.table)))
+
+    @staticmethod
+    def uninstall():
+        from ._lib import check, lib
+        check(lib().rq_set_collectives(None))
+
+    def _to_host(self, ptr, count, dtype, stream):
+        t = torch.empty(count, dtype=self._DTYPES[dtype])
+        if self.hip.hipStreamSynchronize(stream) != 0 or self.hip.hipMemcpy(t.data_ptr(), ptr, count * self._SIZES[dtype], 2) != 0:
+            raise RuntimeError("hip copy to host failed")
+        return t
+
+    def _all_gather(self, send, recv, count, dtype, comm, stream):
+        try:
+            self.calls.append(("all_gather", int(count)))
+            t = self._to_host(send, count, dtype, stream)
+            world = dist.get_world_size(self.group)
+            out = torch.empty(count * world, dtype=t.dtype)
+            dist.all_gather_into_tensor(out, t, group=self.group)
+            return 0 if self.hip.hipMemcpy(recv, out.data_ptr(), out.numel() * self._SIZES[dtype], 1) == 0 else 1
+        except Exception:       # a Python exception must not unwind through the C caller
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def _all_reduce(self, send, recv, count, dtype, op, comm, stream):
+        try:
+            self.calls.append(("all_reduce", int(count)))
+            t = self._to_host(send, count, dtype, stream)
+            dist.all_reduce(t, op={2: dist.ReduceOp.MAX, 3: dist.ReduceOp.MIN}[op], group=self.group)
+            return 0 if self.hip.hipMemcpy(recv, t.data_ptr(), count * self._SIZES[dtype], 1) == 0 else 1
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def _user_rank(self, comm, out_rank):
+        out_rank[0] = dist.get_rank(self.group)
+        return 0

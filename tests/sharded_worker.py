@@ -9,7 +9,12 @@ batch two ways:
      merged probe lists -> rq_query_batch_device_probed -> all-gather of per-shard top-k, merge;
   C  as B, with the thresholds shared between the shards (sharding.SeededShardQuery: nearest list first, one
      all-reduce(min) of the k-th best distances, the other lists seeded with it).
-Rank 0 writes the merged results to argv[1] (npz)."""
+  D  the WHOLE step through the C ABI (rq_query_batch_sharded_device: handshake, sliced coarse ranking + probe-key
+     all-gather, nearest list, all-reduce(min), seeded rest, top-k all-gather + status words), with the host-buffer
+     transport of sharding.HostCollectives standing in for RCCL; d0 = the same entry on the shards' own thresholds.
+     D must equal C, and d0 must equal B, bit for bit: same partition, same arithmetic, only the plumbing differs.
+Rank 0 writes the merged results to argv[1] (npz).  argv[2] = "big": ~2M vectors over 512 lists generated on the
+device (per-shard thresholds differ there and the seeded step returns short shards)."""
 import os
 import sys
 
@@ -31,8 +36,22 @@ def case_data():
     return x, centres, synth.random_orthogonal(d, seed=74), queries, 12, 10
 
 
+def big_case_data(dev):
+    """2M x 128 over 512 overlapping, Zipf-sized lists, 2000 queries (device tensors)."""
+    import torch
+    from tests import synth
+    n, d, k, nq, sigma = 2_000_000, 128, 512, 2000, 0.9
+    centres = synth.device_centres(k, d, dev, 0.6, seed=81)
+    wz = 1.0 / torch.arange(1, k + 1, device=dev, dtype=torch.float64) ** 0.7
+    w = (wz / wz.sum()).float()[torch.randperm(k, device=dev, generator=torch.Generator(device=dev).manual_seed(82))]
+    x = synth.device_mixture_chunk(centres, 0, n, sigma, 0, 83, 0, k, w)[0].contiguous()
+    q = synth.device_queries(centres, nq, sigma, dev, seed=84, weights=w)
+    return x, centres, synth.random_orthogonal(d, seed=85), q, 32, 10
+
+
 def main():
     out_path = sys.argv[1]
+    big = len(sys.argv) > 2 and sys.argv[2] == "big"
     import torch
     import torch.distributed as dist
     import rabitq_amd
@@ -41,11 +60,19 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     _lib.check(_lib.lib().rq_init(0))
     dev = torch.device("cuda", 0)
-    x, centres, P, queries, probe, topk = case_data()
-    n, d = x.shape
-    k, nq = centres.shape[0], queries.shape[0]
-    full = rabitq_amd.RaBitQ.build(x, centres, P)
-    q = torch.from_numpy(queries).to(dev)
+    if big:
+        xd, cd, P, q, probe, topk = big_case_data(dev)
+        n, d = xd.shape
+        k, nq = cd.shape[0], q.shape[0]
+        full = rabitq_amd.RaBitQ.build_device(xd.data_ptr(), n, d, cd.data_ptr(), k, orthogonal=P)
+        del xd
+        torch.cuda.empty_cache()
+    else:
+        x, centres, P, queries, probe, topk = case_data()
+        n, d = x.shape
+        k, nq = centres.shape[0], queries.shape[0]
+        full = rabitq_amd.RaBitQ.build(x, centres, P)
+        q = torch.from_numpy(queries).to(dev)
     od = torch.empty((nq, topk), device=dev)
     oi = torch.zeros((nq, topk), device=dev, dtype=torch.int32)
     on = torch.zeros(nq, device=dev, dtype=torch.int32)
@@ -86,6 +113,35 @@ def main():
     cd, ci, cn = sharding.merge_shard_topk(sq.payload(0).cpu(), topk, id_bound=n)
     res.update(c_dist=cd.numpy(), c_ids=ci.numpy(), c_cnt=cn.numpy(), c_thr=sq.thr.cpu().numpy(),
                c_local_rerank=np.array([sq.profile_a["rerank_candidates"] + rabitq_amd.index.last_profile()["rerank_candidates"]]))
+    # ---- D: the whole step through the C ABI, host-buffer collectives instead of RCCL -------------------------------
+    hc = sharding.HostCollectives()
+    hc.install()
+    for tag, shared in (("d", 1), ("d0", 0)):
+        rabitq_amd.index.set_option("shared_thresholds", shared)
+        hc.calls.clear()
+        od.fill_(-1.0), oi.zero_(), on.zero_()
+        shb.query_batch_sharded_device(1, world, 0, q.data_ptr(), nq, d, probe, topk, od.data_ptr(), oi.data_ptr(), on.data_ptr())
+        res.update({f"{tag}_dist": od.cpu().numpy(), f"{tag}_ids": oi.cpu().numpy().view(np.uint32).astype(np.int64),
+                    f"{tag}_cnt": on.cpu().numpy().astype(np.int64),
+                    f"{tag}_local_rerank": np.array([rabitq_amd.index.last_profile()["rerank_candidates"]])})
+        want = ([("all_reduce", 4), ("all_gather", nq * probe), ("all_reduce", nq), ("all_gather", nq * 2 * topk + 1)] if shared else
+                [("all_reduce", 4), ("all_gather", nq * probe), ("all_gather", nq * topk + 1)])
+        assert hc.calls == want, (hc.calls, want)
+    rabitq_amd.index.set_option("shared_thresholds", 1)
+    # a rank called with other parameters: the handshake makes EVERY rank fail, nobody blocks in a collective
+    try:
+        shb.query_batch_sharded_device(1, world, 0, q.data_ptr(), nq, d, probe, topk + rank, od.data_ptr(), oi.data_ptr(), on.data_ptr())
+        raise SystemExit("parameter mismatch between the ranks was not detected")
+    except rabitq_amd.RabitqError as e:
+        assert e.status == -1 and "different" in str(e), str(e)
+    # ... and a rank that fails validation (null output on rank 1 only): the others return an error too
+    try:
+        shb.query_batch_sharded_device(1, world, 0, q.data_ptr(), nq, d, probe, topk, od.data_ptr() if rank == 0 else 0,
+                                       oi.data_ptr(), on.data_ptr())
+        raise SystemExit("a failed rank was not reported to its peers")
+    except rabitq_amd.RabitqError as e:
+        assert e.status == -1, str(e)
+    sharding.HostCollectives.uninstall()
     shb.close()
     full.close()
     dist.barrier()
