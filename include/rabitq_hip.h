@@ -344,13 +344,8 @@ rq_status rq_set_profiling(int level);
  * distance is at or above the stage's threshold (then the reference rejects it whatever its value).  0 = never.
  * Results are bit-identical either way.
  * "max_scan_blocks": test hook, blocks per scan launch (0 = hardware bound).
- * "scan_dense": 0 (default) / 1 / 2: use the dense matrix-core kernel (16x16x128 MFMA, every cell evaluated exactly) for
- * the early cluster-major stages at dim 128 / 256: never / when a list meets >= 8 queries / always.  Identical results;
- * off by default because it measured slower than the VALU kernel.
  * "coarse_impl": test hook, coarse-distance kernel: 0 = automatic (default), 1 = query rows through LDS, 2 = query
- * rows in scalar registers (what large batches use), 3 = approximate f32 matrix-core product + exact refinement of the
- * lists that can still be among the nprobe nearest inside the probe selection (dim 64 / 128 / 256, >= 256 lists; exact
- * results, not yet faster: DESIGN.md section 8).
+ * rows in scalar registers (what large batches use).
  * "shared_thresholds": rq_query_batch_sharded_device: 1 (default) = with more than one shard the step runs the nearest
  * list first, all-reduces (min) the k-th best distances and seeds the rest of the probe list with them (see
  * rq_query_batch_device_seeded); 0 = every shard prunes with its own thresholds only; 2 = also with one shard (tests).

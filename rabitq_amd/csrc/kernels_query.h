@@ -293,160 +293,13 @@ __global__ __launch_bounds__(256) void select_probe_kernel(const float *__restri
 // ~20 steps, stopping as soon as a threshold selects exactly nprobe), ties at the threshold are broken
 // by list id (a second bisection, rare), the winners are compacted by ballot and sorted across the 64
 // lanes with a shuffle bitonic network.  No LDS atomics, no block barriers.
-// ------------------------------------------------------------------------------------------------
-// Coarse ranking of a large batch through the matrix cores, WITHOUT giving up the exact distances.
-//   1. coarse_approx_kernel: a[q][i] = (|c_i|^2 + |y_q|^2) - 2 <c_i, y_q> with the inner products from
-//      v_mfma_f32_32x32x2_f32 (plain f32 FMAs, 64 per 32 x 32 tile at dim 128): 1/3 of the time of the exact-order
-//      VALU kernel.  Against the reference's f32 value e[q][i] (src/simd.rs:14-73 order)
-//          |a - e| <= m_q = (9 dim/8 + 16) 1.05 2^-24 (Cmax + |y_q|)^2
-//      (dim roundings each in the two norms and the product, two in the final ops, dim/8 + 5 in the reference's own
-//      chain; Cmax = the largest centroid norm of the index).
-//   2. select_probe_wave_kernel (refine): T = an upper bound of the nprobe-th smallest a (the 64th smallest of the
-//      lanes' two smallest values each: 128 actual entries of the row).  Every list of the exact top-nprobe has
-//      a <= T + 2 m_q: at least nprobe lists have e <= T + m_q, so the nprobe-th smallest e is <= T + m_q, and a list
-//      at or below it has a <= e + m_q.  Those candidates (~80 of 4096) get their EXACT distance, computed in the
-//      reference's lane order by one lane each; everything else is dropped; the selection then runs on exact values
-//      only, as before.  The result is the exact ranking, bit for bit (ties included: tied lists are all candidates).
-// ------------------------------------------------------------------------------------------------
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-// squared norms of n rows of `dim` floats (sequential f32 chain per row) and, optionally, their maximum (as u32 bits:
-// non-negative floats order like their bit patterns)
-__global__ void row_sqnorm_kernel(const float *__restrict__ rows, uint32_t n, uint32_t dim, float *__restrict__ out,
-                                  uint32_t *__restrict__ max_bits) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const float4 *p = reinterpret_cast<const float4 *>(rows + (uint64_t)r * dim);
-    float s = 0.0f;
-    for (uint32_t c = 0; c < dim / 4; ++c) {
-        const float4 v = p[c];
-        s = fmaf(v.x, v.x, s), s = fmaf(v.y, v.y, s), s = fmaf(v.z, v.z, s), s = fmaf(v.w, v.w, s);
-    }
-    out[r] = s;
-    if (max_bits) atomicMax(max_bits, __builtin_bit_cast(uint32_t, s));  // NaN / inf bit patterns sort above every finite norm
-}
-
-// one wave = 32 queries (MFMA rows, their dim values resident: dim/2 VGPRs) against every 32-list tile (MFMA columns,
-// read from the transposed centroids, coalesced); block = 4 waves = 128 queries.  DIM <= 256.
-template <int DIM>
-__global__ __launch_bounds__(256) void coarse_approx_kernel(const float *__restrict__ y, const float *__restrict__ cent_t,
-                                                            const float *__restrict__ cnorm, const float *__restrict__ ynorm,
-                                                            float *__restrict__ dist, uint32_t k, uint32_t nq, uint32_t kstride) {
-    constexpr int NM = DIM / 2;  // MFMAs per tile (K = 2 each)
-    const uint32_t lane = threadIdx.x & 63, li = lane & 31, kk = lane >> 5;
-    const uint32_t q0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
-    if (q0 >= nq) return;
-    const uint32_t qa = q0 + li < nq ? q0 + li : nq - 1;
-    float a[NM];
-#pragma unroll
-    for (int m = 0; m < NM; ++m) a[m] = y[(uint64_t)qa * DIM + 2 * m + kk];
-    float yn[16];  // |y|^2 of this lane's 16 output rows
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const uint32_t q = q0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-        yn[r] = ynorm[q < nq ? q : nq - 1];
-    }
-    const uint32_t ntile = (k + 31) / 32;
-    float b0[NM], b1[NM];  // two operand sets, used alternately: the next tile's loads fly during this tile's MFMAs, no copies
-    auto load_b = [&](uint32_t t, float (&bb)[NM], float &cn) {
-        const uint32_t i = 32 * t + li < k ? 32 * t + li : k - 1;
-#pragma unroll
-        for (int m = 0; m < NM; ++m) bb[m] = cent_t[(uint64_t)(2 * m + kk) * kstride + i];
-        cn = cnorm[i];
-    };
-    const bool rows_full = q0 + 32 <= nq;
-    auto tile = [&](uint32_t t, const float (&bb)[NM], float cn) {
-        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int m = 0; m < NM; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bb[m], acc, 0, 0, 0);
-        const uint32_t i = 32 * t + li;
-        float *out = dist + (uint64_t)(q0 + 4 * kk) * k + i;
-        if (rows_full && 32 * t + 32 <= k) {  // wave-uniform: sixteen plain stores
-#pragma unroll
-            for (int r = 0; r < 16; ++r) out[(uint64_t)((r & 3) + 8 * (r >> 2)) * k] = (cn + yn[r]) - 2.0f * acc[r];
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t q = q0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                if (q < nq && i < k) out[(uint64_t)((r & 3) + 8 * (r >> 2)) * k] = (cn + yn[r]) - 2.0f * acc[r];
-            }
-        }
-    };
-    float cn0 = 0.0f, cn1 = 0.0f;
-    load_b(0, b0, cn0);
-    for (uint32_t t = 0; t < ntile; t += 2) {
-        if (t + 1 < ntile) load_b(t + 1, b1, cn1);
-        tile(t, b0, cn0);
-        if (t + 1 >= ntile) break;
-        if (t + 2 < ntile) load_b(t + 2, b0, cn0);
-        tile(t + 1, b1, cn1);
-    }
-}
-
-// the reference's l2_squared_distance(centroid, y) by ONE lane (src/simd.rs:14-73: 8 lanes of fused multiply-adds, folded
-// pairwise); y in LDS.  (Force-inlined: as a real call -- __noinline__ -- it returned wrong keys on this toolchain.)
-__device__ __forceinline__ uint32_t refine_exact_key(const float *__restrict__ c, const float *yq, uint32_t dim) {
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (uint32_t e = 0; e < dim; e += 8) {
-        const float4 c0 = *reinterpret_cast<const float4 *>(c + e), c1 = *reinterpret_cast<const float4 *>(c + e + 4);
-        const float4 y0 = *reinterpret_cast<const float4 *>(yq + e), y1 = *reinterpret_cast<const float4 *>(yq + e + 4);
-        const float d0 = c0.x - y0.x, d1 = c0.y - y0.y, d2 = c0.z - y0.z, d3 = c0.w - y0.w;
-        const float d4 = c1.x - y1.x, d5 = c1.y - y1.y, d6 = c1.z - y1.z, d7 = c1.w - y1.w;
-        acc[0] = fmaf(d0, d0, acc[0]), acc[1] = fmaf(d1, d1, acc[1]), acc[2] = fmaf(d2, d2, acc[2]), acc[3] = fmaf(d3, d3, acc[3]);
-        acc[4] = fmaf(d4, d4, acc[4]), acc[5] = fmaf(d5, d5, acc[5]), acc[6] = fmaf(d6, d6, acc[6]), acc[7] = fmaf(d7, d7, acc[7]);
-    }
-    return ord32_biased(reduce8_regs(acc));
-}
-#define RQ_REFINE_MAX_DIM 256u   // the approximate product keeps a query's dim/2 operand registers resident
-// what the refining probe selection needs besides the approximate row (cent == nullptr: the row is exact already)
-struct RefineArgs {
-    const float *cent;   // the ranked lists' centroids, row-major (row i = list i of the row)
-    const float *y;      // rotated queries, nq x dim
-    const float *ynorm;  // |y|^2
-    float err_coef;      // (9 dim/8 + 16) 1.05 2^-24
-    float cmax;          // largest centroid norm (finite)
-    uint32_t dim;
-};
-
-// refine phase of select_probe_wave_kernel: registers [G0, G1) of the wave's row
-template <int KPL, int G0, int G1>
-__device__ __forceinline__ void refine_registers(uint32_t (&key)[KPL], uint32_t tkey, uint32_t *cand_w, const float *yq_w,
-                                                 const RefineArgs &rf, uint32_t lane) {
-    uint32_t nc = 0;  // wave-uniform
-#pragma unroll
-    for (int i = G0; i < G1; ++i) {
-        const bool is_c = key[i] <= tkey && key[i] != 0xFFFFFFFFu;
-        const uint64_t m = __ballot(is_c);
-        if (m) {
-            if (is_c) cand_w[nc + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = 256u * (uint32_t)(i >> 2) + 4u * lane + (uint32_t)(i & 3);
-            nc += (uint32_t)__popcll(m);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    for (uint32_t jx = lane; jx < nc; jx += 64) cand_w[jx] = refine_exact_key(rf.cent + (uint64_t)cand_w[jx] * rf.dim, yq_w, rf.dim);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    uint32_t at0 = 0;
-#pragma unroll
-    for (int i = G0; i < G1; ++i) {
-        const bool is_c = key[i] <= tkey && key[i] != 0xFFFFFFFFu;
-        const uint64_t m = __ballot(is_c);
-        key[i] = is_c ? cand_w[at0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] : 0xFFFFFFFFu;
-        at0 += (uint32_t)__popcll(m);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the buffer may be reused
-}
-template <int KPL, bool REFINE = false>
-__global__ __launch_bounds__(256) void select_probe_wave_kernel(const float *__restrict__ dist, uint32_t k,
-                                                                uint32_t nprobe, uint32_t *__restrict__ out_cluster,
-                                                                float *__restrict__ out_dist, uint32_t id_offset,
-                                                                uint32_t out_stride, uint32_t nq, const RefineArgs rf) {
-    // waves per block: 4, or what the refine buffers (a whole row of list ids per wave) leave room for
-    constexpr uint32_t WPB = REFINE ? (KPL <= 16 ? 4u : (KPL <= 64 ? 2u : 1u)) : 4u;
-    __shared__ unsigned long long win[WPB][64];
-    __shared__ uint32_t cand[REFINE ? WPB : 1][REFINE ? 64 * KPL : 1];                             // refine: candidate lists, then their exact keys
-    __shared__ __attribute__((aligned(16))) float yq[REFINE ? WPB : 1][REFINE ? RQ_REFINE_MAX_DIM : 4];  // refine: the wave's query
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t b = blockIdx.x * WPB + wave;
-    if (b >= nq) return;
+// One wave's selection for query row b; `win`: 64 u64 of LDS owned by the calling wave.
+template <int KPL>
+__device__ __forceinline__ void select_probe_wave(const float *__restrict__ dist, uint32_t k, uint32_t nprobe,
+                                                  uint32_t *__restrict__ out_cluster, float *__restrict__ out_dist,
+                                                  uint32_t id_offset, uint32_t out_stride, uint32_t b,
+                                                  unsigned long long *win) {
+    const uint32_t lane = threadIdx.x & 63;
     const float *d = dist + (uint64_t)b * k;
     uint32_t key[KPL];
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
@@ -477,48 +330,6 @@ __global__ __launch_bounds__(256) void select_probe_wave_kernel(const float *__r
                 kmax = key[i] > kmax ? key[i] : kmax;
             }
         }
-    }
-    if constexpr (REFINE) {  // the row is approximate: exact distances for everything that can be among the nprobe nearest
-        // T: the 64th smallest of the lanes' two smallest keys (128 entries of the row, so at least 64 >= nprobe lists lie at
-        // or below it)
-        uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
-#pragma unroll
-        for (int i = 0; i < KPL; ++i) {
-            const uint32_t x = key[i];
-            m2 = x < m1 ? m1 : (x < m2 ? x : m2);
-            m1 = x < m1 ? x : m1;
-        }
-        uint32_t lo = 0, hi = 0xFFFFFFFFu;  // smallest T with #(m1, m2 <= T) >= 64
-        while (lo < hi) {
-            const uint32_t mid = lo + ((hi - lo) >> 1);
-            const uint32_t c = (uint32_t)__popcll(__ballot(m1 <= mid)) + (uint32_t)__popcll(__ballot(m2 <= mid));
-            if (c >= 64) hi = mid;
-            else lo = mid + 1;
-        }
-        // candidates: a <= T + 2 m_q, evaluated in floats and rounded up; anything not finite -> every list is a candidate
-        const float yn = rf.ynorm[b];
-        const float rad = rf.cmax + sqrtf(yn) * 1.000001f;
-        const float mq = rf.err_coef * (rad * rad) * 1.000001f;
-        const float tf = ord32_unbias(lo) + 2.0f * mq;
-        uint32_t tkey = 0xFFFFFFFEu;
-        if (lo != 0xFFFFFFFFu && tf == tf && fabsf(tf) < 3.0e38f) {
-            const float up = tf + fabsf(tf) * 1.0e-6f + 1.0e-30f;
-            tkey = ord32_biased(up);
-            if (tkey < lo) tkey = lo;
-        }
-        for (uint32_t c = lane * 4; c < rf.dim; c += 256)
-            *reinterpret_cast<float4 *>(&yq[wave][c]) = *reinterpret_cast<const float4 *>(rf.y + (uint64_t)b * rf.dim + c);
-        // compact the candidates' list ids into LDS (the buffer holds a whole row: the margin decides how many there are,
-        // usually ~80), one exact distance per lane and round -- balanced whatever lanes the candidates sit in --, read the
-        // keys back
-        refine_registers<KPL, 0, KPL>(key, tkey, cand[wave], yq[wave], rf, lane);
-        kmin = 0xFFFFFFFFu, kmax = 0u;
-#pragma unroll
-        for (int i = 0; i < KPL; ++i)
-            if (key[i] != 0xFFFFFFFFu) {
-                kmin = key[i] < kmin ? key[i] : kmin;
-                kmax = key[i] > kmax ? key[i] : kmax;
-            }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -577,12 +388,12 @@ __global__ __launch_bounds__(256) void select_probe_wave_kernel(const float *__r
         const bool take = key[i] < T || (key[i] == T && j <= J && j < k);
         const uint64_t m = __ballot(take);
         if (m) {  // wave-uniform
-            if (take) win[wave][base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)key[i] << 32) | j;
+            if (take) win[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)key[i] << 32) | j;
             base += (uint32_t)__popcll(m);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    unsigned long long v = lane < nprobe ? win[wave][lane] : ~0ull;
+    unsigned long long v = lane < nprobe ? win[lane] : ~0ull;
     // bitonic sort across the 64 lanes, ascending
 #pragma unroll
     for (int size = 2; size <= 64; size <<= 1)
@@ -603,6 +414,16 @@ __global__ __launch_bounds__(256) void select_probe_wave_kernel(const float *__r
         out_cluster[(uint64_t)b * out_stride + i] = 0xFFFFFFFFu;
         out_dist[(uint64_t)b * out_stride + i] = __builtin_inff();
     }
+}
+template <int KPL>
+__global__ __launch_bounds__(256) void select_probe_wave_kernel(const float *__restrict__ dist, uint32_t k,
+                                                                uint32_t nprobe, uint32_t *__restrict__ out_cluster,
+                                                                float *__restrict__ out_dist, uint32_t id_offset,
+                                                                uint32_t out_stride, uint32_t nq) {
+    __shared__ unsigned long long win[4][64];
+    const uint32_t wave = threadIdx.x >> 6, b = blockIdx.x * 4 + wave;
+    if (b >= nq) return;
+    select_probe_wave<KPL>(dist, k, nprobe, out_cluster, out_dist, id_offset, out_stride, b, win[wave]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1883,248 +1704,6 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
     if (count_stat && lane == 0) {  // 64 pairs of counters, by block: a single address would serialise a million atomics
         atomicAdd(stat + 2 * (blockIdx.x & 63u), (unsigned long long)n_steps);
         atomicAdd(stat + 2 * (blockIdx.x & 63u) + 1, (unsigned long long)n_flag);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Dense scan on the matrix cores: the EARLY cluster-major stages of a large batch (positions inside a query's nearest
-// list or two).  There a list meets only ~16 queries and thresholds are still loose (several per cent of the
-// candidates pass), so the kernel above is the wrong tool twice over: its 32-query tiles stay half empty and nearly
-// every sub-tile takes its (per-register, rare-event) exact path; the VALU kernel spends 32 of its ~64 instructions
-// per (wave, query) on v_dot8 and runs issue-bound.  Here the dot products come from v_mfma_f32_16x16x128_f8f6f4 and
-// EVERY cell is then evaluated exactly:
-//   rows    = 16 candidates (A: code bits as fp6, expanded once per block and resident),
-//   columns = 16 queries (B: their fp6 images straight from the stage records),
-//   D lane map: column j = lane & 15 is ONE query per lane (its six scalars live in registers), rows 4g .. 4g+3
-//   (g = lane >> 4) are four candidates per sub-tile whose factors are resident as packed pairs, so the reference's
-//   expression runs as v_pk_* ops on whole registers with no per-row operand fetch.
-// A wave owns 64 consecutive list positions: lane group g owns positions 16g .. 16g+15 (row 4g+r of sub-tile t holds
-// position 16g + 4t + r: a lane's 16 pass bits are then in position order and a survivor's rank among its query's
-// survivors is popcounts over four bit fields).  One reservation atomic and one run descriptor per (query, wave) with
-// survivors, issued by 16 lanes at once.  Results are those of scan_kernel (same expression, same order).
-// ------------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-#define RQ_DENSE_TILE 1024u  // list positions per block: each of the four waves streams 256 of them, 16 at a time
-
-template <int W>
-__global__ __launch_bounds__(256) void scan_dense_kernel(SCAN_PARAMS) {
-    static_assert(W % 2 == 0 && W <= 4, "one 16x16x128 MFMA covers two code words; operands resident in registers");
-    constexpr int KB = W / 2;  // 128-dimension blocks
-    constexpr uint32_t OPDW = 12 * W, STRIDE = OPDW + RQ_REC_TAIL;
-    __shared__ __attribute__((aligned(16))) uint2 lut[256];
-    // each wave's 256 candidates, staged once by LDS-DMA: code words and factors
-    __shared__ __attribute__((aligned(16))) uint32_t codesL[4][256][2 * W];
-    __shared__ __attribute__((aligned(16))) float4 facL[4][256];
-    const uint32_t gl = blockIdx.x / a.tiles_per_group;
-    const uint32_t g = a.group_base + gl;
-    const uint32_t first = (a.tile_base + (blockIdx.x - gl * a.tiles_per_group)) * RQ_DENSE_TILE;
-    const uint32_t list_begin = offsets[g], list_len = offsets[g + 1] - list_begin;
-    const uint32_t pb = grp_start[g], pe = grp_start[g + 1];
-    if (pb >= pe || first >= list_len) return;  // block-uniform
-    const uint32_t tid = threadIdx.x, lane = tid & 63, j = lane & 15, kb = lane >> 4;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    {  // byte -> 8 fp6 fields (bit e -> 1.0 = 0b001000 at bits 6e .. 6e+5)
-        uint64_t f = 0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f |= (uint64_t)((tid >> e) & 1u) << (6 * e + 3);
-        lut[tid] = make_uint2((uint32_t)f, (uint32_t)(f >> 32));
-    }
-    __syncthreads();  // table visible
-    const uint32_t wfirst = first + 256 * wave;  // this wave's 256 positions
-    if (wfirst >= list_len) return;              // wave-uniform (after the barrier)
-    const uint32_t wend = wfirst + 256 < list_len ? wfirst + 256 : list_len;
-    {  // stage the wave's candidates (positions past the list's end re-read its first member: never in a stage range)
-        constexpr uint32_t PPP = (2 * W) / 4;  // 16-byte pieces per code
-        const uint32_t cbase = lds_addr(&codesL[wave][0][0]), fbase = lds_addr(&facL[wave][0]);
-#pragma unroll
-        for (uint32_t i = 0; i < 4 * PPP; ++i) {
-            const uint32_t piece = i * 64 + lane, lp = wfirst + piece / PPP;
-            glds16(codes + (uint64_t)(list_begin + (lp < list_len ? lp : 0)) * (2 * W) + 4 * (piece % PPP), cbase + i * 1024);
-        }
-#pragma unroll
-        for (uint32_t i = 0; i < 4; ++i) {
-            const uint32_t lp = wfirst + i * 64 + lane;
-            glds16(factors + list_begin + (lp < list_len ? lp : 0), fbase + i * 1024);
-        }
-    }
-
-    // ---- the queries (columns): two tiles of 16 resident per pass ----
-    struct QTile {
-        uint32_t b[KB][6];  // fp6 fragments of this lane's query (column j), K block kb
-        float lower, delta, sumq, ycd, ycd_sqrt, thr;
-        uint32_t lo, hi, row, slot;
-        bool valid;
-    };
-    const uint32_t npairs = pe - pb;
-    auto f32_of = [](uint32_t v) { return __builtin_bit_cast(float, v); };
-    auto load_tile = [&](uint32_t qt, QTile &q) {
-        const uint32_t r = 16 * qt + j;
-        q.valid = r < npairs;
-        const uint32_t *rec = recs + (uint64_t)(pb + (q.valid ? r : npairs - 1)) * STRIDE;
-#pragma unroll
-        for (int m = 0; m < KB; ++m) {
-            // dimensions 128 m + 32 kb .. +31 = slab 2m + (kb >> 1), half kb & 1 of the record's fp6 image
-            const uint32_t *src = rec + 6 * W * (kb & 1) + 6 * (2 * m + (kb >> 1));
-#pragma unroll
-            for (int e = 0; e < 6; e += 2) {
-                const uint2 v = *reinterpret_cast<const uint2 *>(src + e);
-                q.b[m][e] = v.x, q.b[m][e + 1] = v.y;
-            }
-        }
-        const uint4 ta = *reinterpret_cast<const uint4 *>(rec + OPDW);      // lower delta sumq ycd
-        const uint4 tb = *reinterpret_cast<const uint4 *>(rec + OPDW + 4);  // ycd_sqrt thr lo hi
-        const uint2 tc = *reinterpret_cast<const uint2 *>(rec + OPDW + 8);  // row slot
-        q.lower = f32_of(ta.x), q.delta = f32_of(ta.y), q.sumq = f32_of(ta.z), q.ycd = f32_of(ta.w);
-        q.ycd_sqrt = f32_of(tb.x), q.thr = f32_of(tb.y), q.lo = tb.z, q.hi = tb.w;
-        q.row = tc.x, q.slot = tc.y;
-        if (!q.valid) q.lo = 0, q.hi = 0;
-    };
-    // ---- the candidates (rows), streamed 16 at a time: row 4g + r of sub-tile (grp, t) = position
-    //      wfirst + 64 grp + 16 g + 4 t + r.  A lane fetches, as an A-operand lane (row j), one code dword per K block,
-    //      and as an output lane (group kb) the factors of its four rows.
-    struct Sub {
-        uint32_t craw[KB];
-        float4 f[4];
-    };
-    auto load_sub = [&](uint32_t u, Sub &sd) {  // u = 4 grp + t, from the staged copy
-        const uint32_t base = 64 * (u >> 2) + 4 * (u & 3);
-#pragma unroll
-        for (int m = 0; m < KB; ++m) sd.craw[m] = codesL[wave][base + 16 * (j >> 2) + (j & 3)][4 * m + kb];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sd.f[r] = facL[wave][base + 16 * kb + r];
-    };
-    const uint32_t ngroups = (wend - wfirst + 63) / 64;  // groups of 64 positions in this wave's range
-    const uint32_t ntiles = (npairs + 15) / 16;
-
-    for (uint32_t qt0 = 0; qt0 < ntiles; qt0 += 2) {
-        QTile qa, qb;
-        load_tile(qt0, qa);
-        load_tile(qt0 + 1 < ntiles ? qt0 + 1 : qt0, qb);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged candidates (and these tiles) have landed
-        if (qt0 + 1 >= ntiles) qb.valid = false, qb.lo = 0, qb.hi = 0;
-        // groups of this wave some query of the pass reaches: [g_lo, g_hi) (wave-uniform)
-        uint32_t mn = qa.lo < qb.lo || qb.hi == 0 ? qa.lo : qb.lo, mx = qa.hi > qb.hi ? qa.hi : qb.hi;
-        if (qa.hi == 0) mn = qb.lo;
-        if (mx == 0) mn = 0xFFFFFFFFu;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const uint32_t omn = (uint32_t)__shfl_xor((int)mn, o, 64), omx = (uint32_t)__shfl_xor((int)mx, o, 64);
-            mn = omn < mn ? omn : mn, mx = omx > mx ? omx : mx;
-        }
-        mn = __builtin_amdgcn_readfirstlane(mn), mx = __builtin_amdgcn_readfirstlane(mx);
-        if (mx <= wfirst || mn >= wend) continue;
-        const uint32_t g_lo = mn > wfirst ? (mn - wfirst) / 64 : 0u;
-        const uint32_t g_hi = mx < wend ? (mx - wfirst + 63) / 64 : ngroups;
-        for (uint32_t grp = g_lo; grp < g_hi; ++grp) {
-            const uint32_t gp = wfirst + 64 * grp;  // first position of the group
-            const uint32_t lbase = gp + 16 * kb;    // this lane's 16 cells: positions lbase + b, b = 4 t + r
-            float rough_a[16], rough_b[16];
-            uint32_t pa = 0, pbb = 0;  // pass bits of the two tiles
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                Sub cur;
-                load_sub(4 * grp + t, cur);
-                uint32_t aexp[KB][6];
-#pragma unroll
-                for (int m = 0; m < KB; ++m) {
-                    const uint32_t c = cur.craw[m];
-                    const uint2 p0 = lut[c & 0xFFu], p1 = lut[(c >> 8) & 0xFFu], p2 = lut[(c >> 16) & 0xFFu], p3 = lut[c >> 24];
-                    aexp[m][0] = p0.x;
-                    aexp[m][1] = p0.y | (p1.x << 16);
-                    aexp[m][2] = (p1.x >> 16) | (p1.y << 16);
-                    aexp[m][3] = p2.x;
-                    aexp[m][4] = p2.y | (p3.x << 16);
-                    aexp[m][5] = (p3.x >> 16) | (p3.y << 16);
-                }
-                const f32x2 fip01 = {cur.f[0].x, cur.f[1].x}, fip23 = {cur.f[2].x, cur.f[3].x};
-                const f32x2 ppc01 = {cur.f[0].y, cur.f[1].y}, ppc23 = {cur.f[2].y, cur.f[3].y};
-                const f32x2 eb01 = {cur.f[0].z, cur.f[1].z}, eb23 = {cur.f[2].z, cur.f[3].z};
-                const f32x2 cds01 = {cur.f[0].w, cur.f[1].w}, cds23 = {cur.f[2].w, cur.f[3].w};
-                auto score = [&](const QTile &q, float *rough, uint32_t &pbits) {
-                    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                    for (int m = 0; m < KB; ++m) {
-                        const v8i32 av = {(int)aexp[m][0], (int)aexp[m][1], (int)aexp[m][2], (int)aexp[m][3],
-                                          (int)aexp[m][4], (int)aexp[m][5], 0, 0};
-                        const v8i32 bv = {(int)q.b[m][0], (int)q.b[m][1], (int)q.b[m][2], (int)q.b[m][3],
-                                          (int)q.b[m][4], (int)q.b[m][5], 0, 0};
-                        acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, acc, 2 /*A e2m3*/, 2 /*B e2m3*/, 0, 0, 0, 0);
-                    }
-                    // acc = s/2 exactly (q/2 in e2m3 times 0/1, f32 accumulate), so s as a float is acc + acc; then the
-                    // reference's expression left to right, one rounding per op, two cells per packed instruction
-                    const f32x2 h01 = {acc[0], acc[1]}, h23 = {acc[2], acc[3]};
-                    const f32x2 s01 = h01 + h01, s23 = h23 + h23;
-                    f32x2 t01 = cds01 + q.ycd, t23 = cds23 + q.ycd;
-                    t01 = t01 + q.lower * ppc01, t23 = t23 + q.lower * ppc23;
-                    const f32x2 u01 = (2.0f * s01 - q.sumq) * fip01, u23 = (2.0f * s23 - q.sumq) * fip23;
-                    t01 = t01 + u01 * q.delta, t23 = t23 + u23 * q.delta;
-                    const f32x2 r01 = t01 - eb01 * q.ycd_sqrt, r23 = t23 - eb23 * q.ycd_sqrt;
-                    rough[4 * t] = r01.x, rough[4 * t + 1] = r01.y, rough[4 * t + 2] = r23.x, rough[4 * t + 3] = r23.y;
-                    uint32_t n = r23.y < q.thr ? 1u : 0u;  // src/rerank.rs:84 gate, bits r = 3..0
-                    n = n + n + (r23.x < q.thr ? 1u : 0u);
-                    n = n + n + (r01.y < q.thr ? 1u : 0u);
-                    n = n + n + (r01.x < q.thr ? 1u : 0u);
-                    pbits |= n << (4 * t);
-                };
-                score(qa, rough_a, pa);
-                score(qb, rough_b, pbb);
-            }
-            // stage ranges: a cell counts only if its position is inside its query's [lo, hi)
-            auto clip = [&](const QTile &q, uint32_t &pbits) {
-                if (q.hi <= gp || q.lo >= gp + 64) {
-                    pbits = 0;
-                } else if (!(q.lo <= gp && gp + 64 <= q.hi)) {  // boundary group of this query
-                    uint32_t inr = 0;
-#pragma unroll
-                    for (int b = 15; b >= 0; --b) inr = inr + inr + ((lbase + b >= q.lo && lbase + b < q.hi) ? 1u : 0u);
-                    pbits &= inr;
-                }
-            };
-            clip(qa, pa);
-            clip(qb, pbb);
-            if (a.dbg & 1024u) pa = 0, pbb = 0;  // timing ablation: no survivor is recorded (results are wrong)
-            auto emit = [&](const QTile &q, const float *rough, uint32_t pbits) {
-                if (__ballot(pbits != 0u) == 0ull) return;
-                // the four lane groups' fields of this lane's query, in position order g = 0..3
-                const uint32_t p0 = (uint32_t)__shfl((int)pbits, (int)j, 64), p1 = (uint32_t)__shfl((int)pbits, (int)j + 16, 64);
-                const uint32_t p2 = (uint32_t)__shfl((int)pbits, (int)j + 32, 64), p3 = (uint32_t)__shfl((int)pbits, (int)j + 48, 64);
-                const uint32_t c0 = (uint32_t)__popc(p0), c1 = (uint32_t)__popc(p1), c2 = (uint32_t)__popc(p2), c3 = (uint32_t)__popc(p3);
-                const uint32_t total = c0 + c1 + c2 + c3;
-                const uint32_t before = (kb > 0 ? c0 : 0u) + (kb > 1 ? c1 : 0u) + (kb > 2 ? c2 : 0u);
-                // one reservation per query with survivors: 16 lanes (kb = 0) at once, one run of this group's 64 positions each
-                unsigned long long old = 0;
-                if (kb == 0 && total) old = atomicAdd(surv_cnt + q.row, (1ull << 32) | total);
-                const uint32_t base = (uint32_t)__shfl((int)(uint32_t)old, (int)j, 64);
-                if (kb == 0 && total) {
-                    const uint32_t rbase = (uint32_t)(old >> 32);
-                    if (rbase < a.cap) {
-                        RunRec rr;
-                        rr.pos = list_begin + gp;
-                        rr.slot = q.slot;
-                        rr.base = (uint32_t)old;
-                        rr.cnt = total;
-                        runs[(uint64_t)q.row * a.cap + rbase] = rr;
-                    }
-                }
-                SurvRec *out = surv + (uint64_t)q.row * a.cap;
-#pragma unroll
-                for (int b = 0; b < 16; ++b) {
-                    if ((pbits >> b) & 1u) {
-                        const uint32_t at = base + before + (uint32_t)__popc(pbits & ((1u << b) - 1u));
-                        if (at < a.cap) {
-                            SurvRec r;
-                            r.pos = list_begin + lbase + b;
-                            r.slot = q.slot;
-                            r.rough = rough[b];
-                            r.accurate = 0.0f;
-                            out[at] = r;
-                        }
-                    }
-                }
-            };
-            emit(qa, rough_a, pa);
-            emit(qb, rough_b, pbb);
-        }
     }
 }
 

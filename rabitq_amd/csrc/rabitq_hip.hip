@@ -208,7 +208,6 @@ struct Workspace {
     DevBuf<float> retry_q, retry_pd, retry_pc;  // overflow re-runs: the affected queries (and their probe lists)
     DevBuf<uint32_t> retry_rows;
     DevBuf<uint32_t> q_hist, q_start, q_order;  // rerank order of a large batch (queries grouped by nearest list)
-    DevBuf<float> ynorm;                        // |y|^2 per query (coarse pre-filter)
     DevBuf<uint32_t> pair_rank, rank_base;      // group_rank_kernel: places of a big stage's pairs inside their groups
     DevBuf<uint32_t> probe_cluster, recs, grp_cnt, grp_start, heap_len, heap_id, precise, need,
         nsurv, nshadow, win_count, arr_len, row_map, big_list;
@@ -253,8 +252,6 @@ struct rq_index {
         if (base_host) (void)hipHostFree(base_host);
     }
     DevBuf<float> base, P, centroids, cent_t;
-    DevBuf<float> cnorm;             // |centroid|^2 per list (coarse pre-filter); cmax_norm = the largest norm, inf if unusable
-    float cmax_norm = INFINITY;
     DevBuf<_Float16> base_h;  // fp16 shadow of `base` (rerank pre-filter, derived; untiered indexes with HBM to spare)
     DevBuf<uint32_t> offsets, map_ids;
     DevBuf<uint64_t> codes;
@@ -377,29 +374,6 @@ static std::atomic<int> g_coarse_impl{0};  // 0 auto, 1 LDS-broadcast kernels, 2
 static std::atomic<int> g_scan_dbg{0};
 // the probe selection runs one wave per query (row in registers) for these shapes, one block per query otherwise
 static bool select_is_wave(uint32_t k, uint32_t nprobe, uint32_t nq) { return nprobe <= 64 && k <= 8192 && nq >= 8; }
-// Pre-filtered coarse ranking (kernels_query.h: coarse_approx_kernel + the refine phase of select_probe_wave_kernel):
-// the distance row is approximate and launch_select must be given the RefineArgs this returns.  first = first list of
-// the ranked range, kc lists.
-static bool coarse_prefilter_ok(const rq_index *idx, uint32_t kc, uint32_t nprobe, uint32_t nq) {
-    const int impl = g_coarse_impl.load();
-    return impl == 3 && (idx->dim == 64 || idx->dim == 128 || idx->dim == 256) && kc >= 256 &&
-           select_is_wave(kc, nprobe, nq) && std::isfinite(idx->cmax_norm) && idx->cnorm.p;
-}
-static rq_status launch_coarse_prefiltered(const rq_index *idx, Workspace &ws, uint32_t first, uint32_t kc, uint32_t nq,
-                                           hipStream_t st, RefineArgs *rf) {
-    const uint32_t dim = idx->dim;
-    RQC(ws.ynorm.ensure(nq));
-    row_sqnorm_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(ws.y.p, nq, dim, ws.ynorm.p, nullptr);
-    const dim3 g(ceil_div(nq, 128)), b(256);
-    if (dim == 64) coarse_approx_kernel<64><<<g, b, 0, st>>>(ws.y.p, idx->cent_t.p + first, idx->cnorm.p + first, ws.ynorm.p, ws.dist.p, kc, nq, idx->k);
-    else if (dim == 128) coarse_approx_kernel<128><<<g, b, 0, st>>>(ws.y.p, idx->cent_t.p + first, idx->cnorm.p + first, ws.ynorm.p, ws.dist.p, kc, nq, idx->k);
-    else coarse_approx_kernel<256><<<g, b, 0, st>>>(ws.y.p, idx->cent_t.p + first, idx->cnorm.p + first, ws.ynorm.p, ws.dist.p, kc, nq, idx->k);
-    rf->cent = idx->centroids.p + (uint64_t)first * dim;
-    rf->y = ws.y.p, rf->ynorm = ws.ynorm.p, rf->dim = dim, rf->cmax = idx->cmax_norm;
-    rf->err_coef = (9.0f * dim / 8.0f + 16.0f) * 1.05f * 5.9604645e-8f;
-    if (g_scan_dbg.load() & 2048) rf->err_coef = INFINITY;  // developer check: every list a candidate (the pre-filter selects nothing)
-    return RQ_OK;
-}
 static void launch_coarse(const float *cent_t, const float *y, float *dist, uint32_t k, uint32_t dim, uint32_t nq,
                           uint32_t kstride, hipStream_t st) {
     const int impl = g_coarse_impl.load();
@@ -502,18 +476,6 @@ static void launch_scan(const ScanPtrs &p, const ScanArgs &args, uint32_t W, hip
         }
     });
 }
-// dense matrix-core scan of the early cluster-major stages (scan_dense_kernel): dims 128 and 256
-static bool scan_has_dense(uint32_t W) { return W == 2 || W == 4; }
-static void launch_scan_dense(const ScanPtrs &p, const ScanArgs &args, uint32_t W, hipStream_t st) {
-    launch_scan_chunks(args, [&](const ScanArgs &a, dim3 g) {
-        const dim3 b(256);
-        if (W == 2) scan_dense_kernel<2><<<g, b, 0, st>>>(SCAN_ARGS);
-        else if (W == 4) scan_dense_kernel<4><<<g, b, 0, st>>>(SCAN_ARGS);
-    });
-}
-// 0 never (default: measured slower than the VALU kernel), 1 when a list meets >= 8 queries on
-// average, 2 every cluster-major VALU stage (tests)
-static std::atomic<int> g_scan_dense{0};
 // scan implementation: 0 = auto (matrix cores when many queries share each list, VALU otherwise),
 // 1 = VALU (v_dot8_u32_u4) only, 2 = matrix cores wherever the kernel exists (test hook)
 static std::atomic<int> g_scan_impl{0};
@@ -571,18 +533,12 @@ static uint32_t scan_tile(uint32_t W) {
 
 // probe selection: one wave per query when the row fits in registers and nprobe <= 64, else one block per query
 static void launch_select(const float *dist, uint32_t k, uint32_t nprobe, uint32_t *out_cluster, float *out_dist,
-                          uint32_t id_offset, uint32_t out_stride, uint32_t nq, hipStream_t st, const RefineArgs rf = RefineArgs{}) {
+                          uint32_t id_offset, uint32_t out_stride, uint32_t nq, hipStream_t st) {
     if (select_is_wave(k, nprobe, nq)) {
         const dim3 g(ceil_div(nq, 4)), b(256);
-        if (rf.cent) {  // approximate row: the refining instantiations
-            if (k <= 1024) select_probe_wave_kernel<16, true><<<ceil_div(nq, 4), 256, 0, st>>>(dist, k, nprobe, out_cluster, out_dist, id_offset, out_stride, nq, rf);
-            else if (k <= 4096) select_probe_wave_kernel<64, true><<<ceil_div(nq, 2), 128, 0, st>>>(dist, k, nprobe, out_cluster, out_dist, id_offset, out_stride, nq, rf);
-            else select_probe_wave_kernel<128, true><<<nq, 64, 0, st>>>(dist, k, nprobe, out_cluster, out_dist, id_offset, out_stride, nq, rf);
-            return;
-        }
-        if (k <= 1024) select_probe_wave_kernel<16><<<g, b, 0, st>>>(dist, k, nprobe, out_cluster, out_dist, id_offset, out_stride, nq, rf);
-        else if (k <= 4096) select_probe_wave_kernel<64><<<g, b, 0, st>>>(dist, k, nprobe, out_cluster, out_dist, id_offset, out_stride, nq, rf);
-        else select_probe_wave_kernel<128><<<g, b, 0, st>>>(dist, k, nprobe, out_cluster, out_dist, id_offset, out_stride, nq, rf);
+        if (k <= 1024) select_probe_wave_kernel<16><<<g, b, 0, st>>>(dist, k, nprobe, out_cluster, out_dist, id_offset, out_stride, nq);
+        else if (k <= 4096) select_probe_wave_kernel<64><<<g, b, 0, st>>>(dist, k, nprobe, out_cluster, out_dist, id_offset, out_stride, nq);
+        else select_probe_wave_kernel<128><<<g, b, 0, st>>>(dist, k, nprobe, out_cluster, out_dist, id_offset, out_stride, nq);
         return;
     }
     select_probe_kernel<<<nq, 256, (size_t)nprobe * 8, st>>>(dist, k, nprobe, out_cluster, out_dist, id_offset, out_stride);
@@ -783,13 +739,11 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         probe_cluster = ext_cluster;
         probe_dist = ext_dist;
     } else {
-        RefineArgs rf{};
         pf.begin(PF_COARSE);
-        if (coarse_prefilter_ok(idx, k, nprobe, nq)) RQC(launch_coarse_prefiltered(idx, ws, 0, k, nq, st, &rf));
-        else launch_coarse(idx->cent_t.p, ws.y.p, ws.dist.p, k, dim, nq, k, st);
+        launch_coarse(idx->cent_t.p, ws.y.p, ws.dist.p, k, dim, nq, k, st);
         pf.end();
         pf.begin(PF_SELECT);
-        launch_select(ws.dist.p, k, nprobe, ws.probe_cluster.p, ws.probe_dist.p, 0, nprobe, nq, st, rf);
+        launch_select(ws.dist.p, k, nprobe, ws.probe_cluster.p, ws.probe_dist.p, 0, nprobe, nq, st);
         pf.end();
     }
 
@@ -895,12 +849,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         // kernel wins, measured at any batch size)
         const bool use_mfma = scan_has_mfma(W) && impl != 1 && (impl == 2 || (est_pairs >= 8ull * k && (sg.s_lo >= avg_len || one_stage)));
         const bool cluster_major = use_mfma || (est_pairs >= k / 2 && est_pairs > 64);
-        // early stages of a large batch: a list meets ~16 queries and several per cent of its candidates pass, so
-        // every cell is evaluated exactly, with the dot products from 16x16x128 MFMAs (scan_dense_kernel)
-        const int dense_opt = g_scan_dense.load();
-        const bool use_dense = !use_mfma && cluster_major && scan_has_dense(W) && impl != 1 &&
-                               (dense_opt == 2 || (dense_opt == 1 && est_pairs >= 8ull * k));
-        const bool fp6_records = use_mfma || use_dense;
+        const bool fp6_records = use_mfma;
         pf.begin(PF_GROUP);
         ScanArgs a{};
         ScanPtrs sp{};
@@ -954,12 +903,12 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         sp.stat = ws.stat.p;  // 64 x {sub-tile steps, exact-path steps} of the matrix-core scan (dbg & 128)
         a.cap = qp.cap;
         a.dbg = (uint32_t)g_scan_dbg.load();
-        const uint32_t stage_tile = use_mfma ? scan_mfma_tile(W) : (use_dense ? RQ_DENSE_TILE : tile);
+        const uint32_t stage_tile = use_mfma ? scan_mfma_tile(W) : tile;
         a.tiles_per_group = ceil_div(std::min<uint64_t>(idx->max_list_len, sg.s_hi), stage_tile);
         sp.tile_table = nullptr;
         const uint64_t grid_blocks = (uint64_t)k * a.tiles_per_group, real_tiles = idx->n / stage_tile + k;
         const int tt_opt = g_scan_tile_table.load();  // 0 = never, 1 = when the plain grid is mostly empty blocks, 2 = always
-        if (cluster_major && !use_dense && scan_is_fused(W) && sg.s_hi >= idx->max_list_len &&
+        if (cluster_major && scan_is_fused(W) && sg.s_hi >= idx->max_list_len &&
             (tt_opt == 2 || (tt_opt == 1 && grid_blocks > 4 * real_tiles))) {
             // the stage reaches every position of the lists and the lists are very unequal (one block per existing
             // (list, tile) instead of k x the longest list's tiles; measured neutral-to-slower for moderately unequal
@@ -971,7 +920,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         // large batches, VALU-kernel stages: the run descriptors go into a dense directory indexed by stream position
         // (stage_fill_kernel: RQ_REC_CELL0), so the stage needs no sort of its run directory
         uint32_t dense_cells = 0;
-        if (nq >= 256 && !use_mfma && !use_dense && scan_is_fused(W) && g_dense_dir.load() && sg.s_hi != 0xFFFFFFFFu) {
+        if (nq >= 256 && !use_mfma && scan_is_fused(W) && g_dense_dir.load() && sg.s_hi != 0xFFFFFFFFu) {
             const uint64_t cells = (uint64_t)((sg.s_hi - 1) >> 6) - (sg.s_lo >> 6) + 2ull * slot_hi + 2;
             if (cells <= qp.cap) dense_cells = (uint32_t)cells;
         }
@@ -983,7 +932,6 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         }
         pf.begin(use_mfma ? PF_SCAN_MATRIX : PF_SCAN);
         if (use_mfma) launch_scan_mfma(sp, a, W, st);
-        else if (use_dense) launch_scan_dense(sp, a, W, st);
         else launch_scan(sp, a, W, st);
         pf.end();
         if (prof_acc) prof_acc->scan_launches++;
@@ -1338,18 +1286,6 @@ static rq_status finish_index(rq_index *idx) {
     if (idx->k)
         transpose_kernel<<<dim3(ceil_div(idx->dim, 32), ceil_div(idx->k, 32)), dim3(32, 8)>>>(
             idx->centroids.p, idx->cent_t.p, idx->k, idx->dim);
-    idx->cmax_norm = INFINITY;
-    if (idx->k) {  // centroid norms for the matrix-core pre-filter of the coarse ranking
-        RQC(idx->cnorm.alloc(idx->k));
-        DevBuf<uint32_t> mb;
-        RQC(mb.alloc(1));
-        HIPC(hipMemset(mb.p, 0, 4));
-        row_sqnorm_kernel<<<ceil_div(idx->k, 256), 256>>>(idx->centroids.p, idx->k, idx->dim, idx->cnorm.p, mb.p);
-        uint32_t bits = 0;
-        HIPC(hipMemcpy(&bits, mb.p, 4, hipMemcpyDeviceToHost));
-        const float m2 = __builtin_bit_cast(float, bits);
-        if (std::isfinite(m2) && m2 < 1.0e30f) idx->cmax_norm = std::sqrt(m2) * 1.000001f;
-    }
     DevBuf<uint32_t> mx;
     RQC(mx.alloc(2));
     const uint32_t mx_init[2] = {0u, 0xFFFFFFFFu};
@@ -2413,10 +2349,8 @@ rq_status rq_coarse_topk_device(const rq_index *idx, const float *d_queries, uin
         qp = ws->qpad.p;
     }
     launch_rotate(qp, idx->P.p, ws->y.p, nq, dim, nq >= 32, st);
-    RefineArgs rf{};
-    if (coarse_prefilter_ok(idx, kc, np, nq)) RQC(launch_coarse_prefiltered(idx, *ws, list_lo, kc, nq, st, &rf));
-    else launch_coarse(idx->cent_t.p + list_lo, ws->y.p, ws->dist.p, kc, dim, nq, idx->k, st);
-    launch_select(ws->dist.p, kc, np, d_out_cluster, d_out_dist, list_lo, probe, nq, st, rf);
+    launch_coarse(idx->cent_t.p + list_lo, ws->y.p, ws->dist.p, kc, dim, nq, idx->k, st);
+    launch_select(ws->dist.p, kc, np, d_out_cluster, d_out_dist, list_lo, probe, nq, st);
     HIPC(hipStreamSynchronize(st));
     HIPC(hipGetLastError());
     return RQ_OK;
@@ -2949,13 +2883,8 @@ rq_status rq_set_option(const char *name, int value) {
         return RQ_OK;
     }
     if (std::string(name) == "coarse_impl") {  // test hook: coarse-distance kernel (0 auto, 1 LDS broadcast, 2 scalar registers)
-        if (value < 0 || value > 3) return fail(RQ_ERR_INVALID, "coarse_impl must be 0, 1, 2 or 3");
+        if (value < 0 || value > 2) return fail(RQ_ERR_INVALID, "coarse_impl must be 0, 1 or 2");
         g_coarse_impl = value;
-        return RQ_OK;
-    }
-    if (std::string(name) == "scan_dense") {  // dense matrix-core scan of early cluster-major stages: 0 never, 1 auto, 2 always
-        if (value < 0 || value > 2) return fail(RQ_ERR_INVALID, "scan_dense must be 0, 1 or 2");
-        g_scan_dense = value;
         return RQ_OK;
     }
     if (std::string(name) == "dense_dir") {  // test hook: 0 = run descriptors always appended and sorted, 1 = dense directories where they fit

@@ -624,36 +624,6 @@ def test_ranked_group_placement_matches_oracle(rq, oracle, impl):
     oidx.close()
 
 
-@pytest.mark.parametrize("d,n,k,nq", [(128, 30_000, 12, 300), (128, 9_000, 40, 70), (256, 12_000, 9, 131), (100, 5_000, 3, 33)])
-def test_dense_matrix_scan_matches_oracle(rq, oracle, d, n, k, nq):
-    """scan_dense_kernel (16x16x128 MFMA dot products, every cell evaluated exactly): an alternative to the VALU kernel
-    for the early cluster-major stages at dim 128 / 256 (off by default: measured slower).  Forced
-    here for every cluster-major VALU stage: ragged list lengths
-    (not multiples of 16 / 64 / 256), query counts that are not multiples of 16, stage boundaries inside a wave's 64
-    positions, empty lists, both rankers, deep top-k (loose thresholds: most cells pass)."""
-    from rabitq_amd import index as ix
-    x, centres, _ = synth.mixture(n, d, k - 1, sigma=0.8, seed=d + n, centre_scale=0.6)
-    centres = np.concatenate([centres, np.full((1, d), 40.0, np.float32)])   # one list stays empty
-    P = synth.random_orthogonal((d + 63) // 64 * 64, seed=d + 1)
-    oidx = oracle.OracleIndex.build(x, centres, P)
-    gidx = rq.RaBitQ.build(x, centres, P)
-    queries, _, _ = synth.mixture(nq, d, k - 1, sigma=0.8, seed=d + n + 1, centre_scale=0.6)
-    queries[1] = x[5]
-    try:
-        ix.set_option("scan_dense", 2)
-        for probe, topk, heur in [(min(k, 8), 10, False), (k, 100, False), (2, 3, False), (min(k, 5), 10, True)]:
-            _compare_with_oracle(rq, oracle, oidx, gidx, queries, probe, topk, heur)
-        a = gidx.query_batch(queries, min(k, 8), 10, False)
-        ix.set_option("scan_dense", 0)
-        b = gidx.query_batch(queries, min(k, 8), 10, False)
-        for u, v in zip(a, b):
-            assert_bits_equal(u, v, "dense / VALU early stages")
-    finally:
-        ix.set_option("scan_dense", 0)
-    gidx.close()
-    oidx.close()
-
-
 def test_wide_vectors_dim_3072(rq, oracle):
     # dim in (2048, 4096]: assign_generic_kernel<8> needs > 64 KiB of dynamic LDS, so the attribute must be in
     # place before the FIRST build / quantize of a process (ensure_kernel_attributes); generic-W scan (W = 48)
@@ -859,7 +829,7 @@ def test_begin_end_overflow_retry_matches_sync(rq):
     assert np.array_equal(res[0][0], res[1][0])
 
 
-@pytest.mark.parametrize("coarse_impl", [0, 3])
+@pytest.mark.parametrize("coarse_impl", [0, 2])
 @pytest.mark.parametrize("k", [2000, 5000])
 def test_many_lists_probe_selection_matches_oracle(rq, oracle, k, coarse_impl):
     # the register-resident probe selection is instantiated per list-count bracket (<= 1024, <= 4096, <= 8192):
@@ -888,9 +858,8 @@ def test_many_lists_probe_selection_matches_oracle(rq, oracle, k, coarse_impl):
 @pytest.mark.parametrize("d,k,nq", [(128, 300, 50), (64, 1000, 37), (192, 77, 19), (768, 40, 21), (256, 401, 45), (128, 4100, 33)])
 def test_coarse_distance_kernels_agree_bitwise(rq, oracle, d, k, nq):
     """The coarse ranking (src/rabitq.rs:283-297) has two exact distance kernels -- query rows broadcast through LDS (small
-    batches), query rows in scalar registers (large batches) -- and a pre-filtered form (approximate f32 matrix-core
-    product, then the exact lane-order distance of every list that can still be among the nprobe nearest).  Forcing any
-    of them must give the oracle's probe lists and distances bit for bit (ragged sizes: nq not a multiple of 16 / 32, k
+    batches), query rows in scalar registers (large batches).  Forcing either
+    must give the oracle's probe lists and distances bit for bit (ragged sizes: nq not a multiple of 16 / 32, k
     not a multiple of 32 / 256; duplicate centroids: ties at the selection threshold)."""
     from rabitq_amd import index as ix
     n = 6000
@@ -901,7 +870,7 @@ def test_coarse_distance_kernels_agree_bitwise(rq, oracle, d, k, nq):
     gidx = rq.RaBitQ.build(x, centres, P)
     queries, _, _ = synth.mixture(nq, d, k, sigma=0.9, seed=d + k + 1, centre_scale=0.8)
     try:
-        for impl in (1, 2, 3):    # 3: approximate matrix-core product + exact refinement of the candidates (dim 64/128/256, k >= 256)
+        for impl in (1, 2):
             ix.set_option("coarse_impl", impl)
             _compare_with_oracle(rq, oracle, oidx, gidx, queries, min(k, 40), 10, False)
             _compare_with_oracle(rq, oracle, oidx, gidx, queries[:3], 7, 5, False)
