@@ -329,6 +329,10 @@ typedef struct {
     /* of rerank_candidates: survivors the fp16 shadow rows proved to be at or above their stage's threshold, whose
      * 4*dim-byte row was therefore never fetched (option "rerank_shadow"; large batches) */
     uint64_t rerank_shadow_rejects;
+    /* small-batch path (<= 64 queries: rotate + coarse in one launch, then one block per query doing probe selection, query
+     * quantisation and the early stages in LDS): device time of that second launch, and how many passes took the path */
+    float ms_early;
+    uint32_t small_batch_passes;
 } rq_profile_t;
 /* level: 0 = off; 1 = every kernel group bracketed (each event costs a few microseconds of stream
  * time); 2 = only the scan launches and the whole pass (ms_scan, ms_total; the other fields stay 0). */
@@ -349,6 +353,9 @@ rq_status rq_set_profiling(int level);
  * "shared_thresholds": rq_query_batch_sharded_device: 1 (default) = with more than one shard the step runs the nearest
  * list first, all-reduces (min) the k-th best distances and seeds the rest of the probe list with them (see
  * rq_query_batch_device_seeded); 0 = every shard prunes with its own thresholds only; 2 = also with one shard (tests).
+ * "small_batch": 0 (default) = batches of <= 64 queries (the reference's one-query-per-call loop included) run as a handful
+ * of fat launches (kernels_small.h) whenever the shape allows (nprobe <= 64, <= 8192 lists, topk <= 256, dim in {64, 128,
+ * 256, 512, 768, 1024}), 1 = never (test hook).  Identical results.
  * "dense_dir": test hook, 1 (default) = the VALU stages of large batches write their survivor runs into a directory
  * indexed by stream position (nothing to sort), 0 = runs are appended and the directory is sorted.
  * "group_rank": test hook, placement of a cluster-major stage's (query, list) pairs: 0 = one atomic per pair,

@@ -568,15 +568,15 @@ __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ y,
 // shuffle steps, and the operand images come out of one neighbour exchange each: a lane's four 4-bit codes
 // are half a qnib dword, its four fp6 fields 24 bits of the 6-dword image of its 32-dimension block.
 // Writes the fused scan's operands only (no bit planes); arithmetic identical to prep_kernel.
+// The pairs p0, p0 + 64/LP, ... (PP of them) of one lane group; p0 already includes the group's index lane / LP.
 template <int LP, int R, int PP>
-__global__ __launch_bounds__(256) void prep_small_kernel(const float *__restrict__ y,
-                                                         const float *__restrict__ centroids,
-                                                         const uint32_t *__restrict__ offsets,
-                                                         const uint32_t *__restrict__ pair_cluster,
-                                                         const float *__restrict__ pair_ycd, uint32_t npairs,
-                                                         uint32_t pairs_per_row, PairScalars *__restrict__ scal,
-                                                         uint32_t *__restrict__ qnib, uint32_t *__restrict__ qf6,
-                                                         uint32_t nlists, uint32_t skip_empty) {
+__device__ __forceinline__ void prep_small_pairs(const float *__restrict__ y, const float *__restrict__ centroids,
+                                                 const uint32_t *__restrict__ offsets,
+                                                 const uint32_t *__restrict__ pair_cluster,
+                                                 const float *__restrict__ pair_ycd, uint32_t npairs,
+                                                 uint32_t pairs_per_row, PairScalars *__restrict__ scal,
+                                                 uint32_t *__restrict__ qnib, uint32_t *__restrict__ qf6,
+                                                 uint32_t nlists, uint32_t skip_empty, uint32_t p0) {
     // dim = 4 * LP * R: LP lanes per pair, each owning 4 consecutive dimensions in each of R rounds of 4*LP
     // dimensions (R > 1 only with LP = 64: dim 512, 768, 1024).  Every lane group handles PP pairs: the kernel is a
     // chain of dependent gathers (probe list -> centroid row, list bounds), so the loads of all PP pairs are issued
@@ -584,7 +584,6 @@ __global__ __launch_bounds__(256) void prep_small_kernel(const float *__restrict
     static_assert(R == 1 || LP == 64, "several rounds only with a full wave per pair");
     constexpr uint32_t DIM = 4 * LP * R, W = DIM / 64, PPW = 64 / LP;
     const uint32_t lane = threadIdx.x & 63, sub = lane % LP;
-    const uint32_t p0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (PPW * PP) + lane / LP;  // pairs p0, p0 + PPW, ...
     uint32_t cl[PP], lb[PP], ll[PP];
     float ycd_in[PP];
     bool live[PP];
@@ -689,15 +688,28 @@ __global__ __launch_bounds__(256) void prep_small_kernel(const float *__restrict
     }
 }
 
+template <int LP, int R, int PP>
+__global__ __launch_bounds__(256) void prep_small_kernel(const float *__restrict__ y,
+                                                         const float *__restrict__ centroids,
+                                                         const uint32_t *__restrict__ offsets,
+                                                         const uint32_t *__restrict__ pair_cluster,
+                                                         const float *__restrict__ pair_ycd, uint32_t npairs,
+                                                         uint32_t pairs_per_row, PairScalars *__restrict__ scal,
+                                                         uint32_t *__restrict__ qnib, uint32_t *__restrict__ qf6,
+                                                         uint32_t nlists, uint32_t skip_empty) {
+    constexpr uint32_t PPW = 64 / LP;
+    const uint32_t p0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (PPW * PP) + (threadIdx.x & 63) / LP;
+    prep_small_pairs<LP, R, PP>(y, centroids, offsets, pair_cluster, pair_ycd, npairs, pairs_per_row, scal, qnib, qf6, nlists,
+                                skip_empty, p0);
+}
+
 // Position of every probed list in the query's candidate stream (the order the reference visits
 // candidates: lists nearest-first, members in stored order) and the stream length, which is also
 // what the reference adds to METRICS.rough for this query (src/rerank.rs:105).
-__global__ __launch_bounds__(256) void pair_prefix_kernel(PairScalars *__restrict__ scal, uint32_t nq, uint32_t nprobe,
-                                                          unsigned long long *__restrict__ rough_count) {
-    // one wave per query: 64 slots per step, exclusive scan by shuffles, carry across steps
+// one wave, query row b: 64 slots per step, exclusive scan by shuffles, carry across steps
+__device__ __forceinline__ void pair_prefix_row(PairScalars *__restrict__ scal, uint32_t b, uint32_t nprobe,
+                                                unsigned long long *__restrict__ rough_count) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= nq) return;
     unsigned long long carry = 0;
     for (uint32_t s0 = 0; s0 < nprobe; s0 += 64) {
         const uint32_t s = s0 + lane;
@@ -714,6 +726,11 @@ __global__ __launch_bounds__(256) void pair_prefix_kernel(PairScalars *__restric
         carry += __shfl(incl, 63, 64);
     }
     if (lane == 0) rough_count[b] = carry;
+}
+__global__ __launch_bounds__(256) void pair_prefix_kernel(PairScalars *__restrict__ scal, uint32_t nq, uint32_t nprobe,
+                                                          unsigned long long *__restrict__ rough_count) {
+    const uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b < nq) pair_prefix_row(scal, b, nprobe, rough_count);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -850,22 +867,21 @@ __device__ __forceinline__ uint32_t bf16_rne(float x) {
 }
 __device__ __forceinline__ float bf16_to_f32(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
 
-__global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__restrict__ scal,
-                                                         const uint32_t *__restrict__ probe_cluster,
-                                                         const uint32_t *__restrict__ operand /* opdw dwords per pair */,
-                                                         const float *__restrict__ thr, uint32_t count,
-                                                         uint32_t nprobe, uint32_t slot_hi, uint32_t opdw, uint32_t s_lo,
-                                                         uint32_t s_hi,
-                                                         uint32_t cluster_major,
-                                                         const uint32_t *__restrict__ grp_start,
-                                                         uint32_t *__restrict__ grp_cursor,
-                                                         uint32_t *__restrict__ recs, const FactorStats fs,
-                                                         uint32_t tile_images,
-                                                         const uint32_t *__restrict__ rank /* group_rank_kernel, or null */,
-                                                         const uint32_t *__restrict__ blk_base, uint32_t k) {
+// work item wi = (query, slot < slot_hi), handled by the 16 lanes threadIdx.x & ~15 .. | 15; thr_b: the query's threshold
+__device__ __forceinline__ void stage_fill_item(const PairScalars *__restrict__ scal,
+                                                const uint32_t *__restrict__ probe_cluster,
+                                                const uint32_t *__restrict__ operand /* opdw dwords per pair */,
+                                                const float *__restrict__ thr, uint32_t wi,
+                                                uint32_t nprobe, uint32_t slot_hi, uint32_t opdw, uint32_t s_lo,
+                                                uint32_t s_hi,
+                                                uint32_t cluster_major,
+                                                const uint32_t *__restrict__ grp_start,
+                                                uint32_t *__restrict__ grp_cursor,
+                                                uint32_t *__restrict__ recs, const FactorStats &fs,
+                                                uint32_t tile_images,
+                                                const uint32_t *__restrict__ rank /* group_rank_kernel, or null */,
+                                                const uint32_t *__restrict__ blk_base, uint32_t k) {
     const uint32_t sub = threadIdx.x & 15;                       // 16 lanes per pair
-    const uint32_t wi = blockIdx.x * 16 + (threadIdx.x >> 4);  // work item: (query, slot < slot_hi)
-    if (wi >= count) return;
     const uint32_t wb = wi / slot_hi, p = wb * nprobe + (wi - wb * slot_hi);
     const PairScalars ps = scal[p];
     const bool in = pair_in_stage(ps, s_lo, s_hi);
@@ -978,6 +994,24 @@ __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__re
             if (sub == (uint32_t)i) piece = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
         if (sub < 5) *reinterpret_cast<uint4 *>(tdst + 4 * sub) = piece;
     }
+}
+__global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__restrict__ scal,
+                                                         const uint32_t *__restrict__ probe_cluster,
+                                                         const uint32_t *__restrict__ operand /* opdw dwords per pair */,
+                                                         const float *__restrict__ thr, uint32_t count,
+                                                         uint32_t nprobe, uint32_t slot_hi, uint32_t opdw, uint32_t s_lo,
+                                                         uint32_t s_hi,
+                                                         uint32_t cluster_major,
+                                                         const uint32_t *__restrict__ grp_start,
+                                                         uint32_t *__restrict__ grp_cursor,
+                                                         uint32_t *__restrict__ recs, const FactorStats fs,
+                                                         uint32_t tile_images,
+                                                         const uint32_t *__restrict__ rank /* group_rank_kernel, or null */,
+                                                         const uint32_t *__restrict__ blk_base, uint32_t k) {
+    const uint32_t wi = blockIdx.x * 16 + (threadIdx.x >> 4);  // work item: (query, slot < slot_hi)
+    if (wi >= count) return;
+    stage_fill_item(scal, probe_cluster, operand, thr, wi, nprobe, slot_hi, opdw, s_lo, s_hi, cluster_major, grp_start, grp_cursor,
+                    recs, fs, tile_images, rank, blk_base, k);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -28,6 +28,7 @@
 #include "common.h"
 #include "kernels_build.h"
 #include "kernels_query.h"
+#include "kernels_small.h"
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -112,7 +113,7 @@ static std::atomic<uint64_t> g_rough{0}, g_precise{0}, g_query{0}, g_miss{0};
 // ------------------------------------------------------------------------------------------------
 // profiling
 // ------------------------------------------------------------------------------------------------
-enum { PF_ROTATE = 0, PF_COARSE, PF_SELECT, PF_PREP, PF_GROUP, PF_SCAN, PF_SCAN_MATRIX, PF_RERANK, PF_SORT, PF_REPLAY, PF_TOTAL, PF_N };
+enum { PF_ROTATE = 0, PF_COARSE, PF_SELECT, PF_PREP, PF_GROUP, PF_SCAN, PF_SCAN_MATRIX, PF_RERANK, PF_SORT, PF_REPLAY, PF_EARLY, PF_TOTAL, PF_N };
 static std::atomic<int> g_profiling{0};
 static thread_local rq_profile_t g_profile;
 
@@ -483,6 +484,7 @@ static std::atomic<int> g_stage_growth{0};  // 0 = default schedule
 static std::atomic<int> g_scan_tile_table{1};  // 0 = plain (list x tile) grids everywhere (test / measurement hook)
 static std::atomic<int> g_group_rank{1};  // group_rank_kernel for cluster-major stages: 0 never, 1 big stages, 2 always
 static std::atomic<int> g_shared_thr{1};  // rq_query_batch_sharded_device: thresholds shared between the shards (0 never, 1 world > 1, 2 always)
+static std::atomic<int> g_small_batch{0};  // small-batch path (kernels_small.h): 0 = whenever it applies (default), 1 = never (test hook)
 static std::atomic<int> g_dense_dir{1};  // dense run directories for the VALU stages of large batches (0 = always append + sort: test hook)
 
 // matrix-core scan instantiations: W = dim/64, NT = 32-candidate sub-tiles per wave (resident operand registers
@@ -569,6 +571,7 @@ static rq_status ensure_kernel_attributes() {
         set(reinterpret_cast<const void *>(coarse_dist_kernel<8>), 140 * 1024, "coarse_dist_kernel<8>");
         set(reinterpret_cast<const void *>(assign_generic_kernel<8>), 140 * 1024, "assign_generic_kernel<8>");
         set(reinterpret_cast<const void *>(merge_smallest_u64_kernel), 16384 * 8, "merge_smallest_u64_kernel");
+        set(reinterpret_cast<const void *>(sb_front_kernel), 140 * 1024, "sb_front_kernel");
         auto chk = [&](hipError_t e, const char *name) {
             if (err == hipSuccess && e != hipSuccess) err = e, what = name;
         };
@@ -680,7 +683,7 @@ static rq_status finish_pass(const rq_index *idx, Workspace &ws, PassResult *res
                 for (uint32_t b = 0; b < nq; ++b)
                     prof_acc->matrix_pairs += std::min<unsigned long long>(len[b], r.s_hi) - std::min<unsigned long long>(len[b], r.s_lo);
         }
-        prof_acc->ms_replay += ms[PF_REPLAY], prof_acc->ms_total += ms[PF_TOTAL];
+        prof_acc->ms_replay += ms[PF_REPLAY], prof_acc->ms_total += ms[PF_TOTAL], prof_acc->ms_early += ms[PF_EARLY];
     }
     if (prof_acc) {
         prof_acc->scan_candidates += res->rough;
@@ -722,9 +725,119 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     pf.begin(PF_TOTAL);
     size_t total_span = pf.spans.size() ? pf.spans.size() - 1 : 0;
 
+    const int impl = g_scan_impl.load();  // one consistent choice for the whole pass
+    // Stream stages.  The reference visits a query's candidates as ONE stream: probed lists nearest-first,
+    // members in stored order.  A stage covers stream positions [s_lo, s_hi) (of every query) and is
+    // scanned with the threshold each query's ranker holds at the start of the stage -- an upper
+    // bound of the reference's threshold everywhere in the stage, since it never rises -- then the
+    // survivors are replayed in the reference's order.  Stage 0 = the first topk candidates
+    // (threshold f32::MAX), later stages grow geometrically.
+    struct Stage {
+        uint32_t s_lo, s_hi;
+    };
+    // first_hi: end of the first stage; settle_cap: where the early stages must end at the latest
+    auto build_stages = [&](uint64_t first_hi, uint64_t growth, uint64_t settle_cap) {
+        std::vector<Stage> stages;
+        const uint64_t total_max = std::min<uint64_t>((uint64_t)nprobe * idx->max_list_len, idx->n);
+        uint64_t lo = 0, hi = first_hi;
+        const uint64_t avg = std::max<uint64_t>(1, idx->n / std::max<uint32_t>(k, 1));
+        // the threshold has settled once a query has seen its whole nearest list; with unbalanced lists (Zipf sizes) the
+        // nearest list of many queries is one of the long ones, so the bar is the LONGEST list (capped: a single
+        // monster list must not push the whole batch through many thin stages)
+        const uint64_t settle = std::min(settle_cap, std::max<uint64_t>(avg, std::min<uint64_t>(idx->max_list_len, 16 * avg)));
+        while (lo < total_max) {
+            // past the first two lists' worth of candidates the threshold is already tight: scan the rest of
+            // the stream as ONE stage (every list then meets all its queries at once: full 32-query tiles)
+            const bool last = hi >= total_max || lo >= settle;
+            stages.push_back({(uint32_t)lo, last ? 0xFFFFFFFFu : (uint32_t)hi});
+            if (last) break;
+            lo = hi;
+            hi = std::min<uint64_t>(hi * growth, 0xFFFFFFF0ull);
+            // the geometric step must not carry an early (VALU) stage over many lists when lists are short:
+            // past two lists' worth the rest belongs to the final stage
+            if (lo < 2 * avg && hi > 2 * avg) hi = 2 * avg;
+            // ... and the last early stage ends exactly where the threshold has settled: everything beyond belongs to the
+            // final (matrix-core) stage, where a list meets all its queries at once
+            if (lo < settle && hi > settle) hi = settle;
+        }
+        return stages;
+    };
+    std::vector<Stage> stages;
+    ReplayState rs;
+    rs.thr = ws.thr.p, rs.heap_len = ws.heap_len.p, rs.heap_key = ws.heap_key.p, rs.heap_id = ws.heap_id.p;
+    rs.precise = ws.precise.p, rs.need = ws.need.p, rs.nsurv = ws.nsurv.p, rs.nshadow = ws.nshadow.p, rs.recent_max = ws.recent.p, rs.win_count = ws.win_count.p;
+    rs.arr_len = ws.arr_len.p, rs.arr = ws.arr.p, rs.hcap = qp.hcap;
+    const float *qpad = d_q;
+    const uint32_t *probe_cluster = ws.probe_cluster.p;
+    const float *probe_dist = ws.probe_dist.p;
+    const uint32_t *rerank_order = nullptr;
+    const bool one_stage = qp.thr_init != nullptr && d_row_map == nullptr;  // thresholds are already tight: nothing to learn in early stages
+
+    // ---- small batches: few, fat launches (kernels_small.h) -------------------------------------------------------
+    const bool sb_w = W == 1 || W == 2 || W == 4 || W == 8 || W == 12 || W == 16;
+    bool small = g_small_batch.load() == 0 && nq <= RQ_SB_MAX_NQ && !ext_cluster && !d_row_map && !qp.thr_init && sb_w &&
+                 k <= RQ_SB_MAX_K && nprobe <= 64 && topk <= RQ_SB_MAX_TOPK && qp.cap >= RQ_SB_CAP && qp.cap <= 4 * RQ_DEFAULT_CAP;
+    bool sb_results_done = false;   // results and totals were written by the small-batch kernels (heap ranker)
+    bool sb_fused_finish = false;   // the final stage ends in sb_finish_kernel
+    bool sb_filled = false;         // the final stage's pair-major records were written by sb_query_kernel
+    if (small) {
+        // the early stages run inside one block per query: the first one takes what would be two (16 x topk candidates
+        // under threshold f32::MAX cost one gather round), and the in-block part ends after 64 K candidates at the latest
+        stages = build_stages(16ull * std::max<uint32_t>(topk, 1), 16, 65536);
+        if (stages.size() > RQ_SB_MAX_STAGES) small = false;
+    }
+    if (small) {
+        const uint64_t total_max = std::min<uint64_t>((uint64_t)nprobe * idx->max_list_len, idx->n);
+        SbArgs sa{};
+        // a short remainder (small indexes, few probes) is scanned in the block as well: no further launch
+        const bool whole = stages.empty() || (total_max - stages.back().s_lo) * (uint64_t)(dim / 8 + 16) <= (1ull << 20);
+        sa.nstages = (uint32_t)(whole ? stages.size() : stages.size() - 1);
+        for (uint32_t i = 0; i < sa.nstages; ++i) sa.s_lo[i] = stages[i].s_lo, sa.s_hi[i] = stages[i].s_hi;
+        const Stage fin = whole ? Stage{0, 0} : stages.back();
+        const uint64_t fin_pairs = (uint64_t)nq * nprobe;
+        const bool fin_cluster_major = !whole && fin_pairs >= k / 2 && fin_pairs > 64;  // the stage loop's own rule for a full-probe stage
+        sa.finalize = whole ? 1u : 0u;
+        sa.fill_final = !whole && !fin_cluster_major ? 1u : 0u;
+        sa.final_lo = fin.s_lo;
+        sa.codes = reinterpret_cast<const uint32_t *>(idx->codes.p), sa.factors = idx->factors.p, sa.centroids = idx->centroids.p;
+        sa.offsets = idx->offsets.p, sa.map_ids = idx->map_ids.p, sa.base = idx->view();
+        sa.dist = ws.dist.p, sa.y = ws.y.p, sa.qpad = ws.qpad.p, sa.probe_cluster = ws.probe_cluster.p, sa.probe_dist = ws.probe_dist.p;
+        sa.scal = ws.scal.p, sa.qnib = ws.qnib.p, sa.rough_cnt = ws.rough_cnt.p, sa.surv_cnt = ws.surv_cnt.p, sa.totals = ws.totals.p;
+        sa.rs = rs, sa.out_dist = d_out_dist, sa.out_id = d_out_id, sa.out_n = d_out_n, sa.recs = ws.recs.p, sa.fs = idx->fstats;
+        sa.k = k, sa.dim = dim, sa.nprobe = nprobe, sa.topk = topk, sa.cap = qp.cap, sa.hcap = qp.hcap;
+        pf.begin(PF_COARSE);
+        sb_front_kernel<<<dim3(ceil_div(k, RQ_SB_LISTS), ceil_div(nq, RQ_SB_QT)), 256, (size_t)2 * RQ_SB_QT * dim * sizeof(float), st>>>(
+            d_q, qp.len, idx->P.p, idx->centroids.p, ws.y.p, ws.qpad.p, ws.dist.p, k, dim, nq, ws.totals.p, ws.big_list.p + nq);
+        pf.end();
+        pf.begin(PF_EARLY);
+        const size_t dyn = (size_t)dim * 4 + (size_t)topk * 16;
+        const int mode = qp.heuristic ? 2 : (topk < 64 ? 1 : 0);
+#define RQ_SBQ(WW)                                                                        \
+    do {                                                                                  \
+        if (mode == 2) sb_query_kernel<WW, 2><<<nq, 1024, dyn, st>>>(sa);                 \
+        else if (mode == 1) sb_query_kernel<WW, 1><<<nq, 1024, dyn, st>>>(sa);            \
+        else sb_query_kernel<WW, 0><<<nq, 1024, dyn, st>>>(sa);                           \
+    } while (0)
+        switch (W) {
+            case 1: RQ_SBQ(1); break;
+            case 2: RQ_SBQ(2); break;
+            case 4: RQ_SBQ(4); break;
+            case 8: RQ_SBQ(8); break;
+            case 12: RQ_SBQ(12); break;
+            default: RQ_SBQ(16); break;
+        }
+#undef RQ_SBQ
+        pf.end();
+        qpad = ws.qpad.p;
+        sb_results_done = whole && !qp.heuristic;
+        sb_fused_finish = !whole && !qp.heuristic;
+        sb_filled = sa.fill_final != 0;
+        stages.clear();
+        if (!whole) stages.push_back(fin);
+        if (prof_acc) prof_acc->small_batch_passes++;
+    } else {
     // 1. pad (rabitq.rs:277-280) + rotate (:282)
     pf.begin(PF_ROTATE);
-    const float *qpad = d_q;
     if (qp.len != dim) {
         pad_rows_kernel<<<ceil_div((uint64_t)nq * dim, 256), 256, 0, st>>>(d_q, ws.qpad.p, nq, qp.len, dim);
         qpad = ws.qpad.p;
@@ -733,8 +846,6 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     pf.end();
 
     // 2. coarse distances + probe selection (:283-297)
-    const uint32_t *probe_cluster = ws.probe_cluster.p;
-    const float *probe_dist = ws.probe_dist.p;
     if (ext_cluster) {
         probe_cluster = ext_cluster;
         probe_dist = ext_dist;
@@ -747,7 +858,6 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         pf.end();
     }
 
-    const int impl = g_scan_impl.load();  // one consistent choice for the whole pass
     // 3. per-pair query quantisation (:304-317)
     pf.begin(PF_PREP);
     {
@@ -770,7 +880,6 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                                                              qn, q6, nullptr, k, 1u);
     }
     pair_prefix_kernel<<<ceil_div(nq, 4), 256, 0, st>>>(ws.scal.p, nq, nprobe, ws.rough_cnt.p);
-    const uint32_t *rerank_order = nullptr;
     if (nq >= 256) {  // large batch: rerank queries of the same nearest list back to back (cache locality of the row gather)
         HIPC(hipMemsetAsync(ws.q_hist.p, 0, (size_t)(k + 2) * 4, st));
         order_count_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(probe_cluster, nprobe, nq, k, ws.q_hist.p);
@@ -779,10 +888,6 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                                                                 ws.q_order.p);
         rerank_order = ws.q_order.p;
     }
-    ReplayState rs;
-    rs.thr = ws.thr.p, rs.heap_len = ws.heap_len.p, rs.heap_key = ws.heap_key.p, rs.heap_id = ws.heap_id.p;
-    rs.precise = ws.precise.p, rs.need = ws.need.p, rs.nsurv = ws.nsurv.p, rs.nshadow = ws.nshadow.p, rs.recent_max = ws.recent.p, rs.win_count = ws.win_count.p;
-    rs.arr_len = ws.arr_len.p, rs.arr = ws.arr.p, rs.hcap = qp.hcap;
     // 4. ranker state (rerank.rs:70-77, :129-139) and per-query counters
     init_state_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(rs, ws.surv_cnt.p, nq, qp.thr_init, d_row_map);
     HIPC(hipMemsetAsync(ws.totals.p, 0, 8 * sizeof(unsigned long long), st));
@@ -790,49 +895,19 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     if (g_scan_dbg.load() & (128 | 256)) HIPC(hipMemsetAsync(ws.stat.p, 0, 256 * sizeof(unsigned long long), st));
     pf.end();
 
-    // 5. stages.  The reference visits a query's candidates as ONE stream: probed lists nearest-first,
-    // members in stored order.  A stage covers stream positions [s_lo, s_hi) (of every query) and is
-    // scanned with the threshold each query's ranker holds at the start of the stage -- an upper
-    // bound of the reference's threshold everywhere in the stage, since it never rises -- then the
-    // survivors are replayed in the reference's order.  Stage 0 = the first topk candidates
-    // (threshold f32::MAX), later stages grow geometrically.
-    struct Stage {
-        uint32_t s_lo, s_hi;
-    };
-    std::vector<Stage> stages;
-    const bool one_stage = qp.thr_init != nullptr && d_row_map == nullptr;  // thresholds are already tight: nothing to learn in early stages
+    // 5. stages
     if (one_stage) {
         stages.push_back({0u, 0xFFFFFFFFu});
     } else {
-        const uint64_t total_max = std::min<uint64_t>((uint64_t)nprobe * idx->max_list_len, idx->n);
         // small batches are launch-bound (coarser stages), large ones rerank-bound (tighter thresholds)
         const int gopt = g_stage_growth.load();
         const uint64_t growth = gopt >= 2 ? (uint64_t)gopt : (nq >= 256 ? 8 : 16);
         // the first stage runs with threshold f32::MAX (everything survives) until the ranker's heap is full; in a large
         // batch it also takes what would be the next stage (whose threshold -- the worst of the first topk -- lets most
         // of it through anyway): one stage of launches less for ~1 % more exact distances
-        uint64_t lo = 0, hi = std::max<uint32_t>(topk, 1) * (nq >= 256 ? growth : 1);
-        const uint64_t avg = std::max<uint64_t>(1, idx->n / std::max<uint32_t>(k, 1));
-        // the threshold has settled once a query has seen its whole nearest list; with unbalanced lists (Zipf sizes) the
-        // nearest list of many queries is one of the long ones, so the bar is the LONGEST list (capped: a single
-        // monster list must not push the whole batch through many thin stages)
-        const uint64_t settle = std::max<uint64_t>(avg, std::min<uint64_t>(idx->max_list_len, 16 * avg));
-        while (lo < total_max) {
-            // past the first two lists' worth of candidates the threshold is already tight: scan the rest of
-            // the stream as ONE stage (every list then meets all its queries at once: full 32-query tiles)
-            const bool last = hi >= total_max || lo >= settle;
-            stages.push_back({(uint32_t)lo, last ? 0xFFFFFFFFu : (uint32_t)hi});
-            if (last) break;
-            lo = hi;
-            hi = std::min<uint64_t>(hi * growth, 0xFFFFFFF0ull);
-            // the geometric step must not carry an early (VALU) stage over many lists when lists are short:
-            // past two lists' worth the rest belongs to the final stage
-            if (lo < 2 * avg && hi > 2 * avg) hi = 2 * avg;
-            // ... and the last early stage ends exactly where the threshold has settled: everything beyond belongs to the
-            // final (matrix-core) stage, where a list meets all its queries at once
-            if (lo < settle && hi > settle) hi = settle;
-        }
+        stages = build_stages((uint64_t)std::max<uint32_t>(topk, 1) * (nq >= 256 ? growth : 1), growth, ~0ull);
     }
+    }  // !small
     ws.pend_matrix_ranges.clear();
     // persistent blocks of the long-directory ordering: sized by how many such directories recent passes produced
     const uint32_t big_hint = idx->big_dirs_hint.load();
@@ -885,11 +960,12 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         // pack the stage's work records (query operand + scalars + current threshold + local range)
         const uint32_t *operand = fp6_records ? ws.qf6.p
                                               : (scan_is_fused(W) ? ws.qnib.p : reinterpret_cast<const uint32_t *>(ws.planes.p));
-        stage_fill_kernel<<<ceil_div(stage_pairs, 16), 256, 0, st>>>(ws.scal.p, probe_cluster, operand, ws.thr.p, stage_pairs,
-                                                                nprobe, slot_hi, fp6_records ? 12 * W : 8 * W, sg.s_lo, sg.s_hi,
-                                                                a.cluster_major, ws.grp_start.p, ws.grp_cnt.p, ws.recs.p,
-                                                                idx->fstats, use_mfma ? 1u : 0u, ranked ? ws.pair_rank.p : nullptr,
-                                                                ws.rank_base.p, k);
+        if (!(sb_filled && !cluster_major))  // (the small-batch kernel has written a pair-major final stage's records already)
+            stage_fill_kernel<<<ceil_div(stage_pairs, 16), 256, 0, st>>>(ws.scal.p, probe_cluster, operand, ws.thr.p, stage_pairs,
+                                                                    nprobe, slot_hi, fp6_records ? 12 * W : 8 * W, sg.s_lo, sg.s_hi,
+                                                                    a.cluster_major, ws.grp_start.p, ws.grp_cnt.p, ws.recs.p,
+                                                                    idx->fstats, use_mfma ? 1u : 0u, ranked ? ws.pair_rank.p : nullptr,
+                                                                    ws.rank_base.p, k);
         pf.end();
         sp.codes = reinterpret_cast<const uint32_t *>(idx->codes.p);
         sp.factors = idx->factors.p;
@@ -954,7 +1030,17 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                 sort_runs_mid_kernel<<<std::min(nq, 256u), 256, 0, st>>>(ws.runs.p, ws.use_runs_tmp ? ws.runs_tmp.p : nullptr, ws.surv_cnt.p, qp.cap, ws.big_list.p,
                                                                          ws.big_list.p + nq, nprobe);
             }
-            if (qp.heuristic)
+            if (sb_fused_finish) {  // small-batch path, heap ranker: the stage's finish also writes the results and the totals
+                if (topk < 64)
+                    sb_finish_kernel<true><<<nq, fin_threads, (size_t)dim * sizeof(float), st>>>(
+                        ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->view(), qpad, dim, topk, rs, probe_cluster, nprobe, presorted,
+                        idx->map_ids.p, d_out_dist, d_out_id, d_out_n, ws.rough_cnt.p, ws.totals.p);
+                else
+                    sb_finish_kernel<false><<<nq, fin_threads, (size_t)dim * sizeof(float), st>>>(
+                        ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->view(), qpad, dim, topk, rs, probe_cluster, nprobe, presorted,
+                        idx->map_ids.p, d_out_dist, d_out_id, d_out_n, ws.rough_cnt.p, ws.totals.p);
+                sb_results_done = true;
+            } else if (qp.heuristic)
                 stage_finish_kernel<true><<<nq, fin_threads, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->view(),
                                                               qpad, dim, topk, rs, probe_cluster, nprobe, presorted);
             else
@@ -994,6 +1080,9 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
 
     // 6. results
     pf.begin(PF_REPLAY);
+    if (sb_results_done) {
+        // written by sb_query_kernel / sb_finish_kernel together with the totals
+    } else {
     if (qp.heuristic) {
         sort_survivors_kernel<<<nq, 256, 0, st>>>(ws.arr.p, ws.arr_len.p, qp.hcap);
         finalize_heuristic_kernel<<<ceil_div((uint64_t)nq * topk, 256), 256, 0, st>>>(rs, nq, topk, d_row_map, idx->map_ids.p,
@@ -1005,6 +1094,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     metrics_sum_kernel<<<std::min(256u, ceil_div(nq, 256)), 256, 0, st>>>(
         ws.rough_cnt.p, ws.precise.p, ws.need.p, qp.heuristic ? ws.arr_len.p : nullptr, ws.nsurv.p, ws.nshadow.p, nq, qp.cap, qp.hcap,
         ws.totals.p);
+    }
     pf.end();
     if (pf.on) (void)hipEventRecord(pf.spans[total_span].b, st);
     HIPC(hipMemcpyAsync(ws.h_totals, ws.totals.p, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -2607,6 +2697,7 @@ static void profile_add(rq_profile_t &acc, const rq_profile_t &x) {
     acc.retries += x.retries, acc.ms_scan_matrix += x.ms_scan_matrix, acc.matrix_launches += x.matrix_launches;
     acc.matrix_pairs += x.matrix_pairs, acc.matrix_subtile_steps += x.matrix_subtile_steps;
     acc.matrix_exact_steps += x.matrix_exact_steps, acc.rerank_shadow_rejects += x.rerank_shadow_rejects;
+    acc.ms_early += x.ms_early, acc.small_batch_passes += x.small_batch_passes;
 }
 
 // probe lists <-> merge keys (f32 distance bits << 32 | list id: distances are >= 0, so the bits order like the values;
@@ -2885,6 +2976,11 @@ rq_status rq_set_option(const char *name, int value) {
     if (std::string(name) == "coarse_impl") {  // test hook: coarse-distance kernel (0 auto, 1 LDS broadcast, 2 scalar registers)
         if (value < 0 || value > 2) return fail(RQ_ERR_INVALID, "coarse_impl must be 0, 1 or 2");
         g_coarse_impl = value;
+        return RQ_OK;
+    }
+    if (std::string(name) == "small_batch") {  // 0 = batches of <= 64 queries take the few-launch path when it applies, 1 = never
+        if (value < 0 || value > 1) return fail(RQ_ERR_INVALID, "small_batch must be 0 or 1");
+        g_small_batch = value;
         return RQ_OK;
     }
     if (std::string(name) == "dense_dir") {  // test hook: 0 = run descriptors always appended and sorted, 1 = dense directories where they fit

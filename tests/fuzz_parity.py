@@ -36,7 +36,7 @@ for it in range(rounds):
     knobs = {"base_device_mb": int(rng.choice([-1, -1, 0, 1])), "max_scan_blocks": int(rng.choice([0, 0, 3, 40])),
              "scan_tile_table": int(rng.choice([0, 1, 2])), "group_rank": int(rng.choice([0, 1, 2])),
              "rerank_shadow": int(rng.choice([0, 1, 1])), "coarse_impl": int(rng.choice([0, 1, 2])),
-             "dense_dir": int(rng.choice([0, 1, 1]))}
+             "dense_dir": int(rng.choice([0, 1, 1])), "small_batch": int(rng.choice([0, 0, 1]))}
     for name, v in knobs.items():
         ix.set_option(name, v)
     gidx = rq.RaBitQ.build(x, centres, P)
@@ -62,7 +62,7 @@ for it in range(rounds):
                 raise
     ix.set_option("scan_impl", 0)
     ix.set_option("base_device_mb", -1), ix.set_option("max_scan_blocks", 0), ix.set_option("scan_tile_table", 1)
-    ix.set_option("group_rank", 1), ix.set_option("rerank_shadow", 1), ix.set_option("coarse_impl", 0), ix.set_option("dense_dir", 1)
+    ix.set_option("group_rank", 1), ix.set_option("rerank_shadow", 1), ix.set_option("coarse_impl", 0), ix.set_option("dense_dir", 1), ix.set_option("small_batch", 0)
     gidx.close()
     oidx.close()
     print(f"[{it + 1}/{rounds}] n={n} d={d} k={k} nq={nq} impl={impl} knobs={list(knobs.values())} cfgs={cfgs} ok  ({time.time() - t0:.0f}s)", flush=True)

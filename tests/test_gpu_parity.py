@@ -195,6 +195,56 @@ def _compare_with_oracle(rq, oracle, oidx, gidx, queries, probe, topk, heur):
     assert (m["rough"], m["precise"], m["query"]) == (tot_r, tot_p, len(queries))
 
 
+@pytest.mark.parametrize("n,d,k", [(3000, 64, 9), (200_000, 128, 64), (60_000, 128, 700), (9000, 256, 20), (40_000, 512, 16),
+                                   (30_000, 768, 12), (6000, 1024, 5), (5000, 100, 8)])
+def test_small_batch_path_matches_oracle(rq, oracle, n, d, k):
+    """The few-launch path of batches of <= 64 queries (kernels_small.h: rotate + coarse in one launch, then one block per
+    query for probe selection, query quantisation and the early stages in LDS, then the whole-chip scan of the rest and a
+    finish that writes the results): every supported dim, one query per call (crates/cli/src/main.rs:69-80) up to 64,
+    both rankers, heap sizes around a wave, probe counts from 1 to beyond k; indexes small enough to end inside the block
+    and large enough for the separate final stage (pair-major records written by the block for one or two queries,
+    cluster-major beyond).  Checked against the oracle AND against the staged path (option small_batch = 1), bit for bit,
+    counters included."""
+    from rabitq_amd import index as ix
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.9, seed=n + d, centre_scale=0.6)
+    if k > 4:
+        centres[3] = centres[1]                      # duplicate centroid: a tie in the probe selection
+        centres[k - 1] += 50.0                       # an empty list
+    P = synth.random_orthogonal((d + 63) // 64 * 64, seed=d + 7)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    gidx = rq.RaBitQ.build(x, centres, P)
+    queries, _, _ = synth.mixture(64, d, k, sigma=0.9, seed=n + d + 1, centre_scale=0.6)
+    queries[1] = x[11]
+    cfgs = [(1, min(k, 64), 10, False), (2, min(k, 32), 10, False), (64, min(k, 64), 10, False), (33, 5, 63, False),
+            (7, k + 3 if k < 60 else 64, 64, False), (16, min(k, 8), 256, False), (5, 1, 1, False), (20, min(k, 16), 10, True),
+            (1, min(k, 6), 100, True)]
+    try:
+        for nq, probe, topk, heur in cfgs:
+            q = queries[:nq]
+            ix.set_option("small_batch", 0)
+            try:
+                _compare_with_oracle(rq, oracle, oidx, gidx, q, probe, topk, heur)
+            except RuntimeError as e:       # the oracle reports a reference panic (heuristic ranker without a candidate)
+                if "reference panics" not in str(e):
+                    raise
+                continue
+            assert ix.last_profile()["small_batch_passes"] == 1, (nq, probe, topk, heur)
+            a = gidx.query_batch(q, probe, topk, heur)
+            ma = rq.metrics()
+            ix.set_option("small_batch", 1)
+            rq.metrics_reset()
+            bres = gidx.query_batch(q, probe, topk, heur)
+            assert ix.last_profile()["small_batch_passes"] == 0
+            for u, v in zip(a, bres):
+                assert_bits_equal(u, v, f"small-batch path vs staged path {(nq, probe, topk, heur)}")
+            mb = rq.metrics()
+            assert (ma["rough"], ma["precise"]) == (2 * mb["rough"], 2 * mb["precise"])   # ma: two calls since the reset
+    finally:
+        ix.set_option("small_batch", 0)
+    gidx.close()
+    oidx.close()
+
+
 @pytest.mark.parametrize("n,d,k,sigma,nq,cfgs", [
     (20000, 128, 32, 0.8, 96, [(8, 10, False), (32, 1, False), (64, 100, False), (5, 10, True)]),
     (6000, 64, 300, 1.0, 300, [(20, 10, False), (300, 5, False)]),       # cluster-major path, tiny lists
