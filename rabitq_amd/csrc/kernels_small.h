@@ -280,6 +280,7 @@ struct SbArgs {
     float *probe_dist;
     PairScalars *scal;
     uint32_t *qnib;
+    uint32_t *qf6;  // fp6 operand images, or null when no stage of the pass can use the matrix-core scan
     unsigned long long *rough_cnt, *surv_cnt, *totals;
     ReplayState rs;  // the pass's ranker state in global memory (handed to the final stage's kernels)
     float *out_dist;
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(1024) void sb_query_kernel(const SbArgs a) {
         constexpr uint32_t PPW = 64 / LP;
         for (uint32_t g = wave; g * PPW < nprobe; g += 16)
             prep_small_pairs<LP, R, 1>(a.y, a.centroids, a.offsets, a.probe_cluster, a.probe_dist, (b + 1) * nprobe, nprobe, a.scal,
-                                       a.qnib, nullptr, k, 1u, b * nprobe + g * PPW + lane / LP);
+                                       a.qnib, a.qf6, k, 1u, b * nprobe + g * PPW + lane / LP);
     }
     __syncthreads();
     if (wave == 0) pair_prefix_row(a.scal, b, nprobe, a.rough_cnt);

@@ -802,6 +802,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         sa.codes = reinterpret_cast<const uint32_t *>(idx->codes.p), sa.factors = idx->factors.p, sa.centroids = idx->centroids.p;
         sa.offsets = idx->offsets.p, sa.map_ids = idx->map_ids.p, sa.base = idx->view();
         sa.dist = ws.dist.p, sa.y = ws.y.p, sa.qpad = ws.qpad.p, sa.probe_cluster = ws.probe_cluster.p, sa.probe_dist = ws.probe_dist.p;
+        sa.qf6 = scan_has_mfma(W) && impl != 1 ? ws.qf6.p : nullptr;  // a final stage over few lists may run on the matrix cores
         sa.scal = ws.scal.p, sa.qnib = ws.qnib.p, sa.rough_cnt = ws.rough_cnt.p, sa.surv_cnt = ws.surv_cnt.p, sa.totals = ws.totals.p;
         sa.rs = rs, sa.out_dist = d_out_dist, sa.out_id = d_out_id, sa.out_n = d_out_n, sa.recs = ws.recs.p, sa.fs = idx->fstats;
         sa.k = k, sa.dim = dim, sa.nprobe = nprobe, sa.topk = topk, sa.cap = qp.cap, sa.hcap = qp.hcap;
