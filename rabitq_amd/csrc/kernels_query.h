@@ -1997,7 +1997,9 @@ struct ReplayState {
 #define RQ_MAX_TOPK 2048
 
 // One wave replays a query's survivors (run directory `dir`, records `recs`) through the ranker.
-template <bool HEURISTIC, bool REGHEAP = false>
+// CONTIG: the survivors are recs[0 .. nruns) in visiting order already (no run directory: `dir` is unused and `nruns`
+// counts records) -- the small-batch kernel's LDS-resident survivors.
+template <bool HEURISTIC, bool REGHEAP = false, bool CONTIG = false>
 __device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, const RunRec *__restrict__ dir,
                                             uint32_t nruns, uint32_t topk,
                                             uint32_t b, const ReplayState &st, int32_t *hkey, uint32_t *hid) {
@@ -2048,31 +2050,38 @@ __device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, co
     // survivors (whatever runs they belong to): lane i finds its (run, offset) by a binary search over
     // the chunk's prefix sums in LDS, so a batch costs one round trip however many short runs it spans,
     // and batch k+1 is in flight while batch k is replayed.
-    __shared__ uint32_t s_pref[65], s_base[64];
-    for (uint32_t c0 = 0; c0 < nruns; c0 += 64) {
-        uint32_t dbase = 0, dcnt = 0;
-        if (c0 + lane < nruns) dbase = dir[c0 + lane].base, dcnt = dir[c0 + lane].cnt;
-        uint32_t incl = dcnt;
+    __shared__ uint32_t s_pref[CONTIG ? 1 : 65], s_base[CONTIG ? 1 : 64];
+    for (uint32_t c0 = 0; c0 < (CONTIG ? (nruns ? 1u : 0u) : nruns); c0 += 64) {
+        uint32_t total = nruns;
+        if constexpr (!CONTIG) {
+            uint32_t dbase = 0, dcnt = 0;
+            if (c0 + lane < nruns) dbase = dir[c0 + lane].base, dcnt = dir[c0 + lane].cnt;
+            uint32_t incl = dcnt;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t up = __shfl_up(incl, o, 64);
-            if ((int)lane >= o) incl += up;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = __shfl_up(incl, o, 64);
+                if ((int)lane >= o) incl += up;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // previous chunk's readers are done (one wave)
+            s_pref[lane + 1] = incl;
+            s_base[lane] = dbase;
+            if (lane == 0) s_pref[0] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            total = __shfl(incl, 63, 64);
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // previous chunk's readers are done (one wave)
-        s_pref[lane + 1] = incl;
-        s_base[lane] = dbase;
-        if (lane == 0) s_pref[0] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        const uint32_t total = __shfl(incl, 63, 64);
         auto fetch = [&](uint32_t off, SurvRec &rec) {
             const uint32_t t = off + lane;
             rec.pos = 0, rec.slot = 0, rec.rough = 0.0f, rec.accurate = 0.0f;
             if (t < total) {
-                uint32_t lo = 0;  // largest r with s_pref[r] <= t
+                if constexpr (CONTIG) {
+                    rec = recs[t];
+                } else {
+                    uint32_t lo = 0;  // largest r with s_pref[r] <= t
 #pragma unroll
-                for (int step = 32; step >= 1; step >>= 1)
-                    if (lo + step < 64 && s_pref[lo + step] <= t) lo += step;
-                rec = recs[s_base[lo] + (t - s_pref[lo])];
+                    for (int step = 32; step >= 1; step >>= 1)
+                        if (lo + step < 64 && s_pref[lo + step] <= t) lo += step;
+                    rec = recs[s_base[lo] + (t - s_pref[lo])];
+                }
             }
         };
         SurvRec nxt;

@@ -26,7 +26,7 @@
 #define RQ_SB_MAX_NQ 64u       // batches up to this size take the path
 #define RQ_SB_QT 8             // queries per block of the front kernel
 #define RQ_SB_LISTS 128u       // lists per block of the front kernel (two lanes per list)
-#define RQ_SB_CAP 2048u        // survivor records a query's block keeps in LDS
+#define RQ_SB_CAP 6144u        // survivor records a query's block keeps in LDS (96 KiB; one block per CU)
 #define RQ_SB_TILE 1024u       // stream positions scanned per step (one per thread)
 #define RQ_SB_MAX_STAGES 8
 #define RQ_SB_MAX_TOPK 256u    // ranker state lives in LDS
@@ -250,18 +250,69 @@ __device__ __forceinline__ void select_merge16(const unsigned long long (*cand)[
     const unsigned long long key = cand[w][i];
     if (key == ~0ull) return;
     uint32_t rank = i;
-    for (uint32_t o = 0; o < 16; ++o) {
-        if (o == w) continue;
-        uint32_t lo = 0;  // number of keys of slice o below `key`: largest lo with cand[o][lo-1] < key
+    uint32_t lo[16];  // per slice: the number of its keys below `key` (sixteen independent binary searches: their LDS reads overlap)
 #pragma unroll
-        for (int step = 32; step >= 1; step >>= 1)
-            if (cand[o][lo + step - 1] < key) lo += step;
-        if (lo == 63 && cand[o][63] < key) lo = 64;
-        rank += lo;
-        if (rank >= nprobe) return;
+    for (int o = 0; o < 16; ++o) lo[o] = 0;
+#pragma unroll
+    for (int step = 32; step >= 1; step >>= 1)
+#pragma unroll
+        for (int o = 0; o < 16; ++o)
+            if (cand[o][lo[o] + step - 1] < key) lo[o] += step;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+        if (lo[o] == 63 && cand[o][63] < key) lo[o] = 64;
+        rank += (uint32_t)o == w ? 0u : lo[o];
     }
+    if (rank >= nprobe) return;
     probe_cluster[(uint64_t)b * nprobe + rank] = (uint32_t)key;
     probe_dist[(uint64_t)b * nprobe + rank] = ord32_unbias((uint32_t)(key >> 32));
+}
+
+// accurate_rows for the block's LDS-resident survivors (same arithmetic: two lanes per row, lane half hf = AVX lanes
+// 4hf..4hf+3 of src/simd.rs:14-73, chunks of 64 dimensions in order): up to dim 128 every load of a row is issued before
+// the first one is used.
+template <int W>
+__device__ __forceinline__ void sb_accurate_rows(SurvRec *recs, uint32_t n, const BaseView &base, const float *q_lds,
+                                                 uint32_t dim, const uint32_t *__restrict__ probe_row) {
+    const uint32_t hf = threadIdx.x & 1;
+    for (uint32_t i = threadIdx.x >> 1; i < n; i += 512) {
+        const float *x;
+        if (base.host == nullptr) {
+            x = base.dev + (uint64_t)recs[i].pos * dim + 4 * hf;
+        } else {
+            const ListTier tr = base.lt[probe_row[recs[i].slot]];
+            x = base.row_in_list(recs[i].pos, tr, dim) + 4 * hf;
+        }
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        auto chunk = [&](const float4 (&xv)[8], uint32_t c) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4 qv = *reinterpret_cast<const float4 *>(q_lds + c + 8 * u + 4 * hf);
+                const float d0 = xv[u].x - qv.x, d1 = xv[u].y - qv.y, d2 = xv[u].z - qv.z, d3 = xv[u].w - qv.w;
+                a0 = fmaf(d0, d0, a0), a1 = fmaf(d1, d1, a1), a2 = fmaf(d2, d2, a2), a3 = fmaf(d3, d3, a3);
+            }
+        };
+        if constexpr (W <= 2) {
+            float4 xv[W][8];
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) xv[w][u] = *reinterpret_cast<const float4 *>(x + 64 * w + 8 * u);
+#pragma unroll
+            for (int w = 0; w < W; ++w) chunk(xv[w], 64 * w);
+        } else {
+            for (uint32_t c = 0; c < dim; c += 64) {
+                float4 xv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) xv[u] = *reinterpret_cast<const float4 *>(x + c + 8 * u);
+                chunk(xv, c);
+            }
+        }
+        const float c0 = a0 + __shfl_xor(a0, 1, 2), c1 = a1 + __shfl_xor(a1, 1, 2);
+        const float c2 = a2 + __shfl_xor(a2, 1, 2), c3 = a3 + __shfl_xor(a3, 1, 2);
+        const float r = (c0 + c1) + (c2 + c3);
+        if (hf == 0) recs[i].accurate = r;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -293,6 +344,7 @@ struct SbArgs {
     uint32_t finalize;    // 1: the stream ends in the block: results and totals are written here (heap ranker)
     uint32_t fill_final;  // 1: the pair-major work records of the stage [final_lo, end) are written here
     uint32_t final_lo;
+    unsigned long long *stamps;  // developer hook (scan_debug bit 4096): block 0 records the 100 MHz clock at its phase boundaries
 };
 
 // results of a finished query (src/rerank.rs:108-113: the heap's Vec order) and its share of the pass totals
@@ -325,18 +377,23 @@ __global__ __launch_bounds__(1024) void sb_query_kernel(const SbArgs a) {
     constexpr bool HEUR = MODE == 2, REGHEAP = MODE == 1;
     constexpr int LP = W == 1 ? 16 : (W == 2 ? 32 : 64), R = W <= 4 ? 1 : W / 4;
     static_assert(4 * LP * R == 64 * W, "prep_small_pairs geometry");
-    extern __shared__ __attribute__((aligned(16))) unsigned char sbq_raw[];  // qv[dim] | heap state 2 x topk | heap work 2 x topk
-    __shared__ __attribute__((aligned(16))) SurvRec recs[RQ_SB_CAP];
-    __shared__ __attribute__((aligned(16))) RunRec dir[RQ_SB_CAP / 64];
+    extern __shared__ __attribute__((aligned(16))) unsigned char sbq_raw[];  // recs[RQ_SB_CAP] | qv[dim] | heap state 2 x topk | heap work 2 x topk
     __shared__ unsigned long long cand[16][64];
     __shared__ unsigned long long win[16][64];
     __shared__ __attribute__((aligned(16))) uint32_t s_qn[8 * W];
-    __shared__ uint32_t wcnt[16];
+    __shared__ __attribute__((aligned(16))) uint32_t s_pl[4][2 * W];  // the query's four bit planes (src/simd.rs:83-107), dword w <-> dimensions 32w..32w+31
+    __shared__ uint32_t wcnt[4][16];
     __shared__ float s_thr, s_recent;
     __shared__ uint32_t s_hlen, s_precise, s_need, s_nsurv, s_nshadow, s_wcount, s_alen;
     const uint32_t b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t k = a.k, dim = a.dim, nprobe = a.nprobe, topk = a.topk;
-    float *qv = reinterpret_cast<float *>(sbq_raw);
+    uint32_t n_stamp = 0;
+    auto stamp = [&]() {
+        if (a.stamps && b == 0 && t == 0 && n_stamp < 30) a.stamps[1 + n_stamp] = wall_clock64(), a.stamps[0] = ++n_stamp;
+    };
+    stamp();
+    SurvRec *recs = reinterpret_cast<SurvRec *>(sbq_raw);
+    float *qv = reinterpret_cast<float *>(recs + RQ_SB_CAP);
     int32_t *hk_state = reinterpret_cast<int32_t *>(qv + dim);
     uint32_t *hi_state = reinterpret_cast<uint32_t *>(hk_state + topk);
     int32_t *hk_work = reinterpret_cast<int32_t *>(hi_state + topk);
@@ -350,6 +407,7 @@ __global__ __launch_bounds__(1024) void sb_query_kernel(const SbArgs a) {
         select_slice_wave(a.dist + (uint64_t)b * k + lo, slen, nprobe < slen ? nprobe : slen, (k & 3u) == 0u, lo, cand[wave], win[wave]);
     }
     __syncthreads();
+    stamp();
     select_merge16(cand, nprobe, b, a.probe_cluster, a.probe_dist);
     for (uint32_t c = t * 4; c < dim; c += 4096) *reinterpret_cast<float4 *>(qv + c) = *reinterpret_cast<const float4 *>(a.qpad + (uint64_t)b * dim + c);
     if (t == 0) {  // ranker state of a fresh query (src/rerank.rs:70-77, :129-139)
@@ -358,6 +416,7 @@ __global__ __launch_bounds__(1024) void sb_query_kernel(const SbArgs a) {
         a.surv_cnt[b] = 0ull;
     }
     __syncthreads();
+    stamp();
     // ---- per-list query quantisation (:304-317), stream offsets ------------------------------------------------------
     {
         constexpr uint32_t PPW = 64 / LP;
@@ -366,8 +425,10 @@ __global__ __launch_bounds__(1024) void sb_query_kernel(const SbArgs a) {
                                        a.qnib, a.qf6, k, 1u, b * nprobe + g * PPW + lane / LP);
     }
     __syncthreads();
+    stamp();
     if (wave == 0) pair_prefix_row(a.scal, b, nprobe, a.rough_cnt);
     __syncthreads();
+    stamp();
 
     // ---- the early part of the stream, stage by stage, all in LDS -----------------------------------------------------
     ReplayState ls;
@@ -379,23 +440,23 @@ __global__ __launch_bounds__(1024) void sb_query_kernel(const SbArgs a) {
     // are in visiting order already.  Cutting the stream here is one more stage boundary: never changes a result.
     auto flush = [&]() {
         if (n == 0) return;
-        accurate_rows(recs, n, a.base, qv, dim, t >> 1, 512u, a.probe_cluster + (uint64_t)b * nprobe);
-        if (t < (n + 63) / 64) {
-            RunRec r;
-            r.pos = 0, r.slot = 0, r.base = 64 * t, r.cnt = n - 64 * t < 64 ? n - 64 * t : 64;
-            dir[t] = r;
-        }
+        __syncthreads();  // every record written so far is in LDS
+        stamp();
+        sb_accurate_rows<W>(recs, n, a.base, qv, dim, a.probe_cluster + (uint64_t)b * nprobe);
         __syncthreads();
+        stamp();
         if (wave == 0) {
-            replay_wave<HEUR, REGHEAP>(recs, dir, (n + 63) / 64, topk, 0u, ls, hk_work, hi_work);
-            if (lane == 0) {
-                s_nsurv += n;
-                if (n > s_need) s_need = n;
-            }
+            replay_wave<HEUR, REGHEAP, true>(recs, nullptr, n, topk, 0u, ls, hk_work, hi_work);
+            if (lane == 0) s_nsurv += n;  // (s_need stays 0: these survivors never touch the pass's global buffers)
         }
         __syncthreads();
+        stamp();
         n = 0;
     };
+    // candidates per thread and step: their code / factor loads are all in flight before the first one is scored (a
+    // lone block on an idle chip pays a full memory round trip per dependent step, so steps must be few and fat)
+    constexpr int CPT = W <= 2 ? 4 : (W <= 4 ? 2 : 1);
+    constexpr uint32_t STEP = CPT * RQ_SB_TILE;
     for (uint32_t sg = 0; sg < a.nstages; ++sg) {
         const uint32_t s_lo = a.s_lo[sg], s_hi = a.s_hi[sg];
         for (uint32_t slot = 0; slot < nprobe; ++slot) {
@@ -408,72 +469,87 @@ __global__ __launch_bounds__(1024) void sb_query_kernel(const SbArgs a) {
             hi = hi < ps.list_len ? hi : ps.list_len;
             if (t < 8 * W) s_qn[t] = a.qnib[((uint64_t)b * nprobe + slot) * (8 * W) + t];
             __syncthreads();
-            // the query's 4-bit codes, 8 per dword: in registers for narrow vectors, re-read from LDS (one broadcast
-            // ds_read_b128 per code dword) where 8W registers would spill
-            constexpr bool QN_REGS = W <= 4;
-            uint32_t qn[QN_REGS ? 8 * W : 1];
-            if constexpr (QN_REGS) {
+            // One CU scans alone here, so the scoring is kept as cheap as the data allows: the asymmetric dot product in its
+            // AND + popcount form (src/utils.rs:113-135: sum_p popcount(code & plane_p) << p), 2 VALU ops per (plane, code
+            // dword) instead of the 7 of nibble expansion + v_dot8.  The bit planes come from the 4-bit codes once per list.
+            if (t < 8 * W) {
+                const uint32_t p = t / (2 * W), w = t - p * (2 * W);
+                uint32_t word = 0;
 #pragma unroll
-                for (int m = 0; m < 8 * W; ++m) qn[m] = s_qn[m];
+                for (int j = 0; j < 32; ++j) word |= ((s_qn[4 * w + (j >> 3)] >> (4 * (j & 7) + p)) & 1u) << j;
+                s_pl[p][w] = word;
             }
-            auto qn4 = [&](int cw_index) -> uint4 {  // operand dwords of code dword cw_index
-                if constexpr (QN_REGS) return make_uint4(qn[4 * cw_index], qn[4 * cw_index + 1], qn[4 * cw_index + 2], qn[4 * cw_index + 3]);
-                else return *reinterpret_cast<const uint4 *>(&s_qn[4 * cw_index]);
+            __syncthreads();
+            constexpr bool PL_REGS = W <= 2;  // planes in registers for narrow vectors, broadcast LDS reads beyond
+            uint32_t pl[PL_REGS ? 4 : 1][PL_REGS ? 2 * W : 1];
+            if constexpr (PL_REGS) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int w = 0; w < 2 * W; ++w) pl[p][w] = s_pl[p][w];
+            }
+            auto plane = [&](int p, int w) -> uint32_t {
+                if constexpr (PL_REGS) return pl[p][w];
+                else return s_pl[p][w];
             };
-            for (uint32_t p0 = lo; p0 < hi; p0 += RQ_SB_TILE) {
-                if (n + RQ_SB_TILE > RQ_SB_CAP) flush();
+            for (uint32_t p0 = lo; p0 < hi; p0 += STEP) {
+                if (n + STEP > RQ_SB_CAP) flush();  // room for whatever this step lets through (block-uniform)
                 const float thr = s_thr;  // the threshold the ranker holds now: an upper bound of the reference's for what follows
-                const uint32_t p = p0 + t;
-                const bool in = p < hi;
-                const uint32_t pos = ps.list_begin + (in ? p : lo);
-                const uint32_t *cp = a.codes + (uint64_t)pos * (2 * W);
-                uint32_t acc = 0;
-                if constexpr ((2 * W) % 4 == 0) {
+                uint32_t pos[CPT], code[CPT][2 * W];
+                float4 fac[CPT];
+                bool in[CPT];
 #pragma unroll
-                    for (int i = 0; i < 2 * W; i += 4) {
-                        const uint4 v = *reinterpret_cast<const uint4 *>(cp + i);
-                        const uint32_t cw[4] = {v.x, v.y, v.z, v.w};
+                for (int c = 0; c < CPT; ++c) {  // sub-tile c: positions p0 + 1024 c + t
+                    const uint32_t p = p0 + c * RQ_SB_TILE + t;
+                    in[c] = p < hi;
+                    pos[c] = ps.list_begin + (in[c] ? p : lo);
+                    const uint32_t *cp = a.codes + (uint64_t)pos[c] * (2 * W);
+                    if constexpr ((2 * W) % 4 == 0) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const uint4 q4 = qn4(i + e);
-                            const uint32_t qe[4] = {q4.x, q4.y, q4.z, q4.w};
+                        for (int i = 0; i < 2 * W; i += 4) {
+                            const uint4 v = *reinterpret_cast<const uint4 *>(cp + i);
+                            code[c][i] = v.x, code[c][i + 1] = v.y, code[c][i + 2] = v.z, code[c][i + 3] = v.w;
+                        }
+                    } else {
 #pragma unroll
-                            for (int kq = 0; kq < 4; ++kq) acc = __builtin_amdgcn_udot8(spread8(cw[e] >> (8 * kq)), qe[kq], acc, false);
+                        for (int i = 0; i < 2 * W; i += 2) {
+                            const uint2 v = *reinterpret_cast<const uint2 *>(cp + i);
+                            code[c][i] = v.x, code[c][i + 1] = v.y;
                         }
                     }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 2 * W; i += 2) {
-                        const uint2 v = *reinterpret_cast<const uint2 *>(cp + i);
-                        const uint32_t cw[2] = {v.x, v.y};
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const uint4 q4 = qn4(i + e);
-                            const uint32_t qe[4] = {q4.x, q4.y, q4.z, q4.w};
-#pragma unroll
-                            for (int kq = 0; kq < 4; ++kq) acc = __builtin_amdgcn_udot8(spread8(cw[e] >> (8 * kq)), qe[kq], acc, false);
-                        }
-                    }
+                    fac[c] = a.factors[pos[c]];
                 }
-                const float4 fac = a.factors[pos];
-                const float rough = rough_distance(acc, fac, ps.lower, ps.delta, ps.sumq, ps.ycd, ps.ycd_sqrt);  // src/rabitq.rs:352-363
-                const bool pass = in && rough < thr;                                                              // src/rerank.rs:84
-                const uint64_t m = __ballot(pass);
-                if (lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
+                float rough[CPT];
+                uint64_t m[CPT];
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) {
+                    uint32_t cp[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int i = 0; i < 2 * W; ++i)
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) cp[p] += (uint32_t)__builtin_popcount(code[c][i] & plane(p, i));
+                    const uint32_t acc = cp[0] + (cp[1] << 1) + (cp[2] << 2) + (cp[3] << 3);
+                    rough[c] = rough_distance(acc, fac[c], ps.lower, ps.delta, ps.sumq, ps.ycd, ps.ycd_sqrt);  // src/rabitq.rs:352-363
+                    m[c] = __ballot(in[c] && rough[c] < thr);                                                   // src/rerank.rs:84
+                    if (lane == 0) wcnt[c][wave] = (uint32_t)__popcll(m[c]);
+                }
                 __syncthreads();
-                uint32_t woff = 0, total = 0;
 #pragma unroll
-                for (int w2 = 0; w2 < 16; ++w2) {
-                    const uint32_t c = wcnt[w2];
-                    woff += (uint32_t)w2 < wave ? c : 0u;
-                    total += c;
+                for (int c = 0; c < CPT; ++c) {  // survivors in position order: sub-tile, wave, lane
+                    uint32_t woff = 0, total = 0;
+#pragma unroll
+                    for (int w2 = 0; w2 < 16; ++w2) {
+                        const uint32_t cn = wcnt[c][w2];
+                        woff += (uint32_t)w2 < wave ? cn : 0u;
+                        total += cn;
+                    }
+                    if ((m[c] >> lane) & 1ull) {
+                        SurvRec r;
+                        r.pos = pos[c], r.slot = slot, r.rough = rough[c], r.accurate = 0.0f;
+                        recs[n + woff + (uint32_t)__popcll(m[c] & ((1ull << lane) - 1ull))] = r;
+                    }
+                    n += total;
                 }
-                if (pass) {
-                    SurvRec r;
-                    r.pos = pos, r.slot = slot, r.rough = rough, r.accurate = 0.0f;
-                    recs[n + woff + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
-                }
-                n += total;
                 __syncthreads();
             }
         }
@@ -481,6 +557,7 @@ __global__ __launch_bounds__(1024) void sb_query_kernel(const SbArgs a) {
     }
 
     // ---- hand-over ------------------------------------------------------------------------------------------------------
+    stamp();
     if (a.finalize && !HEUR) {
         if (wave == 0) sb_write_results(ls, 0u, b, topk, a.map_ids, a.out_dist, a.out_id, a.out_n, a.rough_cnt[b], a.cap, a.totals);
         return;
@@ -536,8 +613,9 @@ __global__ __launch_bounds__(1024) void sb_finish_kernel(SurvRec *__restrict__ s
         for (uint32_t c = threadIdx.x * 4; c < dim; c += blockDim.x * 4)
             *reinterpret_cast<float4 *>(fin_q + c) = *reinterpret_cast<const float4 *>(qpad + (uint64_t)b * dim + c);
         __syncthreads();
-        accurate_rows(recs, n, base, fin_q, dim, threadIdx.x >> 1, blockDim.x >> 1, probe_cluster + (uint64_t)b * nprobe);
-        if (nruns <= RQ_SORT_LDS_RECS || !presorted) sort_segment(runs + (uint64_t)b * cap, nruns);
+        if (!(presorted & 2u))  // bit 1: the exact distances were computed by a whole-chip launch already
+            accurate_rows(recs, n, base, fin_q, dim, threadIdx.x >> 1, blockDim.x >> 1, probe_cluster + (uint64_t)b * nprobe);
+        if (nruns <= RQ_SORT_LDS_RECS || !(presorted & 1u)) sort_segment(runs + (uint64_t)b * cap, nruns);
         __syncthreads();
         if (threadIdx.x < 64) replay_wave<false, REGHEAP>(recs, runs + (uint64_t)b * cap, nruns, topk, b, st, hkey, hid);
     }

@@ -484,6 +484,7 @@ static std::atomic<int> g_stage_growth{0};  // 0 = default schedule
 static std::atomic<int> g_scan_tile_table{1};  // 0 = plain (list x tile) grids everywhere (test / measurement hook)
 static std::atomic<int> g_group_rank{1};  // group_rank_kernel for cluster-major stages: 0 never, 1 big stages, 2 always
 static std::atomic<int> g_shared_thr{1};  // rq_query_batch_sharded_device: thresholds shared between the shards (0 never, 1 world > 1, 2 always)
+static std::atomic<int> g_sb_span{2560};  // developer knob: stream positions a query's block scans itself at most (small-batch path)
 static std::atomic<int> g_small_batch{0};  // small-batch path (kernels_small.h): 0 = whenever it applies (default), 1 = never (test hook)
 static std::atomic<int> g_dense_dir{1};  // dense run directories for the VALU stages of large batches (0 = always append + sort: test hook)
 
@@ -572,6 +573,17 @@ static rq_status ensure_kernel_attributes() {
         set(reinterpret_cast<const void *>(assign_generic_kernel<8>), 140 * 1024, "assign_generic_kernel<8>");
         set(reinterpret_cast<const void *>(merge_smallest_u64_kernel), 16384 * 8, "merge_smallest_u64_kernel");
         set(reinterpret_cast<const void *>(sb_front_kernel), 140 * 1024, "sb_front_kernel");
+#define RQ_SBQ_ATTR(WW)                                                                                  \
+    set(reinterpret_cast<const void *>(sb_query_kernel<WW, 0>), 120 * 1024, "sb_query_kernel");          \
+    set(reinterpret_cast<const void *>(sb_query_kernel<WW, 1>), 120 * 1024, "sb_query_kernel");          \
+    set(reinterpret_cast<const void *>(sb_query_kernel<WW, 2>), 120 * 1024, "sb_query_kernel")
+        RQ_SBQ_ATTR(1);
+        RQ_SBQ_ATTR(2);
+        RQ_SBQ_ATTR(4);
+        RQ_SBQ_ATTR(8);
+        RQ_SBQ_ATTR(12);
+        RQ_SBQ_ATTR(16);
+#undef RQ_SBQ_ATTR
         auto chk = [&](hipError_t e, const char *name) {
             if (err == hipSuccess && e != hipSuccess) err = e, what = name;
         };
@@ -699,6 +711,13 @@ static rq_status finish_pass(const rq_index *idx, Workspace &ws, PassResult *res
                         (double)ht[0] / ht[3], (double)ht[1] / ht[3], (double)ht[2] / ht[3], (double)ht[1] / std::max(1ull, ht[4]),
                         (double)ht[2] / std::max(1ull, ht[4]));
         }
+        if ((g_scan_dbg.load() & 4096) && nq <= RQ_SB_MAX_NQ) {  // developer hook: phase boundaries of sb_query_kernel's block 0
+            unsigned long long hs[32];
+            HIPC(hipMemcpy(hs, ws.stat.p, sizeof hs, hipMemcpyDeviceToHost));
+            std::string line = "[rabitq_hip] sb_query_kernel phases (us since entry):";
+            for (unsigned long long i = 1; i < std::min<unsigned long long>(hs[0], 30); ++i) line += " " + std::to_string((hs[1 + i] - hs[1]) / 100.0).substr(0, 6);
+            fprintf(stderr, "%s\n", line.c_str());
+        }
         if (g_scan_dbg.load() & 128) {
             unsigned long long hs[128];
             HIPC(hipMemcpy(hs, ws.stat.p, sizeof hs, hipMemcpyDeviceToHost));
@@ -776,14 +795,15 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     // ---- small batches: few, fat launches (kernels_small.h) -------------------------------------------------------
     const bool sb_w = W == 1 || W == 2 || W == 4 || W == 8 || W == 12 || W == 16;
     bool small = g_small_batch.load() == 0 && nq <= RQ_SB_MAX_NQ && !ext_cluster && !d_row_map && !qp.thr_init && sb_w &&
-                 k <= RQ_SB_MAX_K && nprobe <= 64 && topk <= RQ_SB_MAX_TOPK && qp.cap >= RQ_SB_CAP && qp.cap <= 4 * RQ_DEFAULT_CAP;
+                 k <= RQ_SB_MAX_K && nprobe <= 64 && topk <= RQ_SB_MAX_TOPK && qp.cap <= 4 * RQ_DEFAULT_CAP;
     bool sb_results_done = false;   // results and totals were written by the small-batch kernels (heap ranker)
     bool sb_fused_finish = false;   // the final stage ends in sb_finish_kernel
     bool sb_filled = false;         // the final stage's pair-major records were written by sb_query_kernel
     if (small) {
         // the early stages run inside one block per query: the first one takes what would be two (16 x topk candidates
         // under threshold f32::MAX cost one gather round), and the in-block part ends after 64 K candidates at the latest
-        stages = build_stages(16ull * std::max<uint32_t>(topk, 1), 16, 65536);
+        const int gopt = g_stage_growth.load();
+        stages = build_stages(16ull * std::max<uint32_t>(topk, 1), gopt >= 2 ? (uint64_t)gopt : 8, (uint64_t)std::max(1, g_sb_span.load()));
         if (stages.size() > RQ_SB_MAX_STAGES) small = false;
     }
     if (small) {
@@ -806,12 +826,14 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         sa.scal = ws.scal.p, sa.qnib = ws.qnib.p, sa.rough_cnt = ws.rough_cnt.p, sa.surv_cnt = ws.surv_cnt.p, sa.totals = ws.totals.p;
         sa.rs = rs, sa.out_dist = d_out_dist, sa.out_id = d_out_id, sa.out_n = d_out_n, sa.recs = ws.recs.p, sa.fs = idx->fstats;
         sa.k = k, sa.dim = dim, sa.nprobe = nprobe, sa.topk = topk, sa.cap = qp.cap, sa.hcap = qp.hcap;
+        sa.stamps = (g_scan_dbg.load() & 4096) ? ws.stat.p : nullptr;
+        if (sa.stamps) HIPC(hipMemsetAsync(ws.stat.p, 0, 8, st));
         pf.begin(PF_COARSE);
         sb_front_kernel<<<dim3(ceil_div(k, RQ_SB_LISTS), ceil_div(nq, RQ_SB_QT)), 256, (size_t)2 * RQ_SB_QT * dim * sizeof(float), st>>>(
             d_q, qp.len, idx->P.p, idx->centroids.p, ws.y.p, ws.qpad.p, ws.dist.p, k, dim, nq, ws.totals.p, ws.big_list.p + nq);
         pf.end();
         pf.begin(PF_EARLY);
-        const size_t dyn = (size_t)dim * 4 + (size_t)topk * 16;
+        const size_t dyn = (size_t)RQ_SB_CAP * sizeof(SurvRec) + (size_t)dim * 4 + (size_t)topk * 16;
         const int mode = qp.heuristic ? 2 : (topk < 64 ? 1 : 0);
 #define RQ_SBQ(WW)                                                                        \
     do {                                                                                  \
@@ -1032,6 +1054,15 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                                                                          ws.big_list.p + nq, nprobe);
             }
             if (sb_fused_finish) {  // small-batch path, heap ranker: the stage's finish also writes the results and the totals
+                // a handful of queries: their final-stage survivors (~1000 rows each) are gathered by the whole chip -- one block
+                // per query would pull them through a single CU's memory pipeline (~30 GB/s)
+                uint32_t flags = presorted;
+                if (nq <= 32) {
+                    accurate_kernel<<<dim3(std::max(1u, std::min(16u, 256u / nq)), nq), 256, (size_t)dim * sizeof(float), st>>>(
+                        ws.surv.p, ws.surv_cnt.p, qp.cap, idx->view(), qpad, dim, nullptr, probe_cluster, nprobe);
+                    flags |= 2u;
+                }
+                const uint32_t presorted = flags;
                 if (topk < 64)
                     sb_finish_kernel<true><<<nq, fin_threads, (size_t)dim * sizeof(float), st>>>(
                         ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->view(), qpad, dim, topk, rs, probe_cluster, nprobe, presorted,
@@ -2977,6 +3008,11 @@ rq_status rq_set_option(const char *name, int value) {
     if (std::string(name) == "coarse_impl") {  // test hook: coarse-distance kernel (0 auto, 1 LDS broadcast, 2 scalar registers)
         if (value < 0 || value > 2) return fail(RQ_ERR_INVALID, "coarse_impl must be 0, 1 or 2");
         g_coarse_impl = value;
+        return RQ_OK;
+    }
+    if (std::string(name) == "small_batch_span") {  // developer knob (results identical for every value)
+        if (value < 1) return fail(RQ_ERR_INVALID, "small_batch_span must be >= 1");
+        g_sb_span = value;
         return RQ_OK;
     }
     if (std::string(name) == "small_batch") {  // 0 = batches of <= 64 queries take the few-launch path when it applies, 1 = never

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--sigma", type=float, default=0.5)
     ap.add_argument("--batches", default="1,16,64")
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--spans", default="", help="also try these in-block span caps (small_batch_span), batch 1 and 16")
     args = ap.parse_args()
     import torch
     import rabitq_amd
@@ -74,6 +75,26 @@ def main():
             res["rows"].append(row)
             print(json.dumps(row), flush=True)
     rqi.set_option("small_batch", 0)
+    for span in [int(v) for v in args.spans.split(",") if v]:
+        rqi.set_option("small_batch_span", span)
+        rqi.set_profiling(2)
+        for nb in (1, 16):
+            acc = {}
+            for r in range(args.reps + 3):
+                q = queries[r * nb:(r + 1) * nb]
+                idx.query_batch_device(q.data_ptr(), nb, d, args.nprobe, args.topk, out_d.data_ptr(), out_i.data_ptr(), out_n.data_ptr())
+                if r >= 3:
+                    for key, v in rqi.last_profile().items():
+                        acc[key] = acc.get(key, 0) + v
+            print(json.dumps({"span": span, "batch": nb, "device_ms": round(acc["ms_total"] / args.reps, 4),
+                              "rerank_per_query": round(acc["rerank_candidates"] / args.reps / nb, 1), "retries": acc["retries"]}), flush=True)
+    rqi.set_option("small_batch_span", 2560)
+    rqi.set_option("scan_debug", 4096)      # phase stamps of the per-query kernel (stderr), three single queries
+    rqi.set_profiling(0)
+    for r in range(3):
+        q = queries[r:r + 1]
+        idx.query_batch_device(q.data_ptr(), 1, d, args.nprobe, args.topk, out_d.data_ptr(), out_i.data_ptr(), out_n.data_ptr())
+    rqi.set_option("scan_debug", 0)
     json.dump(res, open("gpurun_out/small_batch_latency.json", "w"), indent=1)
 
 
