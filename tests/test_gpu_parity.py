@@ -1291,3 +1291,21 @@ def test_json_persistence_round_trip(rq, oracle, tmp_path):
     assert all(np.array_equal(u.view(np.uint32), v.view(np.uint32)) for u, v in zip(a, b))
     for g in (gidx, lidx, l2):
         g.close()
+
+
+def test_fuzz_slice(rq, oracle):
+    """A seeded, bounded slice of tests/fuzz_parity.py inside the suite: 60 random rounds (shapes, data families -- SIFT-like
+    integers, 90 % sparse, Student-t tails, vectors on / next to their centroid, near-ties within a few ulp of the
+    thresholds --, scales 1e-3 .. 3e4, query families, engine knobs incl. forced matrix-core scan and both small-batch
+    settings), each compared with the oracle id for id, bit for bit, counters included."""
+    from tests import fuzz_parity
+    rng = np.random.default_rng(20261004)
+    kinds, forced, exact_rounds = {}, 0, 0
+    for it in range(60):
+        desc = fuzz_parity.fuzz_round(rq, oracle, rng, it, nmax=5000)
+        kinds[desc["kind"]] = kinds.get(desc["kind"], 0) + 1
+        if desc["gate"] is not None and desc["gate"][0]:
+            forced += 1
+            exact_rounds += 1 if desc["gate"][1] else 0
+    print(f"fuzz slice: families {kinds}; forced matrix-core rounds {forced}, of them with exact-path steps {exact_rounds}")
+    assert len(kinds) >= 5 and forced >= 5
