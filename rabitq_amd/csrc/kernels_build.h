@@ -522,3 +522,221 @@ __global__ __launch_bounds__(256) void factor_stats_kernel(const float4 *__restr
         atomicMax(&out4[3], __builtin_bit_cast(uint32_t, inv));
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Nearest list through the matrix cores, WITHOUT giving up the exact result (kmeans_nearest_cluster,
+// src/utils.rs:261-277: the first j minimising the exact-order f32 distance).
+//
+// The exact-order VALU kernels above are 3 n k dim flop of vector work: 2.9 of the 3.1 s of a 100M x 128 build.
+// Here every (vector, centroid) distance is first APPROXIMATED as (|c|^2 + |x|^2) - 2 <c~, x~> with the inner products
+// from v_mfma_f32_32x32x16_bf16 (operands rounded to bf16, f32 accumulation: 16x the f32 MFMA rate), which is within
+//     m_x = (2^-8 + (2 dim + 64) 2^-24) 1.05 (Cmax + |x|)^2
+// of the reference's f32 value e_j (src/simd.rs:14-73):  |<x,c> - <x~,c~>| <= (2^-8 + 2^-17) |x||c| by the two operand
+// roundings (2^-9 relative each), (|x||c| <= (|x|+|c|)^2 / 4), the f32 accumulation of the 128-term products, the two
+// norms (a dim-long f32 fma chain each) and the reference's own chain ((dim/8 + 5) 2^-24 relative) are all inside the
+// second term; Cmax = the largest centroid norm.  So the exact minimiser j* (and every exact tie) has
+//     a_{j*} <= e_{j*} + m <= e_j + m <= a_j + 2 m   for every j,   in particular   a_{j*} <= a_min + 2 m:
+// pass 1 finds a_min per vector, pass 2 lists the lists with a <= a_min + 2 m (one on well separated data, a few on
+// overlapping clusters), assign_refine_kernel recomputes THOSE in the reference's lane order and takes the first
+// minimum.  Vectors with no candidate (non-finite input) or more than RQ_ASSIGN_CAND of them (near-equidistant
+// centroids) are listed for the exact-order kernel.  Labels and distances: bit-identical to the kernels above.
+//
+// Geometry: block = 4 waves; a wave keeps the bf16 MFMA B-fragments of NT x 32 vectors in registers for the whole
+// kernel (dim/16 fragments of 4 VGPRs per tile) and streams all centroid tiles (32 lists x dim bf16, pre-rounded once
+// per build) through a double-buffered LDS image (row stride dim * 2 + 16 bytes).  D lane map: column = vector
+// (lane & 31), the 16 registers x 2 half-waves = the 32 lists of the tile.
+// ------------------------------------------------------------------------------------------------
+#define RQ_ASSIGN_CAND 4u
+typedef __bf16 asg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float asg_f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint32_t asg_bf16_pair(float lo, float hi) {  // two f32 -> packed bf16 (round to nearest even)
+    uint32_t a = __builtin_bit_cast(uint32_t, lo), b = __builtin_bit_cast(uint32_t, hi);
+    a += 0x7FFFu + ((a >> 16) & 1u);
+    b += 0x7FFFu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xFFFF0000u);
+}
+// rows x dim f32 -> bf16 (round to nearest even), 8 elements per thread
+__global__ __launch_bounds__(256) void to_bf16_kernel(const float *__restrict__ in, uint64_t total, uint16_t *__restrict__ out) {
+    const uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= total) return;
+    const float4 a = *reinterpret_cast<const float4 *>(in + i), b = *reinterpret_cast<const float4 *>(in + i + 4);
+    *reinterpret_cast<uint4 *>(out + i) = make_uint4(asg_bf16_pair(a.x, a.y), asg_bf16_pair(a.z, a.w), asg_bf16_pair(b.x, b.y), asg_bf16_pair(b.z, b.w));
+}
+// squared norms of n rows (sequential f32 fma chain per row) and their maximum (as u32 bits: non-negative floats order like
+// their bit patterns; NaN / inf patterns sort above every finite norm)
+__global__ void row_sqnorm_kernel(const float *__restrict__ rows, uint32_t n, uint32_t dim, float *__restrict__ out,
+                                  uint32_t *__restrict__ max_bits) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const float4 *p = reinterpret_cast<const float4 *>(rows + (uint64_t)r * dim);
+    float s = 0.0f;
+    for (uint32_t c = 0; c < dim / 4; ++c) {
+        const float4 v = p[c];
+        s = fmaf(v.x, v.x, s), s = fmaf(v.y, v.y, s), s = fmaf(v.z, v.z, s), s = fmaf(v.w, v.w, s);
+    }
+    out[r] = s;
+    if (max_bits) atomicMax(max_bits, __builtin_bit_cast(uint32_t, s));
+}
+
+template <int W, int NT>
+__global__ __launch_bounds__(256, (W <= 4 ? 2 : 1)) void assign_approx_kernel(const float *__restrict__ xrot,
+                                                              const uint16_t *__restrict__ cent_bf /* k x dim bf16 */,
+                                                              const float *__restrict__ cnorm, float cmax, uint64_t n,
+                                                              uint32_t k, uint32_t *__restrict__ cand /* n x RQ_ASSIGN_CAND */,
+                                                              uint32_t *__restrict__ cand_cnt /* n, zeroed */) {
+    constexpr int DIM = 64 * W, NM = DIM / 16;             // MFMAs per (vector tile, centroid tile)
+    constexpr uint32_t ROWB = DIM * 2 + 16;                // LDS row stride of a centroid tile, bytes
+    constexpr uint32_t TILEB = 32 * ROWB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char asg_lds[];  // 2 x (tile image | 32 norms)
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6, col = lane & 31, kh = lane >> 5;
+    const uint64_t v0 = ((uint64_t)blockIdx.x * 4 + wave) * (32 * NT);
+    // ---- this wave's vectors: bf16 B fragments (k-elements 16 m + 8 kh .. + 7 of vector v0 + 32 tile + col) and |x|^2 -------
+    asg_bf16x8 bfrag[NT][NM];
+    float xn[NT];
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) {
+        const uint64_t v = v0 + 32 * tl + col;
+        const float *xp = xrot + (v < n ? v : (n - 1)) * DIM + 8 * kh;
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const float4 a = *reinterpret_cast<const float4 *>(xp + 16 * m), b = *reinterpret_cast<const float4 *>(xp + 16 * m + 4);
+            s0 = fmaf(a.x, a.x, s0), s1 = fmaf(a.y, a.y, s1), s0 = fmaf(a.z, a.z, s0), s1 = fmaf(a.w, a.w, s1);
+            s0 = fmaf(b.x, b.x, s0), s1 = fmaf(b.y, b.y, s1), s0 = fmaf(b.z, b.z, s0), s1 = fmaf(b.w, b.w, s1);
+            const uint4 pk = make_uint4(asg_bf16_pair(a.x, a.y), asg_bf16_pair(a.z, a.w), asg_bf16_pair(b.x, b.y), asg_bf16_pair(b.z, b.w));
+            bfrag[tl][m] = __builtin_bit_cast(asg_bf16x8, pk);
+        }
+        const float s = s0 + s1;
+        xn[tl] = s + __shfl_xor(s, 32, 64);  // both halves of the vector
+    }
+    const uint32_t ntile = (k + 31) / 32;
+    auto stage = [&](uint32_t tile, uint4 (&regs)[(32 * DIM * 2 / 16 + 255) / 256], float &cn) {  // global -> registers
+        constexpr uint32_t PIECES = 32 * DIM * 2 / 16;  // 16-byte pieces of the tile
+#pragma unroll
+        for (uint32_t i = 0; i < (PIECES + 255) / 256; ++i) {
+            const uint32_t pc = t + 256 * i, row = pc / (DIM / 8), within = pc - row * (DIM / 8);
+            const uint32_t j = 32 * tile + row;
+            regs[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (pc < PIECES && j < k) regs[i] = *reinterpret_cast<const uint4 *>(cent_bf + (uint64_t)j * DIM + 8 * within);
+        }
+        cn = __builtin_inff();  // a row past the last list: never the minimum, never a candidate
+        if (t < 32 && 32 * tile + t < k) cn = cnorm[32 * tile + t];
+    };
+    auto land = [&](uint32_t buf, const uint4 (&regs)[(32 * DIM * 2 / 16 + 255) / 256], float cn) {  // registers -> LDS
+        constexpr uint32_t PIECES = 32 * DIM * 2 / 16;
+        unsigned char *img = asg_lds + buf * (TILEB + 128);
+#pragma unroll
+        for (uint32_t i = 0; i < (PIECES + 255) / 256; ++i) {
+            const uint32_t pc = t + 256 * i, row = pc / (DIM / 8), within = pc - row * (DIM / 8);
+            if (pc < PIECES) *reinterpret_cast<uint4 *>(img + row * ROWB + 16 * within) = regs[i];
+        }
+        if (t < 32) reinterpret_cast<float *>(img + TILEB)[t] = cn;
+    };
+    float tmin[NT], thr[NT];
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) tmin[tl] = __builtin_inff(), thr[tl] = 0.0f;
+    for (int pass = 0; pass < 2; ++pass) {
+        uint4 regs[(32 * DIM * 2 / 16 + 255) / 256];
+        float cn_next;
+        __syncthreads();  // the previous pass's last tile has been consumed
+        stage(0, regs, cn_next);
+        land(0, regs, cn_next);
+        for (uint32_t tile = 0; tile < ntile; ++tile) {
+            __syncthreads();  // tile `tile` is in LDS; the other buffer is free
+            if (tile + 1 < ntile) stage(tile + 1, regs, cn_next);
+            const unsigned char *img = asg_lds + (tile & 1u) * (TILEB + 128);
+            const float *cnp = reinterpret_cast<const float *>(img + TILEB);
+            asg_f32x16 acc[NT];
+#pragma unroll
+            for (int tl = 0; tl < NT; ++tl) acc[tl] = asg_f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const asg_bf16x8 af = *reinterpret_cast<const asg_bf16x8 *>(img + col * ROWB + (16 * m + 8 * kh) * 2);
+#pragma unroll
+                for (int tl = 0; tl < NT; ++tl) acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfrag[tl][m], acc[tl], 0, 0, 0);
+            }
+            float cnr[16];  // |c|^2 of this lane's 16 rows: row = (r & 3) + 8 (r >> 2) + 4 kh
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 c4 = *reinterpret_cast<const float4 *>(cnp + 8 * g + 4 * kh);
+                cnr[4 * g] = c4.x, cnr[4 * g + 1] = c4.y, cnr[4 * g + 2] = c4.z, cnr[4 * g + 3] = c4.w;
+            }
+#pragma unroll
+            for (int tl = 0; tl < NT; ++tl) {
+                if (pass == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tmin[tl] = fminf(tmin[tl], fmaf(-2.0f, acc[tl][r], cnr[r]));
+                } else {
+                    const uint64_t v = v0 + 32 * tl + col;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (fmaf(-2.0f, acc[tl][r], cnr[r]) <= thr[tl] && v < n) {
+                            const uint32_t slot = atomicAdd(cand_cnt + v, 1u);
+                            if (slot < RQ_ASSIGN_CAND) cand[v * RQ_ASSIGN_CAND + slot] = 32 * tile + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4 * kh;
+                        }
+                    }
+                }
+            }
+            if (tile + 1 < ntile) land((tile + 1) & 1u, regs, cn_next);
+        }
+        if (pass == 0) {
+#pragma unroll
+            for (int tl = 0; tl < NT; ++tl) {
+                const float other = __shfl_xor(tmin[tl], 32, 64);  // the other 16 rows of every tile
+                tmin[tl] = fminf(tmin[tl], other);
+                const float rad = cmax + sqrtf(xn[tl]) * 1.000001f;
+                const float mx = (0.00390625f + (float)(2 * DIM + 64) * 5.9604645e-8f) * 1.05f * (rad * rad);
+                thr[tl] = tmin[tl] + 2.0f * mx;          // (inf / NaN -> no candidate -> the exact-order kernel takes the vector)
+                thr[tl] = thr[tl] + fabsf(thr[tl]) * 1.0e-6f;  // the comparison's own rounding
+            }
+        }
+    }
+}
+
+// exact-order distances (src/simd.rs:14-73) of every vector to its listed candidates, first minimum (smallest list id among
+// equal distances: kmeans_nearest_cluster's strict `<` over ascending j); two lanes per vector (lane half hf = AVX lanes
+// 4hf..4hf+3).  Vectors with 0 or more than RQ_ASSIGN_CAND candidates are appended to `redo` for the exact-order kernel.
+__global__ __launch_bounds__(256) void assign_refine_kernel(const float *__restrict__ xrot, const float *__restrict__ centroids,
+                                                            uint64_t n, uint32_t dim, const uint32_t *__restrict__ cand,
+                                                            const uint32_t *__restrict__ cand_cnt, uint32_t *__restrict__ label,
+                                                            float *__restrict__ dist, uint32_t *__restrict__ redo,
+                                                            uint32_t *__restrict__ redo_cnt) {
+    const uint32_t hf = threadIdx.x & 1;
+    const uint64_t v = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 1;
+    if (v >= n) return;
+    const uint32_t nc = cand_cnt[v];
+    if (nc == 0 || nc > RQ_ASSIGN_CAND) {
+        if (hf == 0) redo[atomicAdd(redo_cnt, 1u)] = (uint32_t)v;
+        return;
+    }
+    const float *x = xrot + v * dim + 4 * hf;
+    float best = 0.0f;
+    uint32_t lab = 0xFFFFFFFFu;
+    for (uint32_t ci = 0; ci < nc; ++ci) {
+        const uint32_t j = cand[v * RQ_ASSIGN_CAND + ci];
+        const float *c = centroids + (uint64_t)j * dim + 4 * hf;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        for (uint32_t e = 0; e < dim; e += 8) {
+            const float4 cv = *reinterpret_cast<const float4 *>(c + e), xv = *reinterpret_cast<const float4 *>(x + e);
+            const float d0 = cv.x - xv.x, d1 = cv.y - xv.y, d2 = cv.z - xv.z, d3 = cv.w - xv.w;
+            a0 = fmaf(d0, d0, a0), a1 = fmaf(d1, d1, a1), a2 = fmaf(d2, d2, a2), a3 = fmaf(d3, d3, a3);
+        }
+        const float c0 = a0 + __shfl_xor(a0, 1, 2), c1 = a1 + __shfl_xor(a1, 1, 2);
+        const float c2 = a2 + __shfl_xor(a2, 1, 2), c3 = a3 + __shfl_xor(a3, 1, 2);
+        const float dd = (c0 + c1) + (c2 + c3);
+        if (lab == 0xFFFFFFFFu || dd < best || (dd == best && j < lab)) best = dd, lab = j;
+    }
+    if (hf == 0) {
+        // the reference starts from (0, f32::MAX) and takes a list only if its distance is smaller: a minimum that is not
+        // below f32::MAX (NaN cannot get here: such vectors have no candidate) keeps list 0
+        label[v] = best < 3.402823466e+38f ? lab : 0u;
+        dist[v] = best < 3.402823466e+38f ? best : 3.402823466e+38f;
+    }
+}
+// results of the exact-order kernel for the listed vectors back to their rows
+__global__ void assign_scatter_kernel(const uint32_t *__restrict__ redo, uint32_t m, const uint32_t *__restrict__ lab_in,
+                                      const float *__restrict__ dist_in, uint32_t *__restrict__ label, float *__restrict__ dist) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) label[redo[i]] = lab_in[i], dist[redo[i]] = dist_in[i];
+}

@@ -99,6 +99,8 @@ static rq_status copy_out_sized(T *out, T full) {
     return RQ_OK;
 }
 static inline uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+template <int W, int NT>
+static size_t assign_lds_bytes() { return 2 * (32 * (64 * W * 2 + 16) + 128); }  // assign_approx_kernel: two centroid-tile images
 static inline uint32_t pow2_ceil(uint32_t v) {
     uint32_t p = 1;
     while (p < v) p <<= 1;
@@ -573,6 +575,9 @@ static rq_status ensure_kernel_attributes() {
         set(reinterpret_cast<const void *>(assign_generic_kernel<8>), 140 * 1024, "assign_generic_kernel<8>");
         set(reinterpret_cast<const void *>(merge_smallest_u64_kernel), 16384 * 8, "merge_smallest_u64_kernel");
         set(reinterpret_cast<const void *>(sb_front_kernel), 140 * 1024, "sb_front_kernel");
+        set(reinterpret_cast<const void *>(assign_approx_kernel<6, 1>), (int)assign_lds_bytes<6, 1>(), "assign_approx_kernel<6,1>");
+        set(reinterpret_cast<const void *>(assign_approx_kernel<8, 1>), (int)assign_lds_bytes<8, 1>(), "assign_approx_kernel<8,1>");
+        set(reinterpret_cast<const void *>(assign_approx_kernel<12, 1>), (int)assign_lds_bytes<12, 1>(), "assign_approx_kernel<12,1>");
 #define RQ_SBQ_ATTR(WW)                                                                                  \
     set(reinterpret_cast<const void *>(sb_query_kernel<WW, 0>), 120 * 1024, "sb_query_kernel");          \
     set(reinterpret_cast<const void *>(sb_query_kernel<WW, 1>), 120 * 1024, "sb_query_kernel");          \
@@ -1514,6 +1519,74 @@ static void launch_assign(const float *xrot, const rq_index *idx, uint64_t n, ui
             xrot, idx->cent_t.p, n, idx->k, idx->dim, label, dist);
 }
 
+// Nearest list through the matrix cores (kernels_build.h: assign_approx_kernel + assign_refine_kernel; exact results):
+// what it needs besides the index's rotated centroids, built once per build, plus per-chunk scratch.
+static std::atomic<int> g_assign_impl{0};  // 0 = matrix-core pre-filter where the kernel exists (default), 1 = exact-order VALU kernels only
+struct AssignAux {
+    DevBuf<uint16_t> cent_bf;  // k x dim bf16
+    DevBuf<float> cnorm, redo_x, redo_dist;
+    DevBuf<uint32_t> cand, cand_cnt, redo, redo_cnt, redo_lab;
+    float cmax = INFINITY;
+    uint64_t redone = 0;  // vectors that went through the exact-order kernel (no or too many candidates)
+};
+static bool assign_has_mfma(uint32_t W) { return W == 1 || W == 2 || W == 3 || W == 4 || W == 6 || W == 8 || W == 12; }
+static rq_status assign_aux_init(const rq_index *idx, AssignAux &ax, uint64_t chunk_rows) {
+    const uint64_t cells = (uint64_t)idx->k * idx->dim;
+    RQC(ax.cent_bf.alloc(cells));
+    RQC(ax.cnorm.alloc(idx->k));
+    RQC(ax.redo_cnt.alloc(2));
+    HIPC(hipMemset(ax.redo_cnt.p, 0, 8));
+    to_bf16_kernel<<<ceil_div(cells, 2048), 256>>>(idx->centroids.p, cells, ax.cent_bf.p);
+    row_sqnorm_kernel<<<ceil_div(idx->k, 256), 256>>>(idx->centroids.p, idx->k, idx->dim, ax.cnorm.p, ax.redo_cnt.p + 1);
+    uint32_t bits = 0;
+    HIPC(hipMemcpy(&bits, ax.redo_cnt.p + 1, 4, hipMemcpyDeviceToHost));
+    const float m2 = __builtin_bit_cast(float, bits);
+    ax.cmax = std::isfinite(m2) && m2 < 1.0e30f ? std::sqrt(m2) * 1.000001f : INFINITY;  // inf: every vector goes to the exact-order kernel
+    RQC(ax.cand.alloc(chunk_rows * RQ_ASSIGN_CAND));
+    RQC(ax.cand_cnt.alloc(chunk_rows));
+    RQC(ax.redo.alloc(chunk_rows));
+    return RQ_OK;
+}
+// n <= the chunk size given to assign_aux_init; null stream (the builder's)
+static rq_status launch_assign_prefiltered(const float *xrot, const rq_index *idx, AssignAux &ax, uint64_t n, uint32_t *label,
+                                           float *dist) {
+    if (n == 0) return RQ_OK;
+    const uint32_t W = idx->W, k = idx->k;
+    if (g_assign_impl.load() == 1 || !assign_has_mfma(W) || !std::isfinite(ax.cmax)) {
+        launch_assign(xrot, idx, n, label, dist, nullptr);
+        return RQ_OK;
+    }
+    HIPC(hipMemsetAsync(ax.cand_cnt.p, 0, n * 4, nullptr));
+    HIPC(hipMemsetAsync(ax.redo_cnt.p, 0, 4, nullptr));
+#define RQ_ASG(WW, NT)                                                                                                   \
+    assign_approx_kernel<WW, NT><<<ceil_div(n, 128 * NT), 256, assign_lds_bytes<WW, NT>(), nullptr>>>(                  \
+        xrot, ax.cent_bf.p, ax.cnorm.p, ax.cmax, n, k, ax.cand.p, ax.cand_cnt.p)
+    switch (W) {
+        case 1: RQ_ASG(1, 2); break;
+        case 2: RQ_ASG(2, 2); break;
+        case 3: RQ_ASG(3, 1); break;
+        case 4: RQ_ASG(4, 1); break;
+        case 6: RQ_ASG(6, 1); break;
+        case 8: RQ_ASG(8, 1); break;
+        default: RQ_ASG(12, 1); break;
+    }
+#undef RQ_ASG
+    assign_refine_kernel<<<ceil_div(2 * n, 256), 256>>>(xrot, idx->centroids.p, n, idx->dim, ax.cand.p, ax.cand_cnt.p, label, dist,
+                                                        ax.redo.p, ax.redo_cnt.p);
+    uint32_t m = 0;
+    HIPC(hipMemcpy(&m, ax.redo_cnt.p, 4, hipMemcpyDeviceToHost));
+    if (m) {  // no candidate (non-finite input) or more than RQ_ASSIGN_CAND of them: the exact-order kernel over all lists
+        ax.redone += m;
+        RQC(ax.redo_x.ensure((uint64_t)m * idx->dim));
+        RQC(ax.redo_dist.ensure(m));
+        RQC(ax.redo_lab.ensure(m));
+        gather_rows_kernel<<<ceil_div((uint64_t)m * idx->dim, 256), 256>>>(xrot, ax.redo.p, m, idx->dim, ax.redo_x.p);
+        launch_assign(ax.redo_x.p, idx, m, ax.redo_lab.p, ax.redo_dist.p, nullptr);
+        assign_scatter_kernel<<<ceil_div(m, 256), 256>>>(ax.redo.p, m, ax.redo_lab.p, ax.redo_dist.p, label, dist);
+    }
+    return RQ_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Base tiers: how many raw vectors stay in HBM.  budget_bytes: 0 = automatic (what is free now minus a reserve for
 // query workspaces and the caller), ~0 = everything in HBM, else an explicit cap ("base_device_mb" option / the
@@ -1582,6 +1655,7 @@ struct rq_builder {
     DevBuf<float> mind, xpad, xrot;
     DevBuf<uint64_t> codes_tmp;
     DevBuf<float4> factors_tmp;
+    AssignAux assign_aux;
     uint64_t assigned = 0, placed = 0;
     // Rows each pass has seen, as disjoint [begin, end) intervals: chunks may come in any order and size, but every row
     // exactly once per pass.  A duplicated chunk would leave other rows with uninitialised labels / codes (and then
@@ -1664,6 +1738,7 @@ static rq_status builder_create(uint64_t n, uint32_t d, const float *d_centroids
     const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(n, 1), RQ_BUILD_CHUNK);
     if (d != dim) RQC(b->xpad.alloc(chunk * dim));
     RQC(b->xrot.alloc(chunk * dim));
+    if (assign_has_mfma(idx->W) && g_assign_impl.load() != 1) RQC(assign_aux_init(idx, b->assign_aux, chunk));
     for (auto &e : b->ev) HIPC(hipEventCreate(&e));
     *out = b.release();
     return RQ_OK;
@@ -1687,7 +1762,7 @@ static rq_status builder_assign(rq_builder *b, const float *d_rows, uint64_t i0,
         HIPC(hipEventRecord(b->ev[0], nullptr));
         launch_rotate(src, idx->P.p, b->xrot.p, mm, dim, true, nullptr);
         HIPC(hipEventRecord(b->ev[1], nullptr));
-        launch_assign(b->xrot.p, idx, mm, b->label.p + at, b->mind.p + at, nullptr);
+        RQC(launch_assign_prefiltered(b->xrot.p, idx, b->assign_aux, mm, b->label.p + at, b->mind.p + at));
         HIPC(hipEventRecord(b->ev[2], nullptr));
         quantize_kernel<<<ceil_div(mm, 32), 256>>>(b->xrot.p, idx->centroids.p, b->label.p + at, mm, dim,
                                                    b->codes_tmp.p + at * idx->W, b->factors_tmp.p + at);
@@ -1715,6 +1790,11 @@ static rq_status builder_order(rq_builder *b) {
     if (b->assigned != n) return fail(RQ_ERR_INVALID, "rq_builder_order before every row was assigned");
     b->xpad.release();
     b->xrot.release();
+    {
+        AssignAux &ax = b->assign_aux;
+        ax.cent_bf.release(), ax.cnorm.release(), ax.redo_x.release(), ax.redo_dist.release(), ax.cand.release();
+        ax.cand_cnt.release(), ax.redo.release(), ax.redo_cnt.release(), ax.redo_lab.release();
+    }
     DevBuf<uint32_t> cnt;
     DevBuf<unsigned long long> keys;
     RQC(cnt.alloc((size_t)k + 1));
@@ -3010,6 +3090,11 @@ rq_status rq_set_option(const char *name, int value) {
         g_coarse_impl = value;
         return RQ_OK;
     }
+    if (std::string(name) == "assign_impl") {  // nearest-list assignment of builds started from now on: 0 = matrix-core pre-filter + exact refinement, 1 = exact-order VALU kernels only
+        if (value < 0 || value > 1) return fail(RQ_ERR_INVALID, "assign_impl must be 0 or 1");
+        g_assign_impl = value;
+        return RQ_OK;
+    }
     if (std::string(name) == "small_batch_span") {  // developer knob (results identical for every value)
         if (value < 1) return fail(RQ_ERR_INVALID, "small_batch_span must be >= 1");
         g_sb_span = value;
@@ -3117,9 +3202,12 @@ rq_status rq_quantize_pack(const float *x_rot, uint64_t n, uint32_t dim, const f
     HIPC(hipMemcpy(dx.p, x_rot, n * dim * 4, hipMemcpyHostToDevice));
     HIPC(hipMemcpy(tmp.centroids.p, centroids_rot, (size_t)k * dim * 4, hipMemcpyHostToDevice));
     transpose_kernel<<<dim3(ceil_div(dim, 32), ceil_div(k, 32)), dim3(32, 8)>>>(tmp.centroids.p, tmp.cent_t.p, k, dim);
+    AssignAux ax;  // the build's assignment path: matrix-core pre-filter + exact refinement (option assign_impl)
+    HIPC(hipDeviceSynchronize());
+    if (assign_has_mfma(tmp.W) && g_assign_impl.load() != 1) RQC(assign_aux_init(&tmp, ax, std::min<uint64_t>(std::max<uint64_t>(n, 1), 1ull << 20)));
     for (uint64_t i0 = 0; i0 < n; i0 += (1ull << 20)) {  // chunked: launches stay far below 2^32 threads
         const uint64_t m = std::min<uint64_t>(1ull << 20, n - i0);
-        launch_assign(dx.p + i0 * dim, &tmp, m, dl.p + i0, dd.p + i0, nullptr);
+        RQC(launch_assign_prefiltered(dx.p + i0 * dim, &tmp, ax, m, dl.p + i0, dd.p + i0));
         quantize_kernel<<<ceil_div(m, 32), 256>>>(dx.p + i0 * dim, tmp.centroids.p, dl.p + i0, m, dim,
                                                   dc.p + i0 * tmp.W, df.p + i0);
     }

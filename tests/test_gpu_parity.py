@@ -471,6 +471,47 @@ def test_large_index_properties(rq, n, d, k, probe, hbm_mb):
     idx.close()
 
 
+@pytest.mark.parametrize("d", [64, 100, 192, 256, 384, 512, 768])
+def test_prefiltered_assignment_equals_exact_order_kernels(rq, oracle, d):
+    """Nearest-list assignment through the matrix cores (assign_approx_kernel: bf16 MFMA approximation, candidates within
+    2 m of the minimum, exact-order refinement) against the exact-order VALU kernels (option assign_impl = 1) and the
+    oracle: labels and distances bit for bit.  Data that stress the candidate logic: duplicate centroids (exact ties:
+    the first one must win), a tight ring of near-equidistant centroids (more candidates than the list holds: the
+    exact-order kernel takes those vectors), vectors ON centroids, huge and tiny scales in one index, a NaN and an inf
+    coordinate (no candidate at all)."""
+    from rabitq_amd import index as ix
+    rng = np.random.default_rng(d)
+    n, k = 6000, 70
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.8, seed=d, centre_scale=0.7)
+    centres[9] = centres[4]                                               # exact ties
+    centres[20:40] = centres[20] + 1e-5 * rng.standard_normal((20, d))    # twenty lists within the error bound of each other
+    x[:200] = centres[rng.integers(20, 40, 200)] + 1e-3 * rng.standard_normal((200, d))
+    x[200:260] = centres[rng.integers(0, k, 60)]                          # on a centroid
+    x[260:300] *= 1.0e4
+    x[300:340] *= 1.0e-4
+    x = x.astype(np.float32)
+    x[400, 3] = np.nan
+    x[401, 5] = np.inf
+    dp = (d + 63) // 64 * 64
+    P = synth.random_orthogonal(dp, seed=d + 1)
+    xr = rq.ops.rotate(np.pad(x, ((0, 0), (0, dp - d))), P)
+    cr = rq.ops.rotate(np.pad(centres, ((0, 0), (0, dp - d))), P)
+    got = {}
+    try:
+        for impl in (0, 1):
+            ix.set_option("assign_impl", impl)
+            got[impl] = rq.ops.quantize_pack(xr, cr)
+    finally:
+        ix.set_option("assign_impl", 0)
+    for a, b, name in zip(got[0], got[1], ("label", "dist", "codes", "factors")):
+        assert_bits_equal(np.asarray(a), np.asarray(b), f"assign_impl 0 vs 1: {name}")
+    ok = np.isfinite(x).all(axis=1)
+    for i in np.nonzero(ok)[0][::7]:
+        lab, dist = oracle.kmeans_nearest_cluster(cr, xr[i])
+        assert int(got[0][0][i]) == lab, i
+        assert np.float32(got[0][1][i]).view(np.uint32) == np.float32(dist).view(np.uint32), i
+
+
 # ---- f2: centroid training on the GPU (scripts/cluster.py's role) -----------------------------------
 def test_kmeans_centroids_give_recall(rq):
     import torch
