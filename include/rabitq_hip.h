@@ -333,6 +333,10 @@ typedef struct {
      * quantisation and the early stages in LDS): device time of that second launch, and how many passes took the path */
     float ms_early;
     uint32_t small_batch_passes;
+    /* survivor records + run directories of the call's largest pass, bytes; passes whose final stage used per-query segments
+     * (sized by a sampled counting scan) instead of one capacity for every query */
+    uint64_t survivor_workspace_bytes;
+    uint32_t segmented_passes, reserved2;
 } rq_profile_t;
 /* level: 0 = off; 1 = every kernel group bracketed (each event costs a few microseconds of stream
  * time); 2 = only the scan launches and the whole pass (ms_scan, ms_total; the other fields stay 0). */
@@ -353,6 +357,9 @@ rq_status rq_set_profiling(int level);
  * "shared_thresholds": rq_query_batch_sharded_device: 1 (default) = with more than one shard the step runs the nearest
  * list first, all-reduces (min) the k-th best distances and seeds the rest of the probe list with them (see
  * rq_query_batch_device_seeded); 0 = every shard prunes with its own thresholds only; 2 = also with one shard (tests).
+ * "survivor_segments": 1 (default) = once an index has shown that its batches overflow the default survivor capacity, large
+ * batches (>= 256 queries) size the final stage's survivor buffers PER QUERY (a sampled counting scan + prefix sum) instead
+ * of giving every query the worst one's capacity; 0 = never, 2 = every large batch (tests).  Identical results.
  * "small_batch": 0 (default) = batches of <= 64 queries (the reference's one-query-per-call loop included) run as a handful
  * of fat launches (kernels_small.h) whenever the shape allows (nprobe <= 64, <= 8192 lists, topk <= 256, dim in {64, 128,
  * 256, 512, 768, 1024}), 1 = never (test hook).  Identical results.

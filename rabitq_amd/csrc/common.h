@@ -79,6 +79,18 @@ __device__ __forceinline__ uint64_t surv_key(const RunRec &r) {
     return ((uint64_t)r.slot << 32) | r.pos;
 }
 
+// Where a query's survivor records and run descriptors live.  Uniform: query b owns slots [b * ucap, (b + 1) * ucap) of
+// the pass's buffers.  Segmented (final stage of a pass whose survivor counts are very unequal: a sampled counting scan
+// sizes every query's segment): query b owns cap[b] slots from base[b].  The same geometry applies to the survivor
+// records, the run directory and its scratch copy.
+struct QSeg {
+    const unsigned long long *base;  // per query: first slot; nullptr = uniform
+    const uint32_t *cap;             // per query: slots
+    uint32_t ucap;                   // uniform capacity (and the bound of the early stages of a segmented pass)
+    __device__ __forceinline__ uint64_t at(uint32_t b) const { return base ? base[b] : (uint64_t)b * ucap; }
+    __device__ __forceinline__ uint32_t capof(uint32_t b) const { return base ? cap[b] : ucap; }
+};
+
 // Per-(query, probe slot) scalars written by the prep kernel; 40 bytes = s_load_dwordx8 + x2.
 struct __attribute__((aligned(8))) PairScalars {
     float lower;      // lower_bound                      (src/rabitq.rs:305)

@@ -1043,7 +1043,14 @@ struct ScanArgs {   // scalars only; pointers are explicit __restrict__ kernel p
     // RQ_REC_CELL0 + list position / 64: already in the reference's visiting order, nothing to sort) instead of being
     // appended in completion order
     uint32_t dense_dir;
+    // survivor geometry: uniform capacity `cap` per query, or per-query segments (QSeg); read on the survivor path only
+    const unsigned long long *seg_base;
+    const uint32_t *seg_cap;
+    // count_only: nothing is recorded, the survivors of every tile_stride-th tile are only COUNTED into surv_cnt (the
+    // sampled counting scan that sizes the segments)
+    uint32_t count_only, tile_stride;
 };
+__device__ __forceinline__ QSeg scan_seg(const ScanArgs &a) { return QSeg{a.seg_base, a.seg_cap, a.cap}; }
 struct ScanPtrs {   // host-side bundle only
     const uint32_t *codes;        // n * 2W dwords (x_binary_vec, src/rabitq.rs:66)
     const float4 *factors;        // n (src/rabitq.rs:67): x=factor_ip y=factor_ppc z=error_bound w=cds
@@ -1105,6 +1112,10 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
             list_begin = offsets[g];
             list_len = offsets[g + 1] - list_begin;
         }
+    }
+    if (a.tile_stride > 1u) {  // sampled counting scan: every tile_stride-th tile, the phase spread over the lists
+        const uint32_t ti = a.use_table ? a.group_base + blockIdx.x : first / (256 * CPL) + g;
+        if (ti % a.tile_stride) return;
     }
     uint32_t pb, pe;
     if (a.cluster_major) {
@@ -1212,17 +1223,24 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
             uint32_t nruns = 0;
 #pragma unroll
             for (int c = 0; c < CPL; ++c) nruns += m[c] ? 1u : 0u;
+            if (a.count_only) {  // sampled counting scan: survivors are counted, not recorded
+                if (lane == 0) atomicAdd(surv_cnt + b, (unsigned long long)total);
+                return;
+            }
             unsigned long long old = 0;
             if (lane == 0) old = atomicAdd(surv_cnt + b, ((unsigned long long)nruns << 32) | total);
             uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)old);
             uint32_t rbase = __builtin_amdgcn_readfirstlane((uint32_t)(old >> 32));
-            SurvRec *out = surv + (uint64_t)b * a.cap;
+            const QSeg seg = scan_seg(a);
+            const uint64_t qat = seg.at(b);
+            const uint32_t qcap = seg.capof(b);
+            SurvRec *out = surv + qat;
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
                 const uint32_t cntc = (uint32_t)__popcll(m[c]);
                 if ((m[c] >> lane) & 1ull) {
                     uint32_t at = base + (uint32_t)__popcll(m[c] & ((1ull << lane) - 1ull));
-                    if (at < a.cap) {
+                    if (at < qcap) {
                         SurvRec r;
                         r.pos = pos[c];
                         r.slot = slot;
@@ -1233,13 +1251,13 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
                 }
                 // the run's descriptor: appended (sorted later), or straight into its cell of the dense directory
                 const uint32_t dcell = a.dense_dir ? t[RQ_REC_CELL0] + ((first + c * 256 + (threadIdx.x & ~63u)) >> 6) : rbase;
-                if (cntc && lane == 0 && dcell < a.cap) {
+                if (cntc && lane == 0 && dcell < qcap) {
                     RunRec rr;
                     rr.pos = list_begin + first + c * 256 + (threadIdx.x & ~63u);
                     rr.slot = slot;
                     rr.base = base;
                     rr.cnt = cntc;
-                    runs[(uint64_t)b * a.cap + dcell] = rr;
+                    runs[qat + dcell] = rr;
                 }
                 base += cntc;
                 rbase += cntc ? 1u : 0u;
@@ -1400,6 +1418,10 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
         first = (a.tile_base + (blockIdx.x - gl * a.tiles_per_group)) * TILE;
         list_begin = offsets[g], list_len = offsets[g + 1] - list_begin;
     }
+    if (a.tile_stride > 1u) {  // sampled counting scan: every tile_stride-th tile, the phase spread over the lists
+        const uint32_t ti = a.use_table ? a.group_base + blockIdx.x : first / TILE + g;
+        if (ti % a.tile_stride) return;
+    }
     // the group's records (cluster-major only)
     const uint32_t pb = grp_start[g], cnt = grp_cnt[g];
     if (cnt == 0) return;
@@ -1490,31 +1512,39 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
     uint32_t nE = 0, nR = 0;  // wave-uniform fill levels
     auto flush = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // LDS is in-order per wave
+        const QSeg seg = scan_seg(a);
+        if (a.count_only) {  // sampled counting scan: survivors are counted, not recorded
+            if (lane < nR) atomicAdd(surv_cnt + r_b[wave][lane], (unsigned long long)r_cnt[wave][lane]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            nE = 0, nR = 0;
+            return;
+        }
         if (lane < nR) {  // one lane per run: all reservations in flight together
             const uint32_t rb = r_b[wave][lane], rc = r_cnt[wave][lane];
             const unsigned long long old = atomicAdd(surv_cnt + rb, (1ull << 32) | rc);
             const uint32_t base = (uint32_t)old, rbase = (uint32_t)(old >> 32);
             r_base[wave][lane] = base;
-            if (rbase < a.cap) {
+            if (rbase < seg.capof(rb)) {
                 RunRec rr;
                 rr.pos = r_pos[wave][lane];
                 rr.slot = r_slot[wave][lane];
                 rr.base = base;
                 rr.cnt = rc;
-                runs[(uint64_t)rb * a.cap + rbase] = rr;
+                runs[seg.at(rb) + rbase] = rr;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         for (uint32_t e = lane; e < nE; e += 64) {
             const uint32_t r = q_run[wave][e];
             const uint32_t at = r_base[wave][r] + (e - r_off[wave][r]);
-            if (at < a.cap) {
+            const uint32_t rb = r_b[wave][r];
+            if (at < seg.capof(rb)) {
                 SurvRec sr;
                 sr.pos = q_pos[wave][e];
                 sr.slot = r_slot[wave][r];
                 sr.rough = q_rough[wave][e];
                 sr.accurate = 0.0f;
-                surv[(uint64_t)r_b[wave][r] * a.cap + at] = sr;
+                surv[seg.at(rb) + at] = sr;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1797,17 +1827,17 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(SCAN_PARAMS, uint32_t
             uint32_t rbase = __builtin_amdgcn_readfirstlane((uint32_t)(old >> 32));
             if (pass) {
                 uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (at < a.cap) {
+                if (at < scan_seg(a).capof(b)) {
                     SurvRec r;
                     r.pos = pos, r.slot = slot, r.rough = rough, r.accurate = 0.0f;
-                    surv[(uint64_t)b * a.cap + at] = r;
+                    surv[scan_seg(a).at(b) + at] = r;
                 }
             }
-            if (lane == 0 && rbase < a.cap) {
+            if (lane == 0 && rbase < scan_seg(a).capof(b)) {
                 RunRec rr;
                 rr.pos = list_begin + first + (threadIdx.x & ~63u);
                 rr.slot = slot, rr.base = base, rr.cnt = cntc;
-                runs[(uint64_t)b * a.cap + rbase] = rr;
+                runs[scan_seg(a).at(b) + rbase] = rr;
             }
         }
     }
@@ -1983,7 +2013,10 @@ struct ReplayState {
     int32_t *heap_key;       // nq * topk
     uint32_t *heap_id;       // nq * topk
     uint32_t *precise;       // nq   (rerank.rs:91 / :153)
-    uint32_t *need;          // nq   max survivor count seen (overflow detection)
+    uint32_t *need;          // nq   max survivor count of a stage (sizes re-runs and the learnt capacities)
+    uint32_t *ovf;           // nq   1 = a stage dropped records (count > the query's capacity): the query is re-run
+    unsigned long long *early_max;  // one word: largest survivor count of any query in a non-final stage (null: not tracked)
+    uint32_t final_stage;    // the stage being finished is the pass's last one
     uint32_t *nsurv;         // nq   survivors replayed (= accurate distances computed)
     uint32_t *nshadow;       // nq   of those: rejected by the fp16 shadow rows, f32 row never read
     // heuristic ranker
@@ -2244,7 +2277,7 @@ __device__ __forceinline__ void accurate_rows(SurvRec *__restrict__ recs, uint32
 // directory into the reference's visiting order, (C) wave 0 replays the ranker.
 template <bool HEURISTIC>
 __global__ __launch_bounds__(1024) void stage_finish_kernel(SurvRec *__restrict__ surv, RunRec *__restrict__ runs,
-                                                           unsigned long long *__restrict__ surv_cnt, uint32_t cap,
+                                                           unsigned long long *__restrict__ surv_cnt, const QSeg seg,
                                                            const BaseView base,
                                                            const float *__restrict__ qpad, uint32_t dim, uint32_t topk,
                                                            ReplayState st, const uint32_t *__restrict__ probe_cluster,
@@ -2255,17 +2288,21 @@ __global__ __launch_bounds__(1024) void stage_finish_kernel(SurvRec *__restrict_
     const uint32_t b = blockIdx.x;
     const unsigned long long cnt64 = surv_cnt[b];
     const uint32_t cnt = (uint32_t)cnt64;
+    const uint32_t cap = seg.capof(b);
+    const uint64_t qat = seg.at(b);
     const bool overflow = cnt > cap;  // records were dropped: the query is re-run with a larger buffer
     const uint32_t n = overflow ? 0 : cnt;
     const uint32_t nruns = overflow ? 0 : (uint32_t)(cnt64 >> 32);
     __syncthreads();  // every thread has read the counter before thread 0 resets it
     if (threadIdx.x == 0) {
         if (cnt > st.need[b]) st.need[b] = cnt;
+        if (overflow) st.ovf[b] = 1u;
+        if (st.early_max && !st.final_stage && cnt) atomicMax(st.early_max, (unsigned long long)cnt);
         st.nsurv[b] += n;
         surv_cnt[b] = 0;  // ready for the next stage
     }
     if (n == 0) return;
-    SurvRec *recs = surv + (uint64_t)b * cap;
+    SurvRec *recs = surv + qat;
     {  // (A)
         for (uint32_t c = threadIdx.x * 4; c < dim; c += blockDim.x * 4)
             *reinterpret_cast<float4 *>(fin_q + c) = *reinterpret_cast<const float4 *>(qpad + (uint64_t)b * dim + c);
@@ -2274,10 +2311,10 @@ __global__ __launch_bounds__(1024) void stage_finish_kernel(SurvRec *__restrict_
     }
     // (B): up to RQ_SORT_LDS_RECS descriptors in LDS; longer directories were already ordered by sort_runs_mid_kernel
     // when the host launched it ahead of this kernel (presorted != 0), else (rare) bitonic in global memory
-    if (nruns <= RQ_SORT_LDS_RECS || !presorted) sort_segment(runs + (uint64_t)b * cap, nruns);
+    if (nruns <= RQ_SORT_LDS_RECS || !presorted) sort_segment(runs + qat, nruns);
     __syncthreads();                                  // (A)'s stores and (B)'s order visible to wave 0
     if (threadIdx.x < 64)                             // (C)
-        replay_wave<HEURISTIC>(recs, runs + (uint64_t)b * cap, nruns, topk, b, st, hkey, hid);
+        replay_wave<HEURISTIC>(recs, runs + qat, nruns, topk, b, st, hkey, hid);
 }
 
 // Rerank order of a large batch: queries grouped by their nearest list (counting sort: histogram, scan by
@@ -2353,7 +2390,7 @@ __device__ __forceinline__ float exact_l2_pair(const float *__restrict__ x, cons
 // ones it cannot reject queue up in LDS and are re-ranked exactly 128 at a time, so both phases keep every lane busy.
 __global__ __launch_bounds__(256) void accurate_filtered_kernel(SurvRec *__restrict__ surv,
                                                                 const unsigned long long *__restrict__ surv_cnt,
-                                                                uint32_t cap, const float *__restrict__ base,
+                                                                const QSeg seg, const float *__restrict__ base,
                                                                 const _Float16 *__restrict__ base_h,
                                                                 const float *__restrict__ qpad, uint32_t dim,
                                                                 const uint32_t *__restrict__ order,
@@ -2364,12 +2401,12 @@ __global__ __launch_bounds__(256) void accurate_filtered_kernel(SurvRec *__restr
     __shared__ uint32_t qn;
     const uint32_t b = order ? order[blockIdx.y] : blockIdx.y;
     const uint32_t n = (uint32_t)surv_cnt[b];
-    if (n > cap || n == 0) return;  // overflowed: this query is re-run with a larger buffer
+    if (n > seg.capof(b) || n == 0) return;  // overflowed: this query is re-run with a larger buffer
     for (uint32_t c = threadIdx.x * 4; c < dim; c += 1024)
         *reinterpret_cast<float4 *>(acc_q + c) = *reinterpret_cast<const float4 *>(qpad + (uint64_t)b * dim + c);
     if (threadIdx.x == 0) qn = 0;
     __syncthreads();
-    SurvRec *recs = surv + (uint64_t)b * cap;
+    SurvRec *recs = surv + seg.at(b);
     const uint32_t hf = threadIdx.x & 1, pair = threadIdx.x >> 1;
     const float thr = thr_start[b];
     const bool test = thr > 1e-30f && thr < 3.0e38f;  // a finite, normal threshold (false for NaN / inf: everything is exact)
@@ -2442,7 +2479,7 @@ __global__ __launch_bounds__(256) void accurate_filtered_kernel(SurvRec *__restr
 // grid (gx, nq); block 256
 __global__ __launch_bounds__(256) void accurate_kernel(SurvRec *__restrict__ surv,
                                                        const unsigned long long *__restrict__ surv_cnt,
-                                                       uint32_t cap, const BaseView base,
+                                                       const QSeg seg, const BaseView base,
                                                        const float *__restrict__ qpad, uint32_t dim,
                                                        const uint32_t *__restrict__ order,
                                                        const uint32_t *__restrict__ probe_cluster, uint32_t nprobe) {
@@ -2452,21 +2489,21 @@ __global__ __launch_bounds__(256) void accurate_kernel(SurvRec *__restrict__ sur
     extern __shared__ __attribute__((aligned(16))) float acc_q[];  // dynamic LDS: dim floats (the padded query)
     const uint32_t b = order ? order[blockIdx.y] : blockIdx.y;  // consecutive blocks: queries of the same nearest list
     const uint32_t n = (uint32_t)surv_cnt[b];
-    if (n > cap || n == 0) return;  // overflowed: this query is re-run with a larger buffer
+    if (n > seg.capof(b) || n == 0) return;  // overflowed: this query is re-run with a larger buffer
     for (uint32_t c = threadIdx.x * 4; c < dim; c += 1024)
         *reinterpret_cast<float4 *>(acc_q + c) = *reinterpret_cast<const float4 *>(qpad + (uint64_t)b * dim + c);
     __syncthreads();
-    accurate_rows(surv + (uint64_t)b * cap, n, base, acc_q, dim, blockIdx.x * 128 + (threadIdx.x >> 1), gridDim.x * 128,
+    accurate_rows(surv + seg.at(b), n, base, acc_q, dim, blockIdx.x * 128 + (threadIdx.x >> 1), gridDim.x * 128,
                   probe_cluster + (uint64_t)b * nprobe);
 }
 
 __global__ __launch_bounds__(64) void sort_runs_kernel(RunRec *__restrict__ runs,
                                                         const unsigned long long *__restrict__ surv_cnt,
-                                                        uint32_t cap, uint32_t *__restrict__ big_list,
+                                                        const QSeg seg, uint32_t *__restrict__ big_list,
                                                         uint32_t *__restrict__ big_count, uint32_t list_above) {
     const uint32_t b = blockIdx.x;
     const unsigned long long c = surv_cnt[b];
-    if ((uint32_t)c > cap) return;
+    if ((uint32_t)c > seg.capof(b)) return;
     // early stages leave a few dozen runs per query, the stages around one list's worth a few hundred (more at dim 64,
     // where the estimates are noisier): 512 descriptors = 8 KiB of LDS per 64-thread block keep them out of global memory
     const uint32_t nruns = (uint32_t)(c >> 32);
@@ -2478,22 +2515,22 @@ __global__ __launch_bounds__(64) void sort_runs_kernel(RunRec *__restrict__ runs
         if (threadIdx.x == 0) big_list[atomicAdd(big_count, 1u)] = b;
         return;
     }
-    sort_segment<RunRec, 512>(runs + (uint64_t)b * cap, nruns);
+    sort_segment<RunRec, 512>(runs + seg.at(b), nruns);
 }
 
 // Directories of more than 512 runs, listed by sort_runs_kernel, are ordered by a persistent launch that walks the
 // list (it exits at once when the list is empty, the common case): slot-bucketing + per-bucket rank counting through
 // the second directory buffer; the last block out resets the counter for the next stage.
 __global__ __launch_bounds__(256) void sort_runs_mid_kernel(RunRec *__restrict__ runs, RunRec *__restrict__ runs_tmp,
-                                                            const unsigned long long *__restrict__ surv_cnt, uint32_t cap,
+                                                            const unsigned long long *__restrict__ surv_cnt, const QSeg seg,
                                                             const uint32_t *__restrict__ big_list,
                                                             uint32_t *__restrict__ big_count /* [0] entries, [1] blocks done, [2] most entries of a stage */,
                                                             uint32_t nslots) {
     const uint32_t total = big_count[0];
     for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
         const uint32_t b = big_list[i], n = (uint32_t)(surv_cnt[b] >> 32);
-        if (nslots <= 1024 && runs_tmp) sort_runs_by_slot<1024>(runs + (uint64_t)b * cap, runs_tmp + (uint64_t)b * cap, n, nslots);
-        else sort_segment<RunRec, 16>(runs + (uint64_t)b * cap, n);  // more than 1024 probe slots, or no second buffer yet: bitonic sort in global memory
+        if (nslots <= 1024 && runs_tmp) sort_runs_by_slot<1024>(runs + seg.at(b), runs_tmp + seg.at(b), n, nslots);
+        else sort_segment<RunRec, 16>(runs + seg.at(b), n);  // more than 1024 probe slots, or no second buffer yet: bitonic sort in global memory
         __syncthreads();
     }
     __syncthreads();
@@ -2509,7 +2546,7 @@ __global__ __launch_bounds__(256) void sort_runs_mid_kernel(RunRec *__restrict__
 
 template <bool HEURISTIC, bool REGHEAP = false>
 __global__ __launch_bounds__(64) void replay_kernel(const SurvRec *__restrict__ surv, const RunRec *__restrict__ runs,
-                                                    unsigned long long *__restrict__ surv_cnt, uint32_t cap, uint32_t topk,
+                                                    unsigned long long *__restrict__ surv_cnt, const QSeg seg, uint32_t topk,
                                                     ReplayState st, uint32_t dense_cells) {
     extern __shared__ __attribute__((aligned(16))) unsigned char replay_smem[];  // topk * 8 bytes (heap ranker)
     int32_t *hkey = reinterpret_cast<int32_t *>(replay_smem);
@@ -2517,27 +2554,71 @@ __global__ __launch_bounds__(64) void replay_kernel(const SurvRec *__restrict__ 
     const uint32_t b = blockIdx.x;
     const unsigned long long cnt64 = surv_cnt[b];
     const uint32_t cnt = (uint32_t)cnt64;
-    const bool overflow = cnt > cap;
+    const bool overflow = cnt > seg.capof(b);
     const uint32_t n = overflow ? 0 : cnt;
     // dense directory: every cell of the stage is a descriptor (count 0 where nothing survived), already in order
     const uint32_t nruns = overflow ? 0 : (dense_cells ? dense_cells : (uint32_t)(cnt64 >> 32));
     if (threadIdx.x == 0) {
         if (cnt > st.need[b]) st.need[b] = cnt;
+        if (overflow) st.ovf[b] = 1u;
+        if (st.early_max && !st.final_stage && cnt) atomicMax(st.early_max, (unsigned long long)cnt);
         st.nsurv[b] += n;
         surv_cnt[b] = 0;  // ready for the next stage
     }
     if (n == 0) return;
-    replay_wave<HEURISTIC, REGHEAP>(surv + (uint64_t)b * cap, runs + (uint64_t)b * cap, nruns, topk, b, st, hkey, hid);
+    replay_wave<HEURISTIC, REGHEAP>(surv + seg.at(b), runs + seg.at(b), nruns, topk, b, st, hkey, hid);
+}
+
+// Segment sizing of a pass's final stage.  surv_cnt[b] (low word) = the survivors a sampled counting scan saw for query b
+// in every stride-th tile; its segment gets room for the extrapolated count plus half of it, four standard deviations of the
+// sample (Poisson) and a floor, in units of 64 slots; the counter is cleared for the real scan.
+__global__ void seg_caps_kernel(unsigned long long *__restrict__ surv_cnt, uint32_t nq, uint32_t stride, uint32_t floor_cap,
+                                uint32_t *__restrict__ q_cap) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nq) return;
+    const unsigned long long est = (surv_cnt[b] & 0xFFFFFFFFull) * stride;
+    unsigned long long cap = est + est / 2 + 4ull * stride * (unsigned long long)(sqrtf((float)(est / stride) + 1.0f) + 1.0f) + floor_cap;
+    cap = (cap + 63ull) & ~63ull;
+    q_cap[b] = cap > 0x7FFFFFC0ull ? 0x7FFFFFC0u : (uint32_t)cap;
+    surv_cnt[b] = 0ull;
+}
+// exclusive scan of q_cap into q_base (u64); out_total[0] = the sum.  One block of 1024 threads, any nq.
+__global__ __launch_bounds__(1024) void seg_scan_kernel(const uint32_t *__restrict__ q_cap, uint32_t nq,
+                                                        unsigned long long *__restrict__ q_base, unsigned long long *__restrict__ out_total) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned long long carry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nq; base += 1024) {
+        const uint32_t i = base + tid;
+        const unsigned long long v = i < nq ? q_cap[i] : 0ull;
+        unsigned long long incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long up = __shfl_up(incl, o, 64);
+            if ((int)lane >= o) incl += up;
+        }
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        unsigned long long woff = 0;
+        for (uint32_t w = 0; w < wid; ++w) woff += wsum[w];
+        const unsigned long long c0 = carry;
+        if (i < nq) q_base[i] = c0 + woff + incl - v;
+        __syncthreads();
+        if (tid == 1023) carry = c0 + woff + incl;
+        __syncthreads();
+    }
+    if (tid == 0) out_total[0] = carry;
 }
 
 // dense run directory of a stage: cells [0, ncells) of every query start empty
-__global__ void clear_dir_kernel(RunRec *__restrict__ runs, uint32_t nq, uint32_t cap, uint32_t ncells) {
+__global__ void clear_dir_kernel(RunRec *__restrict__ runs, uint32_t nq, const QSeg seg, uint32_t ncells) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint64_t)nq * ncells) return;
     const uint32_t b = (uint32_t)(i / ncells), c = (uint32_t)(i - (uint64_t)b * ncells);
     RunRec z;
     z.pos = 0, z.slot = 0, z.base = 0, z.cnt = 0;
-    runs[(uint64_t)b * cap + c] = z;
+    runs[seg.at(b) + c] = z;
 }
 
 // ranker state of a fresh query (src/rerank.rs:70-77, :129-139) + per-query counters, one launch
@@ -2548,7 +2629,7 @@ __global__ void init_state_kernel(ReplayState st, unsigned long long *__restrict
     if (b >= nq) return;
     st.thr[b] = thr_init ? thr_init[row_map ? row_map[b] : b] : 3.402823466e+38f;  // f32::MAX
     st.recent_max[b] = -3.402823466e+38f;  // f32::MIN
-    st.heap_len[b] = 0, st.precise[b] = 0, st.need[b] = 0, st.nsurv[b] = 0, st.nshadow[b] = 0, st.win_count[b] = 0, st.arr_len[b] = 0;
+    st.heap_len[b] = 0, st.precise[b] = 0, st.need[b] = 0, st.ovf[b] = 0, st.nsurv[b] = 0, st.nshadow[b] = 0, st.win_count[b] = 0, st.arr_len[b] = 0;
     surv_cnt[b] = 0;
 }
 
@@ -2599,14 +2680,14 @@ __global__ __launch_bounds__(256) void metrics_sum_kernel(const unsigned long lo
                                                           const uint32_t *__restrict__ arr_len,
                                                           const uint32_t *__restrict__ nsurv,
                                                           const uint32_t *__restrict__ nshadow, uint32_t nq,
-                                                          uint32_t cap, uint32_t hcap,
+                                                          const uint32_t *__restrict__ ovf, uint32_t hcap,
                                                           unsigned long long *__restrict__ out4) {
     __shared__ unsigned long long s[6];
     if (threadIdx.x < 6) s[threadIdx.x] = 0;
     __syncthreads();
     unsigned long long r = 0, p = 0, o = 0, a = 0, mx = 0, sh = 0;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) {
-        const bool ok = need[i] <= cap && (!arr_len || arr_len[i] <= hcap);
+        const bool ok = !ovf[i] && (!arr_len || arr_len[i] <= hcap);
         r += rough[i];
         p += ok ? precise[i] : 0;
         o += ok ? 0 : 1;

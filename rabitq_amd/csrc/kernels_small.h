@@ -362,7 +362,7 @@ __device__ __forceinline__ void sb_write_results(const ReplayState &st, uint32_t
     if (lane == 0) {
         out_n[b] = len;
         const uint32_t need = st.need[sb];
-        const bool ok = need <= cap;
+        const bool ok = !st.ovf[sb];
         atomicAdd(totals + 0, rough);
         if (ok) atomicAdd(totals + 1, (unsigned long long)st.precise[sb]);
         else atomicAdd(totals + 2, 1ull);
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(1024) void sb_query_kernel(const SbArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_pl[4][2 * W];  // the query's four bit planes (src/simd.rs:83-107), dword w <-> dimensions 32w..32w+31
     __shared__ uint32_t wcnt[4][16];
     __shared__ float s_thr, s_recent;
-    __shared__ uint32_t s_hlen, s_precise, s_need, s_nsurv, s_nshadow, s_wcount, s_alen;
+    __shared__ uint32_t s_hlen, s_precise, s_need, s_nsurv, s_nshadow, s_wcount, s_alen, s_ovf;
     const uint32_t b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t k = a.k, dim = a.dim, nprobe = a.nprobe, topk = a.topk;
     uint32_t n_stamp = 0;
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(1024) void sb_query_kernel(const SbArgs a) {
     for (uint32_t c = t * 4; c < dim; c += 4096) *reinterpret_cast<float4 *>(qv + c) = *reinterpret_cast<const float4 *>(a.qpad + (uint64_t)b * dim + c);
     if (t == 0) {  // ranker state of a fresh query (src/rerank.rs:70-77, :129-139)
         s_thr = 3.402823466e+38f, s_recent = -3.402823466e+38f;
-        s_hlen = 0, s_precise = 0, s_need = 0, s_nsurv = 0, s_nshadow = 0, s_wcount = 0, s_alen = 0;
+        s_hlen = 0, s_precise = 0, s_need = 0, s_nsurv = 0, s_nshadow = 0, s_wcount = 0, s_alen = 0, s_ovf = 0;
         a.surv_cnt[b] = 0ull;
     }
     __syncthreads();
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(1024) void sb_query_kernel(const SbArgs a) {
     // ---- the early part of the stream, stage by stage, all in LDS -----------------------------------------------------
     ReplayState ls;
     ls.thr = &s_thr, ls.heap_len = &s_hlen, ls.heap_key = hk_state, ls.heap_id = hi_state, ls.precise = &s_precise;
-    ls.need = &s_need, ls.nsurv = &s_nsurv, ls.nshadow = &s_nshadow, ls.recent_max = &s_recent, ls.win_count = &s_wcount;
+    ls.need = &s_need, ls.ovf = &s_ovf, ls.early_max = nullptr, ls.final_stage = 0, ls.nsurv = &s_nsurv, ls.nshadow = &s_nshadow, ls.recent_max = &s_recent, ls.win_count = &s_wcount;
     ls.arr_len = &s_alen, ls.arr = a.rs.arr + (uint64_t)b * a.hcap, ls.hcap = a.hcap;
     uint32_t n = 0;  // survivors waiting in `recs` (block-uniform)
     // re-rank the waiting survivors (src/rerank.rs:85-90) and replay the ranker over them (:81-106 / :143-168); they
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(1024) void sb_query_kernel(const SbArgs a) {
     if (t == 0) {
         a.rs.thr[b] = s_thr, a.rs.recent_max[b] = s_recent;
         a.rs.heap_len[b] = s_hlen, a.rs.precise[b] = s_precise, a.rs.need[b] = s_need, a.rs.nsurv[b] = s_nsurv;
-        a.rs.nshadow[b] = 0, a.rs.win_count[b] = s_wcount, a.rs.arr_len[b] = s_alen;
+        a.rs.nshadow[b] = 0, a.rs.win_count[b] = s_wcount, a.rs.arr_len[b] = s_alen, a.rs.ovf[b] = 0;
     }
     if (a.fill_final) {  // the final stage's pair-major work records: what stage_fill_kernel would write
         __syncthreads();
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(1024) void sb_query_kernel(const SbArgs a) {
 // ------------------------------------------------------------------------------------------------
 template <bool REGHEAP>
 __global__ __launch_bounds__(1024) void sb_finish_kernel(SurvRec *__restrict__ surv, RunRec *__restrict__ runs,
-                                                         unsigned long long *__restrict__ surv_cnt, uint32_t cap,
+                                                         unsigned long long *__restrict__ surv_cnt, const QSeg seg,
                                                          const BaseView base, const float *__restrict__ qpad, uint32_t dim,
                                                          uint32_t topk, ReplayState st, const uint32_t *__restrict__ probe_cluster,
                                                          uint32_t nprobe, uint32_t presorted, const uint32_t *__restrict__ map_ids,
@@ -599,25 +599,28 @@ __global__ __launch_bounds__(1024) void sb_finish_kernel(SurvRec *__restrict__ s
     const uint32_t b = blockIdx.x;
     const unsigned long long cnt64 = surv_cnt[b];
     const uint32_t cnt = (uint32_t)cnt64;
+    const uint32_t cap = seg.capof(b);
+    const uint64_t qat = seg.at(b);
     const bool overflow = cnt > cap;  // records were dropped: the query is re-run with a larger buffer
     const uint32_t n = overflow ? 0 : cnt;
     const uint32_t nruns = overflow ? 0 : (uint32_t)(cnt64 >> 32);
     __syncthreads();  // every thread has read the counter before thread 0 resets it
     if (threadIdx.x == 0) {
         if (cnt > st.need[b]) st.need[b] = cnt;
+        if (overflow) st.ovf[b] = 1u;
         st.nsurv[b] += n;
         surv_cnt[b] = 0;
     }
     if (n) {  // block-uniform
-        SurvRec *recs = surv + (uint64_t)b * cap;
+        SurvRec *recs = surv + qat;
         for (uint32_t c = threadIdx.x * 4; c < dim; c += blockDim.x * 4)
             *reinterpret_cast<float4 *>(fin_q + c) = *reinterpret_cast<const float4 *>(qpad + (uint64_t)b * dim + c);
         __syncthreads();
         if (!(presorted & 2u))  // bit 1: the exact distances were computed by a whole-chip launch already
             accurate_rows(recs, n, base, fin_q, dim, threadIdx.x >> 1, blockDim.x >> 1, probe_cluster + (uint64_t)b * nprobe);
-        if (nruns <= RQ_SORT_LDS_RECS || !(presorted & 1u)) sort_segment(runs + (uint64_t)b * cap, nruns);
+        if (nruns <= RQ_SORT_LDS_RECS || !(presorted & 1u)) sort_segment(runs + qat, nruns);
         __syncthreads();
-        if (threadIdx.x < 64) replay_wave<false, REGHEAP>(recs, runs + (uint64_t)b * cap, nruns, topk, b, st, hkey, hid);
+        if (threadIdx.x < 64) replay_wave<false, REGHEAP>(recs, runs + qat, nruns, topk, b, st, hkey, hid);
     }
     __threadfence_block();  // the state lane 0 (and the heap's lanes) stored is read back by the other lanes of the wave below
     if (threadIdx.x < 64)  // the same wave that wrote the state (and thread 0's counter updates above): program order

@@ -205,6 +205,8 @@ struct Workspace {
     bool busy = false;
     // context of a pass that has been enqueued but not yet finished (finish_pass)
     size_t pend_total_span = 0;
+    uint64_t pend_seg_slots = 0;  // slots of the final stage's segments (0: uniform geometry)
+    uint32_t pend_cap = 0;        // uniform capacity of the pass
     uint32_t pend_nq = 0;
     std::vector<StreamRange> pend_matrix_ranges;  // stream ranges scanned on the matrix cores (profiling only)
     DevBuf<float> qpad, y, dist, probe_dist, thr, recent;
@@ -227,6 +229,8 @@ struct Workspace {
     DevBuf<float> sh_dist;
     DevBuf<uint32_t> sh_id, sh_n;
     DevBuf<unsigned long long> sh_packed, sh_gathered, sh_merged;
+    DevBuf<uint32_t> ovf, q_cap;               // per query: overflow flag; segment capacity of the final stage (segmented passes)
+    DevBuf<unsigned long long> q_base;         // per query: first slot of its segment
     DevBuf<uint32_t> sh_flag;                 // handshake / status words of the step
     DevBuf<uint32_t> sh_pc, sh_id_b, sh_n_b;  // shared-threshold step: probe lists (whole | nearest | rest), second call's results
     DevBuf<float> sh_pd, sh_thr, sh_dist_b;
@@ -263,6 +267,7 @@ struct rq_index {
     std::vector<std::unique_ptr<Workspace>> ws_pool;
     FactorStats fstats{0, 0, 0, 0};
     std::atomic<uint32_t> cap_hint{0};  // survivor-buffer capacity learnt from earlier batches
+    std::atomic<uint32_t> early_cap_hint{0};  // the same for the stages before the final one (segmented passes size the final stage per query)
     std::atomic<uint32_t> big_dirs_hint{0};  // most long run directories (> 512 runs) a stage of a recent pass produced
     uint64_t pass_budget = 24ull << 30;  // bytes of survivor / run buffers one query pass may use (set by finish_index)
     // tile tables of the cluster-major scans: per tile size, one {list, first, list begin, list length} entry per
@@ -487,6 +492,7 @@ static std::atomic<int> g_scan_tile_table{1};  // 0 = plain (list x tile) grids 
 static std::atomic<int> g_group_rank{1};  // group_rank_kernel for cluster-major stages: 0 never, 1 big stages, 2 always
 static std::atomic<int> g_shared_thr{1};  // rq_query_batch_sharded_device: thresholds shared between the shards (0 never, 1 world > 1, 2 always)
 static std::atomic<int> g_sb_span{2560};  // developer knob: stream positions a query's block scans itself at most (small-batch path)
+static std::atomic<int> g_seg_opt{1};  // per-query survivor segments in the final stage: 0 never, 1 once the index has shown that the default capacity overflows, 2 every large batch (tests)
 static std::atomic<int> g_small_batch{0};  // small-batch path (kernels_small.h): 0 = whenever it applies (default), 1 = never (test hook)
 static std::atomic<int> g_dense_dir{1};  // dense run directories for the VALU stages of large batches (0 = always append + sort: test hook)
 
@@ -616,6 +622,9 @@ struct QueryParams {
     // Seeded pass (rq_query_batch_device_seeded): per-query initial thresholds (device; f32::MAX = none).  A first pass
     // runs the whole stream as ONE stage under them; an overflow re-run (row map given) starts from them and stages as usual.
     const float *thr_init = nullptr;
+    // Segmented pass: `cap` bounds the early stages only; the final stage's survivors go to per-query segments sized by a
+    // sampled counting scan (the workspace then scales with the sum of the survivors instead of nq x the worst query)
+    bool seg_final = false;
 };
 
 #define RQ_DEFAULT_CAP 4096u
@@ -652,7 +661,7 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
     RQC(ws.runs.ensure(nq * qp.cap));
     // second run directory, through which long directories (> 512 runs) are ordered: only once the index has shown
     // that it produces them (or with enlarged buffers); until then a stray long directory is bitonic-sorted in place
-    ws.use_runs_tmp = qp.cap > RQ_DEFAULT_CAP || idx->big_dirs_hint.load() > 0;
+    ws.use_runs_tmp = qp.cap > RQ_DEFAULT_CAP || qp.seg_final || idx->big_dirs_hint.load() > 0;
     if (ws.use_runs_tmp) RQC(ws.runs_tmp.ensure(nq * qp.cap));
     RQC(ws.surv_cnt.ensure(nq));
     RQC(ws.heap_len.ensure(nq));
@@ -660,6 +669,9 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
     RQC(ws.heap_id.ensure(nq * qp.topk));
     RQC(ws.precise.ensure(nq));
     RQC(ws.need.ensure(nq));
+    RQC(ws.ovf.ensure(nq));
+    RQC(ws.q_cap.ensure(nq));
+    RQC(ws.q_base.ensure(nq));
     RQC(ws.nsurv.ensure(nq));
     RQC(ws.nshadow.ensure(nq));
     RQC(ws.recent.ensure(nq));
@@ -672,7 +684,7 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
 }
 
 struct PassResult {
-    uint64_t rough = 0, precise = 0, overflowed = 0, max_need = 0;
+    uint64_t rough = 0, precise = 0, overflowed = 0, max_need = 0, early_max = 0;
 };
 
 // Second half of a pass: wait for the stream, read the totals, collect the profile.
@@ -685,6 +697,7 @@ static rq_status finish_pass(const rq_index *idx, Workspace &ws, PassResult *res
     res->precise = ws.h_totals[1];
     res->overflowed = ws.h_totals[2];
     res->max_need = ws.h_totals[4];
+    res->early_max = ws.h_totals[6];
     if (nq >= 256) const_cast<rq_index *>(idx)->big_dirs_hint.store((uint32_t)ws.h_totals[7]);
     if (pf.on && prof_acc) {
         float ms[PF_N] = {0};
@@ -703,6 +716,9 @@ static rq_status finish_pass(const rq_index *idx, Workspace &ws, PassResult *res
         prof_acc->ms_replay += ms[PF_REPLAY], prof_acc->ms_total += ms[PF_TOTAL], prof_acc->ms_early += ms[PF_EARLY];
     }
     if (prof_acc) {
+        const uint64_t slots = std::max<uint64_t>((uint64_t)nq * ws.pend_cap, ws.pend_seg_slots);
+        prof_acc->survivor_workspace_bytes = std::max<uint64_t>(prof_acc->survivor_workspace_bytes, slots * (ws.use_runs_tmp ? 48ull : 32ull));
+        prof_acc->segmented_passes += ws.pend_seg_slots ? 1u : 0u;
         prof_acc->scan_candidates += res->rough;
         prof_acc->scan_bytes += res->rough * (uint64_t)(dim / 8 + 16);
         prof_acc->rerank_candidates += ws.h_totals[3];
@@ -791,6 +807,8 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     rs.thr = ws.thr.p, rs.heap_len = ws.heap_len.p, rs.heap_key = ws.heap_key.p, rs.heap_id = ws.heap_id.p;
     rs.precise = ws.precise.p, rs.need = ws.need.p, rs.nsurv = ws.nsurv.p, rs.nshadow = ws.nshadow.p, rs.recent_max = ws.recent.p, rs.win_count = ws.win_count.p;
     rs.arr_len = ws.arr_len.p, rs.arr = ws.arr.p, rs.hcap = qp.hcap;
+    rs.ovf = ws.ovf.p, rs.early_max = ws.totals.p + 6, rs.final_stage = 0;
+    const QSeg useg{nullptr, nullptr, qp.cap};  // uniform geometry: every stage but a segmented final one
     const float *qpad = d_q;
     const uint32_t *probe_cluster = ws.probe_cluster.p;
     const float *probe_dist = ws.probe_dist.p;
@@ -937,6 +955,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     }
     }  // !small
     ws.pend_matrix_ranges.clear();
+    ws.pend_seg_slots = 0;
     // persistent blocks of the long-directory ordering: sized by how many such directories recent passes produced
     const uint32_t big_hint = idx->big_dirs_hint.load();
     const uint32_t mid_blocks = big_hint == 0 ? 64u : std::min(4096u, std::max(256u, big_hint / 4));
@@ -1031,8 +1050,45 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         a.dense_dir = dense_cells ? 1u : 0u;
         if (dense_cells) {
             pf.begin(PF_SORT);
-            clear_dir_kernel<<<ceil_div((uint64_t)nq * dense_cells, 256), 256, 0, st>>>(ws.runs.p, nq, qp.cap, dense_cells);
+            clear_dir_kernel<<<ceil_div((uint64_t)nq * dense_cells, 256), 256, 0, st>>>(ws.runs.p, nq, useg, dense_cells);
             pf.end();
+        }
+        // Segmented final stage: a sampled counting scan (every 16th tile, nothing recorded) sizes a segment per query, an
+        // exclusive scan places them, the host makes room for their sum, then the real scan records into the segments.
+        const bool is_last = &sg == &stages.back();
+        rs.final_stage = is_last ? 1u : 0u;
+        QSeg seg = useg;
+        if (qp.seg_final && is_last && scan_is_fused(W) && nq >= 256) {
+            pf.begin(use_mfma ? PF_SCAN_MATRIX : PF_SCAN);
+            ScanArgs ca = a;
+            ca.count_only = 1u, ca.tile_stride = 16u;
+            if (use_mfma) launch_scan_mfma(sp, ca, W, st);
+            else launch_scan(sp, ca, W, st);
+            pf.end();
+            pf.begin(PF_GROUP);
+            seg_caps_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(ws.surv_cnt.p, nq, 16u, 256u, ws.q_cap.p);
+            seg_scan_kernel<<<1, 1024, 0, st>>>(ws.q_cap.p, nq, ws.q_base.p, ws.totals.p + 7);
+            unsigned long long total_slots = 0;
+            HIPC(hipMemcpyAsync(&total_slots, ws.totals.p + 7, 8, hipMemcpyDeviceToHost, st));
+            HIPC(hipStreamSynchronize(st));
+            pf.end();
+            bool room = total_slots <= ws.surv.count && total_slots <= ws.runs.count && (!ws.use_runs_tmp || total_slots <= ws.runs_tmp.count);
+            if (!room && total_slots * 48ull <= idx->pass_budget * 2) {  // grow (with headroom: the next batches differ a little)
+                const uint64_t want = total_slots + total_slots / 8;
+                room = ws.surv.ensure(want) == RQ_OK && ws.runs.ensure(want) == RQ_OK && (!ws.use_runs_tmp || ws.runs_tmp.ensure(want) == RQ_OK);
+                if (!room) (void)hipGetLastError();
+                sp.surv = ws.surv.p, sp.runs = ws.runs.p;
+            }
+            if (room && ws.surv.p && ws.runs.p) {
+                seg = QSeg{ws.q_base.p, ws.q_cap.p, qp.cap};
+                a.seg_base = ws.q_base.p, a.seg_cap = ws.q_cap.p;
+                ws.pend_seg_slots = total_slots;
+            } else {  // no room for the segments: the uniform geometry (queries beyond it are re-run, as without segments)
+                RQC(ws.surv.ensure((uint64_t)nq * qp.cap));
+                RQC(ws.runs.ensure((uint64_t)nq * qp.cap));
+                if (ws.use_runs_tmp) RQC(ws.runs_tmp.ensure((uint64_t)nq * qp.cap));
+                sp.surv = ws.surv.p, sp.runs = ws.runs.p;
+            }
         }
         pf.begin(use_mfma ? PF_SCAN_MATRIX : PF_SCAN);
         if (use_mfma) launch_scan_mfma(sp, a, W, st);
@@ -1054,8 +1110,8 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             // only what fits its LDS
             const uint32_t presorted = qp.cap > RQ_DEFAULT_CAP && nprobe <= 1024 ? 1u : 0u;
             if (presorted) {
-                sort_runs_kernel<<<nq, 64, 0, st>>>(ws.runs.p, ws.surv_cnt.p, qp.cap, ws.big_list.p, ws.big_list.p + nq, RQ_SORT_LDS_RECS);
-                sort_runs_mid_kernel<<<std::min(nq, 256u), 256, 0, st>>>(ws.runs.p, ws.use_runs_tmp ? ws.runs_tmp.p : nullptr, ws.surv_cnt.p, qp.cap, ws.big_list.p,
+                sort_runs_kernel<<<nq, 64, 0, st>>>(ws.runs.p, ws.surv_cnt.p, seg, ws.big_list.p, ws.big_list.p + nq, RQ_SORT_LDS_RECS);
+                sort_runs_mid_kernel<<<std::min(nq, 256u), 256, 0, st>>>(ws.runs.p, ws.use_runs_tmp ? ws.runs_tmp.p : nullptr, ws.surv_cnt.p, seg, ws.big_list.p,
                                                                          ws.big_list.p + nq, nprobe);
             }
             if (sb_fused_finish) {  // small-batch path, heap ranker: the stage's finish also writes the results and the totals
@@ -1064,24 +1120,24 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                 uint32_t flags = presorted;
                 if (nq <= 32) {
                     accurate_kernel<<<dim3(std::max(1u, std::min(16u, 256u / nq)), nq), 256, (size_t)dim * sizeof(float), st>>>(
-                        ws.surv.p, ws.surv_cnt.p, qp.cap, idx->view(), qpad, dim, nullptr, probe_cluster, nprobe);
+                        ws.surv.p, ws.surv_cnt.p, seg, idx->view(), qpad, dim, nullptr, probe_cluster, nprobe);
                     flags |= 2u;
                 }
                 const uint32_t presorted = flags;
                 if (topk < 64)
                     sb_finish_kernel<true><<<nq, fin_threads, (size_t)dim * sizeof(float), st>>>(
-                        ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->view(), qpad, dim, topk, rs, probe_cluster, nprobe, presorted,
+                        ws.surv.p, ws.runs.p, ws.surv_cnt.p, seg, idx->view(), qpad, dim, topk, rs, probe_cluster, nprobe, presorted,
                         idx->map_ids.p, d_out_dist, d_out_id, d_out_n, ws.rough_cnt.p, ws.totals.p);
                 else
                     sb_finish_kernel<false><<<nq, fin_threads, (size_t)dim * sizeof(float), st>>>(
-                        ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->view(), qpad, dim, topk, rs, probe_cluster, nprobe, presorted,
+                        ws.surv.p, ws.runs.p, ws.surv_cnt.p, seg, idx->view(), qpad, dim, topk, rs, probe_cluster, nprobe, presorted,
                         idx->map_ids.p, d_out_dist, d_out_id, d_out_n, ws.rough_cnt.p, ws.totals.p);
                 sb_results_done = true;
             } else if (qp.heuristic)
-                stage_finish_kernel<true><<<nq, fin_threads, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->view(),
+                stage_finish_kernel<true><<<nq, fin_threads, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, seg, idx->view(),
                                                               qpad, dim, topk, rs, probe_cluster, nprobe, presorted);
             else
-                stage_finish_kernel<false><<<nq, fin_threads, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, idx->view(),
+                stage_finish_kernel<false><<<nq, fin_threads, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, seg, idx->view(),
                                                                qpad, dim, topk, rs, probe_cluster, nprobe, presorted);
             pf.end();
         } else {  // large batch: full-chip rerank, then run-directory sort, then one replay wave per query
@@ -1090,27 +1146,27 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             // past the first stage the thresholds are finite: survivors go through the fp16 shadow rows first
             if (idx->base_h.p && (stage_no > 0 || qp.thr_init) && !(g_scan_dbg & 512))
                 accurate_filtered_kernel<<<dim3(gx, nq), 256, (size_t)dim * sizeof(float), st>>>(
-                    ws.surv.p, ws.surv_cnt.p, qp.cap, idx->base.p, idx->base_h.p, qpad, dim, rerank_order, ws.thr.p,
+                    ws.surv.p, ws.surv_cnt.p, seg, idx->base.p, idx->base_h.p, qpad, dim, rerank_order, ws.thr.p,
                     ws.nshadow.p);
             else
-                accurate_kernel<<<dim3(gx, nq), 256, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.surv_cnt.p, qp.cap, idx->view(), qpad, dim,
+                accurate_kernel<<<dim3(gx, nq), 256, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.surv_cnt.p, seg, idx->view(), qpad, dim,
                                                                                         rerank_order, probe_cluster, nprobe);
             pf.end();
             if (!dense_cells) {
                 pf.begin(PF_SORT);
-                sort_runs_kernel<<<nq, 64, 0, st>>>(ws.runs.p, ws.surv_cnt.p, qp.cap, ws.big_list.p, ws.big_list.p + nq, 512u);
+                sort_runs_kernel<<<nq, 64, 0, st>>>(ws.runs.p, ws.surv_cnt.p, seg, ws.big_list.p, ws.big_list.p + nq, 512u);
                 // queries with long run directories (loose thresholds): slot-bucketed ordering, persistent blocks walking the list
-                sort_runs_mid_kernel<<<mid_blocks, 256, 0, st>>>(ws.runs.p, ws.use_runs_tmp ? ws.runs_tmp.p : nullptr, ws.surv_cnt.p, qp.cap, ws.big_list.p,
+                sort_runs_mid_kernel<<<mid_blocks, 256, 0, st>>>(ws.runs.p, ws.use_runs_tmp ? ws.runs_tmp.p : nullptr, ws.surv_cnt.p, seg, ws.big_list.p,
                                                              ws.big_list.p + nq, nprobe);
                 pf.end();
             }
             pf.begin(PF_REPLAY);
             if (qp.heuristic)
-                replay_kernel<true><<<nq, 64, 16, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, topk, rs, dense_cells);
+                replay_kernel<true><<<nq, 64, 16, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, seg, topk, rs, dense_cells);
             else if (topk < 64)  // the heap in registers, one element per lane (a push before a pop holds topk + 1 elements)
-                replay_kernel<false, true><<<nq, 64, 16, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, topk, rs, dense_cells);
+                replay_kernel<false, true><<<nq, 64, 16, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, seg, topk, rs, dense_cells);
             else
-                replay_kernel<false><<<nq, 64, (size_t)topk * 8, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, qp.cap, topk, rs, dense_cells);
+                replay_kernel<false><<<nq, 64, (size_t)topk * 8, st>>>(ws.surv.p, ws.runs.p, ws.surv_cnt.p, seg, topk, rs, dense_cells);
             pf.end();
         }
     }
@@ -1129,7 +1185,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                                                                                   d_out_id, d_out_n);
     }
     metrics_sum_kernel<<<std::min(256u, ceil_div(nq, 256)), 256, 0, st>>>(
-        ws.rough_cnt.p, ws.precise.p, ws.need.p, qp.heuristic ? ws.arr_len.p : nullptr, ws.nsurv.p, ws.nshadow.p, nq, qp.cap, qp.hcap,
+        ws.rough_cnt.p, ws.precise.p, ws.need.p, qp.heuristic ? ws.arr_len.p : nullptr, ws.nsurv.p, ws.nshadow.p, nq, ws.ovf.p, qp.hcap,
         ws.totals.p);
     }
     pf.end();
@@ -1139,6 +1195,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     HIPC(hipMemcpyAsync(ws.h_totals + 7, ws.big_list.p + nq + 2, 4, hipMemcpyDeviceToHost, st));
     ws.pend_total_span = total_span;
     ws.pend_nq = nq;
+    ws.pend_cap = qp.cap;
     if (defer) return RQ_OK;  // the caller finishes the pass later (rq_query_batch_device_end)
     return finish_pass(idx, ws, res, prof_acc);
 }
@@ -1174,6 +1231,18 @@ static rq_status validate_query(const rq_index *idx, const float *d_q, uint32_t 
     return RQ_OK;
 }
 
+// Uniform survivor capacity of a pass over `remaining` queries, and whether its final stage is segmented.  An index whose
+// batches overflowed the default capacity (cap_hint) used to size EVERY query of a pass for the worst one (learnt capacity
+// 32 768: 100 GB for a 65 536-query pass of the hard benchmark distribution); large batches now keep the uniform
+// capacity for the stages before the final one (early_cap_hint) and give the final stage per-query segments.
+static uint32_t pass_capacity(const rq_index *idx, uint32_t remaining, bool seeded, bool *seg) {
+    const uint32_t hint = idx->cap_hint.load();
+    const int opt = g_seg_opt.load();
+    *seg = !seeded && remaining >= 256 && scan_is_fused(idx->W) && (opt == 2 || (opt == 1 && hint > RQ_DEFAULT_CAP));
+    if (*seg) return std::max(RQ_DEFAULT_CAP, idx->early_cap_hint.load());
+    return std::max(RQ_DEFAULT_CAP, hint);
+}
+
 // queries per pass: survivor / run buffers are 32 B per slot per query (keep one pass under ~24 GiB) and
 // (query, list) pairs per pass <= 2^22 (bounds the per-pair buffers and every launch size)
 static uint32_t pass_queries(const rq_index *idx, uint32_t remaining, uint32_t probe, uint32_t cap0) {
@@ -1192,6 +1261,11 @@ static rq_status after_pass(rq_index *idx, Workspace *ws, const QueryParams &qp,
     const uint32_t len = qp.len, probe = qp.probe, topk = qp.topk;
     const bool heuristic = qp.heuristic;
     const uint32_t npb = std::min(probe, idx->k);
+    if (pr.early_max > RQ_DEFAULT_CAP) {  // the capacity the stages before the final one need (segmented passes use it as their uniform bound)
+        const uint32_t want = pow2_ceil((uint32_t)std::min<uint64_t>(pr.early_max + pr.early_max / 4, RQ_MAX_CAP_HINT));
+        uint32_t cur = idx->early_cap_hint.load();
+        while (cur < want && !idx->early_cap_hint.compare_exchange_weak(cur, want)) {}
+    }
     if (pr.max_need > qp.cap) {  // remember (with headroom) so that later batches do not overflow
         // ... but only up to RQ_MAX_CAP_HINT: survivor buffers are cap x 32 B for EVERY query of the pass, so one outlier
         // query (a loose threshold after an unlucky nearest list) must not shrink the passes of all later batches; beyond
@@ -1202,12 +1276,13 @@ static rq_status after_pass(rq_index *idx, Workspace *ws, const QueryParams &qp,
     }
     if (!pr.overflowed) return RQ_OK;
     uint32_t cap = qp.cap, hcap = qp.hcap;
-    std::vector<uint32_t> h_need(qp.nq), h_alen(qp.nq), over_rows;
+    std::vector<uint32_t> h_need(qp.nq), h_alen(qp.nq), h_ovf(qp.nq), over_rows;
     HIPC(hipMemcpy(h_need.data(), ws->need.p, qp.nq * 4, hipMemcpyDeviceToHost));
     HIPC(hipMemcpy(h_alen.data(), ws->arr_len.p, qp.nq * 4, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(h_ovf.data(), ws->ovf.p, qp.nq * 4, hipMemcpyDeviceToHost));
     uint32_t max_need = 0, max_alen = 0;
     for (uint32_t b = 0; b < qp.nq; ++b)
-        if (h_need[b] > cap || (heuristic && h_alen[b] > hcap)) {
+        if (h_ovf[b] || (heuristic && h_alen[b] > hcap)) {
             over_rows.push_back(b);
             max_need = std::max(max_need, h_need[b]);
             max_alen = std::max(max_alen, h_alen[b]);
@@ -1257,11 +1332,12 @@ static rq_status after_pass(rq_index *idx, Workspace *ws, const QueryParams &qp,
             RQC(run_pass(idx, rws, sub_q.p, rq, sub_rows.p, d_out_dist, d_out_id, d_out_n, &rr, nullptr, sub_pc, sub_pd));
             tot_precise += rr.precise;
             if (rr.overflowed) {
-                std::vector<uint32_t> n2(m), a2(m);
+                std::vector<uint32_t> n2(m), a2(m), o2(m);
                 HIPC(hipMemcpy(n2.data(), rws.need.p, m * 4, hipMemcpyDeviceToHost));
                 HIPC(hipMemcpy(a2.data(), rws.arr_len.p, m * 4, hipMemcpyDeviceToHost));
+                HIPC(hipMemcpy(o2.data(), rws.ovf.p, m * 4, hipMemcpyDeviceToHost));
                 for (uint32_t b = 0; b < m; ++b)
-                    if (n2[b] > ncap || (heuristic && a2[b] > nhcap)) {
+                    if (o2[b] || (heuristic && a2[b] > nhcap)) {
                         still.push_back(over_rows[o + b]);
                         max_need = std::max(max_need, n2[b]);
                         max_alen = std::max(max_alen, a2[b]);
@@ -1312,9 +1388,11 @@ static rq_status query_device(rq_index *idx, const float *d_q, uint32_t nq, uint
     uint64_t tot_rough = 0, tot_precise = 0;
     const uint32_t npb = std::min(probe, idx->k);
     for (uint32_t q0 = 0, step_nq = 0; q0 < nq; q0 += step_nq) {
-        const uint32_t cap0 = std::max(RQ_DEFAULT_CAP, idx->cap_hint.load());
+        bool seg = false;
+        const uint32_t cap0 = pass_capacity(idx, nq - q0, ext_thr != nullptr, &seg);
         step_nq = pass_queries(idx, nq - q0, probe, cap0);
-        QueryParams qp{step_nq, len, probe, topk, heuristic, cap0, cap0};
+        QueryParams qp{step_nq, len, probe, topk, heuristic, cap0, std::max(cap0, std::max(RQ_DEFAULT_CAP, idx->cap_hint.load()))};
+        qp.seg_final = seg && step_nq >= 256;
         qp.thr_init = ext_thr ? ext_thr + q0 : nullptr;
         RQC(ws_prepare(idx, *ws, qp));
         PassResult pr;
@@ -1357,14 +1435,16 @@ static rq_status query_device_begin(rq_index *idx, const float *d_q, uint32_t nq
     std::unique_ptr<rq_ticket> t(new rq_ticket());
     t->idx = idx;
     memset(&t->prof, 0, sizeof t->prof);
-    const uint32_t cap0 = std::max(RQ_DEFAULT_CAP, idx->cap_hint.load());
+    bool seg = false;
+    const uint32_t cap0 = pass_capacity(idx, nq, false, &seg);
     if (nq == 0 || pass_queries(idx, nq, probe, cap0) < nq) {  // nothing to overlap / several passes: synchronous
         t->status = query_device(idx, d_q, nq, len, probe, topk, heuristic, d_out_dist, d_out_id, d_out_n);
         t->done = true;
         *out = t.release();
         return RQ_OK;
     }
-    t->qp = QueryParams{nq, len, probe, topk, heuristic, cap0, cap0};
+    t->qp = QueryParams{nq, len, probe, topk, heuristic, cap0, std::max(cap0, std::max(RQ_DEFAULT_CAP, idx->cap_hint.load()))};
+    t->qp.seg_final = seg && nq >= 256;
     t->d_q = d_q, t->d_out_dist = d_out_dist, t->d_out_id = d_out_id, t->d_out_n = d_out_n;
     t->ws = ws_acquire(idx);
     rq_status st = ws_prepare(idx, *t->ws, t->qp);
@@ -2810,6 +2890,7 @@ static void profile_add(rq_profile_t &acc, const rq_profile_t &x) {
     acc.matrix_pairs += x.matrix_pairs, acc.matrix_subtile_steps += x.matrix_subtile_steps;
     acc.matrix_exact_steps += x.matrix_exact_steps, acc.rerank_shadow_rejects += x.rerank_shadow_rejects;
     acc.ms_early += x.ms_early, acc.small_batch_passes += x.small_batch_passes;
+    acc.survivor_workspace_bytes = std::max(acc.survivor_workspace_bytes, x.survivor_workspace_bytes), acc.segmented_passes += x.segmented_passes;
 }
 
 // probe lists <-> merge keys (f32 distance bits << 32 | list id: distances are >= 0, so the bits order like the values;
@@ -3088,6 +3169,11 @@ rq_status rq_set_option(const char *name, int value) {
     if (std::string(name) == "coarse_impl") {  // test hook: coarse-distance kernel (0 auto, 1 LDS broadcast, 2 scalar registers)
         if (value < 0 || value > 2) return fail(RQ_ERR_INVALID, "coarse_impl must be 0, 1 or 2");
         g_coarse_impl = value;
+        return RQ_OK;
+    }
+    if (std::string(name) == "survivor_segments") {  // 0 never, 1 automatic (default), 2 every batch of >= 256 queries (tests)
+        if (value < 0 || value > 2) return fail(RQ_ERR_INVALID, "survivor_segments must be 0, 1 or 2");
+        g_seg_opt = value;
         return RQ_OK;
     }
     if (std::string(name) == "assign_impl") {  // nearest-list assignment of builds started from now on: 0 = matrix-core pre-filter + exact refinement, 1 = exact-order VALU kernels only

@@ -1189,6 +1189,56 @@ def test_streamed_builder_equals_one_shot_build(rq, oracle, d, budget):
     oidx.close()
 
 
+def test_segmented_final_stage_matches_oracle(rq, oracle):
+    """Per-query survivor segments (option survivor_segments): a batch whose queries leave very different numbers of
+    survivors -- most a few dozen, some tens of thousands (queries at the data's radius in one long list, deep top-k) -- gets
+    its final stage sized per query by a sampled counting scan instead of one capacity for all.  Forced (2) from the first
+    call and automatic (1: after the default capacity has overflowed once); both scan implementations; the workspace of the
+    segmented pass is a fraction of the uniform one; results bit-identical to the oracle in every mode."""
+    from rabitq_amd import index as ix
+    n, d, k = 300_000, 64, 6
+    rng = np.random.default_rng(33)
+    centres = (rng.standard_normal((k, d)) * 4.0).astype(np.float32)
+    sizes = np.array([0.8, 0.04, 0.04, 0.04, 0.04, 0.04])
+    lab = rng.choice(k, n, p=sizes)
+    x = (centres[lab] + rng.standard_normal((n, d))).astype(np.float32)
+    P = synth.random_orthogonal(d, seed=34)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    nq = 300
+    queries = (centres[rng.choice(k, nq, p=sizes)] + 0.2 * rng.standard_normal((nq, d))).astype(np.float32)
+    queries[:40] = (x[lab == 0][:40] + 0.1 * rng.standard_normal((40, d))).astype(np.float32)   # at the radius of the long list: loose thresholds
+    try:
+        for impl in (1, 2):
+            ix.set_option("scan_impl", impl)
+            ix.set_option("survivor_segments", 2)
+            gidx = rq.RaBitQ.build(x, centres, P)
+            _compare_with_oracle(rq, oracle, oidx, gidx, queries, k, 100, False)
+            pr = ix.last_profile()
+            assert pr["segmented_passes"] == 1 and pr["retries"] == 0, pr
+            seg_bytes = pr["survivor_workspace_bytes"]
+            _compare_with_oracle(rq, oracle, oidx, gidx, queries, 3, 10, True)
+            gidx.close()
+            ix.set_option("survivor_segments", 1)        # automatic: uniform until the default capacity has overflowed once
+            gidx = rq.RaBitQ.build(x, centres, P)
+            _compare_with_oracle(rq, oracle, oidx, gidx, queries, k, 100, False)
+            first = ix.last_profile()
+            _compare_with_oracle(rq, oracle, oidx, gidx, queries, k, 100, False)
+            second = ix.last_profile()
+            if first["retries"]:                          # the default capacity overflowed: from now on the final stage is segmented
+                assert second["segmented_passes"] == 1 and second["retries"] == 0, (first, second)
+            ix.set_option("survivor_segments", 0)
+            _compare_with_oracle(rq, oracle, oidx, gidx, queries, k, 100, False)
+            uni = ix.last_profile()
+            assert uni["segmented_passes"] == 0
+            if first["retries"]:
+                assert seg_bytes < uni["survivor_workspace_bytes"], (seg_bytes, uni["survivor_workspace_bytes"])
+            gidx.close()
+    finally:
+        ix.set_option("survivor_segments", 1)
+        ix.set_option("scan_impl", 0)
+    oidx.close()
+
+
 @pytest.mark.parametrize("dense_dir", [0, 1])
 def test_long_run_directories_large_batch(rq, oracle, dense_dir):
     """Loose thresholds (deep top-k, one long list) leave more than 512 survivor runs per query in a large batch.
