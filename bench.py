@@ -403,6 +403,7 @@ def run_workload(args, ctx, extras=True):
                     for pr in [rqi.last_profile()] + extra_prof:
                         for key, v in pr.items():
                             prof[key] = prof.get(key, 0) + v
+                        prof["survivor_workspace_bytes_max"] = max(prof.get("survivor_workspace_bytes_max", 0), pr.get("survivor_workspace_bytes", 0))
             return res
         pending = []
         for i in range(count + depth - 1):
@@ -570,7 +571,10 @@ def run_workload(args, ctx, extras=True):
             # of those: rejected on the fp16 shadow row alone (2*dim bytes read instead of 4*dim; results identical)
             "rerank_shadow_rejects_per_query": prof["rerank_shadow_rejects"] / (B * args.steps),
             "matrix_exact_path_rate": None if exact_rate is None else round(exact_rate, 5),
-            "retries": int(prof["retries"]), "roofline": roofline, "roofline_scan_all_launches": scan_all,
+            "retries": int(prof["retries"]),
+            "survivor_workspace_GB": round(prof.get("survivor_workspace_bytes_max", 0) / 1e9, 2),
+            "segmented_passes_per_step": prof.get("segmented_passes", 0) / args.steps,
+            "roofline": roofline, "roofline_scan_all_launches": scan_all,
             "roofline_rotation": rotation,
             "scan_small_batch": small, "single_query": single, "two_batches_in_flight": overlap}
 

@@ -1046,10 +1046,41 @@ struct ScanArgs {   // scalars only; pointers are explicit __restrict__ kernel p
     // survivor geometry: uniform capacity `cap` per query, or per-query segments (QSeg); read on the survivor path only
     const unsigned long long *seg_base;
     const uint32_t *seg_cap;
-    // count_only: nothing is recorded, the survivors of every tile_stride-th tile are only COUNTED into surv_cnt (the
-    // sampled counting scan that sizes the segments)
-    uint32_t count_only, tile_stride;
+    // Arena mode (stages of a large batch that can exceed the uniform capacity): the survivors of a stage are first appended,
+    // in no particular order, to ONE arena shared by all queries (RQ_ARENA_SHARDS shards, each with its own 64-bit cursor
+    // -- records | runs << 32 --, chosen by block id: an append costs one more, uncontended atomic), while surv_cnt only
+    // COUNTS per query; the exact counts then size a segment per query and arena_scatter_kernel moves every run to its
+    // query's segment.  Nothing is sized for a worst query.
+    SurvRec *arena_recs;        // nullptr: records go straight to the query's buffer
+    uint4 *arena_runs;          // {pos, slot | cnt << 16, query, record offset in the arena}
+    unsigned long long *arena_cur;  // RQ_ARENA_SHARDS cursors, [SHARDS] overflow flag, [SHARDS + 1] (host), [SHARDS + 2] cursor of the common area
+    uint32_t arena_sub, arena_rsub;  // capacity of a shard: records, runs (the same for both arrays)
+    uint32_t arena_common;      // capacity of the common area behind the shards (records = runs), for what a full shard turns away
+    unsigned int *arena_fail;   // per shard: run index of the first append it turned away (0xFFFFFFFF: none)
 };
+#define RQ_ARENA_SHARDS 2048u
+#define RQ_ARENA_COMMON_BLOCKS 512u
+// Reserve `nrec` records + `nrun` run descriptors of the arena for the calling lane's block: in the block's shard, or --
+// when that is full (few, heavy blocks) -- in the common area.  Returns false if neither has room (the overflow flag is
+// set: the host doubles the arena and repeats the stage).  rec_off / run_off: indices into arena_recs / arena_runs.
+__device__ __forceinline__ bool arena_reserve(const ScanArgs &a, uint32_t nrec, uint32_t nrun, uint32_t *rec_off, uint32_t *run_off) {
+    const uint32_t shard = blockIdx.x & (RQ_ARENA_SHARDS - 1u);
+    const unsigned long long o = atomicAdd(a.arena_cur + shard, ((unsigned long long)nrun << 32) | nrec);
+    const uint32_t ab = (uint32_t)o, rb = (uint32_t)(o >> 32);
+    if (ab + nrec <= a.arena_sub && rb + nrun <= a.arena_rsub) {
+        *rec_off = shard * a.arena_sub + ab, *run_off = shard * a.arena_rsub + rb;
+        return true;
+    }
+    atomicMin(a.arena_fail + shard, rb);  // the shard's valid runs end here (every later append fails as well)
+    const unsigned long long oc = atomicAdd(a.arena_cur + RQ_ARENA_SHARDS + 2, ((unsigned long long)nrun << 32) | nrec);
+    const uint32_t cb = (uint32_t)oc, crb = (uint32_t)(oc >> 32);
+    if (cb + nrec <= a.arena_common && crb + nrun <= a.arena_common) {
+        *rec_off = RQ_ARENA_SHARDS * a.arena_sub + cb, *run_off = RQ_ARENA_SHARDS * a.arena_rsub + crb;
+        return true;
+    }
+    *reinterpret_cast<unsigned int *>(a.arena_cur + RQ_ARENA_SHARDS) = 1u;
+    return false;
+}
 __device__ __forceinline__ QSeg scan_seg(const ScanArgs &a) { return QSeg{a.seg_base, a.seg_cap, a.cap}; }
 struct ScanPtrs {   // host-side bundle only
     const uint32_t *codes;        // n * 2W dwords (x_binary_vec, src/rabitq.rs:66)
@@ -1112,10 +1143,6 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
             list_begin = offsets[g];
             list_len = offsets[g + 1] - list_begin;
         }
-    }
-    if (a.tile_stride > 1u) {  // sampled counting scan: every tile_stride-th tile, the phase spread over the lists
-        const uint32_t ti = a.use_table ? a.group_base + blockIdx.x : first / (256 * CPL) + g;
-        if (ti % a.tile_stride) return;
     }
     uint32_t pb, pe;
     if (a.cluster_major) {
@@ -1223,8 +1250,26 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
             uint32_t nruns = 0;
 #pragma unroll
             for (int c = 0; c < CPL; ++c) nruns += m[c] ? 1u : 0u;
-            if (a.count_only) {  // sampled counting scan: survivors are counted, not recorded
-                if (lane == 0) atomicAdd(surv_cnt + b, (unsigned long long)total);
+            if (a.arena_recs) {  // arena mode: count per query, append to this block's shard of the arena
+                uint32_t off = 0xFFFFFFFFu, roff = 0;
+                if (lane == 0) {
+                    atomicAdd(surv_cnt + b, ((unsigned long long)nruns << 32) | total);
+                    if (!arena_reserve(a, total, nruns, &off, &roff)) off = 0xFFFFFFFFu;
+                }
+                off = __builtin_amdgcn_readfirstlane(off), roff = __builtin_amdgcn_readfirstlane(roff);
+                if (off == 0xFFFFFFFFu) return;
+                uint4 *rdst = a.arena_runs + roff;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const uint32_t cntc = (uint32_t)__popcll(m[c]);
+                    if ((m[c] >> lane) & 1ull) {
+                        SurvRec r;
+                        r.pos = pos[c], r.slot = slot, r.rough = rough[c], r.accurate = 0.0f;
+                        a.arena_recs[off + (uint32_t)__popcll(m[c] & ((1ull << lane) - 1ull))] = r;
+                    }
+                    if (cntc && lane == 0) *rdst++ = make_uint4(list_begin + first + c * 256 + (threadIdx.x & ~63u), slot | (cntc << 16), b, off);
+                    off += cntc;
+                }
                 return;
             }
             unsigned long long old = 0;
@@ -1418,10 +1463,6 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
         first = (a.tile_base + (blockIdx.x - gl * a.tiles_per_group)) * TILE;
         list_begin = offsets[g], list_len = offsets[g + 1] - list_begin;
     }
-    if (a.tile_stride > 1u) {  // sampled counting scan: every tile_stride-th tile, the phase spread over the lists
-        const uint32_t ti = a.use_table ? a.group_base + blockIdx.x : first / TILE + g;
-        if (ti % a.tile_stride) return;
-    }
     // the group's records (cluster-major only)
     const uint32_t pb = grp_start[g], cnt = grp_cnt[g];
     if (cnt == 0) return;
@@ -1513,8 +1554,22 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
     auto flush = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // LDS is in-order per wave
         const QSeg seg = scan_seg(a);
-        if (a.count_only) {  // sampled counting scan: survivors are counted, not recorded
-            if (lane < nR) atomicAdd(surv_cnt + r_b[wave][lane], (unsigned long long)r_cnt[wave][lane]);
+        if (a.arena_recs) {  // arena mode: count per query, ONE reservation for the whole queue in this block's shard
+            if (lane < nR) atomicAdd(surv_cnt + r_b[wave][lane], (1ull << 32) | r_cnt[wave][lane]);
+            uint32_t off0 = 0xFFFFFFFFu, roff = 0;
+            if (lane == 0 && nR && !arena_reserve(a, nE, nR, &off0, &roff)) off0 = 0xFFFFFFFFu;
+            off0 = __builtin_amdgcn_readfirstlane(off0), roff = __builtin_amdgcn_readfirstlane(roff);
+            if (off0 != 0xFFFFFFFFu) {
+                if (lane < nR)
+                    a.arena_runs[roff + lane] =
+                        make_uint4(r_pos[wave][lane], r_slot[wave][lane] | (r_cnt[wave][lane] << 16), r_b[wave][lane], off0 + r_off[wave][lane]);
+                for (uint32_t e = lane; e < nE; e += 64) {
+                    SurvRec sr;
+                    sr.pos = q_pos[wave][e], sr.slot = r_slot[wave][q_run[wave][e]], sr.rough = q_rough[wave][e], sr.accurate = 0.0f;
+                    a.arena_recs[off0 + e] = sr;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             nE = 0, nR = 0;
             return;
@@ -2569,19 +2624,80 @@ __global__ __launch_bounds__(64) void replay_kernel(const SurvRec *__restrict__ 
     replay_wave<HEURISTIC, REGHEAP>(surv + seg.at(b), runs + seg.at(b), nruns, topk, b, st, hkey, hid);
 }
 
-// Segment sizing of a pass's final stage.  surv_cnt[b] (low word) = the survivors a sampled counting scan saw for query b
-// in every stride-th tile; its segment gets room for the extrapolated count plus half of it, four standard deviations of the
-// sample (Poisson) and a floor, in units of 64 slots; the counter is cleared for the real scan.
-__global__ void seg_caps_kernel(unsigned long long *__restrict__ surv_cnt, uint32_t nq, uint32_t stride, uint32_t floor_cap,
-                                uint32_t *__restrict__ q_cap) {
+// Segment sizing of an arena stage: query b's segment = its exact survivor count (surv_cnt low word, counted by the scan)
+// rounded up to 64 slots, at least floor_cap; the counter is cleared and becomes the scatter's cursor.
+__global__ void seg_exact_kernel(unsigned long long *__restrict__ surv_cnt, uint32_t nq, uint32_t floor_cap,
+                                 uint32_t *__restrict__ q_cap) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nq) return;
-    const unsigned long long est = (surv_cnt[b] & 0xFFFFFFFFull) * stride;
-    unsigned long long cap = est + est / 2 + 4ull * stride * (unsigned long long)(sqrtf((float)(est / stride) + 1.0f) + 1.0f) + floor_cap;
-    cap = (cap + 63ull) & ~63ull;
-    q_cap[b] = cap > 0x7FFFFFC0ull ? 0x7FFFFFC0u : (uint32_t)cap;
+    const uint32_t cnt = (uint32_t)surv_cnt[b];
+    const uint32_t cap = cnt > floor_cap ? cnt : floor_cap;
+    q_cap[b] = cap > 0xFFFFFF80u ? 0xFFFFFFC0u : ((cap + 63u) & ~63u);
     surv_cnt[b] = 0ull;
 }
+// The arena's runs to their queries' segments.  A wave takes 64 runs of a shard at a time: lane r claims its run's place
+// with the per-query 64-bit counter (exactly the reservation the direct path makes) and writes the descriptor; the records
+// of all 64 runs are then copied by the whole wave, one record per lane and step (a lane finds its run by bisection over
+// the chunk's prefix sums, like the replay's fetch), so reads and writes stay as coalesced as the runs are long.
+__global__ __launch_bounds__(256) void arena_scatter_kernel(const SurvRec *__restrict__ arena_recs, const uint4 *__restrict__ arena_runs,
+                                                            const unsigned long long *__restrict__ arena_cur,
+                                                            const unsigned int *__restrict__ arena_fail, uint32_t arena_rsub,
+                                                            const unsigned long long *__restrict__ q_base,
+                                                            unsigned long long *__restrict__ surv_cnt, SurvRec *__restrict__ surv,
+                                                            RunRec *__restrict__ runs) {
+    __shared__ uint32_t s_pref[4][65], s_src[4][64];
+    __shared__ unsigned long long s_dst[4][64];
+    // blocks 0 .. SHARDS-1: the shards (valid runs: up to the first append the shard turned away); block SHARDS: the common area
+    // (the common area is walked by RQ_ARENA_COMMON_BLOCKS columns of blocks: it can hold a good part of the runs)
+    const bool common = blockIdx.x >= RQ_ARENA_SHARDS;
+    const uint32_t shard = common ? RQ_ARENA_SHARDS : blockIdx.x;
+    uint32_t nr;
+    if (!common) {
+        nr = (uint32_t)(arena_cur[shard] >> 32);
+        const uint32_t fl = arena_fail[shard];
+        nr = nr < fl ? nr : fl;
+    } else {
+        nr = (uint32_t)(arena_cur[RQ_ARENA_SHARDS + 2] >> 32);
+    }
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint4 *src = arena_runs + (uint64_t)shard * arena_rsub;
+    const uint32_t col = common ? blockIdx.x - RQ_ARENA_SHARDS : 0u, ncol = common ? RQ_ARENA_COMMON_BLOCKS : 1u;
+    for (uint32_t r0 = ((col * gridDim.y + blockIdx.y) * 4 + wave) * 64; r0 < nr; r0 += ncol * gridDim.y * 256) {
+        uint32_t cnt = 0;
+        if (r0 + lane < nr) {
+            const uint4 d = src[r0 + lane];
+            cnt = d.y >> 16;
+            const unsigned long long old = atomicAdd(surv_cnt + d.z, (1ull << 32) | cnt);
+            const uint32_t base = (uint32_t)old, rbase = (uint32_t)(old >> 32);
+            const unsigned long long qat = q_base[d.z];
+            RunRec rr;
+            rr.pos = d.x, rr.slot = d.y & 0xFFFFu, rr.base = base, rr.cnt = cnt;
+            runs[qat + rbase] = rr;
+            s_src[wave][lane] = d.w;
+            s_dst[wave][lane] = qat + base;
+        }
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o, 64);
+            if ((int)lane >= o) incl += up;
+        }
+        s_pref[wave][lane + 1] = incl;
+        if (lane == 0) s_pref[wave][0] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const uint32_t total = __shfl(incl, 63, 64);
+        for (uint32_t e = lane; e < total; e += 64) {
+            uint32_t lo = 0;  // largest r with s_pref[r] <= e
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1)
+                if (lo + step < 64 && s_pref[wave][lo + step] <= e) lo += step;
+            const uint32_t i = e - s_pref[wave][lo];
+            surv[s_dst[wave][lo] + i] = arena_recs[s_src[wave][lo] + i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the chunk's LDS rows are free again
+    }
+}
+
 // exclusive scan of q_cap into q_base (u64); out_total[0] = the sum.  One block of 1024 threads, any nq.
 __global__ __launch_bounds__(1024) void seg_scan_kernel(const uint32_t *__restrict__ q_cap, uint32_t nq,
                                                         unsigned long long *__restrict__ q_base, unsigned long long *__restrict__ out_total) {

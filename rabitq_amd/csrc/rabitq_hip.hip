@@ -231,6 +231,10 @@ struct Workspace {
     DevBuf<unsigned long long> sh_packed, sh_gathered, sh_merged;
     DevBuf<uint32_t> ovf, q_cap;               // per query: overflow flag; segment capacity of the final stage (segmented passes)
     DevBuf<unsigned long long> q_base;         // per query: first slot of its segment
+    DevBuf<SurvRec> arena_recs;                // arena stages: survivors of all queries, unordered (256 shards)
+    DevBuf<RunRec> arena_runs;                 //   their run descriptors as uint4 {pos, slot | cnt << 16, query, offset}
+    DevBuf<unsigned long long> arena_cur;      //   RQ_ARENA_SHARDS shard cursors (records | runs << 32), overflow flag, total, cursor of the common area
+    DevBuf<unsigned int> arena_fail;           //   per shard: first run index it turned away
     DevBuf<uint32_t> sh_flag;                 // handshake / status words of the step
     DevBuf<uint32_t> sh_pc, sh_id_b, sh_n_b;  // shared-threshold step: probe lists (whole | nearest | rest), second call's results
     DevBuf<float> sh_pd, sh_thr, sh_dist_b;
@@ -267,6 +271,7 @@ struct rq_index {
     std::vector<std::unique_ptr<Workspace>> ws_pool;
     FactorStats fstats{0, 0, 0, 0};
     std::atomic<uint32_t> cap_hint{0};  // survivor-buffer capacity learnt from earlier batches
+    std::atomic<uint64_t> arena_hint{0};  // slots the largest arena stage of earlier batches needed (+ headroom)
     std::atomic<uint32_t> early_cap_hint{0};  // the same for the stages before the final one (segmented passes size the final stage per query)
     std::atomic<uint32_t> big_dirs_hint{0};  // most long run directories (> 512 runs) a stage of a recent pass produced
     uint64_t pass_budget = 24ull << 30;  // bytes of survivor / run buffers one query pass may use (set by finish_index)
@@ -717,7 +722,9 @@ static rq_status finish_pass(const rq_index *idx, Workspace &ws, PassResult *res
     }
     if (prof_acc) {
         const uint64_t slots = std::max<uint64_t>((uint64_t)nq * ws.pend_cap, ws.pend_seg_slots);
-        prof_acc->survivor_workspace_bytes = std::max<uint64_t>(prof_acc->survivor_workspace_bytes, slots * (ws.use_runs_tmp ? 48ull : 32ull));
+        prof_acc->survivor_workspace_bytes = std::max<uint64_t>(prof_acc->survivor_workspace_bytes,
+            ws.pend_seg_slots ? (ws.surv.count + ws.runs.count + ws.runs_tmp.count + ws.arena_recs.count + ws.arena_runs.count) * 16ull
+                              : slots * (ws.use_runs_tmp ? 48ull : 32ull));
         prof_acc->segmented_passes += ws.pend_seg_slots ? 1u : 0u;
         prof_acc->scan_candidates += res->rough;
         prof_acc->scan_bytes += res->rough * (uint64_t)(dim / 8 + 16);
@@ -1043,57 +1050,89 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         // large batches, VALU-kernel stages: the run descriptors go into a dense directory indexed by stream position
         // (stage_fill_kernel: RQ_REC_CELL0), so the stage needs no sort of its run directory
         uint32_t dense_cells = 0;
-        if (nq >= 256 && !use_mfma && scan_is_fused(W) && g_dense_dir.load() && sg.s_hi != 0xFFFFFFFFu) {
+        if (nq >= 256 && !use_mfma && scan_is_fused(W) && g_dense_dir.load() && sg.s_hi != 0xFFFFFFFFu &&
+            !(qp.seg_final && span > qp.cap)) {  // (an arena stage appends its runs: they are placed by the scatter pass)
             const uint64_t cells = (uint64_t)((sg.s_hi - 1) >> 6) - (sg.s_lo >> 6) + 2ull * slot_hi + 2;
             if (cells <= qp.cap) dense_cells = (uint32_t)cells;
         }
         a.dense_dir = dense_cells ? 1u : 0u;
-        if (dense_cells) {
-            pf.begin(PF_SORT);
-            clear_dir_kernel<<<ceil_div((uint64_t)nq * dense_cells, 256), 256, 0, st>>>(ws.runs.p, nq, useg, dense_cells);
-            pf.end();
-        }
-        // Segmented final stage: a sampled counting scan (every 16th tile, nothing recorded) sizes a segment per query, an
-        // exclusive scan places them, the host makes room for their sum, then the real scan records into the segments.
+        // Arena stage (large batches of an index whose survivor counts are very unequal -- hard distribution, final stage:
+        // median 12 survivors per query, mean 2 800, maximum beyond 100 000): every stage that CAN exceed the uniform capacity
+        // (span > capacity) appends its survivors to one arena shared by all queries while counting them per query; the
+        // exact counts size a segment per query (prefix sum), the host makes room for their sum, and a scatter pass moves
+        // every run to its query's segment.  The workspace follows the SUM of the survivors, not nq x the worst query, and
+        // no query can overflow.
         const bool is_last = &sg == &stages.back();
         rs.final_stage = is_last ? 1u : 0u;
         QSeg seg = useg;
-        if (qp.seg_final && is_last && scan_is_fused(W) && nq >= 256) {
-            pf.begin(use_mfma ? PF_SCAN_MATRIX : PF_SCAN);
-            ScanArgs ca = a;
-            ca.count_only = 1u, ca.tile_stride = 16u;
-            if (use_mfma) launch_scan_mfma(sp, ca, W, st);
-            else launch_scan(sp, ca, W, st);
-            pf.end();
-            pf.begin(PF_GROUP);
-            seg_caps_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(ws.surv_cnt.p, nq, 16u, 256u, ws.q_cap.p);
-            seg_scan_kernel<<<1, 1024, 0, st>>>(ws.q_cap.p, nq, ws.q_base.p, ws.totals.p + 7);
+        const bool arena_stage = qp.seg_final && span > qp.cap && scan_is_fused(W) && nq >= 256;
+        if (arena_stage) {
+            // capacity: what earlier batches needed (+ headroom), at least half the uniform buffers' worth; a shard holds
+            // 1 / RQ_ARENA_SHARDS of it
+            uint64_t want = std::max<uint64_t>(idx->arena_hint.load(), (uint64_t)nq * qp.cap / 2);
             unsigned long long total_slots = 0;
-            HIPC(hipMemcpyAsync(&total_slots, ws.totals.p + 7, 8, hipMemcpyDeviceToHost, st));
-            HIPC(hipStreamSynchronize(st));
+            for (int attempt = 0;; ++attempt) {
+                want = std::min<uint64_t>(want, 0xFFFF0000ull);
+                RQC(ws.arena_recs.ensure(want));
+                RQC(ws.arena_runs.ensure(want));
+                RQC(ws.arena_cur.ensure(RQ_ARENA_SHARDS + 4));
+                RQC(ws.arena_fail.ensure(RQ_ARENA_SHARDS));
+                HIPC(hipMemsetAsync(ws.arena_cur.p, 0, (RQ_ARENA_SHARDS + 4) * 8, st));
+                HIPC(hipMemsetAsync(ws.arena_fail.p, 0xFF, RQ_ARENA_SHARDS * 4, st));
+                a.arena_recs = ws.arena_recs.p, a.arena_runs = reinterpret_cast<uint4 *>(ws.arena_runs.p), a.arena_cur = ws.arena_cur.p;
+                a.arena_fail = ws.arena_fail.p;
+                {  // seven eighths of the arena in shards, the rest as the common area (what a full shard turns away: few, heavy blocks)
+                    const uint64_t have = std::min<uint64_t>(ws.arena_recs.count, ws.arena_runs.count);
+                    a.arena_sub = a.arena_rsub = (uint32_t)(have * 7 / 8 / RQ_ARENA_SHARDS);
+                    a.arena_common = (uint32_t)std::min<uint64_t>(have - (uint64_t)a.arena_sub * RQ_ARENA_SHARDS, 0xFFFFFF00ull);
+                }
+                a.dense_dir = 0u;
+                pf.begin(use_mfma ? PF_SCAN_MATRIX : PF_SCAN);
+                if (use_mfma) launch_scan_mfma(sp, a, W, st);
+                else launch_scan(sp, a, W, st);
+                pf.end();
+                pf.begin(PF_GROUP);
+                // sizes from the exact counts, one round trip for the shard-overflow flag and the sum of the segments
+                seg_exact_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(ws.surv_cnt.p, nq, 64u, ws.q_cap.p);
+                seg_scan_kernel<<<1, 1024, 0, st>>>(ws.q_cap.p, nq, ws.q_base.p, ws.arena_cur.p + RQ_ARENA_SHARDS + 1);
+                unsigned long long tail[2] = {0, 0};
+                HIPC(hipMemcpyAsync(tail, ws.arena_cur.p + RQ_ARENA_SHARDS, 16, hipMemcpyDeviceToHost, st));
+                HIPC(hipStreamSynchronize(st));
+                total_slots = tail[1];
+                if (!(uint32_t)tail[0]) break;
+                pf.end();
+                if (attempt >= 6) return fail(RQ_ERR_OOM, "survivor arena kept overflowing");
+                want = std::max<uint64_t>(want * 2, 1u << 20);  // a shard ran full: twice the arena, the stage again (the counters were cleared by seg_exact_kernel)
+            }
+            {  // remember what this stage needed
+                uint64_t cur = idx->arena_hint.load();
+                const uint64_t learnt = total_slots + total_slots * 3 / 5;
+                while (cur < learnt && !const_cast<rq_index *>(idx)->arena_hint.compare_exchange_weak(cur, learnt)) {}
+            }
+            if (total_slots > ws.surv.count || total_slots > ws.runs.count || total_slots > ws.runs_tmp.count) {
+                const uint64_t grow = total_slots + total_slots / 8;
+                RQC(ws.surv.ensure(grow));
+                RQC(ws.runs.ensure(grow));
+                RQC(ws.runs_tmp.ensure(grow));
+            }
+            sp.surv = ws.surv.p, sp.runs = ws.runs.p;
+            arena_scatter_kernel<<<dim3(RQ_ARENA_SHARDS + RQ_ARENA_COMMON_BLOCKS, 2), 256, 0, st>>>(ws.arena_recs.p, reinterpret_cast<const uint4 *>(ws.arena_runs.p), ws.arena_cur.p,
+                                                                              ws.arena_fail.p, a.arena_rsub, ws.q_base.p, ws.surv_cnt.p, ws.surv.p, ws.runs.p);
             pf.end();
-            bool room = total_slots <= ws.surv.count && total_slots <= ws.runs.count && (!ws.use_runs_tmp || total_slots <= ws.runs_tmp.count);
-            if (!room && total_slots * 48ull <= idx->pass_budget * 2) {  // grow (with headroom: the next batches differ a little)
-                const uint64_t want = total_slots + total_slots / 8;
-                room = ws.surv.ensure(want) == RQ_OK && ws.runs.ensure(want) == RQ_OK && (!ws.use_runs_tmp || ws.runs_tmp.ensure(want) == RQ_OK);
-                if (!room) (void)hipGetLastError();
-                sp.surv = ws.surv.p, sp.runs = ws.runs.p;
-            }
-            if (room && ws.surv.p && ws.runs.p) {
-                seg = QSeg{ws.q_base.p, ws.q_cap.p, qp.cap};
-                a.seg_base = ws.q_base.p, a.seg_cap = ws.q_cap.p;
-                ws.pend_seg_slots = total_slots;
-            } else {  // no room for the segments: the uniform geometry (queries beyond it are re-run, as without segments)
-                RQC(ws.surv.ensure((uint64_t)nq * qp.cap));
-                RQC(ws.runs.ensure((uint64_t)nq * qp.cap));
-                if (ws.use_runs_tmp) RQC(ws.runs_tmp.ensure((uint64_t)nq * qp.cap));
-                sp.surv = ws.surv.p, sp.runs = ws.runs.p;
-            }
+            seg = QSeg{ws.q_base.p, ws.q_cap.p, qp.cap};
+            ws.pend_seg_slots = std::max<uint64_t>(ws.pend_seg_slots, total_slots);
         }
-        pf.begin(use_mfma ? PF_SCAN_MATRIX : PF_SCAN);
-        if (use_mfma) launch_scan_mfma(sp, a, W, st);
-        else launch_scan(sp, a, W, st);
-        pf.end();
+        if (dense_cells) {
+            pf.begin(PF_SORT);
+            clear_dir_kernel<<<ceil_div((uint64_t)nq * dense_cells, 256), 256, 0, st>>>(ws.runs.p, nq, seg, dense_cells);
+            pf.end();
+        }
+        if (!arena_stage) {
+            pf.begin(use_mfma ? PF_SCAN_MATRIX : PF_SCAN);
+            if (use_mfma) launch_scan_mfma(sp, a, W, st);
+            else launch_scan(sp, a, W, st);
+            pf.end();
+        }
         if (prof_acc) prof_acc->scan_launches++;
         if (prof_acc && use_mfma) {
             prof_acc->matrix_launches++;
@@ -1233,13 +1272,13 @@ static rq_status validate_query(const rq_index *idx, const float *d_q, uint32_t 
 
 // Uniform survivor capacity of a pass over `remaining` queries, and whether its final stage is segmented.  An index whose
 // batches overflowed the default capacity (cap_hint) used to size EVERY query of a pass for the worst one (learnt capacity
-// 32 768: 100 GB for a 65 536-query pass of the hard benchmark distribution); large batches now keep the uniform
-// capacity for the stages before the final one (early_cap_hint) and give the final stage per-query segments.
+// 32 768: 100 GB for a 65 536-query pass of the hard benchmark distribution); large batches now keep the default
+// capacity for the stages that cannot exceed it and give every other stage per-query segments.
 static uint32_t pass_capacity(const rq_index *idx, uint32_t remaining, bool seeded, bool *seg) {
     const uint32_t hint = idx->cap_hint.load();
     const int opt = g_seg_opt.load();
     *seg = !seeded && remaining >= 256 && scan_is_fused(idx->W) && (opt == 2 || (opt == 1 && hint > RQ_DEFAULT_CAP));
-    if (*seg) return std::max(RQ_DEFAULT_CAP, idx->early_cap_hint.load());
+    if (*seg) return RQ_DEFAULT_CAP;  // stages that cannot exceed it stay uniform, the others are segmented
     return std::max(RQ_DEFAULT_CAP, hint);
 }
 
