@@ -30,6 +30,8 @@
 #define RQ_SB_TILE 1024u       // stream positions scanned per step (one per thread)
 #define RQ_SB_MAX_STAGES 8
 #define RQ_SB_MAX_TOPK 256u    // ranker state lives in LDS
+#define RQ_SBF_RUNS 2048u      // sb_finish_kernel's LDS path: run descriptors ...
+#define RQ_SBF_RECS 2048u      // ... and survivors of the final stage it holds
 #define RQ_SB_MAX_K 8192u      // 16 wave slices of <= 512 lists each in the probe selection
 
 // ------------------------------------------------------------------------------------------------
@@ -595,7 +597,7 @@ __global__ __launch_bounds__(1024) void sb_finish_kernel(SurvRec *__restrict__ s
                                                          unsigned long long *__restrict__ totals) {
     __shared__ int32_t hkey[REGHEAP ? 1 : RQ_MAX_TOPK];
     __shared__ uint32_t hid[REGHEAP ? 1 : RQ_MAX_TOPK];
-    extern __shared__ __attribute__((aligned(16))) float fin_q[];  // dim floats: the padded query
+    extern __shared__ __attribute__((aligned(16))) float fin_q[];  // dim floats: the padded query | 2 x RQ_SBF_RUNS descriptors | RQ_SBF_RECS records
     const uint32_t b = blockIdx.x;
     const unsigned long long cnt64 = surv_cnt[b];
     const uint32_t cnt = (uint32_t)cnt64;
@@ -618,9 +620,82 @@ __global__ __launch_bounds__(1024) void sb_finish_kernel(SurvRec *__restrict__ s
         __syncthreads();
         if (!(presorted & 2u))  // bit 1: the exact distances were computed by a whole-chip launch already
             accurate_rows(recs, n, base, fin_q, dim, threadIdx.x >> 1, blockDim.x >> 1, probe_cluster + (uint64_t)b * nprobe);
-        if (nruns <= RQ_SORT_LDS_RECS || !(presorted & 1u)) sort_segment(runs + qat, nruns);
-        __syncthreads();
-        if (threadIdx.x < 64) replay_wave<false, REGHEAP>(recs, runs + qat, nruns, topk, b, st, hkey, hid);
+        if (nruns <= RQ_SBF_RUNS && n <= RQ_SBF_RECS && nprobe <= 64) {
+            // The usual case, all in LDS: the run directory is ordered by (probe slot, position) with a counting sort on the
+            // slot and rank counting inside a slot's bucket (four barriers instead of a bitonic network's fifty), the
+            // survivors are gathered into visiting order by the whole block, and the ranker replays over contiguous LDS
+            // records -- no global round trip inside the serial replay loop.
+            RunRec *R = reinterpret_cast<RunRec *>(fin_q + dim), *B = R + RQ_SBF_RUNS;
+            SurvRec *L = reinterpret_cast<SurvRec *>(B + RQ_SBF_RUNS);
+            uint32_t *off = reinterpret_cast<uint32_t *>(B);  // (after the sort: exclusive prefix sums of the runs' counts)
+            __shared__ uint32_t hist[64], bstart[65], bcur[64], wsum[16];
+            const uint32_t t = threadIdx.x, nt = blockDim.x;
+            __syncthreads();  // (accurate_rows' stores are visible to the gather below)
+            if (t < 64) hist[t] = 0;
+            __syncthreads();
+            for (uint32_t i = t; i < nruns; i += nt) {
+                R[i] = runs[qat + i];
+                atomicAdd(&hist[R[i].slot & 63u], 1u);
+            }
+            __syncthreads();
+            if (t < 64) {
+                const uint32_t h = hist[t];
+                uint32_t incl = h;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t up = __shfl_up(incl, o, 64);
+                    if ((int)t >= o) incl += up;
+                }
+                bstart[t] = incl - h, bcur[t] = incl - h;
+                if (t == 63) bstart[64] = incl;
+            }
+            __syncthreads();
+            for (uint32_t i = t; i < nruns; i += nt) B[atomicAdd(&bcur[R[i].slot & 63u], 1u)] = R[i];
+            __syncthreads();
+            for (uint32_t j = t; j < nruns; j += nt) {  // rank inside the slot's bucket: positions are unique there
+                const RunRec me = B[j];
+                const uint32_t lo = bstart[me.slot & 63u], hi = bstart[(me.slot & 63u) + 1];
+                uint32_t rank = 0;
+                for (uint32_t q2 = lo; q2 < hi; ++q2) rank += B[q2].pos < me.pos ? 1u : 0u;
+                R[lo + rank] = me;
+            }
+            __syncthreads();
+            {  // exclusive prefix sums of the ordered runs' counts (B is free now): every thread owns a contiguous stretch
+                const uint32_t per = (nruns + nt - 1) / nt, i0 = t * per < nruns ? t * per : nruns, i1 = i0 + per < nruns ? i0 + per : nruns;
+                uint32_t sum = 0;
+                for (uint32_t i = i0; i < i1; ++i) sum += R[i].cnt;
+                uint32_t incl = sum;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t up = __shfl_up(incl, o, 64);
+                    if ((int)(t & 63) >= o) incl += up;
+                }
+                if ((t & 63) == 63) wsum[t >> 6] = incl;
+                __syncthreads();
+                uint32_t run = incl - sum;
+                for (uint32_t w = 0; w < (t >> 6); ++w) run += wsum[w];
+                for (uint32_t i = i0; i < i1; ++i) {
+                    off[i] = run;
+                    run += R[i].cnt;
+                }
+            }
+            __syncthreads();
+            for (uint32_t e = t; e < n; e += nt) {  // record e of the visiting order: its run by bisection over the prefix sums
+                uint32_t lo = 0, hi = nruns;  // largest r with off[r] <= e
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (off[mid] <= e) lo = mid;
+                    else hi = mid;
+                }
+                L[e] = recs[R[lo].base + (e - off[lo])];
+            }
+            __syncthreads();
+            if (t < 64) replay_wave<false, REGHEAP, true>(L, nullptr, n, topk, b, st, hkey, hid);
+        } else {
+            if (nruns <= RQ_SORT_LDS_RECS || !(presorted & 1u)) sort_segment(runs + qat, nruns);
+            __syncthreads();
+            if (threadIdx.x < 64) replay_wave<false, REGHEAP>(recs, runs + qat, nruns, topk, b, st, hkey, hid);
+        }
     }
     __threadfence_block();  // the state lane 0 (and the heap's lanes) stored is read back by the other lanes of the wave below
     if (threadIdx.x < 64)  // the same wave that wrote the state (and thread 0's counter updates above): program order

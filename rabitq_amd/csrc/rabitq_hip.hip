@@ -589,6 +589,8 @@ static rq_status ensure_kernel_attributes() {
         set(reinterpret_cast<const void *>(assign_approx_kernel<6, 1>), (int)assign_lds_bytes<6, 1>(), "assign_approx_kernel<6,1>");
         set(reinterpret_cast<const void *>(assign_approx_kernel<8, 1>), (int)assign_lds_bytes<8, 1>(), "assign_approx_kernel<8,1>");
         set(reinterpret_cast<const void *>(assign_approx_kernel<12, 1>), (int)assign_lds_bytes<12, 1>(), "assign_approx_kernel<12,1>");
+        set(reinterpret_cast<const void *>(sb_finish_kernel<true>), 104 * 1024, "sb_finish_kernel");   // (+ 33 KiB of static LDS)
+        set(reinterpret_cast<const void *>(sb_finish_kernel<false>), 104 * 1024, "sb_finish_kernel");  // (+ 49 KiB of static LDS)
 #define RQ_SBQ_ATTR(WW)                                                                                  \
     set(reinterpret_cast<const void *>(sb_query_kernel<WW, 0>), 120 * 1024, "sb_query_kernel");          \
     set(reinterpret_cast<const void *>(sb_query_kernel<WW, 1>), 120 * 1024, "sb_query_kernel");          \
@@ -1164,11 +1166,11 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                 }
                 const uint32_t presorted = flags;
                 if (topk < 64)
-                    sb_finish_kernel<true><<<nq, fin_threads, (size_t)dim * sizeof(float), st>>>(
+                    sb_finish_kernel<true><<<nq, fin_threads, (size_t)dim * sizeof(float) + (2 * RQ_SBF_RUNS + RQ_SBF_RECS) * 16, st>>>(
                         ws.surv.p, ws.runs.p, ws.surv_cnt.p, seg, idx->view(), qpad, dim, topk, rs, probe_cluster, nprobe, presorted,
                         idx->map_ids.p, d_out_dist, d_out_id, d_out_n, ws.rough_cnt.p, ws.totals.p);
                 else
-                    sb_finish_kernel<false><<<nq, fin_threads, (size_t)dim * sizeof(float), st>>>(
+                    sb_finish_kernel<false><<<nq, fin_threads, (size_t)dim * sizeof(float) + (2 * RQ_SBF_RUNS + RQ_SBF_RECS) * 16, st>>>(
                         ws.surv.p, ws.runs.p, ws.surv_cnt.p, seg, idx->view(), qpad, dim, topk, rs, probe_cluster, nprobe, presorted,
                         idx->map_ids.p, d_out_dist, d_out_id, d_out_n, ws.rough_cnt.p, ws.totals.p);
                 sb_results_done = true;
