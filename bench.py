@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--cpu-queries", type=int, default=1000,
                     help="CPU-baseline sample: the 1000-query subset of SURVEY.md 8(d) (0 = skip); bounded to ~25 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--small-batch", default="64,16",
+    ap.add_argument("--small-batch", default="64,16,1",
                     help="batch sizes of the HBM-regime scan measurement (lists hardly shared; '0' or '' = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo = single-GPU rehearsal)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -616,6 +616,10 @@ def small_batch_regime(idx, queries, sb, d, nprobe, topk, out_d, out_i, out_n, n
     small = {"batch": sb, "scan_ms_per_batch": round(sp["ms_scan"] / reps, 4),
              "total_ms_per_batch": round(sp["ms_total"] / reps, 4),
              "scan_algorithmic_GBps": round(gbs, 1), "algorithmic_frac_of_8TBps": round(gbs / 8000.0, 4),
+             # the whole call (every launch, HIP events around the pass): algorithmic bytes over its device time
+             "whole_call_algorithmic_GBps": round(sp["scan_bytes"] / (sp["ms_total"] * 1e-3) / 1e9, 1),
+             "whole_call_frac_of_8TBps": round(sp["scan_bytes"] / (sp["ms_total"] * 1e-3) / 1e9 / 8000.0, 4),
+             "path": "few-launch small-batch path (kernels_small.h)" if sp.get("small_batch_passes", 0) else "staged path",
              "queries_per_s": round(sb * reps / (sp["ms_total"] * 1e-3), 1)}
     # physical HBM rate of the same regime: PMC FETCH_SIZE (x2) over kernel-trace durations, committed profile
     hp = next((os.path.join(ROOT, "profiles", f) for f in ("r03_hbm_regime.json", "r02_hbm_regime.json")

@@ -64,6 +64,8 @@ def main():
         res["regimes"].append({
             "batch": b, "calls": args.reps, "warmup_calls": 3,
             "scan_launches_per_call": acc["scan_launches"] / args.reps,
+            "small_batch_passes_per_call": acc.get("small_batch_passes", 0) / args.reps,
+            "early_ms_per_call": acc.get("ms_early", 0.0) / args.reps,
             "scan_ms_per_call": acc["ms_scan"] / args.reps, "total_ms_per_call": acc["ms_total"] / args.reps,
             "algorithmic_bytes_per_call": acc["scan_bytes"] / args.reps,
             "algorithmic_GBps": acc["scan_bytes"] / (acc["ms_scan"] * 1e-3) / 1e9,

@@ -17,6 +17,7 @@ csv.field_size_limit(10**9)
 OUTDIR = os.environ.get("RQ_PROFILE_OUT", os.path.join(ROOT, "profiles"))
 os.makedirs(OUTDIR, exist_ok=True)
 is_scan = re.compile(r"^(void )?scan_(kernel|mfma_kernel|generic_kernel)")
+is_early = re.compile(r"^(void )?sb_query_kernel")   # small-batch path: the per-query block that scans the head of the stream itself
 
 
 def newest(pattern):
@@ -24,21 +25,21 @@ def newest(pattern):
     return fs[-1] if fs else None
 
 
-def scan_dispatches_pmc(tag):
+def scan_dispatches_pmc(tag, pat=is_scan):
     cc = newest(f"hbm_{tag}_pmc/*/*counter_collection.csv")
     disp = collections.OrderedDict()
     for r in csv.DictReader(open(cc)):
-        if r["Counter_Name"] != "FETCH_SIZE" or not is_scan.match(r["Kernel_Name"]):
+        if r["Counter_Name"] != "FETCH_SIZE" or not pat.match(r["Kernel_Name"]):
             continue
         d = disp.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"].split("(")[0].replace("void ", ""), "kb": 0.0})
         d["kb"] += float(r["Counter_Value"])
     return [disp[i] for i in sorted(disp)]
 
 
-def scan_dispatches_kt(tag):
+def scan_dispatches_kt(tag, pat=is_scan):
     kt = newest(f"hbm_{tag}_kt/*/*kernel_trace.csv")
     rows = [(int(r["Dispatch_Id"]), r["Kernel_Name"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-            for r in csv.DictReader(open(kt)) if is_scan.match(r["Kernel_Name"])]
+            for r in csv.DictReader(open(kt)) if pat.match(r["Kernel_Name"])]
     rows.sort()
     return [{"name": n.split("(")[0].replace("void ", ""), "ns": ns} for _, n, ns in rows]
 
@@ -51,6 +52,8 @@ for tag in ("d128", "d768"):
         continue
     plain = json.load(open(pj))
     pmc, kt = scan_dispatches_pmc(tag), scan_dispatches_kt(tag)
+    e_pmc, e_kt = scan_dispatches_pmc(tag, is_early), scan_dispatches_kt(tag, is_early)
+    e_at = 0
     wl = {"config": plain["config"],
           "commands": [f"python3 scripts/hbm_regime.py ... (HIP events)",
                        "rocprofv3 --kernel-trace --stats -- (same)", "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- (same)"],
@@ -69,7 +72,20 @@ for tag in ("d128", "d768"):
             per_launch[j % L][0] += p["kb"] * 2048 / rg["calls"]
             per_launch[j % L][1] += kk["ns"] / rg["calls"]
         dom = max(per_launch, key=lambda j: per_launch[j][0])
+        early = None
+        if rg.get("small_batch_passes_per_call", 0) >= 0.5:   # one sb_query_kernel per call (warm-up calls included)
+            n_e = rg["warmup_calls"] + rg["calls"]
+            ep, ek = e_pmc[e_at:e_at + n_e][-rg["calls"]:], e_kt[e_at:e_at + n_e][-rg["calls"]:]
+            e_at += n_e
+            if ep and ek:
+                early = {"kernel": "sb_query_kernel (probe selection, query quantisation, the first stages in LDS)",
+                         "ms_per_call_kernel_trace": sum(d["ns"] for d in ek) / len(ek) / 1e6,
+                         "physical_hbm_bytes_per_call": sum(d["kb"] for d in ep) * 2048 / len(ep)}
         wl["regimes"].append({
+            "whole_call_ms_hip_events": rg["total_ms_per_call"],
+            "whole_call_algorithmic_GBps": rg["algorithmic_bytes_per_call"] / (rg["total_ms_per_call"] * 1e-3) / 1e9,
+            "whole_call_algorithmic_frac_of_8TBps": rg["algorithmic_bytes_per_call"] / (rg["total_ms_per_call"] * 1e-3) / 1e9 / 8000.0,
+            "early_part": early,
             "batch": rg["batch"], "scan_launches_per_call": L, "kernels": sorted({d["name"] for d in sl_p}),
             "algorithmic_bytes_per_call": rg["algorithmic_bytes_per_call"],
             "physical_hbm_bytes_per_call": phys,
