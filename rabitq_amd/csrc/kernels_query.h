@@ -1043,27 +1043,36 @@ struct ScanArgs {   // scalars only; pointers are explicit __restrict__ kernel p
     // RQ_REC_CELL0 + list position / 64: already in the reference's visiting order, nothing to sort) instead of being
     // appended in completion order
     uint32_t dense_dir;
-    // survivor geometry: uniform capacity `cap` per query, or per-query segments (QSeg); read on the survivor path only
+    // per-query segments / arena mode: everything about them lives in a ScanExtra in device memory (nullptr: the uniform
+    // geometry, records straight to the query's buffer) and is read on the survivor path only -- the hot loops keep their
+    // kernel arguments in scalar registers, and a fat argument block costs them spills
+    const struct ScanExtra *x;
+};
+// Survivor geometry beyond the uniform one.
+// Segments: query b owns seg_cap[b] slots from seg_base[b] (QSeg).
+// Arena mode (stages of a large batch that can exceed the uniform capacity): the survivors of a stage are first appended,
+// in no particular order, to ONE arena shared by all queries (RQ_ARENA_SHARDS shards, each with its own 64-bit cursor
+// -- records | runs << 32 --, chosen by block id: an append costs one more, uncontended atomic), while surv_cnt only
+// COUNTS per query; the exact counts then size a segment per query and arena_scatter_kernel moves every run to its
+// query's segment.  Nothing is sized for a worst query.
+struct ScanExtra {
     const unsigned long long *seg_base;
     const uint32_t *seg_cap;
-    // Arena mode (stages of a large batch that can exceed the uniform capacity): the survivors of a stage are first appended,
-    // in no particular order, to ONE arena shared by all queries (RQ_ARENA_SHARDS shards, each with its own 64-bit cursor
-    // -- records | runs << 32 --, chosen by block id: an append costs one more, uncontended atomic), while surv_cnt only
-    // COUNTS per query; the exact counts then size a segment per query and arena_scatter_kernel moves every run to its
-    // query's segment.  Nothing is sized for a worst query.
-    SurvRec *arena_recs;        // nullptr: records go straight to the query's buffer
+    SurvRec *arena_recs;        // nullptr: records go straight to the query's segment
     uint4 *arena_runs;          // {pos, slot | cnt << 16, query, record offset in the arena}
     unsigned long long *arena_cur;  // RQ_ARENA_SHARDS cursors, [SHARDS] overflow flag, [SHARDS + 1] (host), [SHARDS + 2] cursor of the common area
+    unsigned int *arena_fail;   // per shard: run index of the first append it turned away (0xFFFFFFFF: none)
     uint32_t arena_sub, arena_rsub;  // capacity of a shard: records, runs (the same for both arrays)
     uint32_t arena_common;      // capacity of the common area behind the shards (records = runs), for what a full shard turns away
-    unsigned int *arena_fail;   // per shard: run index of the first append it turned away (0xFFFFFFFF: none)
+    uint32_t pad;
 };
 #define RQ_ARENA_SHARDS 2048u
 #define RQ_ARENA_COMMON_BLOCKS 512u
 // Reserve `nrec` records + `nrun` run descriptors of the arena for the calling lane's block: in the block's shard, or --
 // when that is full (few, heavy blocks) -- in the common area.  Returns false if neither has room (the overflow flag is
 // set: the host doubles the arena and repeats the stage).  rec_off / run_off: indices into arena_recs / arena_runs.
-__device__ __forceinline__ bool arena_reserve(const ScanArgs &a, uint32_t nrec, uint32_t nrun, uint32_t *rec_off, uint32_t *run_off) {
+__device__ __forceinline__ bool arena_reserve(const ScanExtra *xp, uint32_t nrec, uint32_t nrun, uint32_t *rec_off, uint32_t *run_off) {
+    const ScanExtra a = *xp;
     const uint32_t shard = blockIdx.x & (RQ_ARENA_SHARDS - 1u);
     const unsigned long long o = atomicAdd(a.arena_cur + shard, ((unsigned long long)nrun << 32) | nrec);
     const uint32_t ab = (uint32_t)o, rb = (uint32_t)(o >> 32);
@@ -1081,7 +1090,9 @@ __device__ __forceinline__ bool arena_reserve(const ScanArgs &a, uint32_t nrec, 
     *reinterpret_cast<unsigned int *>(a.arena_cur + RQ_ARENA_SHARDS) = 1u;
     return false;
 }
-__device__ __forceinline__ QSeg scan_seg(const ScanArgs &a) { return QSeg{a.seg_base, a.seg_cap, a.cap}; }
+// (the scans record either into the uniform buffers or, in their ARENA instantiations, into the arena: segments are what
+// the scatter pass and the consumers see)
+__device__ __forceinline__ QSeg scan_seg(const ScanArgs &a) { return QSeg{nullptr, nullptr, a.cap}; }
 struct ScanPtrs {   // host-side bundle only
     const uint32_t *codes;        // n * 2W dwords (x_binary_vec, src/rabitq.rs:66)
     const float4 *factors;        // n (src/rabitq.rs:67): x=factor_ip y=factor_ppc z=error_bound w=cds
@@ -1126,7 +1137,7 @@ __device__ __forceinline__ float rough_distance(uint32_t s, const float4 &f, flo
 // expands its candidates' code bits to nibbles ONCE per block (amortised over every query of the
 // group) and the per-query work is 8W chained v_dot8_u32_u4 (8 dimensions each, u32 accumulate,
 // query operand in an SGPR) instead of 8W v_and + 8W v_bcnt + adds.
-template <int W, int CPL>
+template <int W, int CPL, bool ARENA = false>
 __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
     constexpr uint32_t STRIDE = 8 * W + RQ_REC_TAIL;
     uint32_t g, first, list_begin = 0, list_len = 0;
@@ -1250,28 +1261,30 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
             uint32_t nruns = 0;
 #pragma unroll
             for (int c = 0; c < CPL; ++c) nruns += m[c] ? 1u : 0u;
-            if (a.arena_recs) {  // arena mode: count per query, append to this block's shard of the arena
+            if constexpr (ARENA) {  // arena mode: count per query, append to this block's shard of the arena
                 uint32_t off = 0xFFFFFFFFu, roff = 0;
                 if (lane == 0) {
                     atomicAdd(surv_cnt + b, ((unsigned long long)nruns << 32) | total);
-                    if (!arena_reserve(a, total, nruns, &off, &roff)) off = 0xFFFFFFFFu;
+                    if (!arena_reserve(a.x, total, nruns, &off, &roff)) off = 0xFFFFFFFFu;
                 }
                 off = __builtin_amdgcn_readfirstlane(off), roff = __builtin_amdgcn_readfirstlane(roff);
                 if (off == 0xFFFFFFFFu) return;
-                uint4 *rdst = a.arena_runs + roff;
+                SurvRec *arecs = a.x->arena_recs;
+                uint4 *rdst = a.x->arena_runs + roff;
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
                     const uint32_t cntc = (uint32_t)__popcll(m[c]);
                     if ((m[c] >> lane) & 1ull) {
                         SurvRec r;
                         r.pos = pos[c], r.slot = slot, r.rough = rough[c], r.accurate = 0.0f;
-                        a.arena_recs[off + (uint32_t)__popcll(m[c] & ((1ull << lane) - 1ull))] = r;
+                        arecs[off + (uint32_t)__popcll(m[c] & ((1ull << lane) - 1ull))] = r;
                     }
                     if (cntc && lane == 0) *rdst++ = make_uint4(list_begin + first + c * 256 + (threadIdx.x & ~63u), slot | (cntc << 16), b, off);
                     off += cntc;
                 }
                 return;
             }
+            if constexpr (ARENA) return;  // (unreachable: keeps the direct path out of the arena instantiation)
             unsigned long long old = 0;
             if (lane == 0) old = atomicAdd(surv_cnt + b, ((unsigned long long)nruns << 32) | total);
             uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)old);
@@ -1423,7 +1436,7 @@ constexpr uint32_t scan_mfma_ring_slots() {
     return scan_mfma_tiles_per_barrier<W>() > 1 ? 2 * scan_mfma_tiles_per_barrier<W>() : (W >= 16 ? 5u : 3u);
 }
 
-template <int W, int NT>
+template <int W, int NT, bool ARENA = false>
 __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_kernel(const uint32_t *__restrict__ codes,
                                                            const float4 *__restrict__ factors,
                                                            const uint32_t *__restrict__ offsets,
@@ -1554,19 +1567,21 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
     auto flush = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // LDS is in-order per wave
         const QSeg seg = scan_seg(a);
-        if (a.arena_recs) {  // arena mode: count per query, ONE reservation for the whole queue in this block's shard
+        if constexpr (ARENA) {  // arena mode: count per query, ONE reservation for the whole queue in this block's shard
             if (lane < nR) atomicAdd(surv_cnt + r_b[wave][lane], (1ull << 32) | r_cnt[wave][lane]);
             uint32_t off0 = 0xFFFFFFFFu, roff = 0;
-            if (lane == 0 && nR && !arena_reserve(a, nE, nR, &off0, &roff)) off0 = 0xFFFFFFFFu;
+            if (lane == 0 && nR && !arena_reserve(a.x, nE, nR, &off0, &roff)) off0 = 0xFFFFFFFFu;
             off0 = __builtin_amdgcn_readfirstlane(off0), roff = __builtin_amdgcn_readfirstlane(roff);
             if (off0 != 0xFFFFFFFFu) {
+                SurvRec *arecs = a.x->arena_recs;
+                uint4 *aruns = a.x->arena_runs;
                 if (lane < nR)
-                    a.arena_runs[roff + lane] =
+                    aruns[roff + lane] =
                         make_uint4(r_pos[wave][lane], r_slot[wave][lane] | (r_cnt[wave][lane] << 16), r_b[wave][lane], off0 + r_off[wave][lane]);
                 for (uint32_t e = lane; e < nE; e += 64) {
                     SurvRec sr;
                     sr.pos = q_pos[wave][e], sr.slot = r_slot[wave][q_run[wave][e]], sr.rough = q_rough[wave][e], sr.accurate = 0.0f;
-                    a.arena_recs[off0 + e] = sr;
+                    arecs[off0 + e] = sr;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1574,6 +1589,7 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
             nE = 0, nR = 0;
             return;
         }
+        if constexpr (ARENA) return;  // (unreachable)
         if (lane < nR) {  // one lane per run: all reservations in flight together
             const uint32_t rb = r_b[wave][lane], rc = r_cnt[wave][lane];
             const unsigned long long old = atomicAdd(surv_cnt + rb, (1ull << 32) | rc);
@@ -2070,8 +2086,6 @@ struct ReplayState {
     uint32_t *precise;       // nq   (rerank.rs:91 / :153)
     uint32_t *need;          // nq   max survivor count of a stage (sizes re-runs and the learnt capacities)
     uint32_t *ovf;           // nq   1 = a stage dropped records (count > the query's capacity): the query is re-run
-    unsigned long long *early_max;  // one word: largest survivor count of any query in a non-final stage (null: not tracked)
-    uint32_t final_stage;    // the stage being finished is the pass's last one
     uint32_t *nsurv;         // nq   survivors replayed (= accurate distances computed)
     uint32_t *nshadow;       // nq   of those: rejected by the fp16 shadow rows, f32 row never read
     // heuristic ranker
@@ -2352,7 +2366,6 @@ __global__ __launch_bounds__(1024) void stage_finish_kernel(SurvRec *__restrict_
     if (threadIdx.x == 0) {
         if (cnt > st.need[b]) st.need[b] = cnt;
         if (overflow) st.ovf[b] = 1u;
-        if (st.early_max && !st.final_stage && cnt) atomicMax(st.early_max, (unsigned long long)cnt);
         st.nsurv[b] += n;
         surv_cnt[b] = 0;  // ready for the next stage
     }
@@ -2616,7 +2629,6 @@ __global__ __launch_bounds__(64) void replay_kernel(const SurvRec *__restrict__ 
     if (threadIdx.x == 0) {
         if (cnt > st.need[b]) st.need[b] = cnt;
         if (overflow) st.ovf[b] = 1u;
-        if (st.early_max && !st.final_stage && cnt) atomicMax(st.early_max, (unsigned long long)cnt);
         st.nsurv[b] += n;
         surv_cnt[b] = 0;  // ready for the next stage
     }

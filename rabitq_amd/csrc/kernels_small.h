@@ -435,7 +435,7 @@ __global__ __launch_bounds__(1024) void sb_query_kernel(const SbArgs a) {
     // ---- the early part of the stream, stage by stage, all in LDS -----------------------------------------------------
     ReplayState ls;
     ls.thr = &s_thr, ls.heap_len = &s_hlen, ls.heap_key = hk_state, ls.heap_id = hi_state, ls.precise = &s_precise;
-    ls.need = &s_need, ls.ovf = &s_ovf, ls.early_max = nullptr, ls.final_stage = 0, ls.nsurv = &s_nsurv, ls.nshadow = &s_nshadow, ls.recent_max = &s_recent, ls.win_count = &s_wcount;
+    ls.need = &s_need, ls.ovf = &s_ovf, ls.nsurv = &s_nsurv, ls.nshadow = &s_nshadow, ls.recent_max = &s_recent, ls.win_count = &s_wcount;
     ls.arr_len = &s_alen, ls.arr = a.rs.arr + (uint64_t)b * a.hcap, ls.hcap = a.hcap;
     uint32_t n = 0;  // survivors waiting in `recs` (block-uniform)
     // re-rank the waiting survivors (src/rerank.rs:85-90) and replay the ranker over them (:81-106 / :143-168); they

@@ -235,6 +235,7 @@ struct Workspace {
     DevBuf<RunRec> arena_runs;                 //   their run descriptors as uint4 {pos, slot | cnt << 16, query, offset}
     DevBuf<unsigned long long> arena_cur;      //   RQ_ARENA_SHARDS shard cursors (records | runs << 32), overflow flag, total, cursor of the common area
     DevBuf<unsigned int> arena_fail;           //   per shard: first run index it turned away
+    DevBuf<ScanExtra> scan_extra;              //   what the scan reads on its survivor path in arena mode
     DevBuf<uint32_t> sh_flag;                 // handshake / status words of the step
     DevBuf<uint32_t> sh_pc, sh_id_b, sh_n_b;  // shared-threshold step: probe lists (whole | nearest | rest), second call's results
     DevBuf<float> sh_pd, sh_thr, sh_dist_b;
@@ -473,21 +474,29 @@ static void launch_scan_chunks(const ScanArgs &a, F &&launch) {
 }
 
 #define SCAN_ARGS p.codes, p.factors, p.offsets, p.grp_start, p.recs, p.surv, p.runs, p.surv_cnt, p.tile_table, a
-static void launch_scan(const ScanPtrs &p, const ScanArgs &args, uint32_t W, hipStream_t st) {
+template <bool ARENA>
+static void launch_scan_t(const ScanPtrs &p, const ScanArgs &args, uint32_t W, hipStream_t st) {
     launch_scan_chunks(args, [&](const ScanArgs &a, dim3 g) {
         const dim3 b(256);
         switch (W) {
-            case 1: scan_kernel<1, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
-            case 2: scan_kernel<2, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
-            case 3: scan_kernel<3, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
-            case 4: scan_kernel<4, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
-            case 6: scan_kernel<6, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
-            case 8: scan_kernel<8, 2><<<g, b, 0, st>>>(SCAN_ARGS); break;
-            case 12: scan_kernel<12, 1><<<g, b, 0, st>>>(SCAN_ARGS); break;
-            case 16: scan_kernel<16, 1><<<g, b, 0, st>>>(SCAN_ARGS); break;
-            default: scan_generic_kernel<<<g, b, 0, st>>>(SCAN_ARGS, W); break;
+            case 1: scan_kernel<1, 2, ARENA><<<g, b, 0, st>>>(SCAN_ARGS); break;
+            case 2: scan_kernel<2, 2, ARENA><<<g, b, 0, st>>>(SCAN_ARGS); break;
+            case 3: scan_kernel<3, 2, ARENA><<<g, b, 0, st>>>(SCAN_ARGS); break;
+            case 4: scan_kernel<4, 2, ARENA><<<g, b, 0, st>>>(SCAN_ARGS); break;
+            case 6: scan_kernel<6, 2, ARENA><<<g, b, 0, st>>>(SCAN_ARGS); break;
+            case 8: scan_kernel<8, 2, ARENA><<<g, b, 0, st>>>(SCAN_ARGS); break;
+            case 12: scan_kernel<12, 1, ARENA><<<g, b, 0, st>>>(SCAN_ARGS); break;
+            case 16: scan_kernel<16, 1, ARENA><<<g, b, 0, st>>>(SCAN_ARGS); break;
+            default:
+                if constexpr (!ARENA) scan_generic_kernel<<<g, b, 0, st>>>(SCAN_ARGS, W);  // (arena stages exist for the fused dims only)
+                break;
         }
     });
+}
+// args.x != nullptr: the arena instantiations (the stage appends to the shared arena, ScanExtra)
+static void launch_scan(const ScanPtrs &p, const ScanArgs &args, uint32_t W, hipStream_t st) {
+    if (args.x) launch_scan_t<true>(p, args, W, st);
+    else launch_scan_t<false>(p, args, W, st);
 }
 // scan implementation: 0 = auto (matrix cores when many queries share each list, VALU otherwise),
 // 1 = VALU (v_dot8_u32_u4) only, 2 = matrix cores wherever the kernel exists (test hook)
@@ -512,26 +521,31 @@ static bool scan_has_mfma(uint32_t W) {
 static uint32_t scan_mfma_nt(uint32_t W) { return W == 2 ? 3 : (W == 12 ? 1 : (W >= 4 ? 2 : 4)); }
 static uint32_t scan_mfma_tile(uint32_t W) { return 128 * scan_mfma_nt(W); }
 static size_t scan_mfma_ring_bytes(uint32_t W) { return (W <= 2 ? 4ull : (W >= 16 ? 5ull : 3ull)) * (32 * (12 * W + 2) + RQ_REC_TAIL * 32) * 4; }  // scan_mfma_ring_slots<W>()
-template <int W, int NT>
+template <int W, int NT, bool ARENA>
 static void launch_scan_mfma_t(const ScanPtrs &p, const ScanArgs &a, dim3 g, hipStream_t st) {
-    scan_mfma_kernel<W, NT><<<g, dim3(256), scan_mfma_ring_bytes(W), st>>>(p.codes, p.factors, p.offsets, p.grp_start, p.grp_cnt,
-                                                                             p.recs, p.surv, p.runs, p.surv_cnt, p.stat, p.tile_table, a);
+    scan_mfma_kernel<W, NT, ARENA><<<g, dim3(256), scan_mfma_ring_bytes(W), st>>>(p.codes, p.factors, p.offsets, p.grp_start, p.grp_cnt,
+                                                                                    p.recs, p.surv, p.runs, p.surv_cnt, p.stat, p.tile_table, a);
 }
-// callers check scan_has_mfma(W) first
-static void launch_scan_mfma(const ScanPtrs &p, const ScanArgs &args, uint32_t W, hipStream_t st) {
+// callers check scan_has_mfma(W) first; args.x != nullptr: the arena instantiations
+template <bool ARENA>
+static void launch_scan_mfma_a(const ScanPtrs &p, const ScanArgs &args, uint32_t W, hipStream_t st) {
     launch_scan_chunks(args, [&](const ScanArgs &a, dim3 g) {
         switch (W) {
-            case 1: launch_scan_mfma_t<1, 4>(p, a, g, st); break;
-            case 2: launch_scan_mfma_t<2, 3>(p, a, g, st); break;
-            case 3: launch_scan_mfma_t<3, 4>(p, a, g, st); break;
-            case 4: launch_scan_mfma_t<4, 2>(p, a, g, st); break;
-            case 6: launch_scan_mfma_t<6, 2>(p, a, g, st); break;
-            case 8: launch_scan_mfma_t<8, 2>(p, a, g, st); break;
-            case 12: launch_scan_mfma_t<12, 1>(p, a, g, st); break;
-            case 16: launch_scan_mfma_t<16, 2>(p, a, g, st); break;
+            case 1: launch_scan_mfma_t<1, 4, ARENA>(p, a, g, st); break;
+            case 2: launch_scan_mfma_t<2, 3, ARENA>(p, a, g, st); break;
+            case 3: launch_scan_mfma_t<3, 4, ARENA>(p, a, g, st); break;
+            case 4: launch_scan_mfma_t<4, 2, ARENA>(p, a, g, st); break;
+            case 6: launch_scan_mfma_t<6, 2, ARENA>(p, a, g, st); break;
+            case 8: launch_scan_mfma_t<8, 2, ARENA>(p, a, g, st); break;
+            case 12: launch_scan_mfma_t<12, 1, ARENA>(p, a, g, st); break;
+            case 16: launch_scan_mfma_t<16, 2, ARENA>(p, a, g, st); break;
             default: break;
         }
     });
+}
+static void launch_scan_mfma(const ScanPtrs &p, const ScanArgs &args, uint32_t W, hipStream_t st) {
+    if (args.x) launch_scan_mfma_a<true>(p, args, W, st);
+    else launch_scan_mfma_a<false>(p, args, W, st);
 }
 
 static bool scan_is_fused(uint32_t W) {
@@ -567,7 +581,10 @@ static void launch_select(const float *dist, uint32_t k, uint32_t nprobe, uint32
 // ------------------------------------------------------------------------------------------------
 template <int W, int NT>
 static hipError_t set_scan_mfma_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(scan_mfma_kernel<W, NT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(scan_mfma_kernel<W, NT, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_mfma_ring_bytes(W));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(scan_mfma_kernel<W, NT, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_mfma_ring_bytes(W));
 }
 static rq_status ensure_kernel_attributes() {
@@ -816,7 +833,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     rs.thr = ws.thr.p, rs.heap_len = ws.heap_len.p, rs.heap_key = ws.heap_key.p, rs.heap_id = ws.heap_id.p;
     rs.precise = ws.precise.p, rs.need = ws.need.p, rs.nsurv = ws.nsurv.p, rs.nshadow = ws.nshadow.p, rs.recent_max = ws.recent.p, rs.win_count = ws.win_count.p;
     rs.arr_len = ws.arr_len.p, rs.arr = ws.arr.p, rs.hcap = qp.hcap;
-    rs.ovf = ws.ovf.p, rs.early_max = ws.totals.p + 6, rs.final_stage = 0;
+    rs.ovf = ws.ovf.p;
     const QSeg useg{nullptr, nullptr, qp.cap};  // uniform geometry: every stage but a segmented final one
     const float *qpad = d_q;
     const uint32_t *probe_cluster = ws.probe_cluster.p;
@@ -1064,8 +1081,6 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         // exact counts size a segment per query (prefix sum), the host makes room for their sum, and a scatter pass moves
         // every run to its query's segment.  The workspace follows the SUM of the survivors, not nq x the worst query, and
         // no query can overflow.
-        const bool is_last = &sg == &stages.back();
-        rs.final_stage = is_last ? 1u : 0u;
         QSeg seg = useg;
         const bool arena_stage = qp.seg_final && span > qp.cap && scan_is_fused(W) && nq >= 256;
         if (arena_stage) {
@@ -1073,6 +1088,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             // 1 / RQ_ARENA_SHARDS of it
             uint64_t want = std::max<uint64_t>(idx->arena_hint.load(), (uint64_t)nq * qp.cap / 2);
             unsigned long long total_slots = 0;
+            uint32_t arena_rsub = 0;
             for (int attempt = 0;; ++attempt) {
                 want = std::min<uint64_t>(want, 0xFFFF0000ull);
                 RQC(ws.arena_recs.ensure(want));
@@ -1081,13 +1097,19 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                 RQC(ws.arena_fail.ensure(RQ_ARENA_SHARDS));
                 HIPC(hipMemsetAsync(ws.arena_cur.p, 0, (RQ_ARENA_SHARDS + 4) * 8, st));
                 HIPC(hipMemsetAsync(ws.arena_fail.p, 0xFF, RQ_ARENA_SHARDS * 4, st));
-                a.arena_recs = ws.arena_recs.p, a.arena_runs = reinterpret_cast<uint4 *>(ws.arena_runs.p), a.arena_cur = ws.arena_cur.p;
-                a.arena_fail = ws.arena_fail.p;
+                ScanExtra hx{};
+                hx.seg_base = nullptr, hx.seg_cap = nullptr;
+                hx.arena_recs = ws.arena_recs.p, hx.arena_runs = reinterpret_cast<uint4 *>(ws.arena_runs.p), hx.arena_cur = ws.arena_cur.p;
+                hx.arena_fail = ws.arena_fail.p;
                 {  // seven eighths of the arena in shards, the rest as the common area (what a full shard turns away: few, heavy blocks)
                     const uint64_t have = std::min<uint64_t>(ws.arena_recs.count, ws.arena_runs.count);
-                    a.arena_sub = a.arena_rsub = (uint32_t)(have * 7 / 8 / RQ_ARENA_SHARDS);
-                    a.arena_common = (uint32_t)std::min<uint64_t>(have - (uint64_t)a.arena_sub * RQ_ARENA_SHARDS, 0xFFFFFF00ull);
+                    hx.arena_sub = hx.arena_rsub = (uint32_t)(have * 7 / 8 / RQ_ARENA_SHARDS);
+                    hx.arena_common = (uint32_t)std::min<uint64_t>(have - (uint64_t)hx.arena_sub * RQ_ARENA_SHARDS, 0xFFFFFF00ull);
                 }
+                arena_rsub = hx.arena_rsub;
+                RQC(ws.scan_extra.ensure(1));
+                HIPC(hipMemcpyAsync(ws.scan_extra.p, &hx, sizeof hx, hipMemcpyHostToDevice, st));
+                a.x = ws.scan_extra.p;
                 a.dense_dir = 0u;
                 pf.begin(use_mfma ? PF_SCAN_MATRIX : PF_SCAN);
                 if (use_mfma) launch_scan_mfma(sp, a, W, st);
@@ -1119,7 +1141,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             }
             sp.surv = ws.surv.p, sp.runs = ws.runs.p;
             arena_scatter_kernel<<<dim3(RQ_ARENA_SHARDS + RQ_ARENA_COMMON_BLOCKS, 2), 256, 0, st>>>(ws.arena_recs.p, reinterpret_cast<const uint4 *>(ws.arena_runs.p), ws.arena_cur.p,
-                                                                              ws.arena_fail.p, a.arena_rsub, ws.q_base.p, ws.surv_cnt.p, ws.surv.p, ws.runs.p);
+                                                                              ws.arena_fail.p, arena_rsub, ws.q_base.p, ws.surv_cnt.p, ws.surv.p, ws.runs.p);
             pf.end();
             seg = QSeg{ws.q_base.p, ws.q_cap.p, qp.cap};
             ws.pend_seg_slots = std::max<uint64_t>(ws.pend_seg_slots, total_slots);
