@@ -1965,16 +1965,21 @@ __global__ __launch_bounds__(256) void accurate_flat_kernel(const uint32_t *__re
 // ------------------------------------------------------------------------------------------------
 #define RQ_SORT_LDS_RECS 2048
 template <typename T, uint32_t LDS_RECS = RQ_SORT_LDS_RECS>
-__device__ __forceinline__ void sort_segment(T *__restrict__ recs, uint32_t n) {
+__device__ __forceinline__ void sort_segment(T *recs, uint32_t n, const T *src = nullptr /* the unsorted records, when not in place */) {
     __shared__ T lds[LDS_RECS];
-    if (n < 2) return;
+    if (!src) src = recs;
+    if (n < 2 && src == recs) return;
     auto key = [](const T &r) { return surv_key(r); };
     if (n <= LDS_RECS) {
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) lds[i] = recs[i];
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) lds[i] = src[i];
         __syncthreads();
         bitonic_sort_block(lds, n, key);
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) recs[i] = lds[i];
     } else {
+        if (src != recs) {
+            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) recs[i] = src[i];
+            __threadfence_block();
+        }
         __syncthreads();
         bitonic_sort_block(recs, n, key);  // in global memory (L2), rare
     }
@@ -1985,6 +1990,7 @@ __device__ __forceinline__ void sort_segment(T *__restrict__ recs, uint32_t n) {
 // smaller positions in its bucket; the bucket's positions are staged through LDS in chunks and compared four at a
 // time) and written back to the directory at its final index.  Block-cooperative; needs nslots <= MAX_SLOTS.
 #define RQ_BUCKET_CHUNK 1024u
+#define RQ_SORT_MID_LDS_WORDS 14336u  // dwords of each of the two dynamic-LDS arrays of order_runs_bitmap: 458 752 cells = 14.7M list positions per query
 template <uint32_t MAX_SLOTS>
 __device__ __forceinline__ void sort_runs_by_slot(RunRec *__restrict__ dir, RunRec *__restrict__ tmp, uint32_t n, uint32_t nslots) {
     __shared__ uint32_t start[MAX_SLOTS + 1], cursor[MAX_SLOTS];
@@ -2058,6 +2064,98 @@ __device__ __forceinline__ void sort_runs_by_slot(RunRec *__restrict__ dir, RunR
             if (e0 + lane < m) dir[b0 + rank] = mine;  // positions are unique within a bucket: ranks are a permutation
         }
     }
+}
+
+// The same ordering in O(n), for directories whose position span fits an LDS bitmap (the usual case: the final stage of a
+// batch on an index with very unequal lists leaves tens of thousands of runs per query, thousands per list, where the rank
+// counting above is quadratic).  Within a probe slot (= one list) the runs of one stage sit on distinct 32-position
+// cells of the list (a run = one query x one 32- or 64-position sub-tile, common.h), so a run's final index is the number
+// of occupied cells before its own: cell = cellbase[slot] + (pos - minpos[slot]) / 32 over a bitmap of the query's cells
+// (one bit per 32 list positions of every probed list that contributed), rank = popcount prefix.  Three passes over the
+// descriptors (L2), no comparison.  `src` are the unsorted descriptors, `out` receives the order (out != src).  Returns
+// false -- nothing written -- when the bitmap does not fit `cap_words` or two runs share a cell (not produced by the
+// scans; the caller then falls back to the bucket ranking).
+template <uint32_t MAX_SLOTS>
+__device__ __forceinline__ bool order_runs_bitmap(const RunRec *src, RunRec *out, uint32_t n, uint32_t nslots, uint32_t *words /* [cap_words] */,
+                                                  uint32_t *wpre /* [cap_words] */, uint32_t cap_words) {
+    __shared__ uint32_t minpos[MAX_SLOTS], cellbase[MAX_SLOTS];  // cellbase holds the slot's largest position first
+    __shared__ uint32_t bsum[17];
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t i = tid; i < nslots; i += nthr) minpos[i] = 0xFFFFFFFFu, cellbase[i] = 0u;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += nthr) {
+        const RunRec r = src[i];
+        atomicMin(&minpos[r.slot], r.pos);
+        atomicMax(&cellbase[r.slot], r.pos);
+    }
+    __syncthreads();
+    // exclusive scan of the slots' cell counts (each thread owns a contiguous stretch of slots)
+    uint32_t total_cells;
+    {
+        const uint32_t per = (nslots + nthr - 1) / nthr, b0 = tid * per < nslots ? tid * per : nslots;
+        const uint32_t b1 = b0 + per < nslots ? b0 + per : nslots;
+        uint32_t sum = 0;
+        for (uint32_t i = b0; i < b1; ++i) sum += minpos[i] == 0xFFFFFFFFu ? 0u : ((cellbase[i] - minpos[i]) >> 5) + 1u;
+        uint32_t incl = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o, 64);
+            if ((int)lane >= o) incl += up;
+        }
+        if (lane == 63) bsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum, all = 0;
+        for (uint32_t w = 0; w < (nthr >> 6); ++w) {
+            if (w < wave) run += bsum[w];
+            all += bsum[w];
+        }
+        total_cells = all;
+        for (uint32_t i = b0; i < b1; ++i) {
+            const uint32_t c = minpos[i] == 0xFFFFFFFFu ? 0u : ((cellbase[i] - minpos[i]) >> 5) + 1u;
+            cellbase[i] = run;
+            run += c;
+        }
+    }
+    const uint32_t nwords = (total_cells + 31) >> 5;
+    if (nwords > cap_words) return false;  // (block-uniform)
+    for (uint32_t i = tid; i < nwords; i += nthr) words[i] = 0u;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += nthr) {
+        const RunRec r = src[i];
+        const uint32_t cell = cellbase[r.slot] + ((r.pos - minpos[r.slot]) >> 5);
+        atomicOr(&words[cell >> 5], 1u << (cell & 31u));
+    }
+    __syncthreads();
+    {  // exclusive popcount prefix over the words
+        const uint32_t per = (nwords + nthr - 1) / nthr, w0 = tid * per < nwords ? tid * per : nwords;
+        const uint32_t w1 = w0 + per < nwords ? w0 + per : nwords;
+        uint32_t sum = 0;
+        for (uint32_t i = w0; i < w1; ++i) sum += (uint32_t)__popc(words[i]);
+        uint32_t incl = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o, 64);
+            if ((int)lane >= o) incl += up;
+        }
+        __syncthreads();  // bsum is free again
+        if (lane == 63) bsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum, all = 0;
+        for (uint32_t w = 0; w < (nthr >> 6); ++w) {
+            if (w < wave) run += bsum[w];
+            all += bsum[w];
+        }
+        if (all != n) return false;  // two runs on one cell (block-uniform)
+        for (uint32_t i = w0; i < w1; ++i) {
+            wpre[i] = run;
+            run += (uint32_t)__popc(words[i]);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += nthr) {
+        const RunRec r = src[i];
+        const uint32_t cell = cellbase[r.slot] + ((r.pos - minpos[r.slot]) >> 5);
+        out[wpre[cell >> 5] + (uint32_t)__popc(words[cell >> 5] & ((1u << (cell & 31u)) - 1u))] = r;
+    }
+    return true;
 }
 
 // heuristic ranker's accepted array (src/rerank.rs:170-176): by (Ord32(accurate), arrival)
@@ -2565,10 +2663,13 @@ __global__ __launch_bounds__(256) void accurate_kernel(SurvRec *__restrict__ sur
                   probe_cluster + (uint64_t)b * nprobe);
 }
 
+// `runs_src`: where the stage's unsorted descriptors are when not in `runs` itself (an arena stage scatters them into the
+// second directory buffer, so that the ordering pass is the one that writes the directory); same geometry.
 __global__ __launch_bounds__(64) void sort_runs_kernel(RunRec *__restrict__ runs,
                                                         const unsigned long long *__restrict__ surv_cnt,
                                                         const QSeg seg, uint32_t *__restrict__ big_list,
-                                                        uint32_t *__restrict__ big_count, uint32_t list_above) {
+                                                        uint32_t *__restrict__ big_count, uint32_t list_above,
+                                                        const RunRec *runs_src) {
     const uint32_t b = blockIdx.x;
     const unsigned long long c = surv_cnt[b];
     if ((uint32_t)c > seg.capof(b)) return;
@@ -2579,26 +2680,50 @@ __global__ __launch_bounds__(64) void sort_runs_kernel(RunRec *__restrict__ runs
         if (nruns > list_above && threadIdx.x == 0) big_list[atomicAdd(big_count, 1u)] = b;
         return;
     }
-    if (nruns > 512) {  // a loose threshold: handed to sort_runs_mid_kernel (slot buckets + rank counting)
+    if (nruns > 512) {  // a loose threshold: handed to sort_runs_mid_kernel (cell bitmap, or slot buckets + rank counting)
         if (threadIdx.x == 0) big_list[atomicAdd(big_count, 1u)] = b;
         return;
     }
-    sort_segment<RunRec, 512>(runs + seg.at(b), nruns);
+    sort_segment<RunRec, 512>(runs + seg.at(b), nruns, runs_src ? runs_src + seg.at(b) : nullptr);
 }
 
 // Directories of more than 512 runs, listed by sort_runs_kernel, are ordered by a persistent launch that walks the
-// list (it exits at once when the list is empty, the common case): slot-bucketing + per-bucket rank counting through
-// the second directory buffer; the last block out resets the counter for the next stage.
+// list (it exits at once when the list is empty, the common case): the cell bitmap (order_runs_bitmap, dynamic LDS:
+// 2 x lds_words dwords), else slot-bucketing + per-bucket rank counting through the second directory buffer; the last
+// block out resets the counter for the next stage.  src_is_tmp: the unsorted descriptors are in runs_tmp.
 __global__ __launch_bounds__(256) void sort_runs_mid_kernel(RunRec *__restrict__ runs, RunRec *__restrict__ runs_tmp,
                                                             const unsigned long long *__restrict__ surv_cnt, const QSeg seg,
                                                             const uint32_t *__restrict__ big_list,
                                                             uint32_t *__restrict__ big_count /* [0] entries, [1] blocks done, [2] most entries of a stage */,
-                                                            uint32_t nslots) {
+                                                            uint32_t nslots, uint32_t src_is_tmp, uint32_t lds_words) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t mid_lds[];
     const uint32_t total = big_count[0];
     for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
         const uint32_t b = big_list[i], n = (uint32_t)(surv_cnt[b] >> 32);
-        if (nslots <= 1024 && runs_tmp) sort_runs_by_slot<1024>(runs + seg.at(b), runs_tmp + seg.at(b), n, nslots);
-        else sort_segment<RunRec, 16>(runs + seg.at(b), n);  // more than 1024 probe slots, or no second buffer yet: bitonic sort in global memory
+        RunRec *dir = runs + seg.at(b), *tmp = runs_tmp ? runs_tmp + seg.at(b) : nullptr;
+        bool done = false;
+        if (nslots <= 1024 && tmp && lds_words) {
+            if (src_is_tmp) {
+                done = order_runs_bitmap<1024>(tmp, dir, n, nslots, mid_lds, mid_lds + lds_words, lds_words);
+            } else {
+                done = order_runs_bitmap<1024>(dir, tmp, n, nslots, mid_lds, mid_lds + lds_words, lds_words);
+                if (done) {  // back into the directory (the block's own writes: L2)
+                    __threadfence_block();
+                    __syncthreads();
+                    for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) dir[e] = tmp[e];
+                }
+            }
+        }
+        if (!done) {
+            if (src_is_tmp && tmp) {  // the fall-backs order the directory itself
+                __syncthreads();
+                for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) dir[e] = tmp[e];
+                __threadfence_block();
+                __syncthreads();
+            }
+            if (nslots <= 1024 && tmp) sort_runs_by_slot<1024>(dir, tmp, n, nslots);
+            else sort_segment<RunRec, 16>(dir, n);  // more than 1024 probe slots, or no second buffer yet: bitonic sort in global memory
+        }
         __syncthreads();
     }
     __syncthreads();

@@ -603,6 +603,7 @@ static rq_status ensure_kernel_attributes() {
         set(reinterpret_cast<const void *>(assign_generic_kernel<8>), 140 * 1024, "assign_generic_kernel<8>");
         set(reinterpret_cast<const void *>(merge_smallest_u64_kernel), 16384 * 8, "merge_smallest_u64_kernel");
         set(reinterpret_cast<const void *>(sb_front_kernel), 140 * 1024, "sb_front_kernel");
+        set(reinterpret_cast<const void *>(sort_runs_mid_kernel), RQ_SORT_MID_LDS_WORDS * 8, "sort_runs_mid_kernel");  // (+ 34 KiB of static LDS)
         set(reinterpret_cast<const void *>(assign_approx_kernel<6, 1>), (int)assign_lds_bytes<6, 1>(), "assign_approx_kernel<6,1>");
         set(reinterpret_cast<const void *>(assign_approx_kernel<8, 1>), (int)assign_lds_bytes<8, 1>(), "assign_approx_kernel<8,1>");
         set(reinterpret_cast<const void *>(assign_approx_kernel<12, 1>), (int)assign_lds_bytes<12, 1>(), "assign_approx_kernel<12,1>");
@@ -1082,6 +1083,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         // every run to its query's segment.  The workspace follows the SUM of the survivors, not nq x the worst query, and
         // no query can overflow.
         QSeg seg = useg;
+        bool runs_in_tmp = false;
         const bool arena_stage = qp.seg_final && span > qp.cap && scan_is_fused(W) && nq >= 256;
         if (arena_stage) {
             // capacity: what earlier batches needed (+ headroom), at least half the uniform buffers' worth; a shard holds
@@ -1141,7 +1143,8 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             }
             sp.surv = ws.surv.p, sp.runs = ws.runs.p;
             arena_scatter_kernel<<<dim3(RQ_ARENA_SHARDS + RQ_ARENA_COMMON_BLOCKS, 2), 256, 0, st>>>(ws.arena_recs.p, reinterpret_cast<const uint4 *>(ws.arena_runs.p), ws.arena_cur.p,
-                                                                              ws.arena_fail.p, arena_rsub, ws.q_base.p, ws.surv_cnt.p, ws.surv.p, ws.runs.p);
+                                                                              ws.arena_fail.p, arena_rsub, ws.q_base.p, ws.surv_cnt.p, ws.surv.p, ws.runs_tmp.p);
+            runs_in_tmp = true;  // the ordering pass below writes the directory
             pf.end();
             seg = QSeg{ws.q_base.p, ws.q_cap.p, qp.cap};
             ws.pend_seg_slots = std::max<uint64_t>(ws.pend_seg_slots, total_slots);
@@ -1173,9 +1176,10 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             // only what fits its LDS
             const uint32_t presorted = qp.cap > RQ_DEFAULT_CAP && nprobe <= 1024 ? 1u : 0u;
             if (presorted) {
-                sort_runs_kernel<<<nq, 64, 0, st>>>(ws.runs.p, ws.surv_cnt.p, seg, ws.big_list.p, ws.big_list.p + nq, RQ_SORT_LDS_RECS);
-                sort_runs_mid_kernel<<<std::min(nq, 256u), 256, 0, st>>>(ws.runs.p, ws.use_runs_tmp ? ws.runs_tmp.p : nullptr, ws.surv_cnt.p, seg, ws.big_list.p,
-                                                                         ws.big_list.p + nq, nprobe);
+                sort_runs_kernel<<<nq, 64, 0, st>>>(ws.runs.p, ws.surv_cnt.p, seg, ws.big_list.p, ws.big_list.p + nq, RQ_SORT_LDS_RECS, nullptr);
+                sort_runs_mid_kernel<<<std::min(nq, 256u), 256, RQ_SORT_MID_LDS_WORDS * 8, st>>>(ws.runs.p, ws.use_runs_tmp ? ws.runs_tmp.p : nullptr, ws.surv_cnt.p,
+                                                                                              seg, ws.big_list.p, ws.big_list.p + nq, nprobe, 0u,
+                                                                                              RQ_SORT_MID_LDS_WORDS);
             }
             if (sb_fused_finish) {  // small-batch path, heap ranker: the stage's finish also writes the results and the totals
                 // a handful of queries: their final-stage survivors (~1000 rows each) are gathered by the whole chip -- one block
@@ -1217,10 +1221,12 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             pf.end();
             if (!dense_cells) {
                 pf.begin(PF_SORT);
-                sort_runs_kernel<<<nq, 64, 0, st>>>(ws.runs.p, ws.surv_cnt.p, seg, ws.big_list.p, ws.big_list.p + nq, 512u);
-                // queries with long run directories (loose thresholds): slot-bucketed ordering, persistent blocks walking the list
-                sort_runs_mid_kernel<<<mid_blocks, 256, 0, st>>>(ws.runs.p, ws.use_runs_tmp ? ws.runs_tmp.p : nullptr, ws.surv_cnt.p, seg, ws.big_list.p,
-                                                             ws.big_list.p + nq, nprobe);
+                sort_runs_kernel<<<nq, 64, 0, st>>>(ws.runs.p, ws.surv_cnt.p, seg, ws.big_list.p, ws.big_list.p + nq, 512u,
+                                                    runs_in_tmp ? ws.runs_tmp.p : nullptr);
+                // queries with long run directories (loose thresholds, very unequal lists): cell-bitmap ordering, persistent blocks walking the list
+                sort_runs_mid_kernel<<<mid_blocks, 256, RQ_SORT_MID_LDS_WORDS * 8, st>>>(ws.runs.p, (ws.use_runs_tmp || runs_in_tmp) ? ws.runs_tmp.p : nullptr,
+                                                                                      ws.surv_cnt.p, seg, ws.big_list.p, ws.big_list.p + nq, nprobe,
+                                                                                      runs_in_tmp ? 1u : 0u, RQ_SORT_MID_LDS_WORDS);
                 pf.end();
             }
             pf.begin(PF_REPLAY);
