@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "librabitq_hip.so")
+SO_PATH = os.environ.get("RABITQ_HIP_SO") or os.path.join(_HERE, "librabitq_hip.so")   # (override: kernel experiments)
 CSRC = os.path.join(_HERE, "csrc")
 
 RQ_OK = 0

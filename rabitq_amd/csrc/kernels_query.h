@@ -1420,9 +1420,13 @@ template <int W>
 constexpr int scan_mfma_blocks_per_cu() { return W <= 2 ? 4 : (W <= 12 ? 2 : 1); }
 // Wide vectors (dim >= 384) do not keep the query tile's operand in registers: the candidates' expanded codes
 // (6*W*NT dwords) already fill most of the file, so the query fragments are streamed from the LDS image one
-// 64-dimension slab at a time (3 ds_read_b64 per slab, each feeding the MFMAs of all NT sub-tiles).
+// 64-dimension slab at a time (3 ds_read_b64 per slab, each feeding the MFMAs of all NT sub-tiles).  dim 768 runs
+// TWO sub-tiles per wave this way (240 VGPRs, two blocks per CU): with one, every 128 candidates re-streamed the list's
+// query tiles (20 KB each) from L2 and every MFMA needed its own 1.5 KB fragment from LDS -- both above what the CU's
+// L2 and LDS ports deliver at the matrix rate (100M x 768, batch 32 768: 36.2 -> 26.3 ms, 0.21 -> 0.29 of the fp6 peak;
+// three sub-tiles at one block per CU: 39 ms).
 template <int W>
-constexpr bool scan_mfma_stream_a() { return W > 4 && W <= 8; }  // W = 12 (one sub-tile per wave) and W = 16 (one block per CU) keep A resident
+constexpr bool scan_mfma_stream_a() { return W > 4 && W <= 12; }  // W = 16 (one block per CU) keeps A resident
 // Query tiles consumed per block barrier.  The four waves of a block sit on four SIMDs that each serve other
 // blocks as well, so a barrier per 32-query tile makes every wave advance at the pace of the slowest; narrow
 // vectors (small tile images) afford two tiles per barrier with a 4-slot ring.
@@ -1648,7 +1652,8 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
     // developer hook (dbg & 256): cycles of the block's start-up, of the waits at the top of the tile loop and of the
     // tile bodies, summed over blocks into stat[128..131) (+ block count): where a wave's lifetime goes
     const uint32_t time_stat = __builtin_amdgcn_readfirstlane((a.dbg & 256u) ? 1u : 0u);
-    unsigned long long tm_wait = 0, tm_body = 0, tm_mark = 0, tm_startup = 0;
+    unsigned long long tm_wait = 0, tm_body = 0, tm_mark = 0, tm_startup = 0, tm_exact = 0, tm_flush = 0;
+    uint32_t n_regs = 0, n_flush = 0, n_greg = 0;
     if (time_stat) {
         tm_mark = __builtin_readcyclecounter();
         tm_startup = tm_mark - tm_begin;
@@ -1768,6 +1773,7 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
             if (count_stat) ++n_steps;
             if (__ballot(mxi >= gate_min) != 0ull) {  // wave-uniform; everything below
                 if (count_stat) ++n_flag;
+                const unsigned long long tx0 = time_stat ? __builtin_readcyclecounter() : 0ull;
                 // lives inside this branch so that the common path carries no state of it (not even a zeroed tile)
                 uint32_t gmask = force_any ? 0xFFFFu : 0u;  // accumulator registers with at least one flagged lane
                 f32x16 sc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1778,6 +1784,7 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
                 for (int m = 0; m < W; ++m)
                     sc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(get_a(m), get_b(t, m), sc, 2, 2, 0, 0, 0, 0);
                 if (a.dbg & 1u) gmask = 0;
+                if (time_stat) n_greg += (uint32_t)__popc(gmask);
                 // exact evaluation + emit, for the flagged registers only
                 const float4 fc = facL[lpos[t] - first];
                 while (gmask) {
@@ -1801,7 +1808,12 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
                     pass = pass && row < nvalid && lpos[t] >= tb.z && lpos[t] < tb.w;
                     const uint64_t m = __ballot(pass);
                     if (m == 0) continue;
-                    if (nE + 64 > QE || nR + 2 > QR) flush();
+                    if (time_stat) ++n_regs;
+                    if (nE + 64 > QE || nR + 2 > QR) {
+                        const unsigned long long tf0 = time_stat ? __builtin_readcyclecounter() : 0ull;
+                        flush();
+                        if (time_stat) tm_flush += __builtin_readcyclecounter() - tf0, ++n_flush;
+                    }
                     // each half-wave is one run (one query x 32 consecutive positions); half 0 first
                     const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
                     const uint32_t c0 = (uint32_t)__popc(m0), c1 = (uint32_t)__popc(m1);
@@ -1822,6 +1834,7 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
                     nE += c0 + c1;
                     nR += (c0 ? 1u : 0u) + (c1 ? 1u : 0u);
                 }
+                if (time_stat) tm_exact += __builtin_readcyclecounter() - tx0;
             }
         }
         slot = slot + 1 == scan_mfma_ring_slots<W>() ? 0 : slot + 1;
@@ -1834,6 +1847,8 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
     if (time_stat && tid == 0) {
         atomicAdd(stat + 128, tm_startup), atomicAdd(stat + 129, tm_wait), atomicAdd(stat + 130, tm_body);
         atomicAdd(stat + 131, 1ull), atomicAdd(stat + 132, (unsigned long long)ntiles);
+        atomicAdd(stat + 133, tm_exact), atomicAdd(stat + 134, tm_flush), atomicAdd(stat + 135, (unsigned long long)n_regs);
+        atomicAdd(stat + 136, (unsigned long long)n_flush), atomicAdd(stat + 137, (unsigned long long)n_greg);
     }
     if (nE) flush();
     if (count_stat && lane == 0) {  // 64 pairs of counters, by block: a single address would serialise a million atomics

@@ -518,7 +518,7 @@ static bool scan_has_mfma(uint32_t W) {
         default: return false;
     }
 }
-static uint32_t scan_mfma_nt(uint32_t W) { return W == 2 ? 3 : (W == 12 ? 1 : (W >= 4 ? 2 : 4)); }
+static uint32_t scan_mfma_nt(uint32_t W) { return W == 2 ? 3 : (W >= 4 ? 2 : 4); }
 static uint32_t scan_mfma_tile(uint32_t W) { return 128 * scan_mfma_nt(W); }
 static size_t scan_mfma_ring_bytes(uint32_t W) { return (W <= 2 ? 4ull : (W >= 16 ? 5ull : 3ull)) * (32 * (12 * W + 2) + RQ_REC_TAIL * 32) * 4; }  // scan_mfma_ring_slots<W>()
 template <int W, int NT, bool ARENA>
@@ -537,7 +537,7 @@ static void launch_scan_mfma_a(const ScanPtrs &p, const ScanArgs &args, uint32_t
             case 4: launch_scan_mfma_t<4, 2, ARENA>(p, a, g, st); break;
             case 6: launch_scan_mfma_t<6, 2, ARENA>(p, a, g, st); break;
             case 8: launch_scan_mfma_t<8, 2, ARENA>(p, a, g, st); break;
-            case 12: launch_scan_mfma_t<12, 1, ARENA>(p, a, g, st); break;
+            case 12: launch_scan_mfma_t<12, 2, ARENA>(p, a, g, st); break;
             case 16: launch_scan_mfma_t<16, 2, ARENA>(p, a, g, st); break;
             default: break;
         }
@@ -629,7 +629,7 @@ static rq_status ensure_kernel_attributes() {
         chk(set_scan_mfma_attr<4, 2>(), "scan_mfma_kernel<4,2>");
         chk(set_scan_mfma_attr<6, 2>(), "scan_mfma_kernel<6,2>");
         chk(set_scan_mfma_attr<8, 2>(), "scan_mfma_kernel<8,2>");
-        chk(set_scan_mfma_attr<12, 1>(), "scan_mfma_kernel<12,1>");
+        chk(set_scan_mfma_attr<12, 2>(), "scan_mfma_kernel<12,2>");
         chk(set_scan_mfma_attr<16, 2>(), "scan_mfma_kernel<16,2>");
     });
     if (err != hipSuccess)
@@ -751,8 +751,12 @@ static rq_status finish_pass(const rq_index *idx, Workspace &ws, PassResult *res
         prof_acc->rerank_candidates += ws.h_totals[3];
         prof_acc->rerank_shadow_rejects += ws.h_totals[5];
         if (g_scan_dbg.load() & 256) {  // developer hook: where the matrix-core scan's waves spend their cycles
-            unsigned long long ht[8];
+            unsigned long long ht[12];
             HIPC(hipMemcpy(ht, ws.stat.p + 128, sizeof ht, hipMemcpyDeviceToHost));
+            if (ht[3])
+                fprintf(stderr, "[rabitq_hip] scan_mfma exact path (wave 0 of every block): %.0f cycles per block inside it (of which flushes %.0f), "
+                        "%.1f flagged registers, %.1f with survivors and %.2f flushes per block\n", (double)ht[5] / ht[3], (double)ht[6] / ht[3],
+                        (double)ht[9] / ht[3], (double)ht[7] / ht[3], (double)ht[8] / ht[3]);
             if (ht[3])
                 fprintf(stderr, "[rabitq_hip] scan_mfma timing: %llu blocks, %.1f tiles/block; per block cycles: start-up %.0f, "
                         "tile-loop waits %.0f, tile bodies %.0f (per tile: wait %.0f, body %.0f)\n", ht[3], (double)ht[4] / ht[3],
