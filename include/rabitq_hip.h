@@ -111,6 +111,8 @@ typedef struct {
     float ms_rotate, ms_assign, ms_quantize;   /* device time of the three pass-1 kernels, HIP events, summed over chunks */
     uint64_t rows_assigned;                    /* rotation flops so far = 2 * rows_assigned * dim^2 */
     uint64_t rows_in_hbm, rows_in_host_memory; /* base tiers (known after rq_builder_order) */
+    uint64_t rows_exact_redo;                  /* rows whose nearest list the exact-order kernel decided alone: the bf16 pre-filter
+                                                  left none or more than four candidates (appended in revision 3) */
 } rq_build_stats_t;
 rq_status rq_builder_create(uint64_t n, uint32_t d, const float *d_centroids, uint32_t k, const float *orthogonal_host,
                             uint64_t seed, uint64_t max_device_base_bytes, rq_builder **out);
@@ -333,8 +335,9 @@ typedef struct {
      * quantisation and the early stages in LDS): device time of that second launch, and how many passes took the path */
     float ms_early;
     uint32_t small_batch_passes;
-    /* survivor records + run directories of the call's largest pass, bytes; passes whose final stage used per-query segments
-     * (sized by a sampled counting scan) instead of one capacity for every query */
+    /* survivor records + run directories (+ the shared arena) of the call's largest pass, bytes; passes in which a stage
+     * appended its survivors to the shared arena and scattered them into per-query segments sized by their exact counts,
+     * instead of one capacity for every query */
     uint64_t survivor_workspace_bytes;
     uint32_t segmented_passes, reserved2;
 } rq_profile_t;
@@ -358,8 +361,9 @@ rq_status rq_set_profiling(int level);
  * list first, all-reduces (min) the k-th best distances and seeds the rest of the probe list with them (see
  * rq_query_batch_device_seeded); 0 = every shard prunes with its own thresholds only; 2 = also with one shard (tests).
  * "survivor_segments": 1 (default) = once an index has shown that its batches overflow the default survivor capacity, large
- * batches (>= 256 queries) size the final stage's survivor buffers PER QUERY (a sampled counting scan + prefix sum) instead
- * of giving every query the worst one's capacity; 0 = never, 2 = every large batch (tests).  Identical results.
+ * batches (>= 256 queries) size the survivor buffers of the stages that can exceed it PER QUERY (the scan appends to one shared
+ * arena while counting per query; exact counts + prefix sum + a scatter pass) instead of giving every query the worst one's
+ * capacity; 0 = never, 2 = every large batch (tests).  Identical results.
  * "small_batch": 0 (default) = batches of <= 64 queries (the reference's one-query-per-call loop included) run as a handful
  * of fat launches (kernels_small.h) whenever the shape allows (nprobe <= 64, <= 8192 lists, topk <= 256, dim in {64, 128,
  * 256, 512, 768, 1024}), 1 = never (test hook).  Identical results.

@@ -56,7 +56,8 @@ class MetricsT(C.Structure):
 
 class BuildStatsT(_Sized):
     _fields_ = [("struct_size", C.c_uint32), ("ms_rotate", C.c_float), ("ms_assign", C.c_float), ("ms_quantize", C.c_float),
-                ("rows_assigned", C.c_uint64), ("rows_in_hbm", C.c_uint64), ("rows_in_host_memory", C.c_uint64)]
+                ("rows_assigned", C.c_uint64), ("rows_in_hbm", C.c_uint64), ("rows_in_host_memory", C.c_uint64),
+                ("rows_exact_redo", C.c_uint64)]
 
 
 class ProfileT(_Sized):

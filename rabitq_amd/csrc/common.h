@@ -80,8 +80,9 @@ __device__ __forceinline__ uint64_t surv_key(const RunRec &r) {
 }
 
 // Where a query's survivor records and run descriptors live.  Uniform: query b owns slots [b * ucap, (b + 1) * ucap) of
-// the pass's buffers.  Segmented (final stage of a pass whose survivor counts are very unequal: a sampled counting scan
-// sizes every query's segment): query b owns cap[b] slots from base[b].  The same geometry applies to the survivor
+// the pass's buffers.  Segmented (stages of a pass whose survivor counts are very unequal: the scan appends to a shared arena
+// while counting per query, the exact counts size every query's segment, a scatter pass fills it): query b owns cap[b]
+// slots from base[b].  The same geometry applies to the survivor
 // records, the run directory and its scratch copy.
 struct QSeg {
     const unsigned long long *base;  // per query: first slot; nullptr = uniform

@@ -647,8 +647,9 @@ struct QueryParams {
     // Seeded pass (rq_query_batch_device_seeded): per-query initial thresholds (device; f32::MAX = none).  A first pass
     // runs the whole stream as ONE stage under them; an overflow re-run (row map given) starts from them and stages as usual.
     const float *thr_init = nullptr;
-    // Segmented pass: `cap` bounds the early stages only; the final stage's survivors go to per-query segments sized by a
-    // sampled counting scan (the workspace then scales with the sum of the survivors instead of nq x the worst query)
+    // Segmented pass: `cap` bounds the stages whose span fits it; a stage that can exceed it appends to the shared arena and
+    // its survivors are scattered into per-query segments sized by their exact counts (the workspace then scales with the
+    // sum of the survivors instead of nq x the worst query)
     bool seg_final = false;
 };
 
@@ -1930,6 +1931,7 @@ static rq_status builder_assign(rq_builder *b, const float *d_rows, uint64_t i0,
     }
     b->assigned += m;
     b->stats.rows_assigned = b->assigned;
+    b->stats.rows_exact_redo = b->assign_aux.redone;
     return RQ_OK;
 }
 
