@@ -2219,6 +2219,12 @@ __device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, co
                                             uint32_t nruns, uint32_t topk,
                                             uint32_t b, const ReplayState &st, int32_t *hkey, uint32_t *hid) {
     const uint32_t lane = threadIdx.x & 63;
+    // Everything that steers the loops below is the same in every lane; saying so (v_readfirstlane / v_readlane) keeps the
+    // loop counters, the heap indices and the branch conditions in scalar registers.  Left to the compiler's divergence
+    // analysis, a bound that came out of a memory load or a cross-lane shuffle made the survivor loop "divergent" and with
+    // it every value it carries: the sift loops then ran under exec masks with their indices in vector registers.
+    nruns = __builtin_amdgcn_readfirstlane(nruns);
+    topk = __builtin_amdgcn_readfirstlane(topk);
     float thr = st.thr[b];
     uint32_t precise = 0;
     uint32_t hlen = 0, wcount = 0, alen = 0;
@@ -2245,9 +2251,8 @@ __device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, co
         }
     };
     if constexpr (!HEURISTIC) {
-        hlen = st.heap_len[b];
+        hlen = __builtin_amdgcn_readfirstlane(st.heap_len[b]);
         if constexpr (REGHEAP) {
-            hlen = __builtin_amdgcn_readfirstlane(hlen);
             if (lane < hlen) rk = st.heap_key[(uint64_t)b * topk + lane], ri = st.heap_id[(uint64_t)b * topk + lane];
         } else {
             for (uint32_t i = lane; i < hlen; i += 64) {
@@ -2257,8 +2262,8 @@ __device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, co
         }
     } else {
         recent = st.recent_max[b];
-        wcount = st.win_count[b];
-        alen = st.arr_len[b];
+        wcount = __builtin_amdgcn_readfirstlane(st.win_count[b]);
+        alen = __builtin_amdgcn_readfirstlane(st.arr_len[b]);
     }
     // The survivors are replayed in stream order = directory order, then record order inside a run.  The
     // directory is read 64 descriptors at a time; within such a chunk the stream is cut into batches of 64
@@ -2282,7 +2287,7 @@ __device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, co
             s_base[lane] = dbase;
             if (lane == 0) s_pref[0] = 0;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            total = __shfl(incl, 63, 64);
+            total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
         auto fetch = [&](uint32_t off, SurvRec &rec) {
             const uint32_t t = off + lane;
@@ -2318,9 +2323,10 @@ __device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, co
             const uint64_t upto = (2ull << i) - 1ull;  // lanes 0..i (i = 63 wraps to all ones)
             precise += (uint32_t)__popcll(m & upto);
             m &= ~upto;
-            const float acc = __shfl(r.accurate, i, 64);
+            // (lane i's values through v_readlane: i is wave-uniform, a shuffle would go through LDS)
+            const float acc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.accurate), i));
             // the rankers carry the cluster-order POSITION; finalize_* maps it to the original id (rabitq.rs:324)
-            const uint32_t id = __shfl(r.pos, i, 64);
+            const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)r.pos, i);
             if constexpr (!HEURISTIC) {
                 // push: append + sift_up(0, old_len)
                 int32_t key = ord32_from_f32(acc);

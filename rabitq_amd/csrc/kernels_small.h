@@ -467,7 +467,14 @@ __global__ __launch_bounds__(1024) void sb_query_kernel(const SbArgs a) {
     for (uint32_t sg = 0; sg < a.nstages; ++sg) {
         const uint32_t s_lo = a.s_lo[sg], s_hi = a.s_hi[sg];
         for (uint32_t slot = 0; slot < nprobe; ++slot) {
-            const PairScalars ps = a.scal[(uint64_t)b * nprobe + slot];
+            PairScalars ps = a.scal[(uint64_t)b * nprobe + slot];
+            {  // the same record in every lane: held in scalar registers, so that the loops below are scalar-controlled and the
+               // query-side terms of the rough distance enter the vector ops as scalar operands
+                auto uf = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+                ps.lower = uf(ps.lower), ps.delta = uf(ps.delta), ps.sumq = uf(ps.sumq), ps.ycd = uf(ps.ycd), ps.ycd_sqrt = uf(ps.ycd_sqrt);
+                ps.list_begin = __builtin_amdgcn_readfirstlane(ps.list_begin), ps.list_len = __builtin_amdgcn_readfirstlane(ps.list_len);
+                ps.stream_begin = __builtin_amdgcn_readfirstlane(ps.stream_begin);
+            }
             if (ps.list_len == 0) continue;
             if (ps.stream_begin >= s_hi) break;
             if ((uint64_t)ps.stream_begin + ps.list_len <= s_lo) continue;
@@ -501,7 +508,8 @@ __global__ __launch_bounds__(1024) void sb_query_kernel(const SbArgs a) {
             };
             for (uint32_t p0 = lo; p0 < hi; p0 += STEP) {
                 if (n + STEP > RQ_SB_CAP) flush();  // room for whatever this step lets through (block-uniform)
-                const float thr = s_thr;  // the threshold the ranker holds now: an upper bound of the reference's for what follows
+                // the threshold the ranker holds now: an upper bound of the reference's for what follows
+                const float thr = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_thr)));
                 uint32_t pos[CPT], code[CPT][2 * W];
                 float4 fac[CPT];
                 bool in[CPT];
@@ -555,7 +563,7 @@ __global__ __launch_bounds__(1024) void sb_query_kernel(const SbArgs a) {
                         r.pos = pos[c], r.slot = slot, r.rough = rough[c], r.accurate = 0.0f;
                         recs[n + woff + (uint32_t)__popcll(m[c] & ((1ull << lane) - 1ull))] = r;
                     }
-                    n += total;
+                    n += __builtin_amdgcn_readfirstlane(total);
                 }
                 __syncthreads();
             }
