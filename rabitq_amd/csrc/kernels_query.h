@@ -346,6 +346,8 @@ __device__ __forceinline__ void select_probe_wave(const float *__restrict__ dist
         return c;
     };
     // smallest T with count(key <= T) >= nprobe (nprobe <= k, so T <= kmax)
+    // (kmin / kmax are the same in every lane after the butterfly: said explicitly, the bisection runs on scalar registers)
+    kmin = __builtin_amdgcn_readfirstlane(kmin), kmax = __builtin_amdgcn_readfirstlane(kmax);
     uint32_t lo = kmin, hi = kmax, T = kmax;
     bool exact = false;
     while (lo < hi) {
@@ -374,6 +376,7 @@ __device__ __forceinline__ void select_probe_wave(const float *__restrict__ dist
                 for (int i = 0; i < KPL; ++i) c += (key[i] == T && list_of(i) <= jm) ? 1u : 0u;
 #pragma unroll
                 for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+                c = __builtin_amdgcn_readfirstlane(c);
                 if (c >= need) jh = jm;
                 else jl = jm + 1;
             }

@@ -189,6 +189,8 @@ __device__ __forceinline__ void select_slice_wave(const float *__restrict__ d, u
         for (int i = 0; i < KPL; ++i) c += (uint32_t)__popcll(__ballot(key[i] <= t));
         return c;
     };
+    // (the same in every lane after the butterfly: said explicitly so that the bisection below runs on scalar registers)
+    kmin = __builtin_amdgcn_readfirstlane(kmin), kmax = __builtin_amdgcn_readfirstlane(kmax);
     uint32_t lo = kmin, hi = kmax, T = kmax;
     bool exact = false;
     while (lo < hi) {
@@ -217,6 +219,7 @@ __device__ __forceinline__ void select_slice_wave(const float *__restrict__ d, u
                 for (int i = 0; i < KPL; ++i) c += (key[i] == T && list_of(i) <= jm) ? 1u : 0u;
 #pragma unroll
                 for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+                c = __builtin_amdgcn_readfirstlane(c);
                 if (c >= need) jh = jm;
                 else jl = jm + 1;
             }

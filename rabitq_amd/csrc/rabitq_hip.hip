@@ -1266,7 +1266,8 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     if (pf.on) (void)hipEventRecord(pf.spans[total_span].b, st);
     HIPC(hipMemcpyAsync(ws.h_totals, ws.totals.p, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     ws.h_totals[7] = 0;
-    HIPC(hipMemcpyAsync(ws.h_totals + 7, ws.big_list.p + nq + 2, 4, hipMemcpyDeviceToHost, st));
+    if (nq >= 256)  // (the long-directory hint only sizes launches of large batches: a small batch saves the copy's round trip)
+        HIPC(hipMemcpyAsync(ws.h_totals + 7, ws.big_list.p + nq + 2, 4, hipMemcpyDeviceToHost, st));
     ws.pend_total_span = total_span;
     ws.pend_nq = nq;
     ws.pend_cap = qp.cap;
