@@ -112,7 +112,7 @@ typedef struct {
     uint64_t rows_assigned;                    /* rotation flops so far = 2 * rows_assigned * dim^2 */
     uint64_t rows_in_hbm, rows_in_host_memory; /* base tiers (known after rq_builder_order) */
     uint64_t rows_exact_redo;                  /* rows whose nearest list the exact-order kernel decided alone: the bf16 pre-filter
-                                                  left none or more than four candidates (appended in revision 3) */
+                                                  left none or more than 16 candidates (appended in revision 3) */
 } rq_build_stats_t;
 rq_status rq_builder_create(uint64_t n, uint32_t d, const float *d_centroids, uint32_t k, const float *orthogonal_host,
                             uint64_t seed, uint64_t max_device_base_bytes, rq_builder **out);

@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void factor_stats_kernel(const float4 *__restr
 // per build) through a double-buffered LDS image (row stride dim * 2 + 16 bytes).  D lane map: column = vector
 // (lane & 31), the 16 registers x 2 half-waves = the 32 lists of the tile.
 // ------------------------------------------------------------------------------------------------
-#define RQ_ASSIGN_CAND 4u
+#define RQ_ASSIGN_CAND 16u
 typedef __bf16 asg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float asg_f32x16 __attribute__((ext_vector_type(16)));
 

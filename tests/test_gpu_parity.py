@@ -484,8 +484,8 @@ def test_prefiltered_assignment_equals_exact_order_kernels(rq, oracle, d):
     n, k = 6000, 70
     x, centres, _ = synth.mixture(n, d, k, sigma=0.8, seed=d, centre_scale=0.7)
     centres[9] = centres[4]                                               # exact ties
-    centres[20:40] = centres[20] + 1e-5 * rng.standard_normal((20, d))    # twenty lists within the error bound of each other
-    x[:200] = centres[rng.integers(20, 40, 200)] + 1e-3 * rng.standard_normal((200, d))
+    centres[20:50] = centres[20] + 1e-5 * rng.standard_normal((30, d))    # thirty lists within the error bound of each other (> the 16 candidate slots)
+    x[:200] = centres[rng.integers(20, 50, 200)] + 1e-3 * rng.standard_normal((200, d))
     x[200:260] = centres[rng.integers(0, k, 60)]                          # on a centroid
     x[260:300] *= 1.0e4
     x[300:340] *= 1.0e-4
