@@ -83,11 +83,19 @@ def main():
                     help="after the timed region (whose steps run one batch at a time, so that every launch runs alone and "
                          "per-kernel times from HIP events and rocprofv3 --stats stay comparable), also measure the throughput "
                          "with two batches in flight (rq_query_batch_device_begin/_end) and report it as an extra field")
+    ap.add_argument("--emulate-world", type=int, default=1,
+                    help="one-GPU rehearsal of ONE rank of a W-GPU run: W x --lists centroids of which this process owns the first "
+                         "--lists (its vectors come from them), queries drawn over all of them, the C-ABI multi-GPU step with a "
+                         "one-rank communicator (shared-threshold passes as on a real rank; the coarse ranking is NOT sliced, "
+                         "so its share is W times a real rank's).  Per-kernel times show where a rank's step goes at W GPUs")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="batches kept in flight in the timed loop (rq_query_batch_device_begin/_end); 1 = one blocking "
                          "call per step (default: per-kernel times are then clean); see --two-in-flight")
     args = ap.parse_args()
-    explicit_workload = args.vectors is not None or args.dim != 128 or args.distribution != "easy"
+    explicit_workload = args.vectors is not None or args.dim != 128 or args.distribution != "easy" or args.emulate_world > 1
+    if args.emulate_world > 1:
+        assert args.gpus == 1, "--emulate-world is a one-GPU rehearsal"
+        args.sharded_path = True
     if args.vectors is None:
         args.vectors = 125_000_000 if args.gpus == 8 else 100_000_000
 
@@ -167,7 +175,7 @@ def run_workload(args, ctx, extras=True):
     from tests import synth
     world, rank, dev = ctx["world"], ctx["rank"], ctx["dev"]
     n, d, k_local, nprobe, topk, B = args.vectors, args.dim, args.lists, args.nprobe, args.topk, args.batch
-    k = k_local * world                      # global list count; every rank knows all centroids
+    k = k_local * world * max(1, getattr(args, "emulate_world", 1))   # global list count; every rank knows all centroids
     t0 = time.time()
 
     # ---- synthetic inputs: mixture of Gaussians, generated on device ------------
@@ -308,7 +316,12 @@ def run_workload(args, ctx, extras=True):
     if sharded and args.collective_path == "c-abi":
         ok, why = True, ""
         try:
-            if args.backend == "gloo":
+            if getattr(args, "emulate_world", 1) > 1:
+                hc = sharding.EmulatedPeers()      # one rank of W: the absent peers' threshold seeds are filled in (see the class)
+                hc.install()
+                keep_alive.append(hc)
+                comm_handle = 1
+            elif args.backend == "gloo":
                 hc = sharding.HostCollectives()
                 hc.install()
                 keep_alive.append(hc)
@@ -323,7 +336,8 @@ def run_workload(args, ctx, extras=True):
         except Exception as e:
             ok, why = False, f"{type(e).__name__}: {e}"
         if all_agree(ok):
-            collective_path = "rq_query_batch_sharded_device/" + ("host-buffer collectives (gloo rehearsal)" if args.backend == "gloo" else "RCCL")
+            collective_path = "rq_query_batch_sharded_device/" + ("emulated peers (one-GPU rehearsal of one rank)" if getattr(args, "emulate_world", 1) > 1 else
+                                                                  "host-buffer collectives (gloo rehearsal)" if args.backend == "gloo" else "RCCL")
         else:
             log(f"C-ABI collective path unavailable ({why or 'another rank failed'}): falling back to torch.distributed")
             if args.backend == "gloo":
@@ -556,6 +570,8 @@ def run_workload(args, ctx, extras=True):
                                    (" (BASELINE.json configs[2])" if (n, d, k_local, nprobe, world, args.distribution) == (100_000_000, 128, 4096, 64, 1, "easy") else "") +
                                    (" (BASELINE.json configs[3])" if (n, d, k_local, nprobe, world, args.distribution) == (100_000_000, 768, 4096, 64, 1, "easy") else "") +
                                    (f" = {world * n // 1_000_000}M x {d} over {k} lists on {world} GPUs" if world > 1 else "") +
+                                   (f" -- REHEARSAL of one rank of a {args.emulate_world}-GPU run ({k} lists in all, this rank owns {k_local}; "
+                                    f"coarse ranking unsliced, recall against this rank's own vectors only)" if getattr(args, "emulate_world", 1) > 1 else "") +
                                    (" (BASELINE.json configs[4]: 1B x 128; k is unspecified there: 32 768 = 4096 per GPU, SURVEY.md 8d)"
                                     if (n, d, k_local, nprobe, world, args.distribution) == (125_000_000, 128, 4096, 64, 8, "easy") else ""),
                        "batches_in_flight": depth,
@@ -588,7 +604,7 @@ def run_workload(args, ctx, extras=True):
         else:
             line["cpu_baseline"] = cpu_baseline(idx, queries[:args.cpu_queries].cpu().numpy(), nprobe, topk, ri, d)
     # everything this workload holds on the device goes before the next one is built
-    if args.backend == "gloo" and keep_alive and sharded:
+    if (args.backend == "gloo" or getattr(args, "emulate_world", 1) > 1) and keep_alive and sharded:
         sharding.HostCollectives.uninstall()
     for obj in keep_alive:
         if hasattr(obj, "close"):

@@ -185,6 +185,19 @@ class _UniqueId(C.Structure):
     _fields_ = [("internal", C.c_char * 128)]   # ncclUniqueId (rccl.h)
 
 
+def _uid_to_bytes(uid: "_UniqueId") -> bytes:
+    """All 128 bytes of the id (reading the c_char array FIELD would stop at its first NUL byte)."""
+    return C.string_at(C.addressof(uid), C.sizeof(uid))
+
+
+def _uid_from_bytes(raw) -> "_UniqueId":
+    if not isinstance(raw, (bytes, bytearray)) or len(raw) != C.sizeof(_UniqueId):
+        raise RuntimeError("the RCCL unique id did not arrive intact")
+    uid = _UniqueId()
+    C.memmove(C.addressof(uid), bytes(raw), C.sizeof(uid))
+    return uid
+
+
 def _rccl_lib():
     """The RCCL this process already carries (torch's bundled copy), so that the communicator handle and the
     collectives the engine resolves with dlsym come from the same library (RABITQ_RCCL_LIB overrides)."""
@@ -213,10 +226,10 @@ class RcclComm:
             rc = self.lib.ncclGetUniqueId(C.byref(uid))
             if rc != 0:
                 raise RuntimeError(f"ncclGetUniqueId failed ({rc})")
-        box = [bytes(uid.internal)] if rank == 0 else [None]
+        box = [_uid_to_bytes(uid)] if rank == 0 else [None]
         if world > 1:
             dist.broadcast_object_list(box, src=0, group=group)
-        C.memmove(C.byref(uid), box[0], 128)
+        uid = _uid_from_bytes(box[0])
         self.comm = C.c_void_p()
         self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
         rc = self.lib.ncclCommInitRank(C.byref(self.comm), world, uid, rank)
@@ -308,4 +321,41 @@ class HostCollectives:
 
     def _user_rank(self, comm, out_rank):
         out_rank[0] = dist.get_rank(self.group)
+        return 0
+
+
+class EmulatedPeers(HostCollectives):
+    """One-GPU rehearsal of ONE rank of a W-GPU step (bench.py --emulate-world W): the collectives of a one-rank world,
+    except that the all-reduce(min) of the shared thresholds fills in what the absent peers would contribute -- a query
+    whose nearest list lives on another rank gets no seed from this rank's pass A (f32::MAX); its owner would send the k-th
+    best distance it found there.  On a homogeneous mixture those distances are alike for all queries, so the MEDIAN of
+    the seeds this rank did find stands in for them.  Results of such a run are not parity material; the per-kernel times
+    are what a real rank's step costs."""
+
+    def _all_gather(self, send, recv, count, dtype, comm, stream):
+        try:
+            self.calls.append(("all_gather", int(count)))
+            t = self._to_host(send, count, dtype, stream)
+            return 0 if self.hip.hipMemcpy(recv, t.data_ptr(), count * self._SIZES[dtype], 1) == 0 else 1
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def _all_reduce(self, send, recv, count, dtype, op, comm, stream):
+        try:
+            self.calls.append(("all_reduce", int(count)))
+            t = self._to_host(send, count, dtype, stream)
+            if dtype == 7 and op == 3:      # f32 min: the shared thresholds
+                have = t < 3.0e38
+                if bool(have.any()):
+                    t[~have] = t[have].median()
+            return 0 if self.hip.hipMemcpy(recv, t.data_ptr(), count * self._SIZES[dtype], 1) == 0 else 1
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def _user_rank(self, comm, out_rank):
+        out_rank[0] = 0
         return 0

@@ -188,19 +188,13 @@ def test_sharded_entry_through_rccl_world1(rq):
     communicator.  Results: the single index's top-k, ascending."""
     import torch
     torch.zeros(1, device="cuda:0")   # a live HIP context in this process before RCCL is initialised
-    path = os.environ.get("RABITQ_RCCL_LIB") or "librccl.so"
-    try:
-        nccl = C.CDLL(path, mode=C.RTLD_GLOBAL)
-    except OSError:
-        nccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=C.RTLD_GLOBAL)
-
-    class UniqueId(C.Structure):
-        _fields_ = [("internal", C.c_char * 128)]
-    uid = UniqueId()
-    assert nccl.ncclGetUniqueId(C.byref(uid)) == 0
-    comm = C.c_void_p()
-    nccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
-    assert nccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    # the communicator exactly as bench.py --gpus N makes it (sharding.RcclComm: ncclGetUniqueId, the 128 id bytes carried
+    # as a Python bytes object, ncclCommInitRank): round 3 found that path passing a truncated id (a c_char array field
+    # reads up to its first NUL byte), which no test had run
+    from rabitq_amd import sharding
+    rc = sharding.RcclComm(0, 1)
+    comm = C.c_void_p(rc.handle)
+    assert comm.value
     dev = torch.device("cuda", 0)
     x, centres, P, queries, probe, topk = case_data()
     nq, d = queries.shape
@@ -224,6 +218,5 @@ def test_sharded_entry_through_rccl_world1(rq):
             assert np.array_equal(gi[b, :wn[b]], wi[b, :wn[b]][order] + 1000)
             assert np.array_equal(gd[b, :wn[b]].view(np.uint32), wd[b, :wn[b]][order].view(np.uint32))
     ix.set_option("shared_thresholds", 1)
-    nccl.ncclCommDestroy.argtypes = [C.c_void_p]
-    nccl.ncclCommDestroy(comm)
+    rc.close()
     full.close()

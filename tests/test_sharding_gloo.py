@@ -92,3 +92,20 @@ def test_two_rank_allgather_merge(tmp_path):
     gt = synth.brute_force_topk(x, queries, topk)
     hits = sum(len(set(r[0]["i"][q, :int(r[0]["c"][q])].tolist()) & set(gt[q].tolist())) for q in range(nq) if q != 3)
     assert hits / (10 * (nq - 1)) >= 0.95
+
+
+def test_rccl_unique_id_survives_nul_bytes():
+    """The 128-byte ncclUniqueId travels from rank 0 to the others as a Python bytes object (sharding.RcclComm); ids contain
+    NUL bytes, and a c_char array field read stops at the first one (round 3: every rank but 0 got a truncated id)."""
+    import ctypes as C
+    from rabitq_amd import sharding
+    raw = bytes([3, 0, 0, 9] + [0] * 60 + list(range(64)))
+    uid = sharding._UniqueId()
+    C.memmove(C.addressof(uid), raw, 128)
+    assert len(bytes(uid.internal)) < 128          # the trap
+    assert sharding._uid_to_bytes(uid) == raw
+    back = sharding._uid_from_bytes(raw)
+    assert C.string_at(C.addressof(back), 128) == raw
+    import pytest
+    with pytest.raises(RuntimeError):
+        sharding._uid_from_bytes(raw[:100])
