@@ -47,7 +47,7 @@ def test_ctypes_mirror_matches_the_compiled_header(tmp_path):
 #include "rabitq_hip.h"
 int main(void) {
     printf("%zu %zu %zu %zu\\n", sizeof(rq_info_t), offsetof(rq_info_t, n), offsetof(rq_info_t, n_hbm), offsetof(rq_info_t, max_list_len));
-    printf("%zu %zu %zu\\n", sizeof(rq_build_stats_t), offsetof(rq_build_stats_t, rows_assigned), offsetof(rq_build_stats_t, rows_in_host_memory));
+    printf("%zu %zu %zu %zu\\n", sizeof(rq_build_stats_t), offsetof(rq_build_stats_t, rows_assigned), offsetof(rq_build_stats_t, rows_in_host_memory), offsetof(rq_build_stats_t, rows_exact_redo));
     printf("%zu %zu %zu %zu\\n", sizeof(rq_profile_t), offsetof(rq_profile_t, ms_rotate), offsetof(rq_profile_t, scan_bytes), offsetof(rq_profile_t, rerank_shadow_rejects));
     printf("%d\\n", RQ_ABI_VERSION);
     return 0;
@@ -57,7 +57,7 @@ int main(void) {
     rows = [[int(v) for v in ln.split()] for ln in subprocess.check_output([str(exe)]).decode().splitlines()]
     I, B, P = _lib.Info, _lib.BuildStatsT, _lib.ProfileT
     assert rows[0] == [C.sizeof(I), I.n.offset, I.n_hbm.offset, I.max_list_len.offset]
-    assert rows[1] == [C.sizeof(B), B.rows_assigned.offset, B.rows_in_host_memory.offset]
+    assert rows[1] == [C.sizeof(B), B.rows_assigned.offset, B.rows_in_host_memory.offset, B.rows_exact_redo.offset]
     assert rows[2] == [C.sizeof(P), P.ms_rotate.offset, P.scan_bytes.offset, P.rerank_shadow_rejects.offset]
     assert rows[3] == [_lib.ABI_VERSION]
 
