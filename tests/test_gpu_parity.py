@@ -1189,10 +1189,56 @@ def test_streamed_builder_equals_one_shot_build(rq, oracle, d, budget):
     oidx.close()
 
 
+def test_arena_stages_equal_uniform_buffers_at_scale(rq):
+    """The survivor arena at scale (no oracle at this size: the engine against itself): 8M vectors in 512 lists of
+    Zipf-distributed sizes with overlapping clusters -- thousands of survivors for some queries, a handful for most, shards
+    that run full so that the common area and the arena's growth are exercised --, 8 192 queries.  Arena stages + per-query
+    segments + cell-bitmap ordering (survivor_segments = 2) must return, bit for bit, what the uniform buffers with overflow
+    re-runs return (survivor_segments = 0), for both scan implementations."""
+    import torch
+    from rabitq_amd import index as ix
+    dev = torch.device("cuda", 0)
+    n, d, k, nq, probe, topk, sigma = 8_000_000, 128, 512, 8192, 32, 10, 0.5
+    centres = synth.device_centres(k, d, dev, scale=sigma, seed=77)            # centre spacing ~ cluster radius
+    wz = 1.0 / torch.arange(1, k + 1, device=dev, dtype=torch.float64) ** 0.9
+    weights = (wz / wz.sum()).float()
+    x = synth.device_mixture_chunk(centres, 0, n, sigma, 0, 4242, 0, k, weights)[0].contiguous()
+    q = synth.device_queries(centres, nq, sigma, dev, seed=78, weights=weights)
+    P = synth.random_orthogonal(d, seed=79)
+    idx = rq.RaBitQ.build_device(x.data_ptr(), n, d, centres.data_ptr(), k, orthogonal=P)
+    del x
+    torch.cuda.empty_cache()
+
+    def run():
+        od = torch.full((nq, topk), -1.0, device=dev)
+        oi = torch.zeros((nq, topk), device=dev, dtype=torch.int32)
+        on = torch.zeros(nq, device=dev, dtype=torch.int32)
+        idx.query_batch_device(q.data_ptr(), nq, d, probe, topk, od.data_ptr(), oi.data_ptr(), on.data_ptr())
+        return od.cpu().numpy().view(np.uint32), oi.cpu().numpy(), on.cpu().numpy(), ix.last_profile()
+
+    try:
+        for impl in (0, 2):
+            ix.set_option("scan_impl", impl)
+            ix.set_option("survivor_segments", 0)
+            want = run()
+            want = run()                       # (second call: capacities learnt)
+            ix.set_option("survivor_segments", 2)
+            got = run()
+            got2 = run()                       # (arena sized from the first pass)
+            for a, b in ((want, got), (want, got2)):
+                assert np.array_equal(a[2], b[2]) and np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+            assert want[3]["segmented_passes"] == 0 and got2[3]["segmented_passes"] == 1 and got2[3]["retries"] == 0, (want[3], got2[3])
+    finally:
+        ix.set_option("scan_impl", 0)
+        ix.set_option("survivor_segments", 1)
+        idx.close()
+
+
 def test_segmented_final_stage_matches_oracle(rq, oracle):
     """Per-query survivor segments (option survivor_segments): a batch whose queries leave very different numbers of
     survivors -- most a few dozen, some tens of thousands (queries at the data's radius in one long list, deep top-k) -- gets
-    its final stage sized per query by a sampled counting scan instead of one capacity for all.  Forced (2) from the first
+    stages that can exceed the uniform capacity appended to a shared arena and scattered into per-query segments sized by
+    their exact counts, instead of one capacity for all.  Forced (2) from the first
     call and automatic (1: after the default capacity has overflowed once); both scan implementations; results bit-identical
     to the oracle in every mode.  (What the segments save is measured on the hard benchmark distribution: bench.py.)"""
     from rabitq_amd import index as ix
