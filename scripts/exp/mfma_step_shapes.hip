@@ -1,0 +1,97 @@
+// Experiment (round 3): would the dominant scan step be cheaper on 16x16 tiles?  One "step" = 32 queries x 32 candidates x
+// 128 dimensions = 1024 gate cells:
+//   MODE 0 (what scan_mfma_kernel<2,3> issues): 1 x v_mfma_f32_32x32x16_bf16 (threshold) + 2 x v_mfma_f32_32x32x64_f8f6f4
+//           on one 16-register accumulator, gate = 8 x v_max3_i32 + compare over the accumulator
+//   MODE 1: 4 tiles of 16x16: each 1 x v_mfma_f32_16x16x32_bf16 + 1 x v_mfma_f32_16x16x128_f8f6f4 on a 4-register
+//           accumulator, gate = 2 max per tile + 3 to combine + compare
+// plus NF independent vector instructions per step (addressing, start-up share).  Three independent steps per loop
+// iteration (as NT = 3), 16 waves per CU (4 per SIMD, as the kernel runs).  Prints clock ticks per step and wave.
+// Build: hipcc -O2 --offload-arch=gfx950 mfma_step_shapes.hip -o mfma_step_shapes
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+
+#define OPAQUE(x) asm volatile("" : "+v"(x))   // the compiler may not assume anything about x: no CSE / hoisting of the MFMAs
+__device__ __forceinline__ int imax3(int a, int b, int c) {
+    int r;
+    asm volatile("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+template <int MODE, int NF>
+__global__ __launch_bounds__(1024) void k(float *out, long long *cyc, int iters) {
+    v8i a, b;
+    for (int e = 0; e < 8; ++e) a[e] = threadIdx.x * 7 + e, b[e] = threadIdx.x * 3 + e;
+    a[6] = a[7] = b[6] = b[7] = 0;
+    v4i b4 = {b[0], b[1], b[2], b[3]};
+    int f[8];
+    for (int i = 0; i < 8; ++i) f[i] = threadIdx.x + i;
+    int flagged = 0;
+    __syncthreads();
+    long long t0 = clock64();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            int mx;
+            v4i a4 = {a[1], a[2], a[3], a[4]};
+            if (MODE == 0) {
+                v16f c = {0};
+                OPAQUE(a4[0]);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, a4), __builtin_bit_cast(v8bf, b4), c, 0, 0, 0);
+                OPAQUE(a[0]);
+                c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 2, 2, 0, 0, 0, 0);
+                OPAQUE(b[0]);
+                c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b, a, c, 2, 2, 0, 0, 0, 0);
+                const v16i ci = __builtin_bit_cast(v16i, c);
+                mx = imax3(ci[0], ci[1], ci[2]);
+#pragma unroll
+                for (int g = 3; g < 15; g += 2) mx = imax3(mx, ci[g], ci[g + 1]);
+                mx = mx > ci[15] ? mx : ci[15];
+            } else {
+                int m4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v4f c = {0};
+                    OPAQUE(a4[0]);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a4), __builtin_bit_cast(v8bf, b4), c, 0, 0, 0);
+                    OPAQUE(a[0]);
+                    c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 2, 2, 0, 0, 0, 0);
+                    const v4i ci = __builtin_bit_cast(v4i, c);
+                    const int m = imax3(ci[0], ci[1], ci[2]);
+                    m4[q] = m > ci[3] ? m : ci[3];
+                }
+                mx = imax3(m4[0], m4[1], m4[2]);
+                mx = mx > m4[3] ? mx : m4[3];
+            }
+            if (__ballot(mx >= 0x7F000000) != 0ull) ++flagged;  // (never: the operands are small)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(f[j % 8]) : "v"(f[(j + 1) % 8]), "v"(f[(j + 2) % 8]));
+            a[0] ^= t;  // keep the steps distinct
+        }
+    }
+    long long t1 = clock64();
+    float s = flagged;
+    for (int j = 0; j < 8; ++j) s += f[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s + a[0];
+    if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+}
+template <int MODE, int NF>
+double run(float *o, long long *c) {
+    long long h = 0;
+    for (int r = 0; r < 2; ++r) { k<MODE, NF><<<256, 1024>>>(o, c, 2048); hipDeviceSynchronize(); }
+    hipMemcpy(&h, c, 8, hipMemcpyDeviceToHost);
+    return (double)h / 2048 / 3;   // ticks per step and wave (four waves share a SIMD: divide by 4 for SIMD ticks per step)
+}
+int main() {
+    float *o; long long *c;
+    hipMalloc(&o, 256 * 1024 * 4); hipMalloc(&c, 8);
+    printf("ticks per step and wave (4 waves per SIMD); extra VALU per step:   0      4      9     14\n");
+    printf("32x32 (bf16 32x32x16 + 2 fp6 32x32x64, 9-op gate):           %6.1f %6.1f %6.1f %6.1f\n", run<0, 0>(o, c), run<0, 4>(o, c), run<0, 9>(o, c), run<0, 14>(o, c));
+    printf("16x16 (4 x (bf16 16x16x32 + fp6 16x16x128), 12-op gate):     %6.1f %6.1f %6.1f %6.1f\n", run<1, 0>(o, c), run<1, 4>(o, c), run<1, 9>(o, c), run<1, 14>(o, c));
+    return 0;
+}
