@@ -1443,8 +1443,17 @@ constexpr uint32_t scan_mfma_ring_slots() {
     return scan_mfma_tiles_per_barrier<W>() > 1 ? 2 * scan_mfma_tiles_per_barrier<W>() : (W >= 16 ? 5u : 3u);
 }
 
+// Waves per block.  The block's waves share every staged query tile, so the L2 -> LDS traffic of a launch is one tile image
+// per (candidate tile, query tile): at dim 128 that re-staging was 18 % of the launch (ablation scan_debug bit 1: 8.87 ->
+// 7.31 ms; the block barriers, by contrast, cost nothing: bit 13).  Eight waves per block (768 candidates per tile image,
+// two blocks per CU: the same 16 waves per CU) halve it.
+// (not for the arena instantiations: their exact path and flushes dominate, on the hard distribution eight waves per block
+// were 16 % slower; not for dim 768 either, where eight waves mean ONE block per CU and nothing hides a block's start-up:
+// 26.0 -> 31.1 ms.)
+template <int W, bool ARENA = false>
+constexpr int scan_mfma_waves() { return W == 2 && !ARENA ? 8 : 4; }
 template <int W, int NT, bool ARENA = false>
-__global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_kernel(const uint32_t *__restrict__ codes,
+__global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_blocks_per_cu<W>() /* = waves per SIMD: hipcc's second bound counts waves per execution unit */) void scan_mfma_kernel(const uint32_t *__restrict__ codes,
                                                            const float4 *__restrict__ factors,
                                                            const uint32_t *__restrict__ offsets,
                                                            const uint32_t *__restrict__ grp_start,
@@ -1459,19 +1468,20 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
     constexpr uint32_t OPLD = OPDW + 2;          // row stride (dwords) of the operand image: conflict-free ds_read_b64
     constexpr uint32_t IMG_OP = 32 * OPLD;       // a query tile image: 32 operand rows ...
     constexpr uint32_t IMG = IMG_OP + RQ_REC_TAIL * 32;  // ... + the 32 record tails
-    constexpr uint32_t WQ4 = IMG / 16;           // 16-byte pieces each wave copies (a quarter of the image)
+    constexpr uint32_t NW = scan_mfma_waves<W, ARENA>();  // waves per block
+    constexpr uint32_t WQ4 = IMG / (4 * NW);     // 16-byte pieces each wave copies (its share of the image)
     constexpr uint32_t NI = (WQ4 + 63) / 64;     // LDS-DMA instructions per wave per tile
-    static_assert(IMG % 16 == 0, "tile image must split into four 16-byte-aligned quarters");
-    constexpr uint32_t TILE = 128 * NT;
+    static_assert(IMG % (4 * NW) == 0, "tile image must split into NW 16-byte-aligned shares");
+    constexpr uint32_t TILE = 32 * NW * NT;
     __shared__ __attribute__((aligned(16))) uint2 lut[256];
     extern __shared__ __attribute__((aligned(16))) uint32_t ring[];  // scan_mfma_ring_slots<W>() x IMG dwords: query tiles in flight (LDS-DMA targets)
     __shared__ __attribute__((aligned(16))) float4 facL[TILE];      // the tile's factors, for the exact path
     // per-wave emit queue: survivors are parked here and written out in bulk (one atomic round trip per flush)
     constexpr uint32_t QE = 128, QR = 32;
-    __shared__ uint32_t q_pos[4][QE];
-    __shared__ float q_rough[4][QE];
-    __shared__ uint32_t q_run[4][QE];
-    __shared__ uint32_t r_b[4][QR], r_slot[4][QR], r_pos[4][QR], r_cnt[4][QR], r_off[4][QR], r_base[4][QR];
+    __shared__ uint32_t q_pos[NW][QE];
+    __shared__ float q_rough[NW][QE];
+    __shared__ uint32_t q_run[NW][QE];
+    __shared__ uint32_t r_b[NW][QR], r_slot[NW][QR], r_pos[NW][QR], r_cnt[NW][QR], r_off[NW][QR], r_base[NW][QR];
 
     uint32_t g, first, list_begin, list_len;
     if (a.use_table) {  // one block per existing (list, tile); the list's bounds come with the entry
@@ -1509,8 +1519,8 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
     const uint32_t ring0 = lds_addr(&ring[0]);
     auto dma_tile = [&](uint32_t qt, uint32_t slot) {  // this wave's quarter of query tile qt -> ring[slot]
         if ((a.dbg & 2u) && qt >= scan_mfma_ring_slots<W>()) return;  // ablation: no re-staging (tiles re-use stale slots)
-        const uint32_t *src = recs + ((uint64_t)(pb >> 5) + qt) * IMG + wave * (IMG / 4);
-        const uint32_t dst = ring0 + (slot * IMG + wave * (IMG / 4)) * 4;
+        const uint32_t *src = recs + ((uint64_t)(pb >> 5) + qt) * IMG + wave * (IMG / NW);
+        const uint32_t dst = ring0 + (slot * IMG + wave * (IMG / NW)) * 4;
 #pragma unroll
         for (uint32_t i = 0; i < NI; ++i) {
             const uint32_t q4 = i * 64 + lane;
@@ -1526,7 +1536,7 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
         dma_tile(0, 0);
         if (ntiles > 1) dma_tile(1, 1);
     }
-    {  // byte -> 8 fp6 fields (bit e -> 1.0 = 0b001000 at bits 6e .. 6e+5)
+    if (tid < 256) {  // byte -> 8 fp6 fields (bit e -> 1.0 = 0b001000 at bits 6e .. 6e+5)
         const uint32_t b = tid;
         uint64_t f = 0;
 #pragma unroll
@@ -1655,6 +1665,9 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
     // developer hook (dbg & 256): cycles of the block's start-up, of the waits at the top of the tile loop and of the
     // tile bodies, summed over blocks into stat[128..131) (+ block count): where a wave's lifetime goes
     const uint32_t time_stat = __builtin_amdgcn_readfirstlane((a.dbg & 256u) ? 1u : 0u);
+    // timing ablation (dbg & 8192; results are wrong): the tile loop without its block barriers -- what the waves of a block
+    // lose by waiting for each other
+    const uint32_t no_barrier = __builtin_amdgcn_readfirstlane((a.dbg & 8192u) ? 1u : 0u);
     unsigned long long tm_wait = 0, tm_body = 0, tm_mark = 0, tm_startup = 0, tm_exact = 0, tm_flush = 0;
     uint32_t n_regs = 0, n_flush = 0, n_greg = 0;
     if (time_stat) {
@@ -1673,13 +1686,13 @@ __global__ __launch_bounds__(256, scan_mfma_blocks_per_cu<W>()) void scan_mfma_k
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NI) : "memory");
             static_assert(PD <= 4 && 3 * NI < 64, "vmcnt immediates are spelled out for up to three later tiles");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // every wave's quarter of tile qt is in; everyone is done with tile qt-1
+            if (!no_barrier) __builtin_amdgcn_s_barrier();  // every wave's quarter of tile qt is in; everyone is done with tile qt-1
             if (qt + PD < ntiles) dma_tile(qt + PD, slot == 0 ? SLOTS - 1 : slot - 1);  // into the slot tile qt-1 occupied
         } else if (qt % QPB == 0) {  // 2*QPB slots, one barrier per QPB tiles: tiles qt .. qt+QPB-1 were requested one
                                      // barrier ago (a period of QPB tiles of compute), the next QPB go out now
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if (!no_barrier) __builtin_amdgcn_s_barrier();
 #pragma unroll
             for (uint32_t i = 0; i < QPB; ++i)
                 if (qt + QPB + i < ntiles) dma_tile(qt + QPB + i, (slot + QPB + i) % (2 * QPB));

@@ -519,11 +519,12 @@ static bool scan_has_mfma(uint32_t W) {
     }
 }
 static uint32_t scan_mfma_nt(uint32_t W) { return W == 2 ? 3 : (W >= 4 ? 2 : 4); }
-static uint32_t scan_mfma_tile(uint32_t W) { return 128 * scan_mfma_nt(W); }
+static uint32_t scan_mfma_nw(uint32_t W, bool arena) { return W == 2 && !arena ? 8u : 4u; }  // scan_mfma_waves<W, ARENA>()
+static uint32_t scan_mfma_tile(uint32_t W, bool arena) { return 32 * scan_mfma_nw(W, arena) * scan_mfma_nt(W); }
 static size_t scan_mfma_ring_bytes(uint32_t W) { return (W <= 2 ? 4ull : (W >= 16 ? 5ull : 3ull)) * (32 * (12 * W + 2) + RQ_REC_TAIL * 32) * 4; }  // scan_mfma_ring_slots<W>()
 template <int W, int NT, bool ARENA>
 static void launch_scan_mfma_t(const ScanPtrs &p, const ScanArgs &a, dim3 g, hipStream_t st) {
-    scan_mfma_kernel<W, NT, ARENA><<<g, dim3(256), scan_mfma_ring_bytes(W), st>>>(p.codes, p.factors, p.offsets, p.grp_start, p.grp_cnt,
+    scan_mfma_kernel<W, NT, ARENA><<<g, dim3(64 * scan_mfma_waves<W, ARENA>()), scan_mfma_ring_bytes(W), st>>>(p.codes, p.factors, p.offsets, p.grp_start, p.grp_cnt,
                                                                                     p.recs, p.surv, p.runs, p.surv_cnt, p.stat, p.tile_table, a);
 }
 // callers check scan_has_mfma(W) first; args.x != nullptr: the arena instantiations
@@ -1058,7 +1059,9 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         sp.stat = ws.stat.p;  // 64 x {sub-tile steps, exact-path steps} of the matrix-core scan (dbg & 128)
         a.cap = qp.cap;
         a.dbg = (uint32_t)g_scan_dbg.load();
-        const uint32_t stage_tile = use_mfma ? scan_mfma_tile(W) : tile;
+        // (an arena stage, below: a stage that can exceed the uniform survivor capacity; its scan instantiation has its own tile)
+        const bool arena_stage = qp.seg_final && span > qp.cap && scan_is_fused(W) && nq >= 256;
+        const uint32_t stage_tile = use_mfma ? scan_mfma_tile(W, arena_stage) : tile;
         a.tiles_per_group = ceil_div(std::min<uint64_t>(idx->max_list_len, sg.s_hi), stage_tile);
         sp.tile_table = nullptr;
         const uint64_t grid_blocks = (uint64_t)k * a.tiles_per_group, real_tiles = idx->n / stage_tile + k;
@@ -1089,7 +1092,6 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         // no query can overflow.
         QSeg seg = useg;
         bool runs_in_tmp = false;
-        const bool arena_stage = qp.seg_final && span > qp.cap && scan_is_fused(W) && nq >= 256;
         if (arena_stage) {
             // capacity: what earlier batches needed (+ headroom), at least half the uniform buffers' worth; a shard holds
             // 1 / RQ_ARENA_SHARDS of it

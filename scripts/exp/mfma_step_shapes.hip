@@ -80,11 +80,23 @@ __global__ __launch_bounds__(1024) void k(float *out, long long *cyc, int iters)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s + a[0];
     if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
 }
+static double g_ns_per_step = 0;
 template <int MODE, int NF>
 double run(float *o, long long *c) {
     long long h = 0;
-    for (int r = 0; r < 2; ++r) { k<MODE, NF><<<256, 1024>>>(o, c, 2048); hipDeviceSynchronize(); }
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0), hipEventCreate(&e1);
+    float ms = 0;
+    for (int r = 0; r < 2; ++r) {
+        hipEventRecord(e0, 0);
+        k<MODE, NF><<<256, 1024>>>(o, c, 2048);
+        hipEventRecord(e1, 0);
+        hipDeviceSynchronize();
+        hipEventElapsedTime(&ms, e0, e1);
+    }
     hipMemcpy(&h, c, 8, hipMemcpyDeviceToHost);
+    // every SIMD runs 4 waves x 2048 x 3 steps: wall nanoseconds per step and SIMD
+    g_ns_per_step = ms * 1e6 / (4.0 * 2048 * 3);
     return (double)h / 2048 / 3;   // ticks per step and wave (four waves share a SIMD: divide by 4 for SIMD ticks per step)
 }
 int main() {
@@ -92,6 +104,8 @@ int main() {
     hipMalloc(&o, 256 * 1024 * 4); hipMalloc(&c, 8);
     printf("ticks per step and wave (4 waves per SIMD); extra VALU per step:   0      4      9     14\n");
     printf("32x32 (bf16 32x32x16 + 2 fp6 32x32x64, 9-op gate):           %6.1f %6.1f %6.1f %6.1f\n", run<0, 0>(o, c), run<0, 4>(o, c), run<0, 9>(o, c), run<0, 14>(o, c));
+    run<0, 9>(o, c);
+    printf("   wall time: %.1f ns per step and SIMD at 9 extra (the kernel itself: 8.9 ms / 96 000 steps per SIMD = 93 ns)\n", g_ns_per_step);
     printf("16x16 (4 x (bf16 16x16x32 + fp6 16x16x128), 12-op gate):     %6.1f %6.1f %6.1f %6.1f\n", run<1, 0>(o, c), run<1, 4>(o, c), run<1, 9>(o, c), run<1, 14>(o, c));
     return 0;
 }
