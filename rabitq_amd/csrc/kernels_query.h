@@ -1435,14 +1435,6 @@ constexpr bool scan_mfma_stream_a() { return W > 4 && W <= 12; }  // W = 16 (one
 // vectors (small tile images) afford two tiles per barrier with a 4-slot ring.
 template <int W>
 constexpr uint32_t scan_mfma_tiles_per_barrier() { return W <= 2 ? 2u : 1u; }
-template <int W>
-constexpr uint32_t scan_mfma_ring_slots() {
-    // one tile per barrier: slots - 1 tiles in flight.  The wide instantiations run one block per CU and wait on the
-    // arrival of their (large) tile images, not on the matrix pipe: they take the LDS a second block would have used
-    // for a deeper ring
-    return scan_mfma_tiles_per_barrier<W>() > 1 ? 2 * scan_mfma_tiles_per_barrier<W>() : (W >= 16 ? 5u : 3u);
-}
-
 // Waves per block.  The block's waves share every staged query tile, so the L2 -> LDS traffic of a launch is one tile image
 // per (candidate tile, query tile): at dim 128 that re-staging was 18 % of the launch (ablation scan_debug bit 1: 8.87 ->
 // 7.31 ms; the block barriers, by contrast, cost nothing: bit 13).  Eight waves per block (768 candidates per tile image,
@@ -1452,6 +1444,18 @@ constexpr uint32_t scan_mfma_ring_slots() {
 // 26.0 -> 31.1 ms.)
 template <int W, bool ARENA = false>
 constexpr int scan_mfma_waves() { return W == 2 && !ARENA ? 8 : 4; }
+// Periods of query tiles in flight ahead of the one being consumed (several tiles per barrier only).  Two periods (a
+// six-slot ring) were measured for the eight-wave blocks against one on the same box: 8.71 / 8.74 ms against 8.63 / 8.77 --
+// the copies are not late, what re-staging costs is their traffic.
+template <int W, bool ARENA = false>
+constexpr uint32_t scan_mfma_periods_ahead() { return 1u; }
+template <int W, bool ARENA = false>
+constexpr uint32_t scan_mfma_ring_slots() {
+    // one tile per barrier: slots - 1 tiles in flight.  The wide instantiations run one block per CU and wait on the
+    // arrival of their (large) tile images, not on the matrix pipe: they take the LDS a second block would have used
+    // for a deeper ring
+    return scan_mfma_tiles_per_barrier<W>() > 1 ? (1 + scan_mfma_periods_ahead<W, ARENA>()) * scan_mfma_tiles_per_barrier<W>() : (W >= 16 ? 5u : 3u);
+}
 template <int W, int NT, bool ARENA = false>
 __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_blocks_per_cu<W>() /* = waves per SIMD: hipcc's second bound counts waves per execution unit */) void scan_mfma_kernel(const uint32_t *__restrict__ codes,
                                                            const float4 *__restrict__ factors,
@@ -1474,7 +1478,7 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
     static_assert(IMG % (4 * NW) == 0, "tile image must split into NW 16-byte-aligned shares");
     constexpr uint32_t TILE = 32 * NW * NT;
     __shared__ __attribute__((aligned(16))) uint2 lut[256];
-    extern __shared__ __attribute__((aligned(16))) uint32_t ring[];  // scan_mfma_ring_slots<W>() x IMG dwords: query tiles in flight (LDS-DMA targets)
+    extern __shared__ __attribute__((aligned(16))) uint32_t ring[];  // scan_mfma_ring_slots<W, ARENA>() x IMG dwords: query tiles in flight (LDS-DMA targets)
     __shared__ __attribute__((aligned(16))) float4 facL[TILE];      // the tile's factors, for the exact path
     // per-wave emit queue: survivors are parked here and written out in bulk (one atomic round trip per flush)
     constexpr uint32_t QE = 128, QR = 32;
@@ -1518,7 +1522,7 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
     }
     const uint32_t ring0 = lds_addr(&ring[0]);
     auto dma_tile = [&](uint32_t qt, uint32_t slot) {  // this wave's quarter of query tile qt -> ring[slot]
-        if ((a.dbg & 2u) && qt >= scan_mfma_ring_slots<W>()) return;  // ablation: no re-staging (tiles re-use stale slots)
+        if ((a.dbg & 2u) && qt >= scan_mfma_ring_slots<W, ARENA>()) return;  // ablation: no re-staging (tiles re-use stale slots)
         const uint32_t *src = recs + ((uint64_t)(pb >> 5) + qt) * IMG + wave * (IMG / NW);
         const uint32_t dst = ring0 + (slot * IMG + wave * (IMG / NW)) * 4;
 #pragma unroll
@@ -1530,11 +1534,12 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
     constexpr uint32_t QPB = scan_mfma_tiles_per_barrier<W>();
     if constexpr (QPB == 1) {
 #pragma unroll
-        for (uint32_t i = 0; i + 1 < scan_mfma_ring_slots<W>(); ++i)
+        for (uint32_t i = 0; i + 1 < scan_mfma_ring_slots<W, ARENA>(); ++i)
             if (i < ntiles) dma_tile(i, i);
     } else {
-        dma_tile(0, 0);
-        if (ntiles > 1) dma_tile(1, 1);
+#pragma unroll
+        for (uint32_t i = 0; i < scan_mfma_periods_ahead<W, ARENA>() * QPB; ++i)
+            if (i < ntiles) dma_tile(i, i);
     }
     if (tid < 256) {  // byte -> 8 fp6 fields (bit e -> 1.0 = 0b001000 at bits 6e .. 6e+5)
         const uint32_t b = tid;
@@ -1677,7 +1682,7 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
     uint32_t slot = 0;  // ring slot of query tile qt
     for (uint32_t qt = 0; qt < ((a.dbg & 4u) ? 0u : ntiles); ++qt) {
         if constexpr (QPB == 1) {  // SLOTS slots, one barrier per tile, PD = SLOTS - 1 tiles in flight
-            constexpr uint32_t SLOTS = scan_mfma_ring_slots<W>(), PD = SLOTS - 1;
+            constexpr uint32_t SLOTS = scan_mfma_ring_slots<W, ARENA>(), PD = SLOTS - 1;
             // tile qt has landed once only the copies of the (up to PD - 1) later tiles are still in flight (in-order counter)
             const uint32_t later = ntiles - 1 - qt < PD - 1 ? ntiles - 1 - qt : PD - 1;  // wave-uniform
             if (later == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1688,14 +1693,20 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (!no_barrier) __builtin_amdgcn_s_barrier();  // every wave's quarter of tile qt is in; everyone is done with tile qt-1
             if (qt + PD < ntiles) dma_tile(qt + PD, slot == 0 ? SLOTS - 1 : slot - 1);  // into the slot tile qt-1 occupied
-        } else if (qt % QPB == 0) {  // 2*QPB slots, one barrier per QPB tiles: tiles qt .. qt+QPB-1 were requested one
-                                     // barrier ago (a period of QPB tiles of compute), the next QPB go out now
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (qt % QPB == 0) {  // (1 + AHEAD) * QPB slots, one barrier per QPB tiles: tiles qt .. qt+QPB-1 were requested
+                                     // AHEAD barriers ago, the copies of the AHEAD - 1 periods after them may still be in
+                                     // flight (in-order counter), and the QPB tiles AHEAD periods on go out now
+            constexpr uint32_t AHEAD = scan_mfma_periods_ahead<W, ARENA>();
+            static_assert(QPB == 2 && AHEAD <= 2 && 2 * NI < 64, "the vmcnt immediates below are spelled out for two tiles per barrier, two periods");
+            const uint32_t later = AHEAD < 2 || ntiles - qt <= QPB ? 0u : (ntiles - qt - QPB < QPB ? ntiles - qt - QPB : QPB);  // wave-uniform
+            if (later == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (!no_barrier) __builtin_amdgcn_s_barrier();
 #pragma unroll
             for (uint32_t i = 0; i < QPB; ++i)
-                if (qt + QPB + i < ntiles) dma_tile(qt + QPB + i, (slot + QPB + i) % (2 * QPB));
+                if (qt + AHEAD * QPB + i < ntiles) dma_tile(qt + AHEAD * QPB + i, (slot + AHEAD * QPB + i) % ((1 + AHEAD) * QPB));
         }
         if (time_stat) {
             const unsigned long long now = __builtin_readcyclecounter();
@@ -1853,7 +1864,7 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
                 if (time_stat) tm_exact += __builtin_readcyclecounter() - tx0;
             }
         }
-        slot = slot + 1 == scan_mfma_ring_slots<W>() ? 0 : slot + 1;
+        slot = slot + 1 == scan_mfma_ring_slots<W, ARENA>() ? 0 : slot + 1;
         if (time_stat) {
             const unsigned long long now = __builtin_readcyclecounter();
             tm_body += now - tm_mark;

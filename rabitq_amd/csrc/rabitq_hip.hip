@@ -521,10 +521,14 @@ static bool scan_has_mfma(uint32_t W) {
 static uint32_t scan_mfma_nt(uint32_t W) { return W == 2 ? 3 : (W >= 4 ? 2 : 4); }
 static uint32_t scan_mfma_nw(uint32_t W, bool arena) { return W == 2 && !arena ? 8u : 4u; }  // scan_mfma_waves<W, ARENA>()
 static uint32_t scan_mfma_tile(uint32_t W, bool arena) { return 32 * scan_mfma_nw(W, arena) * scan_mfma_nt(W); }
-static size_t scan_mfma_ring_bytes(uint32_t W) { return (W <= 2 ? 4ull : (W >= 16 ? 5ull : 3ull)) * (32 * (12 * W + 2) + RQ_REC_TAIL * 32) * 4; }  // scan_mfma_ring_slots<W>()
+static size_t scan_mfma_ring_bytes(uint32_t W, bool arena = false) {  // scan_mfma_ring_slots<W, ARENA>() tile images
+    (void)arena;
+    const uint64_t slots = W <= 2 ? 4ull : (W >= 16 ? 5ull : 3ull);
+    return slots * (32 * (12 * W + 2) + RQ_REC_TAIL * 32) * 4;
+}
 template <int W, int NT, bool ARENA>
 static void launch_scan_mfma_t(const ScanPtrs &p, const ScanArgs &a, dim3 g, hipStream_t st) {
-    scan_mfma_kernel<W, NT, ARENA><<<g, dim3(64 * scan_mfma_waves<W, ARENA>()), scan_mfma_ring_bytes(W), st>>>(p.codes, p.factors, p.offsets, p.grp_start, p.grp_cnt,
+    scan_mfma_kernel<W, NT, ARENA><<<g, dim3(64 * scan_mfma_waves<W, ARENA>()), scan_mfma_ring_bytes(W, ARENA), st>>>(p.codes, p.factors, p.offsets, p.grp_start, p.grp_cnt,
                                                                                     p.recs, p.surv, p.runs, p.surv_cnt, p.stat, p.tile_table, a);
 }
 // callers check scan_has_mfma(W) first; args.x != nullptr: the arena instantiations
