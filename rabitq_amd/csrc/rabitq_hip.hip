@@ -1008,6 +1008,9 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         // kernel wins, measured at any batch size)
         const bool use_mfma = scan_has_mfma(W) && impl != 1 && (impl == 2 || (est_pairs >= 8ull * k && (sg.s_lo >= avg_len || one_stage)));
         const bool cluster_major = use_mfma || (est_pairs >= k / 2 && est_pairs > 64);
+        if (g_scan_dbg.load() & 16384)  // developer hook: the pass's stage list
+            fprintf(stderr, "[rabitq_hip] stage %u: [%u, %u) span %llu est_pairs %llu %s\n", stage_no, sg.s_lo, sg.s_hi,
+                    (unsigned long long)span, (unsigned long long)est_pairs, use_mfma ? "matrix cores" : (cluster_major ? "VALU, list-major" : "VALU, pair-major"));
         const bool fp6_records = use_mfma;
         pf.begin(PF_GROUP);
         ScanArgs a{};
@@ -1326,11 +1329,15 @@ static uint32_t pass_capacity(const rq_index *idx, uint32_t remaining, bool seed
 
 // queries per pass: survivor / run buffers are 32 B per slot per query (keep one pass under ~24 GiB) and
 // (query, list) pairs per pass <= 2^22 (bounds the per-pair buffers and every launch size)
-static uint32_t pass_queries(const rq_index *idx, uint32_t remaining, uint32_t probe, uint32_t cap0) {
-    // survivor records + two run directories: 48 B per slot per query; the budget is a third of the HBM that was free
-    // once the index was resident (at least 4 GiB: an index that fills the HBM still answers 20 000-query passes)
+static uint32_t pass_queries(const rq_index *idx, uint32_t remaining, uint32_t probe, uint32_t cap0, bool seg) {
+    // survivor records + run directory: 32 B per slot per query, 48 B when the pass also keeps the second directory buffer
+    // (ws_prepare: capacities beyond the default, segmented passes, long directories); the budget is a third of the HBM that
+    // was free once the index was resident (at least 4 GiB: an index that fills the HBM -- 100M x 768 -- still answers a
+    // 32 768-query batch in ONE pass; split in two, every block of the matrix-core scan paid its start-up twice: a third
+    // of that launch at dim 768)
+    const uint64_t slot_bytes = cap0 > RQ_DEFAULT_CAP || seg || idx->big_dirs_hint.load() > 0 ? 48 : 32;
     uint32_t step_nq = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(remaining, RQ_MAX_NQ_PER_PASS),
-                                                    std::max<uint64_t>(1, idx->pass_budget / ((uint64_t)cap0 * 48)));
+                                                    std::max<uint64_t>(1, idx->pass_budget / ((uint64_t)cap0 * slot_bytes)));
     return std::min<uint32_t>(step_nq, std::max<uint32_t>(1, (1u << 22) / std::min(probe, idx->k)));
 }
 
@@ -1471,7 +1478,7 @@ static rq_status query_device(rq_index *idx, const float *d_q, uint32_t nq, uint
     for (uint32_t q0 = 0, step_nq = 0; q0 < nq; q0 += step_nq) {
         bool seg = false;
         const uint32_t cap0 = pass_capacity(idx, nq - q0, ext_thr != nullptr, &seg);
-        step_nq = pass_queries(idx, nq - q0, probe, cap0);
+        step_nq = pass_queries(idx, nq - q0, probe, cap0, seg);
         QueryParams qp{step_nq, len, probe, topk, heuristic, cap0, std::max(cap0, std::max(RQ_DEFAULT_CAP, idx->cap_hint.load()))};
         qp.seg_final = seg && step_nq >= 256;
         qp.thr_init = ext_thr ? ext_thr + q0 : nullptr;
@@ -1518,7 +1525,7 @@ static rq_status query_device_begin(rq_index *idx, const float *d_q, uint32_t nq
     memset(&t->prof, 0, sizeof t->prof);
     bool seg = false;
     const uint32_t cap0 = pass_capacity(idx, nq, false, &seg);
-    if (nq == 0 || pass_queries(idx, nq, probe, cap0) < nq) {  // nothing to overlap / several passes: synchronous
+    if (nq == 0 || pass_queries(idx, nq, probe, cap0, seg) < nq) {  // nothing to overlap / several passes: synchronous
         t->status = query_device(idx, d_q, nq, len, probe, topk, heuristic, d_out_dist, d_out_id, d_out_n);
         t->done = true;
         *out = t.release();

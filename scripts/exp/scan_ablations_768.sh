@@ -1,0 +1,7 @@
+# matrix-core scan launch time at 100M x 768 under timing ablations (results are WRONG with most of them)
+for o in 64 8256 66 68; do timeout -k 10 400 python bench.py --no-secondary --dim 768 --batch 32768 --steps 3 --warmup 2 --no-cpu-baseline --no-two-in-flight --small-batch 0 --gt-queries 10 --option scan_debug=$o > gpurun_out/b_abl768_$o.json 2> gpurun_out/b_abl768_$o.err; python - <<PY
+import json
+j=json.loads(open("gpurun_out/b_abl768_$o.json").read().strip().splitlines()[-1])
+print("scan_debug=$o", "scan_matrix ms", j["kernel_ms_per_step"]["scan_matrix"], "launches", j["roofline"]["launches"], "avg launch", j["roofline"]["avg_launch_ms"])
+PY
+done
