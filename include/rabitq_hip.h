@@ -372,8 +372,12 @@ rq_status rq_set_profiling(int level);
  * "group_rank": test hook, placement of a cluster-major stage's (query, list) pairs: 0 = one atomic per pair,
  * 1 = automatic (default: per-block LDS histograms for big stages), 2 = histograms whenever they fit.
  * Developer knobs: "stage_growth" (geometric growth of the early stages, 0 = default; results are
- * identical for every value), "scan_debug" (bit 128: count sub-tile / exact-path steps into rq_profile_t, results unchanged;
- * the other bits are timing ablations of the matrix-core scan: results are WRONG while they are set). */
+ * identical for every value), "scan_debug": measurement hooks with unchanged results -- bit 128 counts sub-tile / exact-path
+ * steps into rq_profile_t, 256 prints in-kernel cycle counters of the matrix-core scan, 4096 the phases of the small-batch
+ * kernel, 16384 the stage list of every pass (stderr) -- and TIMING ABLATIONS of the matrix-core scan under which results are
+ * WRONG: 1 flagged steps evaluate nothing, 2 no re-staging of query tiles, 4 no tile loop (start-up only), 64 the gate never
+ * fires, 512 no fp16 shadow rows in the rerank (results right), 1024 no survivor is recorded, 8192 no block barriers
+ * (profiles/r03_scan_mfma_ablations.txt). */
 rq_status rq_set_option(const char *name, int value);
 rq_status rq_last_profile(rq_profile_t *out);
 
