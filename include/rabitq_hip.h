@@ -371,6 +371,12 @@ rq_status rq_set_profiling(int level);
  * indexed by stream position (nothing to sort), 0 = runs are appended and the directory is sorted.
  * "group_rank": test hook, placement of a cluster-major stage's (query, list) pairs: 0 = one atomic per pair,
  * 1 = automatic (default: per-block LDS histograms for big stages), 2 = histograms whenever they fit.
+ * "assign_impl": nearest-list assignment of builds from now on: 0 (default) = bf16 matrix-core pre-filter + exact-order
+ * refinement wherever the shape is supported, 1 = exact-order kernels only (test hook); bit-identical labels and distances.
+ * "scan_tile_table": test hook, grids of the list-major scan stages: 0 = lists x tiles-of-the-longest-list everywhere,
+ * 1 (default) = one block per existing (list, tile) when most of the plain grid would be empty blocks, 2 = always.
+ * "small_batch_span": developer knob, stream positions a query's block of the small-batch path scans itself at most
+ * (default 2560; results are identical for every value).
  * Developer knobs: "stage_growth" (geometric growth of the early stages, 0 = default; results are
  * identical for every value), "scan_debug": measurement hooks with unchanged results -- bit 128 counts sub-tile / exact-path
  * steps into rq_profile_t, 256 prints in-kernel cycle counters of the matrix-core scan, 4096 the phases of the small-batch
