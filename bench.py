@@ -328,6 +328,16 @@ def run_workload(args, ctx, extras=True):
                 comm_handle = 1          # passed through to the callbacks untouched
             else:
                 os.environ.setdefault("RABITQ_RCCL_LIB", os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+                # ncclCommInitRank blocks until EVERY rank has called it: first make sure every rank can (library and symbols
+                # present), so that a rank which cannot does not leave the others waiting in the bootstrap
+                can = True
+                try:
+                    lib_ = sharding._rccl_lib()
+                    lib_.ncclGetUniqueId, lib_.ncclCommInitRank, lib_.ncclAllGather, lib_.ncclAllReduce, lib_.ncclCommUserRank   # noqa: B018
+                except Exception as e:
+                    can, why = False, f"{type(e).__name__}: {e}"
+                if not all_agree(can):
+                    raise RuntimeError(why or "RCCL is not available on another rank")
                 rc = sharding.RcclComm(rank, world)
                 keep_alive.append(rc)
                 comm_handle = rc.handle
