@@ -1105,6 +1105,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             uint64_t want = std::max<uint64_t>(idx->arena_hint.load(), (uint64_t)nq * qp.cap / 2);
             unsigned long long total_slots = 0;
             uint32_t arena_rsub = 0;
+            bool arena_retried = false;
             for (int attempt = 0;; ++attempt) {
                 want = std::min<uint64_t>(want, 0xFFFF0000ull);
                 RQC(ws.arena_recs.ensure(want));
@@ -1141,12 +1142,21 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                 total_slots = tail[1];
                 if (!(uint32_t)tail[0]) break;
                 pf.end();
-                if (attempt >= 6) return fail(RQ_ERR_OOM, "survivor arena kept overflowing");
-                want = std::max<uint64_t>(want * 2, 1u << 20);  // a shard ran full: twice the arena, the stage again (the counters were cleared by seg_exact_kernel)
+                if (attempt >= 6 || want >= 0xFFFF0000ull) return fail(RQ_ERR_OOM, "survivor arena kept overflowing");
+                // A shard AND the common area ran full: the stage again (the counters were cleared by seg_exact_kernel) with a
+                // larger arena: the exact counts are known now.  A grid of at least 2048 blocks spreads over all the shards: twice
+                // the arena, at least the survivors + a quarter.  A SMALL grid uses only a few of the 2048 shards, so doubling
+                // alone could stay short for ever (found by the fuzz driver: 700 queries whose every candidate survives, on a
+                // 130-block grid): there the common area (an eighth of the arena) is made to hold ALL of the stage's survivors,
+                // which takes whatever the shards turn away
+                const uint64_t nblocks = a.use_table ? a.ngroups : (uint64_t)a.ngroups * a.tiles_per_group;
+                want = std::max<uint64_t>(want * 2, 1u << 20);
+                if (nblocks < RQ_ARENA_SHARDS) want = std::max<uint64_t>(want, 8 * total_slots + (1u << 16)), arena_retried = true;
+                else want = std::max<uint64_t>(want, total_slots + total_slots / 4);
             }
             {  // remember what this stage needed
                 uint64_t cur = idx->arena_hint.load();
-                const uint64_t learnt = total_slots + total_slots * 3 / 5;
+                const uint64_t learnt = std::max<uint64_t>(total_slots + total_slots * 3 / 5, arena_retried ? std::min<uint64_t>(want, 0xFFFF0000ull) : 0ull);
                 while (cur < learnt && !const_cast<rq_index *>(idx)->arena_hint.compare_exchange_weak(cur, learnt)) {}
             }
             if (total_slots > ws.surv.count || total_slots > ws.runs.count || total_slots > ws.runs_tmp.count) {

@@ -1189,6 +1189,35 @@ def test_streamed_builder_equals_one_shot_build(rq, oracle, d, budget):
     oidx.close()
 
 
+def test_arena_on_a_small_grid_where_everything_survives(rq, oracle):
+    """Found by the fuzz driver (round 3, SEED=424242 N_MAX=40000, round 327; the generator state of that round is restored
+    here): 700 queries one ulp off their centroids on sparse data at scale 3e4, heuristic ranker with top-256 and 70 probes
+    -- thresholds stay loose, nearly every candidate of the probed lists survives -- on an index whose scan grid has ~130
+    blocks, so only ~130 of the arena's 2048 shards are ever used: doubling the arena six times never made room and the call
+    failed with RQ_ERR_OOM.  The retry now sizes the arena from the stage's exact survivor count."""
+    from rabitq_amd import index as ix
+    from tests import fuzz_parity as fz
+    rng = np.random.default_rng(0)
+    rng.bit_generator.state = {"bit_generator": "PCG64", "state": {"state": 39638530704376725464236549544941942162,
+                                                                     "inc": 90750984832771704908184579979025356679},
+                               "has_uint32": 0, "uinteger": 2370564739}
+    x, centres, P, queries, desc = fz.make_case(rng, 327, 40000)
+    assert (desc["n"], desc["d"], desc["k"], desc["nq"], desc["kind"]) == (33664, 128, 120, 700, "sparse"), desc
+    knobs = {"base_device_mb": 0, "scan_tile_table": 2, "rerank_shadow": 0, "small_batch_span": 100, "scan_impl": 1, "survivor_segments": 1}
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    try:
+        for name, v in knobs.items():
+            ix.set_option(name, v)
+        gidx = rq.RaBitQ.build(x, centres, P)
+        for probe, topk, heur in ((70, 256, True), (123, 200, False)):
+            _compare_with_oracle(rq, oracle, oidx, gidx, queries, probe, topk, heur)
+        gidx.close()
+    finally:
+        for name, v in fz.KNOB_DEFAULTS.items():
+            ix.set_option(name, v)
+        oidx.close()
+
+
 def test_arena_stages_equal_uniform_buffers_at_scale(rq):
     """The survivor arena at scale (no oracle at this size: the engine against itself): 8M vectors in 512 lists of
     Zipf-distributed sizes with overlapping clusters -- thousands of survivors for some queries, a handful for most, shards
