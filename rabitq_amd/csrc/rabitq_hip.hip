@@ -225,6 +225,7 @@ struct Workspace {
     DevBuf<SurvRec> surv, arr;
     DevBuf<RunRec> runs, runs_tmp;
     bool use_runs_tmp = false;
+    bool arena_failed = false;  // the last pass gave up inside an arena stage (no room for the arena): the caller repeats it on the uniform buffers
     // multi-GPU step (rq_query_batch_sharded_device): this shard's results, the all-gathered keys, the merged keys
     DevBuf<float> sh_dist;
     DevBuf<uint32_t> sh_id, sh_n;
@@ -1106,6 +1107,8 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             unsigned long long total_slots = 0;
             uint32_t arena_rsub = 0;
             bool arena_retried = false;
+            ws.arena_failed = true;  // (until the stage has its arena: an allocation failure or a give-up below returns from inside the loop)
+            if (g_seg_opt.load() == 3) return fail(RQ_ERR_OOM, "survivor arena: injected failure (test hook survivor_segments = 3)");
             for (int attempt = 0;; ++attempt) {
                 want = std::min<uint64_t>(want, 0xFFFF0000ull);
                 RQC(ws.arena_recs.ensure(want));
@@ -1154,6 +1157,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                 if (nblocks < RQ_ARENA_SHARDS) want = std::max<uint64_t>(want, 8 * total_slots + (1u << 16)), arena_retried = true;
                 else want = std::max<uint64_t>(want, total_slots + total_slots / 4);
             }
+            ws.arena_failed = false;
             {  // remember what this stage needed
                 uint64_t cur = idx->arena_hint.load();
                 const uint64_t learnt = std::max<uint64_t>(total_slots + total_slots * 3 / 5, arena_retried ? std::min<uint64_t>(want, 0xFFFF0000ull) : 0ull);
@@ -1332,7 +1336,7 @@ static rq_status validate_query(const rq_index *idx, const float *d_q, uint32_t 
 static uint32_t pass_capacity(const rq_index *idx, uint32_t remaining, bool seeded, bool *seg) {
     const uint32_t hint = idx->cap_hint.load();
     const int opt = g_seg_opt.load();
-    *seg = !seeded && remaining >= 256 && scan_is_fused(idx->W) && (opt == 2 || (opt == 1 && hint > RQ_DEFAULT_CAP));
+    *seg = !seeded && remaining >= 256 && scan_is_fused(idx->W) && (opt >= 2 || (opt == 1 && hint > RQ_DEFAULT_CAP));
     if (*seg) return RQ_DEFAULT_CAP;  // stages that cannot exceed it stay uniform, the others are segmented
     return std::max(RQ_DEFAULT_CAP, hint);
 }
@@ -1499,7 +1503,19 @@ static rq_status query_device(rq_index *idx, const float *d_q, uint32_t nq, uint
         uint32_t *oi = d_out_id + (uint64_t)q0 * topk, *on = d_out_n + q0;
         const uint32_t *ec = ext_cluster ? ext_cluster + (uint64_t)q0 * npb : nullptr;
         const float *ed = ext_dist ? ext_dist + (uint64_t)q0 * npb : nullptr;
-        RQC(run_pass(idx, *ws, q_at, qp, nullptr, od, oi, on, &pr, &prof, ec, ed));
+        ws->arena_failed = false;
+        rq_status ps = run_pass(idx, *ws, q_at, qp, nullptr, od, oi, on, &pr, &prof, ec, ed);
+        if (ps != RQ_OK && ws->arena_failed && qp.seg_final) {
+            // no room for the survivor arena (or it kept overflowing): the pass again on the uniform buffers, where a query that
+            // overflows is simply re-run with the capacity it asks for -- slower, never wrong
+            (void)hipStreamSynchronize(ws->stream);
+            ws->arena_failed = false;
+            qp.seg_final = false;
+            RQC(ws_prepare(idx, *ws, qp));
+            pr = PassResult();
+            ps = run_pass(idx, *ws, q_at, qp, nullptr, od, oi, on, &pr, &prof, ec, ed);
+        }
+        RQC(ps);
         tot_rough += pr.rough;
         tot_precise += pr.precise;
         RQC(after_pass(idx, ws, qp, q_at, od, oi, on, ec, ed, pr, prof, tot_precise));
@@ -1547,8 +1563,17 @@ static rq_status query_device_begin(rq_index *idx, const float *d_q, uint32_t nq
     t->ws = ws_acquire(idx);
     rq_status st = ws_prepare(idx, *t->ws, t->qp);
     PassResult pr;
-    if (st == RQ_OK)
+    if (st == RQ_OK) {
+        t->ws->arena_failed = false;
         st = run_pass(idx, *t->ws, d_q, t->qp, nullptr, d_out_dist, d_out_id, d_out_n, &pr, &t->prof, nullptr, nullptr, true);
+        if (st != RQ_OK && t->ws->arena_failed && t->qp.seg_final) {  // as in query_device: the pass again on the uniform buffers
+            (void)hipStreamSynchronize(t->ws->stream);
+            t->ws->arena_failed = false;
+            t->qp.seg_final = false;
+            st = ws_prepare(idx, *t->ws, t->qp);
+            if (st == RQ_OK) st = run_pass(idx, *t->ws, d_q, t->qp, nullptr, d_out_dist, d_out_id, d_out_n, &pr, &t->prof, nullptr, nullptr, true);
+        }
+    }
     if (st != RQ_OK) {
         (void)hipStreamSynchronize(t->ws->stream);
         ws_release(idx, t->ws);
@@ -3270,8 +3295,8 @@ rq_status rq_set_option(const char *name, int value) {
         g_coarse_impl = value;
         return RQ_OK;
     }
-    if (std::string(name) == "survivor_segments") {  // 0 never, 1 automatic (default), 2 every batch of >= 256 queries (tests)
-        if (value < 0 || value > 2) return fail(RQ_ERR_INVALID, "survivor_segments must be 0, 1 or 2");
+    if (std::string(name) == "survivor_segments") {  // 0 never, 1 automatic (default), 2 every batch of >= 256 queries (tests), 3 = 2 with every arena stage failing (tests: the fall-back)
+        if (value < 0 || value > 3) return fail(RQ_ERR_INVALID, "survivor_segments must be 0, 1, 2 or 3");
         g_seg_opt = value;
         return RQ_OK;
     }

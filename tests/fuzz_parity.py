@@ -3,6 +3,7 @@ implementations, both rankers, random engine knobs that must never change a resu
 order, distance bits, rough / precise counters).
 
     gpurun -- 'ROUNDS=400 SEED=3 python tests/fuzz_parity.py'
+    (N_MAX = largest index, default 12000; BIG_BATCHES=1 also draws batches of 2100 / 4100 queries)
 
 A seeded, bounded slice of the same rounds runs inside the suite (tests/test_gpu_parity.py::test_fuzz_slice).
 
@@ -40,6 +41,8 @@ def make_case(rng, it, nmax):
     k = int(rng.choice([1, 2, 5, 16, 40, 120, 300]))
     n = int(rng.integers(max(k, 200), nmax if d <= 256 else max(4000, nmax // 4)))
     nq = int(rng.choice([1, 3, 9, 33, 64, 70, 260, 300, 700]))
+    if os.environ.get("BIG_BATCHES") and rng.random() < 0.15:   # the large-batch regime (scalar-register coarse kernel, ranked groups, ...)
+        nq = int(rng.choice([2100, 4100]))
     sigma = float(rng.choice([0.4, 0.8, 1.2]))
     kind = str(rng.choice(KINDS))
     scale = float(rng.choice(SCALES))

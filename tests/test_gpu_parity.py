@@ -1308,6 +1308,10 @@ def test_segmented_final_stage_matches_oracle(rq, oracle):
             _compare_with_oracle(rq, oracle, oidx, gidx, queries, k, 100, False)
             uni = ix.last_profile()
             assert uni["segmented_passes"] == 0 and seg_bytes <= uni["survivor_workspace_bytes"]
+            ix.set_option("survivor_segments", 3)        # every arena stage fails: the pass is repeated on the uniform buffers
+            _compare_with_oracle(rq, oracle, oidx, gidx, queries, k, 100, False)
+            assert ix.last_profile()["segmented_passes"] == 0
+            _compare_with_oracle(rq, oracle, oidx, gidx, queries, 3, 10, True)
             gidx.close()
     finally:
         ix.set_option("survivor_segments", 1)
