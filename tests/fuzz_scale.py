@@ -20,16 +20,19 @@ DEFAULTS = {"max_scan_blocks": 0, "scan_tile_table": 1, "group_rank": 1, "coarse
             "scan_impl": 0, "survivor_segments": 1, "small_batch": 0, "small_batch_span": 2560}
 
 
-def main():
+def main(**over):
+    """`over`: VECTORS / LISTS / DIM / BATCH / ROUNDS / SEED / HARD instead of the environment (the suite's slice)."""
+    env = dict(os.environ)
+    env.update({k: str(v) for k, v in over.items()})
     import torch
     import rabitq_amd as rq
     from rabitq_amd import _lib, index as ix
     from tests import synth
     _lib.check(_lib.lib().rq_init(0))
     dev = torch.device("cuda", 0)
-    n, k, d = int(os.environ.get("VECTORS", 20_000_000)), int(os.environ.get("LISTS", 1024)), int(os.environ.get("DIM", 128))
-    rounds, seed = int(os.environ.get("ROUNDS", 20)), int(os.environ.get("SEED", 1))
-    hard = bool(os.environ.get("HARD"))
+    n, k, d = int(env.get("VECTORS", 20_000_000)), int(env.get("LISTS", 1024)), int(env.get("DIM", 128))
+    rounds, seed = int(env.get("ROUNDS", 20)), int(env.get("SEED", 1))
+    hard = bool(env.get("HARD"))
     sigma = 0.5
     rng = np.random.default_rng(seed)
     centres = synth.device_centres(k, d, dev, scale=sigma if hard else 1.0, seed=seed + 10)
@@ -52,7 +55,7 @@ def main():
     idx = b.finish()
     del x
     torch.cuda.empty_cache()
-    nq_max = int(os.environ.get("BATCH", 16384))
+    nq_max = int(env.get("BATCH", 16384))
     queries = synth.device_queries(centres, nq_max, sigma, dev, seed=seed + 12, weights=weights)
     t0 = time.time()
 

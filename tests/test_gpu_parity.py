@@ -1189,6 +1189,13 @@ def test_streamed_builder_equals_one_shot_build(rq, oracle, d, budget):
     oidx.close()
 
 
+def test_fuzz_scale_slice(rq):
+    """A bounded slice of tests/fuzz_scale.py (the engine against itself where the oracle cannot go): 10M vectors, hard
+    distribution, batches up to 16 384 queries, 16 random knob sets against the default-knob answer, bit for bit."""
+    from tests import fuzz_scale
+    fuzz_scale.main(VECTORS=10_000_000, LISTS=1024, DIM=128, BATCH=16384, ROUNDS=16, SEED=5, HARD=1)
+
+
 def test_arena_on_a_small_grid_where_everything_survives(rq, oracle):
     """Found by the fuzz driver (round 3, SEED=424242 N_MAX=40000, round 327; the generator state of that round is restored
     here): 700 queries one ulp off their centroids on sparse data at scale 3e4, heuristic ranker with top-256 and 70 probes
