@@ -3,7 +3,7 @@ random engine knobs that must never change a result -- scan implementation, surv
 directories, group placement, coarse kernel, stage growth, chunked grids, tile tables, shadow rows off, small-batch path --
 against the answer under the default knobs, bit for bit (ids in order, distance bits, counts).
 
-    gpurun -- 'ROUNDS=40 SEED=1 python tests/fuzz_scale.py'          (VECTORS, LISTS, DIM, BATCH, HARD=1 in the environment)
+    gpurun -- 'ROUNDS=40 SEED=1 python tests/fuzz_scale.py'          (VECTORS, LISTS, DIM, BATCH, HARD=1, BASE_MB, SHADOW=0 in the environment)
 """
 import os
 import sys
@@ -42,6 +42,9 @@ def main(**over):
         weights = (wz / wz.sum()).float()
     P = synth.random_orthogonal(d, seed=seed + 11)
     chunk = max(262_144, min(4_000_000, (512 << 20) // d))
+    # build-time knobs: BASE_MB = HBM budget of the raw vectors in MiB (the rest in pinned host memory), SHADOW=0 = no fp16 rows
+    ix.set_option("base_device_mb", int(env.get("BASE_MB", -1)))
+    ix.set_option("rerank_shadow", int(env.get("SHADOW", 1)))
     b = rq.RaBitQ.builder(n, d, centres.data_ptr(), k, orthogonal=P)
     for ci, i0 in enumerate(range(0, n, chunk)):
         m = min(chunk, n - i0)
@@ -53,7 +56,10 @@ def main(**over):
         x = synth.device_mixture_chunk(centres, i0, m, sigma, ci, 9000 + seed, 0, k, weights)[0].contiguous()
         b.place_chunk(x.data_ptr(), i0, m)
     idx = b.finish()
+    ix.set_option("base_device_mb", -1)
+    ix.set_option("rerank_shadow", 1)
     del x
+    idx_n_host = idx.n - idx.n_hbm
     torch.cuda.empty_cache()
     nq_max = int(env.get("BATCH", 16384))
     queries = synth.device_queries(centres, nq_max, sigma, dev, seed=seed + 12, weights=weights)
@@ -100,7 +106,8 @@ def main(**over):
         for name, v in DEFAULTS.items():
             ix.set_option(name, v)
         idx.close()
-    print(f"scale fuzz: all {rounds} rounds identical to the default-knob answer ({n} x {d}, {k} lists{', hard distribution' if hard else ''})")
+    print(f"scale fuzz: all {rounds} rounds identical to the default-knob answer ({n} x {d}, {k} lists{', hard distribution' if hard else ''}"
+          f"{', ' + str(idx_n_host) + ' rows in pinned host memory' if idx_n_host else ''}{', no shadow rows' if env.get('SHADOW') == '0' else ''})")
 
 
 if __name__ == "__main__":
