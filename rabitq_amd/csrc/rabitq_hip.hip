@@ -889,6 +889,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         sa.k = k, sa.dim = dim, sa.nprobe = nprobe, sa.topk = topk, sa.cap = qp.cap, sa.hcap = qp.hcap;
         sa.stamps = (g_scan_dbg.load() & 4096) ? ws.stat.p : nullptr;
         if (sa.stamps) HIPC(hipMemsetAsync(ws.stat.p, 0, 8, st));
+        else if (g_scan_dbg.load() & (128 | 256)) HIPC(hipMemsetAsync(ws.stat.p, 0, 256 * sizeof(unsigned long long), st));  // (the counters of a final matrix-core stage, if any)
         pf.begin(PF_COARSE);
         sb_front_kernel<<<dim3(ceil_div(k, RQ_SB_LISTS), ceil_div(nq, RQ_SB_QT)), 256, (size_t)2 * RQ_SB_QT * dim * sizeof(float), st>>>(
             d_q, qp.len, idx->P.p, idx->centroids.p, ws.y.p, ws.qpad.p, ws.dist.p, k, dim, nq, ws.totals.p, ws.big_list.p + nq);
