@@ -3,7 +3,7 @@ implementations, both rankers, random engine knobs that must never change a resu
 order, distance bits, rough / precise counters).
 
     gpurun -- 'ROUNDS=400 SEED=3 python tests/fuzz_parity.py'
-    (N_MAX = largest index, default 12000; BIG_BATCHES=1 also draws batches of 2100 / 4100 queries)
+    (N_MAX = largest index, default 12000; BIG_BATCHES=1 also draws batches of 2100 / 4100 queries, BIG_K=1 also 700 .. 6000 lists)
 
 A seeded, bounded slice of the same rounds runs inside the suite (tests/test_gpu_parity.py::test_fuzz_slice).
 
@@ -39,6 +39,8 @@ def make_case(rng, it, nmax):
     from tests import synth
     d = int(rng.choice([64, 100, 128, 128, 192, 256, 384, 512, 768, 960]))
     k = int(rng.choice([1, 2, 5, 16, 40, 120, 300]))
+    if os.environ.get("BIG_K") and rng.random() < 0.25:   # many short lists: the wide probe-selection kernels, ranked groups over thousands of lists
+        k = int(rng.choice([700, 2000, 4096, 6000]))
     n = int(rng.integers(max(k, 200), nmax if d <= 256 else max(4000, nmax // 4)))
     nq = int(rng.choice([1, 3, 9, 33, 64, 70, 260, 300, 700]))
     if os.environ.get("BIG_BATCHES") and rng.random() < 0.15:   # the large-batch regime (scalar-register coarse kernel, ranked groups, ...)
