@@ -523,6 +523,35 @@ __global__ __launch_bounds__(256) void factor_stats_kernel(const float4 *__restr
     }
 }
 
+// Per-list reference U0 of u' = (1, cds, ppc, eb) / factor_ip for the additive gate of the matrix-core scan (kernels_query.h,
+// scan_mfma_kernel<.., ADD>): the mean over the list's regular vectors of components 0, 1 and 3 (component 2 = 2 popcount - dim is
+// centred on 0 by construction and keeps the reference 0).  ANY value is a valid reference -- the bound it enters holds for every
+// U0 -- a good one only keeps |u' - U0| small.  One block per list.
+__global__ __launch_bounds__(256) void list_uref_kernel(const float4 *__restrict__ factors, const uint32_t *__restrict__ offsets,
+                                                        float4 *__restrict__ uref) {
+    const uint32_t c = blockIdx.x, b = offsets[c], e = offsets[c + 1];
+    float s0 = 0.0f, s1 = 0.0f, s3 = 0.0f, n = 0.0f;
+    for (uint32_t i = b + threadIdx.x; i < e; i += 256) {
+        const float4 f = factors[i];
+        const float rf = __builtin_amdgcn_rcpf(f.x);
+        const float mag = (1.0f + fabsf(f.w) + fabsf(f.y) + fabsf(f.z)) * fabsf(rf);
+        if (f.x < 0.0f && mag < 1.0e37f) s0 += rf, s1 += f.w * rf, s3 += f.z * rf, n += 1.0f;
+    }
+    for (int o = 32; o >= 1; o >>= 1)
+        s0 += __shfl_xor(s0, o, 64), s1 += __shfl_xor(s1, o, 64), s3 += __shfl_xor(s3, o, 64), n += __shfl_xor(n, o, 64);
+    __shared__ float red[4][4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][0] = s0, red[threadIdx.x >> 6][1] = s1, red[threadIdx.x >> 6][2] = s3, red[threadIdx.x >> 6][3] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t[4];
+        for (int r = 0; r < 4; ++r) t[r] = (red[0][r] + red[1][r]) + (red[2][r] + red[3][r]);
+        const float inv = t[3] > 0.0f ? 1.0f / t[3] : 0.0f;
+        float4 u = make_float4(t[0] * inv, t[1] * inv, 0.0f, t[2] * inv);
+        if (!(fabsf(u.x) + fabsf(u.y) + fabsf(u.w) < 1.0e37f)) u = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        uref[c] = u;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Nearest list through the matrix cores, WITHOUT giving up the exact result (kmeans_nearest_cluster,
 // src/utils.rs:261-277: the first j minimising the exact-order f32 distance).

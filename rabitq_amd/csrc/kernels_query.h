@@ -812,6 +812,13 @@ __global__ __launch_bounds__(1024) void group_rank_kernel(const PairScalars *__r
 #define RQ_REC_V0 12         // 8 dwords: per-query bf16 operand of the integer threshold S*(c,q) = sum_r u'_c[r] * v'_q[r]
 #define RQ_REC_CELL0 12      // record-major (VALU) records only: directory cell of this pair's list position 0 (dense directories)
 #define RQ_REC_TAIL 20
+// Tile images of the ADDITIVE-gate matrix-core scan (scan_mfma_kernel<.., ADD = true>): the tail stops before the bf16
+// threshold operand (12 dwords per row), and the 32 rows' accumulator start values C_q follow the tails as ONE 32-float
+// array (the kernel reads them as the C operand of its first MFMA: four broadcast 16-byte LDS reads per tile)
+#define RQ_RECA_TAIL 12
+__host__ __device__ constexpr uint32_t rq_img_dwords(uint32_t opdw, bool additive) {
+    return 32u * (opdw + 2u) + (additive ? 32u * RQ_RECA_TAIL + 32u : 32u * RQ_REC_TAIL);
+}
 
 // exclusive scan of cnt[0..k) into start[0..k]; single block, any k.  Also zeroes cnt for the
 // fill pass (cnt is reused as the per-list cursor, so it holds the counts again afterwards).
@@ -846,8 +853,13 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(uint32_t *__restrict__
             start[i] = st0;
             if ((pad32 & 1u) && recs) {
                 const uint32_t real = cnt[i];
-                const uint32_t opld = opdw + 2, img = 32 * opld + RQ_REC_TAIL * 32;
+                const bool additive = (pad32 & 4u) != 0;  // bit 2: tile images of the additive gate (start value -inf)
+                const uint32_t opld = opdw + 2, img = rq_img_dwords(opdw, additive);
                 for (uint32_t at = st0 + real; at < st0 + v; ++at) {  // at most 31 rows
+                    if (additive) {
+                        recs[(uint64_t)(at >> 5) * img + 32 * opld + 32 * RQ_RECA_TAIL + (at & 31u)] = 0xFF800000u;
+                        continue;
+                    }
                     uint32_t *tl = recs + (uint64_t)(at >> 5) * img + 32 * opld + (at & 31u) * RQ_REC_TAIL + RQ_REC_V0;
                     *reinterpret_cast<uint4 *>(tl) = make_uint4(0u, 0u, 0u, 0x0000FF80u);  // slots 0..7: c0 = -inf
                     *reinterpret_cast<uint4 *>(tl + 4) = make_uint4(0u, 0u, 0u, 0u);        // slots 8..15
@@ -881,17 +893,20 @@ __device__ __forceinline__ void stage_fill_item(const PairScalars *__restrict__ 
                                                 const uint32_t *__restrict__ grp_start,
                                                 uint32_t *__restrict__ grp_cursor,
                                                 uint32_t *__restrict__ recs, const FactorStats &fs,
-                                                uint32_t tile_images,
+                                                uint32_t tile_images /* 0 record-major, 1 tile images, 2 tile images of the additive gate */,
                                                 const uint32_t *__restrict__ rank /* group_rank_kernel, or null */,
-                                                const uint32_t *__restrict__ blk_base, uint32_t k) {
+                                                const uint32_t *__restrict__ blk_base, uint32_t k,
+                                                const float4 *__restrict__ list_uref /* tile_images == 2: U0 per list */) {
     const uint32_t sub = threadIdx.x & 15;                       // 16 lanes per pair
     const uint32_t wb = wi / slot_hi, p = wb * nprobe + (wi - wb * slot_hi);
     const PairScalars ps = scal[p];
     const bool in = pair_in_stage(ps, s_lo, s_hi);
     if (cluster_major && !in) return;
     uint32_t at = p;
+    uint32_t list_id = 0;
     if (cluster_major) {
         const uint32_t c = probe_cluster[p];
+        list_id = c;
         if (rank) {  // places were handed out by group_rank_kernel
             at = grp_start[c] + blk_base[(uint64_t)(wi / RQ_RANK_ITEMS) * k + c] + rank[wi];
         } else {
@@ -906,11 +921,14 @@ __device__ __forceinline__ void stage_fill_item(const PairScalars *__restrict__ 
     const uint32_t stride = opdw + RQ_REC_TAIL;
     uint32_t *r = recs + (uint64_t)at * stride;
     uint32_t *tdst = r + opdw;
+    float *cdst = nullptr;  // additive gate: the row's accumulator start value
     if (tile_images) {
-        const uint32_t opld = opdw + 2, img = 32 * opld + RQ_REC_TAIL * 32;
+        const uint32_t opld = opdw + 2, img = rq_img_dwords(opdw, tile_images == 2);
+        const uint32_t taild = tile_images == 2 ? RQ_RECA_TAIL : RQ_REC_TAIL;
         uint32_t *base = recs + (uint64_t)(at >> 5) * img;
         r = base + (at & 31u) * opld;
-        tdst = base + 32 * opld + (at & 31u) * RQ_REC_TAIL;
+        tdst = base + 32 * opld + (at & 31u) * taild;
+        if (tile_images == 2) cdst = reinterpret_cast<float *>(base + 32 * opld + 32 * taild + (at & 31u));
     }
     {  // operand rows are 8-byte aligned in both layouts (opdw, the record stride and the image row stride are even)
         const uint2 *src = reinterpret_cast<const uint2 *>(operand + (uint64_t)p * opdw);
@@ -957,6 +975,25 @@ __device__ __forceinline__ void stage_fill_item(const PairScalars *__restrict__ 
                          fs.invfip_absmax * fabsf(inv2d);
         const bool safe = ps.delta > 0.0f && qb + ps.sumq < 524288.0f;  // also false for NaN / inf
         const float margin = 2.0f + qb * (1.0f / 8192.0f) + (qb + ps.sumq) * (1.0f / 262144.0f);
+        if (tile_images == 2) {
+            // Additive gate (scan_mfma_kernel<.., ADD>): the query's side of  S* >= B_q + G_c,  B_q = sum_r U0[r] v'_q[r] + sumq / 2 with
+            // the list's reference U0 (U0[2] = 0), as the accumulator's start value C_q = -(B_q - margin) / 2 (the dot products come
+            // out as s / 2): "s/2 + C_q > G_c / 2" then holds for every candidate the exact f32 expression would pass.  The margin is
+            // the bf16 form's (2 for the f32 rounding of the exact expression; qb 2^-13 covers, many times over, the f32 roundings
+            // of B_q, of v' inside the list's V0 / DV and of the candidate's u' -- all relative 2^-22 of terms bounded by qb) with a
+            // wider share for the matrix unit's own accumulation of C_q + s/2 (f32, magnitudes below qb + sumq).
+            const float4 u0 = list_uref[list_id];
+            float bq = u0.x * v[0];
+            bq += u0.y * v[1];
+            bq += u0.w * v[3];
+            bq += 0.5f * ps.sumq;
+            const float margin_a = 2.0f + qb * (1.0f / 8192.0f) + (qb + ps.sumq) * (1.0f / 65536.0f);
+            float cq = -0.5f * (bq - margin_a);
+            if (!safe || !(fabsf(cq) < 1.0e37f)) cq = __builtin_inff();  // always flagged: the exact path decides
+            if (sub == 5) *cdst = cq;
+            if (sub < 3) *reinterpret_cast<uint4 *>(tdst + 4 * sub) = make_uint4(t[4 * sub], t[4 * sub + 1], t[4 * sub + 2], t[4 * sub + 3]);
+            return;
+        }
         const float v4 = -0.5f * (0.5f * ps.sumq - margin);
         uint32_t vh[4], vl[4];
 #pragma unroll
@@ -1010,11 +1047,62 @@ __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__re
                                                          uint32_t *__restrict__ recs, const FactorStats fs,
                                                          uint32_t tile_images,
                                                          const uint32_t *__restrict__ rank /* group_rank_kernel, or null */,
-                                                         const uint32_t *__restrict__ blk_base, uint32_t k) {
+                                                         const uint32_t *__restrict__ blk_base, uint32_t k,
+                                                         const float4 *__restrict__ list_uref) {
     const uint32_t wi = blockIdx.x * 16 + (threadIdx.x >> 4);  // work item: (query, slot < slot_hi)
     if (wi >= count) return;
     stage_fill_item(scal, probe_cluster, operand, thr, wi, nprobe, slot_hi, opdw, s_lo, s_hi, cluster_major, grp_start, grp_cursor,
-                    recs, fs, tile_images, rank, blk_base, k);
+                    recs, fs, tile_images, rank, blk_base, k, list_uref);
+}
+
+// Additive gate of the matrix-core scan: centre V0 and half-range DV of v'_q = ((thr - ycd), -1, -lower, sqrt(ycd)) / (2 delta)
+// over the pairs of a stage that probe list c (the records of group c, tile images of the additive format), written as
+// two float4 per list.  Pairs whose start value is +inf (always flagged: stage_fill_kernel) take no part.  One block per list.
+__global__ __launch_bounds__(256) void group_vrange_kernel(const uint32_t *__restrict__ recs, const uint32_t *__restrict__ grp_start,
+                                                           const uint32_t *__restrict__ grp_cnt, uint32_t opdw,
+                                                           float4 *__restrict__ vref) {
+    const uint32_t c = blockIdx.x, n = grp_cnt[c], st0 = grp_start[c];
+    const uint32_t opld = opdw + 2, img = rq_img_dwords(opdw, true);
+    const float inf = __builtin_inff();
+    float lo[4] = {inf, inf, inf, inf}, hi[4] = {-inf, -inf, -inf, -inf};
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint32_t at = st0 + i;
+        const uint32_t *base = recs + (uint64_t)(at >> 5) * img + 32 * opld;
+        const float cq = __builtin_bit_cast(float, base[32 * RQ_RECA_TAIL + (at & 31u)]);
+        if (!(cq < inf)) continue;
+        const uint32_t *t = base + (at & 31u) * RQ_RECA_TAIL;
+        const float lower = __builtin_bit_cast(float, t[RQ_REC_LOWER]), delta = __builtin_bit_cast(float, t[RQ_REC_DELTA]);
+        const float ycd = __builtin_bit_cast(float, t[RQ_REC_YCD]), ysq = __builtin_bit_cast(float, t[RQ_REC_YCD_SQRT]);
+        const float th = __builtin_bit_cast(float, t[RQ_REC_THR]);
+        const float inv2d = 0.5f / delta;  // the expressions of stage_fill_item
+        const float v[4] = {(th - ycd) * inv2d, -inv2d, -lower * inv2d, ysq * inv2d};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lo[r] = fminf(lo[r], v[r]), hi[r] = fmaxf(hi[r], v[r]);
+    }
+    __shared__ float red[4][8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        for (int o = 32; o >= 1; o >>= 1) lo[r] = fminf(lo[r], __shfl_xor(lo[r], o, 64)), hi[r] = fmaxf(hi[r], __shfl_xor(hi[r], o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[threadIdx.x >> 6][r] = lo[r], red[threadIdx.x >> 6][4 + r] = hi[r];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float v0[4], dv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float l = fminf(fminf(red[0][r], red[1][r]), fminf(red[2][r], red[3][r]));
+            const float u = fmaxf(fmaxf(red[0][4 + r], red[1][4 + r]), fmaxf(red[2][4 + r], red[3][4 + r]));
+            const bool any = l <= u && u < inf && l > -inf;
+            v0[r] = any ? 0.5f * l + 0.5f * u : 0.0f;
+            // half-range, widened so that |v - v0| <= dv survives the roundings of v0 and of the subtraction
+            dv[r] = any ? fmaxf(u - v0[r], v0[r] - l) * 1.000001f : 0.0f;
+        }
+        vref[2 * c] = make_float4(v0[0], v0[1], v0[2], v0[3]);
+        vref[2 * c + 1] = make_float4(dv[0], dv[1], dv[2], dv[3]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1031,6 +1119,14 @@ __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__re
 // over the group's (query, slot) pairs, whose operands are wave-uniform (SGPR / scalar loads).
 // HBM traffic is the list itself: D/8 + 16 bytes per candidate, 16 B/lane coalesced loads at D=128.
 // ------------------------------------------------------------------------------------------------
+// Timing ablations and cycle counters of the scan kernels change results (or cost registers in the hot loops): they are compiled
+// only into the developer build (-DRQ_DEV_ABLATIONS -> librabitq_hip_dev.so, used by scripts/exp/*); the shipped library's
+// kernels carry none of these branches and rq_set_option rejects the bits.
+#ifdef RQ_DEV_ABLATIONS
+#define RQ_DBG(args, bits) ((args).dbg & (bits))
+#else
+#define RQ_DBG(args, bits) 0u
+#endif
 struct ScanArgs {   // scalars only; pointers are explicit __restrict__ kernel parameters so the
                     // compiler keeps the wave-uniform operand fetches on the scalar unit (s_load)
     uint32_t cap, tiles_per_group, ngroups, cluster_major;
@@ -1106,8 +1202,10 @@ struct ScanPtrs {   // host-side bundle only
     SurvRec *surv;                // per query `cap` records
     RunRec *runs;                 // per query `cap` run descriptors
     unsigned long long *surv_cnt; // per query: low 32 bits = records, high 32 bits = runs
-    unsigned long long *stat;     // matrix-core scan measurement hook (ScanArgs::dbg & 128)
+    unsigned long long *stat;     // matrix-core scan: 64 x {sub-tile steps, exact-path steps}
     const uint4 *tile_table;      // {list, first position of the tile in the list, list begin, list length} (use_table)
+    const float4 *list_uref;      // additive gate: U0 per list (index)
+    const float4 *grp_vref;       // additive gate: V0, DV per list (stage; group_vrange_kernel)
 };
 #define SCAN_PARAMS                                                                                  \
     const uint32_t *__restrict__ codes, const float4 *__restrict__ factors,                          \
@@ -1258,7 +1356,7 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
                 total += (uint32_t)__popcll(m[c]);
             }
         }
-        if (a.dbg & 1024u) total = 0;  // timing ablation: no survivor is recorded (results are wrong)
+        if (RQ_DBG(a, 1024u)) total = 0;  // timing ablation: no survivor is recorded (results are wrong)
         if (total) {  // wave-uniform: one 64-bit atomic reserves the records and the run descriptors
             const uint32_t b = t[RQ_REC_ROW], slot = t[RQ_REC_SLOT];
             uint32_t nruns = 0;
@@ -1456,7 +1554,22 @@ constexpr uint32_t scan_mfma_ring_slots() {
     // for a deeper ring
     return scan_mfma_tiles_per_barrier<W>() > 1 ? (1 + scan_mfma_periods_ahead<W, ARENA>()) * scan_mfma_tiles_per_barrier<W>() : (W >= 16 ? 5u : 3u);
 }
-template <int W, int NT, bool ARENA = false>
+// ADD (additive gate; dim <= 128, uniform survivor buffers): the rank-5 threshold S*(c, q) = sum_r u'_c[r] v'_q[r] + v4_q is replaced
+// by the additive lower bound
+//     S*(c, q) >= B_q + G_c,   B_q = sum_r U0[r] v'_q[r] + v4_q,   G_c = sum_r (d_c[r] V0[r] - |d_c[r]| DV[r]),   d_c = u'_c - U0
+// with U0 a per-LIST reference of u' (mean over the list, list_uref_kernel: one float4 per list, part of the index) and
+// V0 / DV the centre / half-range of v' over the pairs that probe the list in THIS stage (group_vrange_kernel):
+// u'v' = U0 v' + d V0 + d (v' - V0) and |v' - V0| <= DV.  B_q travels with the query's record as the accumulator's start value
+// C_q = -(B_q - margin) / 2 (stage_fill_kernel; the C operand of the first fp6 MFMA), G_c is a per-candidate constant of the block,
+// and the hot gate is "max over the 16 accumulator registers > H_c = G_c / 2" -- the bf16 threshold MFMA (a third of the matrix
+// cycles at dim 128, half at dim 64) is gone.  Measured looseness on the benchmark mixture (scripts/exp/additive_gate_sim.py):
+// the bound sits 10-17 below S* where the cells' s sits 166 +- 26 below it: 1e-4 .. 1e-3 of the sub-tile steps are flagged
+// (exact threshold: < 1e-5), each of which is then decided by the exact f32 expression exactly as before.
+// The candidate operand of this form is fp4 (e2m1: a code bit is 1.0 = 0b0010; same MFMA rate as fp6 x fp6, 4 instead of 6
+// registers per 32 dimensions), which pays for the 16 registers of C.
+template <int W, bool ARENA, bool ADD>
+constexpr uint32_t scan_mfma_img_dwords() { return rq_img_dwords(12 * W, ADD); }
+template <int W, int NT, bool ARENA = false, bool ADD = false>
 __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_blocks_per_cu<W>() /* = waves per SIMD: hipcc's second bound counts waves per execution unit */) void scan_mfma_kernel(const uint32_t *__restrict__ codes,
                                                            const float4 *__restrict__ factors,
                                                            const uint32_t *__restrict__ offsets,
@@ -1465,18 +1578,24 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
                                                            const uint32_t *__restrict__ recs,
                                                            SurvRec *__restrict__ surv, RunRec *__restrict__ runs,
                                                            unsigned long long *__restrict__ surv_cnt,
-                                                           unsigned long long *__restrict__ stat /* [128], only with a.dbg & 128 */,
+                                                           unsigned long long *__restrict__ stat /* [128]: sub-tile steps / exact-path steps, 64 pairs by block */,
                                                            const uint4 *__restrict__ tile_table,
+                                                           const float4 *__restrict__ list_uref /* ADD: U0 per list */,
+                                                           const float4 *__restrict__ grp_vref /* ADD: V0, DV per list (two float4) */,
                                                            const ScanArgs a) {
+    static_assert(!(ADD && ARENA), "the additive gate is built for the uniform survivor buffers only");
     constexpr uint32_t OPDW = 12 * W;            // operand dwords per record: dim fp6 fields
     constexpr uint32_t OPLD = OPDW + 2;          // row stride (dwords) of the operand image: conflict-free ds_read_b64
     constexpr uint32_t IMG_OP = 32 * OPLD;       // a query tile image: 32 operand rows ...
-    constexpr uint32_t IMG = IMG_OP + RQ_REC_TAIL * 32;  // ... + the 32 record tails
+    constexpr uint32_t TAILD = ADD ? RQ_RECA_TAIL : RQ_REC_TAIL;
+    constexpr uint32_t IMG = scan_mfma_img_dwords<W, ARENA, ADD>();  // ... + the 32 record tails (+ the 32 start values)
+    constexpr uint32_t IMG_C = IMG_OP + 32 * TAILD;  // ADD: the 32 accumulator start values
     constexpr uint32_t NW = scan_mfma_waves<W, ARENA>();  // waves per block
     constexpr uint32_t WQ4 = IMG / (4 * NW);     // 16-byte pieces each wave copies (its share of the image)
     constexpr uint32_t NI = (WQ4 + 63) / 64;     // LDS-DMA instructions per wave per tile
     static_assert(IMG % (4 * NW) == 0, "tile image must split into NW 16-byte-aligned shares");
     constexpr uint32_t TILE = 32 * NW * NT;
+    constexpr uint32_t BDW = ADD ? 4 : 6;        // candidate operand dwords per 32 dimensions: fp4 / fp6 fields
     __shared__ __attribute__((aligned(16))) uint2 lut[256];
     extern __shared__ __attribute__((aligned(16))) uint32_t ring[];  // scan_mfma_ring_slots<W, ARENA>() x IMG dwords: query tiles in flight (LDS-DMA targets)
     __shared__ __attribute__((aligned(16))) float4 facL[TILE];      // the tile's factors, for the exact path
@@ -1504,7 +1623,9 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
     const uint32_t tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t ntiles = (cnt + 31) / 32;
+#ifdef RQ_DEV_ABLATIONS
     const unsigned long long tm_begin = (a.dbg & 256u) ? __builtin_readcyclecounter() : 0ull;
+#endif
 
     // everything the block needs from memory is requested up front: this lane's candidates (its half of
     // every code word + factors) and the first two query tiles
@@ -1520,9 +1641,11 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
 #pragma unroll
         for (int m = 0; m < W; ++m) craw[t][m] = cp[2 * m + h];
     }
+    float4 u0r = {0, 0, 0, 0}, v0r = {0, 0, 0, 0}, dvr = {0, 0, 0, 0};
+    if constexpr (ADD) u0r = list_uref[g], v0r = grp_vref[2 * g], dvr = grp_vref[2 * g + 1];
     const uint32_t ring0 = lds_addr(&ring[0]);
     auto dma_tile = [&](uint32_t qt, uint32_t slot) {  // this wave's quarter of query tile qt -> ring[slot]
-        if ((a.dbg & 2u) && qt >= scan_mfma_ring_slots<W, ARENA>()) return;  // ablation: no re-staging (tiles re-use stale slots)
+        if (RQ_DBG(a, 2u) && qt >= scan_mfma_ring_slots<W, ARENA>()) return;  // ablation: no re-staging (tiles re-use stale slots)
         const uint32_t *src = recs + ((uint64_t)(pb >> 5) + qt) * IMG + wave * (IMG / NW);
         const uint32_t dst = ring0 + (slot * IMG + wave * (IMG / NW)) * 4;
 #pragma unroll
@@ -1541,15 +1664,23 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
         for (uint32_t i = 0; i < scan_mfma_periods_ahead<W, ARENA>() * QPB; ++i)
             if (i < ntiles) dma_tile(i, i);
     }
-    if (tid < 256) {  // byte -> 8 fp6 fields (bit e -> 1.0 = 0b001000 at bits 6e .. 6e+5)
+    if (tid < 256) {
         const uint32_t b = tid;
-        uint64_t f = 0;
+        if constexpr (ADD) {  // byte -> 8 fp4 fields (bit e -> 1.0 = 0b0010 at bits 4e .. 4e+3)
+            uint32_t f = 0;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f |= (uint64_t)((b >> e) & 1u) << (6 * e + 3);
-        lut[b] = make_uint2((uint32_t)f, (uint32_t)(f >> 32));
+            for (int e = 0; e < 8; ++e) f |= ((b >> e) & 1u) << (4 * e + 1);
+            lut[b] = make_uint2(f, 0u);
+        } else {  // byte -> 8 fp6 fields (bit e -> 1.0 = 0b001000 at bits 6e .. 6e+5)
+            uint64_t f = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f |= (uint64_t)((b >> e) & 1u) << (6 * e + 3);
+            lut[b] = make_uint2((uint32_t)f, (uint32_t)(f >> 32));
+        }
     }
 
-    uint32_t ub[NT][4];   // B operand of the threshold MFMA: 8 bf16 per lane (slots 8h .. 8h+7)
+    uint32_t ub[ADD ? 1 : NT][4];   // B operand of the threshold MFMA: 8 bf16 per lane (slots 8h .. 8h+7)
+    float hc[ADD ? NT : 1];         // ADD: the candidate's side of the gate, H_c = G_c / 2 (-inf: always flagged)
     bool forced = false;  // candidates whose factors do not admit the integer-threshold form
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -1559,26 +1690,55 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
         const float rf = __builtin_amdgcn_rcpf(fac0[t].x);
         const float mag = (1.0f + fabsf(fac0[t].w) + fabsf(fac0[t].y) + fabsf(fac0[t].z)) * fabsf(rf);
         const bool ok = fac0[t].x < 0.0f && mag < 1.0e37f;  // false for NaN / inf / factor_ip >= 0
-        const float x0 = (h ? fac0[t].y : 1.0f) * rf, x1 = (h ? fac0[t].z : fac0[t].w) * rf;
-        f32x2 xs = {x0, x1};
-        const uint32_t hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(xs, bf16x2));  // xh0 | xh1 << 16 (RNE)
-        f32x2 res = {x0 - __builtin_bit_cast(float, hi << 16), x1 - __builtin_bit_cast(float, hi & 0xFFFF0000u)};
-        const uint32_t lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(res, bf16x2));  // xl0 | xl1 << 16
-        const uint32_t one = 0x3F80u;
-        // slots of this half: xh0 xl0 xh0 xh1 xl1 xh1 1 (1 | 0)
-        ub[t][0] = ok ? ((hi & 0xFFFFu) | (lo << 16)) : 0u;
-        ub[t][1] = ok ? hi : 0u;
-        ub[t][2] = ok ? ((lo >> 16) | (hi & 0xFFFF0000u)) : 0u;
-        ub[t][3] = ok ? (h ? one : (one | (one << 16))) : 0u;
-        if (!ok) forced = true;
+        if constexpr (ADD) {
+            const float u0 = rf, u1 = fac0[t].w * rf, u2 = fac0[t].y * rf, u3 = fac0[t].z * rf;
+            const float d0 = u0 - u0r.x, d1 = u1 - u0r.y, d2 = u2, d3 = u3 - u0r.w;
+            float gc = d0 * v0r.x - fabsf(d0) * dvr.x;
+            gc += d1 * v0r.y - fabsf(d1) * dvr.y;
+            gc += d2 * v0r.z - fabsf(d2) * dvr.z;
+            gc += d3 * v0r.w - fabsf(d3) * dvr.w;
+            // the f32 roundings of u', d and of the sums above, and of v' inside V0 / DV (2^-20 of the magnitudes involved;
+            // the query's own margin covers its side, stage_fill_kernel)
+            const float slop = ((fabsf(u0) + fabsf(u0r.x)) * (fabsf(v0r.x) + dvr.x) + (fabsf(u1) + fabsf(u0r.y)) * (fabsf(v0r.y) + dvr.y) +
+                                fabsf(u2) * (fabsf(v0r.z) + dvr.z) + (fabsf(u3) + fabsf(u0r.w)) * (fabsf(v0r.w) + dvr.w)) *
+                               (1.0f / 1048576.0f);
+            const float hv = 0.5f * (gc - slop);
+            const bool fin = fabsf(hv) < 1.0e37f;  // false for NaN / inf
+            hc[t] = ok && fin ? hv : -__builtin_inff();
+        } else {
+            const float x0 = (h ? fac0[t].y : 1.0f) * rf, x1 = (h ? fac0[t].z : fac0[t].w) * rf;
+            f32x2 xs = {x0, x1};
+            const uint32_t hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(xs, bf16x2));  // xh0 | xh1 << 16 (RNE)
+            f32x2 res = {x0 - __builtin_bit_cast(float, hi << 16), x1 - __builtin_bit_cast(float, hi & 0xFFFF0000u)};
+            const uint32_t lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(res, bf16x2));  // xl0 | xl1 << 16
+            const uint32_t one = 0x3F80u;
+            // slots of this half: xh0 xl0 xh0 xh1 xl1 xh1 1 (1 | 0)
+            ub[t][0] = ok ? ((hi & 0xFFFFu) | (lo << 16)) : 0u;
+            ub[t][1] = ok ? hi : 0u;
+            ub[t][2] = ok ? ((lo >> 16) | (hi & 0xFFFF0000u)) : 0u;
+            ub[t][3] = ok ? (h ? one : (one | (one << 16))) : 0u;
+            if (!ok) forced = true;
+        }
     }
-    const uint64_t forcemask = __ballot(forced);
-    // as a scalar, together with the developer switch: the hot loop tests one SGPR instead of rebuilding the condition
-    const uint32_t force_any = __builtin_amdgcn_readfirstlane(forcemask != 0ull ? 1u : 0u);
-    const uint32_t exact_off = __builtin_amdgcn_readfirstlane((a.dbg & 64u) ? 1u : 0u);
-    // the hot test "some cell positive" as ONE compare against a wave-uniform bound: 1 normally (a positive float is an
-    // int32 >= 1), INT_MIN when some candidate of the wave is forced (always true), INT_MAX under the exact-off ablation
-    const int gate_min = (int)__builtin_amdgcn_readfirstlane(exact_off ? 0x7FFFFFFFu : (force_any ? 0x80000000u : 1u));
+    // bf16-threshold form: forced candidates as a scalar, together with the developer switch: the hot loop tests one SGPR
+    // instead of rebuilding the condition.  The hot test "some cell positive" is ONE compare against a wave-uniform bound:
+    // 1 normally (a positive float is an int32 >= 1), INT_MIN when some candidate of the wave is forced (always true),
+    // INT_MAX under the exact-off ablation.  (Additive form: a forced candidate's H_c is -inf, nothing else is needed.)
+    uint32_t force_any = 0;
+    int gate_min = 1;
+    if constexpr (!ADD) {
+        const uint64_t forcemask = __ballot(forced);
+        force_any = __builtin_amdgcn_readfirstlane(forcemask != 0ull ? 1u : 0u);
+        const uint32_t exact_off = __builtin_amdgcn_readfirstlane(RQ_DBG(a, 64u) ? 1u : 0u);
+        gate_min = (int)__builtin_amdgcn_readfirstlane(exact_off ? 0x7FFFFFFFu : (force_any ? 0x80000000u : 1u));
+    } else {
+#ifdef RQ_DEV_ABLATIONS
+        if (a.dbg & 64u) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) hc[t] = __builtin_inff();  // exact path off (timing ablation)
+        }
+#endif
+    }
     if (h == 0) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) facL[lpos[t] - first] = fac0[t];
@@ -1648,25 +1808,32 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
 
     __syncthreads();  // table visible (the LDS-DMA is invisible to this barrier's fence)
 
-    // B: this lane's code bits as fp6 fields, 6 dwords per 32 dimensions, resident for the whole block
-    uint32_t bexp[NT][W][6];
+    // B: this lane's code bits as fp6 (fp4: ADD) fields, BDW dwords per 32 dimensions, resident for the whole block
+    uint32_t bexp[NT][W][BDW];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int m = 0; m < W; ++m) {
             const uint32_t c = craw[t][m];
-            const uint2 p0 = lut[c & 0xFFu], p1 = lut[(c >> 8) & 0xFFu], p2 = lut[(c >> 16) & 0xFFu], p3 = lut[c >> 24];
-            bexp[t][m][0] = p0.x;
-            bexp[t][m][1] = p0.y | (p1.x << 16);
-            bexp[t][m][2] = (p1.x >> 16) | (p1.y << 16);
-            bexp[t][m][3] = p2.x;
-            bexp[t][m][4] = p2.y | (p3.x << 16);
-            bexp[t][m][5] = (p3.x >> 16) | (p3.y << 16);
+            if constexpr (ADD) {
+                bexp[t][m][0] = lut[c & 0xFFu].x, bexp[t][m][1] = lut[(c >> 8) & 0xFFu].x;
+                bexp[t][m][2] = lut[(c >> 16) & 0xFFu].x, bexp[t][m][3] = lut[c >> 24].x;
+            } else {
+                const uint2 p0 = lut[c & 0xFFu], p1 = lut[(c >> 8) & 0xFFu], p2 = lut[(c >> 16) & 0xFFu], p3 = lut[c >> 24];
+                bexp[t][m][0] = p0.x;
+                bexp[t][m][1] = p0.y | (p1.x << 16);
+                bexp[t][m][2] = (p1.x >> 16) | (p1.y << 16);
+                bexp[t][m][3] = p2.x;
+                bexp[t][m][4] = p2.y | (p3.x << 16);
+                bexp[t][m][BDW - 1] = (p3.x >> 16) | (p3.y << 16);
+            }
         }
 
-    // measurement hook (results unchanged): 32x32 sub-tile steps taken, and how many of them took the exact path
-    const uint32_t count_stat = __builtin_amdgcn_readfirstlane((a.dbg & 128u) ? 1u : 0u);
-    uint32_t n_steps = 0, n_flag = 0;
+    // always-on statistic (results unchanged, nothing in the hot loop): 32x32 sub-tile steps taken = NT per tile, and how many of
+    // them took the exact path.  The host reads the totals with the pass's other counters and drops the additive gate for an
+    // index on which it flags too much.
+    uint32_t n_flag = 0;
+#ifdef RQ_DEV_ABLATIONS
     // developer hook (dbg & 256): cycles of the block's start-up, of the waits at the top of the tile loop and of the
     // tile bodies, summed over blocks into stat[128..131) (+ block count): where a wave's lifetime goes
     const uint32_t time_stat = __builtin_amdgcn_readfirstlane((a.dbg & 256u) ? 1u : 0u);
@@ -1679,8 +1846,11 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
         tm_mark = __builtin_readcyclecounter();
         tm_startup = tm_mark - tm_begin;
     }
+#else
+    constexpr uint32_t no_barrier = 0;
+#endif
     uint32_t slot = 0;  // ring slot of query tile qt
-    for (uint32_t qt = 0; qt < ((a.dbg & 4u) ? 0u : ntiles); ++qt) {
+    for (uint32_t qt = 0; qt < (RQ_DBG(a, 4u) ? 0u : ntiles); ++qt) {
         if constexpr (QPB == 1) {  // SLOTS slots, one barrier per tile, PD = SLOTS - 1 tiles in flight
             constexpr uint32_t SLOTS = scan_mfma_ring_slots<W, ARENA>(), PD = SLOTS - 1;
             // tile qt has landed once only the copies of the (up to PD - 1) later tiles are still in flight (in-order counter)
@@ -1708,11 +1878,13 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
             for (uint32_t i = 0; i < QPB; ++i)
                 if (qt + AHEAD * QPB + i < ntiles) dma_tile(qt + AHEAD * QPB + i, (slot + AHEAD * QPB + i) % ((1 + AHEAD) * QPB));
         }
+#ifdef RQ_DEV_ABLATIONS
         if (time_stat) {
             const unsigned long long now = __builtin_readcyclecounter();
             tm_wait += now - tm_mark;
             tm_mark = now;
         }
+#endif
         const uint32_t *img = ring + slot * IMG;
         const uint32_t nvalid = cnt - 32 * qt;  // rows >= nvalid of the last tile are stale memory: masked here
 
@@ -1746,14 +1918,36 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
             }
         };
         auto get_b = [&](int t, int m) {
-            const v8i32 bv = {(int)bexp[t][m][0], (int)bexp[t][m][1], (int)bexp[t][m][2], (int)bexp[t][m][3],
-                              (int)bexp[t][m][4], (int)bexp[t][m][5], 0, 0};
-            return bv;
+            if constexpr (ADD) {
+                const v8i32 bv = {(int)bexp[t][m][0], (int)bexp[t][m][1], (int)bexp[t][m][2], (int)bexp[t][m][3], 0, 0, 0, 0};
+                return bv;
+            } else {
+                const v8i32 bv = {(int)bexp[t][m][0], (int)bexp[t][m][1], (int)bexp[t][m][2], (int)bexp[t][m][3],
+                                  (int)bexp[t][m][4], (int)bexp[t][m][BDW - 1], 0, 0};
+                return bv;
+            }
         };
-        // A operand of the threshold MFMA: slots 8h .. 8h+7 of query row j
+        // one 32 x 32 x 64 product block on top of c: A fp6 (e2m3) x B fp6 / fp4 (e2m1), exact in f32
+        auto mm = [&](const v8i32 av, const v8i32 bv, const f32x16 c) {
+            if constexpr (ADD) return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 2 /*A e2m3*/, 4 /*B e2m1*/, 0, 0, 0, 0);
+            else return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 2 /*A e2m3*/, 2 /*B e2m3*/, 0, 0, 0, 0);
+        };
+        // bf16 form: A operand of the threshold MFMA, slots 8h .. 8h+7 of query row j
         // (rows past the list's last query carry the "no query" operand written by group_scan_kernel: -S* = -inf)
-        const v4i32 ua = *reinterpret_cast<const v4i32 *>(&img[IMG_OP + j * RQ_REC_TAIL + RQ_REC_V0 + 4 * h]);
-        auto tail = [&](uint32_t f, uint32_t row) { return img[IMG_OP + row * RQ_REC_TAIL + f]; };
+        v4i32 ua = {0, 0, 0, 0};
+        // additive form: the accumulator tile's start values C_q (register gq of lane half h = query row (gq & 3) + 8 (gq >> 2) + 4h;
+        // -inf for rows past the list's last query, +inf for a query whose scales do not admit the integer form: always flagged)
+        f32x16 cinit = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if constexpr (ADD) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 cv = *reinterpret_cast<const float4 *>(&img[IMG_C + 8 * g4 + 4 * h]);
+                cinit[4 * g4] = cv.x, cinit[4 * g4 + 1] = cv.y, cinit[4 * g4 + 2] = cv.z, cinit[4 * g4 + 3] = cv.w;
+            }
+        } else {
+            ua = *reinterpret_cast<const v4i32 *>(&img[IMG_OP + j * TAILD + RQ_REC_V0 + 4 * h]);
+        }
+        auto tail = [&](uint32_t f, uint32_t row) { return img[IMG_OP + row * TAILD + f]; };
 
         // accumulator tiles = -S*/2 (query row, candidate col) + s/2, all on the matrix pipe
         // Wide vectors: slab-outer, so that the NT accumulation chains interleave on the matrix pipe (a chain of dependent
@@ -1772,8 +1966,7 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
             for (int m = 0; m < W; ++m) {
                 const v8i32 av = get_a(m);
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    accs[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, get_b(t, m), accs[t], 2, 2, 0, 0, 0, 0);
+                for (int t = 0; t < NT; ++t) accs[t] = mm(av, get_b(t, m), accs[t]);
             }
         }
 #pragma unroll
@@ -1781,37 +1974,57 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
             f32x16 acc;
             if constexpr (SLAB_OUTER) {
                 acc = accs[t];
+            } else if constexpr (ADD) {
+                acc = cinit;
+#pragma unroll
+                for (int m = 0; m < W; ++m) acc = mm(get_a(m), get_b(t, m), acc);
             } else {
                 const v4i32 ubv = {(int)ub[t][0], (int)ub[t][1], (int)ub[t][2], (int)ub[t][3]};
                 const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ua), __builtin_bit_cast(bf16x8, ubv), z, 0, 0, 0);
 #pragma unroll
-                for (int m = 0; m < W; ++m)
-                    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(get_a(m), get_b(t, m), acc, 2 /*A e2m3*/, 2 /*B e2m3*/, 0, 0, 0, 0);
+                for (int m = 0; m < W; ++m) acc = mm(get_a(m), get_b(t, m), acc);
             }
-            // hot path: is any of the 1024 (query, candidate) cells positive?  A float is positive iff its bit
-            // pattern is a positive int32 (a NaN with a clear sign bit counts as positive: conservative), so the
-            // reduction is 7 v_max3_i32 + 1 v_max_i32 + 1 compare, with no canonicalisation
-            const v16i32 ai = __builtin_bit_cast(v16i32, acc);
-            int mxi = imax3(ai[0], ai[1], ai[2]);
+            bool hot;
+            if constexpr (ADD) {
+                // hot path: does any of this lane's 16 cells exceed the candidate's H_c?  The chain starts at H_c itself, so the
+                // reduction is 8 v_max3_f32 + 1 compare (no NaN can occur: C_q is finite or +-inf of one sign per row, the products
+                // are finite)
+                float mx = hc[t];
 #pragma unroll
-            for (int gq = 3; gq < 15; gq += 2) mxi = imax3(mxi, ai[gq], ai[gq + 1]);
-            mxi = mxi > ai[15] ? mxi : ai[15];
-            if (count_stat) ++n_steps;
-            if (__ballot(mxi >= gate_min) != 0ull) {  // wave-uniform; everything below
-                if (count_stat) ++n_flag;
+                for (int gq = 0; gq < 16; gq += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, acc[gq]), acc[gq + 1]);
+                hot = __ballot(mx > hc[t]) != 0ull;
+            } else {
+                // hot path: is any of the 1024 (query, candidate) cells positive?  A float is positive iff its bit
+                // pattern is a positive int32 (a NaN with a clear sign bit counts as positive: conservative), so the
+                // reduction is 7 v_max3_i32 + 1 v_max_i32 + 1 compare, with no canonicalisation
+                const v16i32 ai = __builtin_bit_cast(v16i32, acc);
+                int mxi = imax3(ai[0], ai[1], ai[2]);
+#pragma unroll
+                for (int gq = 3; gq < 15; gq += 2) mxi = imax3(mxi, ai[gq], ai[gq + 1]);
+                mxi = mxi > ai[15] ? mxi : ai[15];
+                hot = __ballot(mxi >= gate_min) != 0ull;
+            }
+            if (hot) {  // wave-uniform; everything below
+                ++n_flag;
+#ifdef RQ_DEV_ABLATIONS
                 const unsigned long long tx0 = time_stat ? __builtin_readcyclecounter() : 0ull;
+#endif
                 // lives inside this branch so that the common path carries no state of it (not even a zeroed tile)
                 uint32_t gmask = force_any ? 0xFFFFu : 0u;  // accumulator registers with at least one flagged lane
                 f32x16 sc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-                for (int gq = 0; gq < 16; ++gq) gmask |= (__ballot(acc[gq] > 0.0f) != 0ull ? 1u : 0u) << gq;
+                for (int gq = 0; gq < 16; ++gq) {
+                    if constexpr (ADD) gmask |= (__ballot(acc[gq] > hc[t]) != 0ull ? 1u : 0u) << gq;
+                    else gmask |= (__ballot(acc[gq] > 0.0f) != 0ull ? 1u : 0u) << gq;
+                }
                 // the flagged cells need s itself: the same products again on a clean accumulator (exact)
 #pragma unroll
-                for (int m = 0; m < W; ++m)
-                    sc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(get_a(m), get_b(t, m), sc, 2, 2, 0, 0, 0, 0);
-                if (a.dbg & 1u) gmask = 0;
+                for (int m = 0; m < W; ++m) sc = mm(get_a(m), get_b(t, m), sc);
+                if (RQ_DBG(a, 1u)) gmask = 0;
+#ifdef RQ_DEV_ABLATIONS
                 if (time_stat) n_greg += (uint32_t)__popc(gmask);
+#endif
                 // exact evaluation + emit, for the flagged registers only
                 const float4 fc = facL[lpos[t] - first];
                 while (gmask) {
@@ -1820,8 +2033,8 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
                     const uint32_t row = (gq & 3) + 8 * (gq >> 2) + 4 * h;
                     const float sf = 2.0f * sc[gq];  // wave-uniform register index
                     // the row's scalars in two 16-byte LDS reads: lower delta sumq ycd | ycd_sqrt thr lo hi
-                    const uint4 ta = *reinterpret_cast<const uint4 *>(&img[IMG_OP + row * RQ_REC_TAIL]);
-                    const uint4 tb = *reinterpret_cast<const uint4 *>(&img[IMG_OP + row * RQ_REC_TAIL + 4]);
+                    const uint4 ta = *reinterpret_cast<const uint4 *>(&img[IMG_OP + row * TAILD]);
+                    const uint4 tb = *reinterpret_cast<const uint4 *>(&img[IMG_OP + row * TAILD + 4]);
                     static_assert(RQ_REC_LOWER == 0 && RQ_REC_DELTA == 1 && RQ_REC_SUMQ == 2 && RQ_REC_YCD == 3 && RQ_REC_YCD_SQRT == 4 &&
                                       RQ_REC_THR == 5 && RQ_REC_LO == 6 && RQ_REC_HI == 7, "tail layout read as two uint4");
                     // the reference's expression, left to right (src/rabitq.rs:352-363)
@@ -1835,11 +2048,17 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
                     pass = pass && row < nvalid && lpos[t] >= tb.z && lpos[t] < tb.w;
                     const uint64_t m = __ballot(pass);
                     if (m == 0) continue;
+#ifdef RQ_DEV_ABLATIONS
                     if (time_stat) ++n_regs;
+#endif
                     if (nE + 64 > QE || nR + 2 > QR) {
+#ifdef RQ_DEV_ABLATIONS
                         const unsigned long long tf0 = time_stat ? __builtin_readcyclecounter() : 0ull;
+#endif
                         flush();
+#ifdef RQ_DEV_ABLATIONS
                         if (time_stat) tm_flush += __builtin_readcyclecounter() - tf0, ++n_flush;
+#endif
                     }
                     // each half-wave is one run (one query x 32 consecutive positions); half 0 first
                     const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
@@ -1861,28 +2080,35 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
                     nE += c0 + c1;
                     nR += (c0 ? 1u : 0u) + (c1 ? 1u : 0u);
                 }
+#ifdef RQ_DEV_ABLATIONS
                 if (time_stat) tm_exact += __builtin_readcyclecounter() - tx0;
+#endif
             }
         }
         slot = slot + 1 == scan_mfma_ring_slots<W, ARENA>() ? 0 : slot + 1;
+#ifdef RQ_DEV_ABLATIONS
         if (time_stat) {
             const unsigned long long now = __builtin_readcyclecounter();
             tm_body += now - tm_mark;
             tm_mark = now;
         }
+#endif
     }
+#ifdef RQ_DEV_ABLATIONS
     if (time_stat && tid == 0) {
         atomicAdd(stat + 128, tm_startup), atomicAdd(stat + 129, tm_wait), atomicAdd(stat + 130, tm_body);
         atomicAdd(stat + 131, 1ull), atomicAdd(stat + 132, (unsigned long long)ntiles);
         atomicAdd(stat + 133, tm_exact), atomicAdd(stat + 134, tm_flush), atomicAdd(stat + 135, (unsigned long long)n_regs);
         atomicAdd(stat + 136, (unsigned long long)n_flush), atomicAdd(stat + 137, (unsigned long long)n_greg);
     }
+#endif
     if (nE) flush();
-    if (count_stat && lane == 0) {  // 64 pairs of counters, by block: a single address would serialise a million atomics
-        atomicAdd(stat + 2 * (blockIdx.x & 63u), (unsigned long long)n_steps);
-        atomicAdd(stat + 2 * (blockIdx.x & 63u) + 1, (unsigned long long)n_flag);
+    if (lane == 0) {  // 64 pairs of counters, by block: a single address would serialise a million atomics
+        atomicAdd(stat + 2 * (blockIdx.x & 63u), (unsigned long long)(ntiles * NT));
+        if (n_flag) atomicAdd(stat + 2 * (blockIdx.x & 63u) + 1, (unsigned long long)n_flag);
     }
 }
+
 
 // generic-W fallback (dim/64 not in the templated set): code words re-read per query (L1-resident)
 __global__ __launch_bounds__(256) void scan_generic_kernel(SCAN_PARAMS, uint32_t W) {
@@ -2975,6 +3201,12 @@ __global__ void finalize_heuristic_kernel(const ReplayState st, uint32_t nq, uin
 // per-batch totals for METRICS (src/metrics.rs:44-53): sums of the per-query counters.
 // out4[0..5) = {rough, precise (queries without overflow only), #overflowed queries, accurate distances
 // computed, max buffer need}
+// sums the matrix-core scan's 64 counter pairs into out[0] (sub-tile steps) and out[1] (steps that took the exact path)
+__global__ __launch_bounds__(64) void stat_fold_kernel(const unsigned long long *__restrict__ stat, unsigned long long *__restrict__ out) {
+    unsigned long long a = stat[2 * threadIdx.x], b = stat[2 * threadIdx.x + 1];
+    for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o, 64), b += __shfl_xor(b, o, 64);
+    if (threadIdx.x == 0) out[0] = a, out[1] = b;
+}
 __global__ __launch_bounds__(256) void metrics_sum_kernel(const unsigned long long *__restrict__ rough,
                                                           const uint32_t *__restrict__ precise,
                                                           const uint32_t *__restrict__ need,

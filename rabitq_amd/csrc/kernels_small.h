@@ -593,7 +593,7 @@ __global__ __launch_bounds__(1024) void sb_query_kernel(const SbArgs a) {
         __syncthreads();
         for (uint32_t slot = t >> 4; slot < nprobe; slot += 64)
             stage_fill_item(a.scal, a.probe_cluster, a.qnib, a.rs.thr, b * nprobe + slot, nprobe, nprobe, 8 * W, a.final_lo, 0xFFFFFFFFu,
-                            0u, nullptr, nullptr, a.recs, a.fs, 0u, nullptr, nullptr, k);
+                            0u, nullptr, nullptr, a.recs, a.fs, 0u, nullptr, nullptr, k, nullptr);
     }
 }
 

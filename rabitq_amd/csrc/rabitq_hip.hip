@@ -222,6 +222,9 @@ struct Workspace {
     DevBuf<uint32_t> qnib;
     DevBuf<uint32_t> qf6;
     DevBuf<unsigned long long> rough_cnt, totals, surv_cnt, stat;
+    DevBuf<float4> grp_vref;  // additive gate: per list, centre and half-range of v' over the stage's pairs (group_vrange_kernel)
+    bool pend_additive = false;  // the pass ran a matrix-core stage with the additive gate (finish_pass reads its flag rate)
+    uint32_t pend_matrix_stages = 0;  // matrix-core stages of the pass
     DevBuf<SurvRec> surv, arr;
     DevBuf<RunRec> runs, runs_tmp;
     bool use_runs_tmp = false;
@@ -240,7 +243,7 @@ struct Workspace {
     DevBuf<uint32_t> sh_flag;                 // handshake / status words of the step
     DevBuf<uint32_t> sh_pc, sh_id_b, sh_n_b;  // shared-threshold step: probe lists (whole | nearest | rest), second call's results
     DevBuf<float> sh_pd, sh_thr, sh_dist_b;
-    unsigned long long *h_totals = nullptr;  // pinned, 8
+    unsigned long long *h_totals = nullptr;  // pinned, 16
     Prof prof;
     ~Workspace() {
         if (h_totals) (void)hipHostFree(h_totals);
@@ -269,6 +272,8 @@ struct rq_index {
     DevBuf<uint32_t> offsets, map_ids;
     DevBuf<uint64_t> codes;
     DevBuf<float4> factors;
+    DevBuf<float4> list_uref;  // per list: mean of u' = (1, cds, ., eb) / factor_ip over its regular vectors (additive gate of the matrix-core scan; derived)
+    std::atomic<int> additive_loose{0};  // the additive gate flagged too many sub-tile steps on this index: later passes use the bf16 threshold
     std::mutex ws_mu;
     std::vector<std::unique_ptr<Workspace>> ws_pool;
     FactorStats fstats{0, 0, 0, 0};
@@ -502,6 +507,9 @@ static void launch_scan(const ScanPtrs &p, const ScanArgs &args, uint32_t W, hip
 // scan implementation: 0 = auto (matrix cores when many queries share each list, VALU otherwise),
 // 1 = VALU (v_dot8_u32_u4) only, 2 = matrix cores wherever the kernel exists (test hook)
 static std::atomic<int> g_scan_impl{0};
+// gate of the matrix-core scan: 0 = auto (additive bound where it exists -- dim 64 / 128, uniform survivor buffers -- unless the index has
+// shown that it flags too much), 1 = the bf16 rank-5 threshold MFMA always, 2 = additive wherever it exists (test hook)
+static std::atomic<int> g_scan_gate{0};
 static std::atomic<int> g_stage_growth{0};  // 0 = default schedule
 static std::atomic<int> g_scan_tile_table{1};  // 0 = plain (list x tile) grids everywhere (test / measurement hook)
 static std::atomic<int> g_group_rank{1};  // group_rank_kernel for cluster-major stages: 0 never, 1 big stages, 2 always
@@ -527,10 +535,21 @@ static size_t scan_mfma_ring_bytes(uint32_t W, bool arena = false) {  // scan_mf
     const uint64_t slots = W <= 2 ? 4ull : (W >= 16 ? 5ull : 3ull);
     return slots * (32 * (12 * W + 2) + RQ_REC_TAIL * 32) * 4;
 }
-template <int W, int NT, bool ARENA>
+template <int W, int NT, bool ARENA, bool ADD = false>
 static void launch_scan_mfma_t(const ScanPtrs &p, const ScanArgs &a, dim3 g, hipStream_t st) {
-    scan_mfma_kernel<W, NT, ARENA><<<g, dim3(64 * scan_mfma_waves<W, ARENA>()), scan_mfma_ring_bytes(W, ARENA), st>>>(p.codes, p.factors, p.offsets, p.grp_start, p.grp_cnt,
-                                                                                    p.recs, p.surv, p.runs, p.surv_cnt, p.stat, p.tile_table, a);
+    scan_mfma_kernel<W, NT, ARENA, ADD><<<g, dim3(64 * scan_mfma_waves<W, ARENA>()), scan_mfma_ring_bytes(W, ARENA), st>>>(p.codes, p.factors, p.offsets, p.grp_start, p.grp_cnt,
+                                                                                    p.recs, p.surv, p.runs, p.surv_cnt, p.stat, p.tile_table, p.list_uref, p.grp_vref, a);
+}
+// the additive-gate instantiations (dim 64 / 128, uniform survivor buffers)
+static bool scan_has_additive(uint32_t W) { return W == 1 || W == 2; }
+static void launch_scan_mfma_add(const ScanPtrs &p, const ScanArgs &args, uint32_t W, hipStream_t st) {
+    launch_scan_chunks(args, [&](const ScanArgs &a, dim3 g) {
+        switch (W) {
+            case 1: launch_scan_mfma_t<1, 4, false, true>(p, a, g, st); break;
+            case 2: launch_scan_mfma_t<2, 3, false, true>(p, a, g, st); break;
+            default: break;
+        }
+    });
 }
 // callers check scan_has_mfma(W) first; args.x != nullptr: the arena instantiations
 template <bool ARENA>
@@ -549,8 +568,9 @@ static void launch_scan_mfma_a(const ScanPtrs &p, const ScanArgs &args, uint32_t
         }
     });
 }
-static void launch_scan_mfma(const ScanPtrs &p, const ScanArgs &args, uint32_t W, hipStream_t st) {
+static void launch_scan_mfma(const ScanPtrs &p, const ScanArgs &args, uint32_t W, hipStream_t st, bool additive = false) {
     if (args.x) launch_scan_mfma_a<true>(p, args, W, st);
+    else if (additive) launch_scan_mfma_add(p, args, W, st);
     else launch_scan_mfma_a<false>(p, args, W, st);
 }
 
@@ -590,6 +610,11 @@ static hipError_t set_scan_mfma_attr() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(scan_mfma_kernel<W, NT, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_mfma_ring_bytes(W));
     if (e != hipSuccess) return e;
+    if constexpr (W <= 2) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(scan_mfma_kernel<W, NT, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_mfma_ring_bytes(W));
+        if (e != hipSuccess) return e;
+    }
     return hipFuncSetAttribute(reinterpret_cast<const void *>(scan_mfma_kernel<W, NT, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_mfma_ring_bytes(W));
 }
@@ -668,7 +693,7 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
     const uint32_t nprobe = std::min(qp.probe, idx->k);
     const uint64_t nq = qp.nq, npairs = nq * nprobe;
     if (!ws.stream) HIPC(hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking));
-    if (!ws.h_totals) HIPC(hipHostMalloc((void **)&ws.h_totals, 8 * sizeof(unsigned long long)));
+    if (!ws.h_totals) HIPC(hipHostMalloc((void **)&ws.h_totals, 16 * sizeof(unsigned long long)));
     RQC(ws.qpad.ensure(nq * idx->dim));
     RQC(ws.y.ensure(nq * idx->dim));
     RQC(ws.dist.ensure(nq * idx->k));
@@ -731,6 +756,12 @@ static rq_status finish_pass(const rq_index *idx, Workspace &ws, PassResult *res
     res->max_need = ws.h_totals[4];
     res->early_max = ws.h_totals[6];
     if (nq >= 256) const_cast<rq_index *>(idx)->big_dirs_hint.store((uint32_t)ws.h_totals[7]);
+    // The additive gate is a looser test than the rank-5 threshold it replaces: an index / workload on which it sends more than
+    // 3 % of the sub-tile steps down the exact path (each costs ~10 plain steps) goes back to the bf16 threshold MFMA for good
+    // (results do not depend on the choice; option scan_gate pins it)
+    if (ws.pend_additive && ws.h_totals[8] >= 4096 && ws.h_totals[9] * 32 > ws.h_totals[8])
+        const_cast<rq_index *>(idx)->additive_loose.store(1);
+    if (prof_acc) prof_acc->matrix_subtile_steps += ws.h_totals[8], prof_acc->matrix_exact_steps += ws.h_totals[9];
     if (pf.on && prof_acc) {
         float ms[PF_N] = {0};
         pf.collect(ms);
@@ -776,11 +807,6 @@ static rq_status finish_pass(const rq_index *idx, Workspace &ws, PassResult *res
             std::string line = "[rabitq_hip] sb_query_kernel phases (us since entry):";
             for (unsigned long long i = 1; i < std::min<unsigned long long>(hs[0], 30); ++i) line += " " + std::to_string((hs[1 + i] - hs[1]) / 100.0).substr(0, 6);
             fprintf(stderr, "%s\n", line.c_str());
-        }
-        if (g_scan_dbg.load() & 128) {
-            unsigned long long hs[128];
-            HIPC(hipMemcpy(hs, ws.stat.p, sizeof hs, hipMemcpyDeviceToHost));
-            for (int i = 0; i < 64; ++i) prof_acc->matrix_subtile_steps += hs[2 * i], prof_acc->matrix_exact_steps += hs[2 * i + 1];
         }
     }
     return RQ_OK;
@@ -889,7 +915,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         sa.k = k, sa.dim = dim, sa.nprobe = nprobe, sa.topk = topk, sa.cap = qp.cap, sa.hcap = qp.hcap;
         sa.stamps = (g_scan_dbg.load() & 4096) ? ws.stat.p : nullptr;
         if (sa.stamps) HIPC(hipMemsetAsync(ws.stat.p, 0, 8, st));
-        else if (g_scan_dbg.load() & (128 | 256)) HIPC(hipMemsetAsync(ws.stat.p, 0, 256 * sizeof(unsigned long long), st));  // (the counters of a final matrix-core stage, if any)
+        else HIPC(hipMemsetAsync(ws.stat.p, 0, 256 * sizeof(unsigned long long), st));  // (the counters of a final matrix-core stage, if any)
         pf.begin(PF_COARSE);
         sb_front_kernel<<<dim3(ceil_div(k, RQ_SB_LISTS), ceil_div(nq, RQ_SB_QT)), 256, (size_t)2 * RQ_SB_QT * dim * sizeof(float), st>>>(
             d_q, qp.len, idx->P.p, idx->centroids.p, ws.y.p, ws.qpad.p, ws.dist.p, k, dim, nq, ws.totals.p, ws.big_list.p + nq);
@@ -977,7 +1003,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     init_state_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(rs, ws.surv_cnt.p, nq, qp.thr_init, d_row_map);
     HIPC(hipMemsetAsync(ws.totals.p, 0, 8 * sizeof(unsigned long long), st));
     HIPC(hipMemsetAsync(ws.big_list.p + nq, 0, 12, st));
-    if (g_scan_dbg.load() & (128 | 256)) HIPC(hipMemsetAsync(ws.stat.p, 0, 256 * sizeof(unsigned long long), st));
+    HIPC(hipMemsetAsync(ws.stat.p, 0, 256 * sizeof(unsigned long long), st));  // the matrix-core scan's step counters (+ developer hooks)
     pf.end();
 
     // 5. stages
@@ -995,6 +1021,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     }  // !small
     ws.pend_matrix_ranges.clear();
     ws.pend_seg_slots = 0;
+    ws.pend_additive = false, ws.pend_matrix_stages = 0;
     // persistent blocks of the long-directory ordering: sized by how many such directories recent passes produced
     const uint32_t big_hint = idx->big_dirs_hint.load();
     const uint32_t mid_blocks = big_hint == 0 ? 64u : std::min(4096u, std::max(256u, big_hint / 4));
@@ -1014,6 +1041,11 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             fprintf(stderr, "[rabitq_hip] stage %u: [%u, %u) span %llu est_pairs %llu %s\n", stage_no, sg.s_lo, sg.s_hi,
                     (unsigned long long)span, (unsigned long long)est_pairs, use_mfma ? "matrix cores" : (cluster_major ? "VALU, list-major" : "VALU, pair-major"));
         const bool fp6_records = use_mfma;
+        // (an arena stage, below: a stage that can exceed the uniform survivor capacity; its scan instantiation has its own tile)
+        const bool arena_stage = qp.seg_final && span > qp.cap && scan_is_fused(W) && nq >= 256;
+        const int gate_opt = g_scan_gate.load();
+        const bool additive = use_mfma && !arena_stage && scan_has_additive(W) && idx->list_uref.p != nullptr && gate_opt != 1 &&
+                              (gate_opt == 2 || !idx->additive_loose.load());
         pf.begin(PF_GROUP);
         ScanArgs a{};
         ScanPtrs sp{};
@@ -1041,7 +1073,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             } else
                 group_count_kernel<<<ceil_div(stage_pairs, 256), 256, 0, st>>>(ws.scal.p, probe_cluster, stage_pairs, nprobe,
                                                                                slot_hi, sg.s_lo, sg.s_hi, ws.grp_cnt.p);
-            group_scan_kernel<<<1, 1024, 0, st>>>(ws.grp_cnt.p, k, ws.grp_start.p, (use_mfma ? 1u : 0u) | (ranked ? 2u : 0u), ws.recs.p, 12 * W);
+            group_scan_kernel<<<1, 1024, 0, st>>>(ws.grp_cnt.p, k, ws.grp_start.p, (use_mfma ? 1u : 0u) | (ranked ? 2u : 0u) | (additive ? 4u : 0u), ws.recs.p, 12 * W);
             a.ngroups = k;
         } else {
             a.ngroups = npairs;
@@ -1053,8 +1085,13 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             stage_fill_kernel<<<ceil_div(stage_pairs, 16), 256, 0, st>>>(ws.scal.p, probe_cluster, operand, ws.thr.p, stage_pairs,
                                                                     nprobe, slot_hi, fp6_records ? 12 * W : 8 * W, sg.s_lo, sg.s_hi,
                                                                     a.cluster_major, ws.grp_start.p, ws.grp_cnt.p, ws.recs.p,
-                                                                    idx->fstats, use_mfma ? 1u : 0u, ranked ? ws.pair_rank.p : nullptr,
-                                                                    ws.rank_base.p, k);
+                                                                    idx->fstats, use_mfma ? (additive ? 2u : 1u) : 0u, ranked ? ws.pair_rank.p : nullptr,
+                                                                    ws.rank_base.p, k, idx->list_uref.p);
+        if (additive) {  // the stage's v' ranges per list (the candidates' side of the additive bound is built from them in the scan)
+            RQC(ws.grp_vref.ensure(2 * (size_t)k));
+            group_vrange_kernel<<<k, 256, 0, st>>>(ws.recs.p, ws.grp_start.p, ws.grp_cnt.p, 12 * W, ws.grp_vref.p);
+            ws.pend_additive = true;
+        }
         pf.end();
         sp.codes = reinterpret_cast<const uint32_t *>(idx->codes.p);
         sp.factors = idx->factors.p;
@@ -1065,11 +1102,10 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         sp.surv = ws.surv.p;
         sp.runs = ws.runs.p;
         sp.surv_cnt = ws.surv_cnt.p;
-        sp.stat = ws.stat.p;  // 64 x {sub-tile steps, exact-path steps} of the matrix-core scan (dbg & 128)
+        sp.stat = ws.stat.p;  // 64 x {sub-tile steps, exact-path steps} of the matrix-core scan
+        sp.list_uref = idx->list_uref.p, sp.grp_vref = ws.grp_vref.p;
         a.cap = qp.cap;
         a.dbg = (uint32_t)g_scan_dbg.load();
-        // (an arena stage, below: a stage that can exceed the uniform survivor capacity; its scan instantiation has its own tile)
-        const bool arena_stage = qp.seg_final && span > qp.cap && scan_is_fused(W) && nq >= 256;
         const uint32_t stage_tile = use_mfma ? scan_mfma_tile(W, arena_stage) : tile;
         a.tiles_per_group = ceil_div(std::min<uint64_t>(idx->max_list_len, sg.s_hi), stage_tile);
         sp.tile_table = nullptr;
@@ -1133,7 +1169,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                 a.x = ws.scan_extra.p;
                 a.dense_dir = 0u;
                 pf.begin(use_mfma ? PF_SCAN_MATRIX : PF_SCAN);
-                if (use_mfma) launch_scan_mfma(sp, a, W, st);
+                if (use_mfma) launch_scan_mfma(sp, a, W, st, false);
                 else launch_scan(sp, a, W, st);
                 pf.end();
                 pf.begin(PF_GROUP);
@@ -1185,10 +1221,11 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         }
         if (!arena_stage) {
             pf.begin(use_mfma ? PF_SCAN_MATRIX : PF_SCAN);
-            if (use_mfma) launch_scan_mfma(sp, a, W, st);
+            if (use_mfma) launch_scan_mfma(sp, a, W, st, additive);
             else launch_scan(sp, a, W, st);
             pf.end();
         }
+        if (use_mfma) ws.pend_matrix_stages++;
         if (prof_acc) prof_acc->scan_launches++;
         if (prof_acc && use_mfma) {
             prof_acc->matrix_launches++;
@@ -1289,7 +1326,11 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     pf.end();
     if (pf.on) (void)hipEventRecord(pf.spans[total_span].b, st);
     HIPC(hipMemcpyAsync(ws.h_totals, ws.totals.p, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    ws.h_totals[7] = 0;
+    ws.h_totals[7] = 0, ws.h_totals[8] = 0, ws.h_totals[9] = 0;
+    if (ws.pend_matrix_stages) {  // sub-tile steps of the matrix-core stages and how many of them took the exact path
+        stat_fold_kernel<<<1, 64, 0, st>>>(ws.stat.p, ws.stat.p + 200);
+        HIPC(hipMemcpyAsync(ws.h_totals + 8, ws.stat.p + 200, 16, hipMemcpyDeviceToHost, st));
+    }
     if (nq >= 256)  // (the long-directory hint only sizes launches of large batches: a small batch saves the copy's round trip)
         HIPC(hipMemcpyAsync(ws.h_totals + 7, ws.big_list.p + nq + 2, 4, hipMemcpyDeviceToHost, st));
     ws.pend_total_span = total_span;
@@ -1633,6 +1674,10 @@ static rq_status finish_index(rq_index *idx) {
         if (idx->n)
             factor_stats_kernel<<<(uint32_t)std::min<uint64_t>(ceil_div(idx->n, 256), 4096), 256>>>(idx->factors.p, idx->n, st4.p);
         HIPC(hipMemcpy(&idx->fstats, st4.p, 16, hipMemcpyDeviceToHost));
+    }
+    if (idx->k) {  // per-list reference of the candidates' side of the additive gate
+        RQC(idx->list_uref.alloc(idx->k));
+        list_uref_kernel<<<idx->k, 256>>>(idx->factors.p, idx->offsets.p, idx->list_uref.p);
     }
     HIPC(hipDeviceSynchronize());
     HIPC(hipGetLastError());
@@ -3336,7 +3381,22 @@ rq_status rq_set_option(const char *name, int value) {
         g_rerank_shadow = value;
         return RQ_OK;
     }
-    if (std::string(name) == "scan_debug") {  // developer ablations of the matrix-core scan (results are WRONG when != 0)
+    if (std::string(name) == "scan_gate") {  // gate of the matrix-core scan (results never depend on it): 0 auto, 1 bf16 threshold, 2 additive where it exists
+        if (value < 0 || value > 2) return fail(RQ_ERR_INVALID, "scan_gate must be 0, 1 or 2");
+        g_scan_gate = value;
+        return RQ_OK;
+    }
+    if (std::string(name) == "scan_debug") {
+        // Measurement hooks that leave every result unchanged: 128 (kept for older hosts: the step counters are always on now),
+        // 512 (rerank without the fp16 shadow rows), 4096 (phase stamps of the small-batch block), 16384 (stage list on stderr).
+        // The timing ablations (1, 2, 4, 64, 1024, 8192: results are WRONG) and the in-kernel cycle counters (256) exist in
+        // the developer build only (make dev -> librabitq_hip_dev.so, -DRQ_DEV_ABLATIONS).
+#ifdef RQ_DEV_ABLATIONS
+        const int allowed = 0x7FFFFFFF;
+#else
+        const int allowed = 128 | 512 | 4096 | 16384;
+#endif
+        if (value < 0 || (value & ~allowed)) return fail(RQ_ERR_INVALID, "scan_debug: this bit exists in the developer build only (librabitq_hip_dev.so)");
         g_scan_dbg = value;
         return RQ_OK;
     }

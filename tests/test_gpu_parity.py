@@ -17,6 +17,11 @@ GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.n
 IDS = [os.path.basename(p)[:-4] for p in GOLDEN]
 
 
+# scan implementation x gate of the matrix-core scan: VALU (v_dot8), matrix cores with the bf16 rank-5 threshold MFMA, matrix cores
+# with the additive bound (dim 64 / 128; elsewhere the option leaves the bf16 form in place)
+SCAN_VARIANTS = [(1, 0), (2, 1), (2, 2)]
+
+
 def bits(a):
     return np.ascontiguousarray(a).view(np.uint8)
 
@@ -625,12 +630,12 @@ def test_concurrent_queries_one_handle(rq, oracle):
 
 
 # ---- the two scan implementations (VALU v_dot8 / fp6 matrix cores) must be indistinguishable ----------
-@pytest.mark.parametrize("impl", [1, 2])
+@pytest.mark.parametrize("impl,gate", SCAN_VARIANTS)
 @pytest.mark.parametrize("n,d,k,nq", [(12000, 128, 24, 160), (5000, 64, 10, 70), (4000, 256, 6, 50), (3000, 100, 8, 40),
                                       (6000, 128, 4, 420),    # 420 pairs per list: 14 query tiles through the 3-slot ring
                                       (3000, 192, 6, 70), (2500, 384, 5, 70), (2000, 512, 4, 66), (2500, 768, 4, 80),
                                       (1500, 1024, 3, 40)])   # the wide-vector instantiations (W = 3, 6, 8, 12, 16)
-def test_scan_implementations_match_oracle(rq, oracle, impl, n, d, k, nq):
+def test_scan_implementations_match_oracle(rq, oracle, impl, gate, n, d, k, nq):
     from rabitq_amd import index as ix
     x, centres, _ = synth.mixture(n, d, k, sigma=0.8, seed=n + impl, centre_scale=0.6)
     P = synth.random_orthogonal((d + 63) // 64 * 64, seed=d + 3)
@@ -639,6 +644,7 @@ def test_scan_implementations_match_oracle(rq, oracle, impl, n, d, k, nq):
     queries, _, _ = synth.mixture(nq, d, k, sigma=0.8, seed=n + 7, centre_scale=0.6)
     queries[2] = x[11]
     ix.set_option("scan_impl", impl)
+    ix.set_option("scan_gate", gate)
     try:
         for probe, topk, heur in ((k, 10, False), (3, 1, False), (k, 50, False), (4, 10, True)):
             _compare_with_oracle(rq, oracle, oidx, gidx, queries, probe, topk, heur)
@@ -647,15 +653,16 @@ def test_scan_implementations_match_oracle(rq, oracle, impl, n, d, k, nq):
         _compare_with_oracle(rq, oracle, oidx, gidx, queries[:33], k, 10, False)
     finally:
         ix.set_option("scan_impl", 0)
+        ix.set_option("scan_gate", 0)
     gidx.close()
     oidx.close()
 
 
 # A stage whose grid exceeds the launch bound is issued as several launches over (group, tile) sub-ranges
 # (launch_scan_chunks): lowered test-only bound, one artificially long list, both implementations, both work layouts.
-@pytest.mark.parametrize("impl", [1, 2])
+@pytest.mark.parametrize("impl,gate", SCAN_VARIANTS)
 @pytest.mark.parametrize("max_blocks,tile_table", [(1, 2), (5, 2), (5, 0), (0, 1)])
-def test_scan_grid_chunking_matches_oracle(rq, oracle, impl, max_blocks, tile_table):
+def test_scan_grid_chunking_matches_oracle(rq, oracle, impl, gate, max_blocks, tile_table):
     from rabitq_amd import index as ix
     n, d = 9000, 128
     rng = np.random.default_rng(77)
@@ -668,6 +675,7 @@ def test_scan_grid_chunking_matches_oracle(rq, oracle, impl, max_blocks, tile_ta
     assert gidx.max_list_len > 8000
     queries = (rng.standard_normal((70, d)) * 0.5).astype(np.float32)
     ix.set_option("scan_impl", impl)
+    ix.set_option("scan_gate", gate)
     ix.set_option("max_scan_blocks", max_blocks)
     ix.set_option("scan_tile_table", tile_table)   # full-list stages: one block per existing (list, tile) (2), plain grid (0), auto (1)
     try:
@@ -678,12 +686,13 @@ def test_scan_grid_chunking_matches_oracle(rq, oracle, impl, max_blocks, tile_ta
         ix.set_option("max_scan_blocks", 0)
         ix.set_option("scan_tile_table", 1)
         ix.set_option("scan_impl", 0)
+        ix.set_option("scan_gate", 0)
     gidx.close()
     oidx.close()
 
 
-@pytest.mark.parametrize("impl", [1, 2])
-def test_ranked_group_placement_matches_oracle(rq, oracle, impl):
+@pytest.mark.parametrize("impl,gate", SCAN_VARIANTS)
+def test_ranked_group_placement_matches_oracle(rq, oracle, impl, gate):
     """Cluster-major stages place their (query, list) pairs either with one atomic per pair or through per-block
     LDS histograms (group_rank_kernel, what big stages use).  Forced on a small batch (several shapes of stage, empty
     lists, padding rows of the matrix-core tiles), then reached the automatic way: 9000 queries x 64 probes is a stage
@@ -697,6 +706,7 @@ def test_ranked_group_placement_matches_oracle(rq, oracle, impl):
     gidx = rq.RaBitQ.build(x, centres, P)
     queries, _, _ = synth.mixture(9000, d, k - 6, sigma=0.8, seed=93, centre_scale=0.6)
     ix.set_option("scan_impl", impl)
+    ix.set_option("scan_gate", gate)
     try:
         ix.set_option("group_rank", 2)
         _compare_with_oracle(rq, oracle, oidx, gidx, queries[:300], 20, 10, False)
@@ -711,6 +721,7 @@ def test_ranked_group_placement_matches_oracle(rq, oracle, impl):
     finally:
         ix.set_option("group_rank", 1)
         ix.set_option("scan_impl", 0)
+        ix.set_option("scan_gate", 0)
     gidx.close()
     oidx.close()
 
@@ -733,8 +744,8 @@ def test_wide_vectors_dim_3072(rq, oracle):
     oidx.close()
 
 
-@pytest.mark.parametrize("impl", [1, 2])
-def test_scan_degenerate_factors_both_implementations(rq, oracle, impl):
+@pytest.mark.parametrize("impl,gate", SCAN_VARIANTS)
+def test_scan_degenerate_factors_both_implementations(rq, oracle, impl, gate):
     # vectors that coincide with their centroid (zero residual: norm not `is_normal` -> ip = 0.8, factor_ip = -0,
     # rabitq.rs:211-215) and queries that coincide with a centroid (delta = 0 -> 1/delta = inf): the integer
     # threshold form of the matrix-core scan is not applicable there and must fall back to the exact gate
@@ -750,11 +761,13 @@ def test_scan_degenerate_factors_both_implementations(rq, oracle, impl):
     assert (oidx.factors[:, 0] == 0).sum() >= 40          # the -0.0 factor_ip rows are really there
     queries = np.concatenate([centres[:4], x[:4], x[100:140] + np.float32(0.01)]).astype(np.float32)
     ix.set_option("scan_impl", impl)
+    ix.set_option("scan_gate", gate)
     try:
         for probe, topk, heur in ((k, 10, False), (2, 3, False), (k, 100, False), (k, 10, True)):
             _compare_with_oracle(rq, oracle, oidx, gidx, queries, probe, topk, heur)
     finally:
         ix.set_option("scan_impl", 0)
+        ix.set_option("scan_gate", 0)
     gidx.close()
     oidx.close()
 
