@@ -70,9 +70,11 @@ typedef struct {
 
 /* ---- library ------------------------------------------------------------------------------- */
 /* ABI revision of this header: bumped whenever a struct layout or the meaning of an entry point changes (3: sized
- * out-structs, rq_get_device_ptr refuses RQ_ARR_BASE on tiered indexes).  A host checks rq_abi_version() ==
+ * out-structs, rq_get_device_ptr refuses RQ_ARR_BASE on tiered indexes; options "scan_dense" and "coarse_impl" = 3 removed.
+ * 4: rq_set_option("scan_debug") refuses the timing-ablation bits -- they exist in the developer build only --, the matrix-core
+ * scan's step counters in rq_profile_t are always filled, new option "scan_gate").  A host checks rq_abi_version() ==
  * RQ_ABI_VERSION once after loading the library. */
-#define RQ_ABI_VERSION 3
+#define RQ_ABI_VERSION 4
 uint32_t rq_abi_version(void);
 const char *rq_version(void);
 const char *rq_last_error(void);              /* thread-local message of the last failure        */
@@ -378,13 +380,24 @@ rq_status rq_set_profiling(int level);
  * 1 (default) = one block per existing (list, tile) when most of the plain grid would be empty blocks, 2 = always.
  * "small_batch_span": developer knob, stream positions a query's block of the small-batch path scans itself at most
  * (default 2560; results are identical for every value).
- * Developer knobs: "stage_growth" (geometric growth of the early stages, 0 = default; results are
- * identical for every value), "scan_debug": measurement hooks with unchanged results -- bit 128 counts sub-tile / exact-path
- * steps into rq_profile_t, 256 prints in-kernel cycle counters of the matrix-core scan, 4096 the phases of the small-batch
- * kernel, 16384 the stage list of every pass (stderr) -- and TIMING ABLATIONS of the matrix-core scan under which results are
- * WRONG: 1 flagged steps evaluate nothing, 2 no re-staging of query tiles, 4 no tile loop (start-up only), 64 the gate never
- * fires, 512 no fp16 shadow rows in the rerank (results right), 1024 no survivor is recorded, 8192 no block barriers
- * (profiles/r03_scan_mfma_ablations.txt). */
+ * "scan_gate": gate of the matrix-core scan (results never depend on it): 0 (default) = the additive bound S* >= B_q + G_c
+ * where it exists (dim 64 / 128, stages on the uniform survivor buffers: no threshold MFMA) until an index shows that it sends
+ * more than 3 % of the sub-tile steps down the exact path, 1 = the bf16 rank-5 threshold MFMA always, 2 = the additive bound
+ * wherever it exists (test hook).
+ * Developer knobs: "stage_growth" (geometric growth of the early stages, 0 = default; results are identical for every
+ * value), "scan_debug": measurement hooks under which every result is UNCHANGED -- 128 (kept for older hosts: the sub-tile /
+ * exact-path step counters of rq_profile_t are always on since ABI revision 4), 512 no fp16 shadow rows in the rerank,
+ * 4096 the phases of the small-batch kernel, 16384 the stage list of every pass (stderr).  Any other bit is refused with
+ * RQ_ERR_INVALID by this library: the TIMING ABLATIONS of the matrix-core scan (1, 2, 4, 64, 1024, 8192: results are WRONG) and
+ * its in-kernel cycle counters (256) are compiled only into the developer build (make -C rabitq_amd/csrc dev ->
+ * librabitq_hip_dev.so, -DRQ_DEV_ABLATIONS; scripts/exp/ select it through RABITQ_HIP_SO), so the shipped kernels carry none
+ * of those branches.
+ *
+ * Threading: options are process-global and result-neutral (every value of every option leaves ids, distances and counters
+ * unchanged: tests/test_gpu_parity.py::test_every_option_value_keeps_golden_results).  A pass reads the ones that pick a
+ * kernel or a record format once per stage, so changing an option while queries are in flight on other threads only
+ * changes which kernels later stages / passes use (test_options_flipped_under_concurrent_queries).
+ * Removed in ABI revision 3: "scan_dense", "coarse_impl" = 3 (both answer RQ_ERR_INVALID). */
 rq_status rq_set_option(const char *name, int value);
 rq_status rq_last_profile(rq_profile_t *out);
 

@@ -34,7 +34,7 @@ class RabitqError(RuntimeError):
         self.status = status
 
 
-ABI_VERSION = 3   # RQ_ABI_VERSION of include/rabitq_hip.h this mirror was written against
+ABI_VERSION = 4   # RQ_ABI_VERSION of include/rabitq_hip.h this mirror was written against
 
 
 class _Sized(C.Structure):

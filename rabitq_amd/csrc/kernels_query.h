@@ -816,8 +816,11 @@ __global__ __launch_bounds__(1024) void group_rank_kernel(const PairScalars *__r
 // threshold operand (12 dwords per row), and the 32 rows' accumulator start values C_q follow the tails as ONE 32-float
 // array (the kernel reads them as the C operand of its first MFMA: four broadcast 16-byte LDS reads per tile)
 #define RQ_RECA_TAIL 12
+// row stride (dwords) of a tile image's operand rows: opdw + 2 keeps 8-byte reads of the rows conflict-free; the additive format
+// pads to opdw + 4, so that rows of 24 dwords (dim 128) are 16-byte aligned (28 = 4 x 7: three conflict-free ds_read_b128 per lane)
+__host__ __device__ constexpr uint32_t rq_img_opld(uint32_t opdw, bool additive) { return opdw + (additive ? 4u : 2u); }
 __host__ __device__ constexpr uint32_t rq_img_dwords(uint32_t opdw, bool additive) {
-    return 32u * (opdw + 2u) + (additive ? 32u * RQ_RECA_TAIL + 32u : 32u * RQ_REC_TAIL);
+    return 32u * rq_img_opld(opdw, additive) + (additive ? 32u * RQ_RECA_TAIL + 32u : 32u * RQ_REC_TAIL);
 }
 
 // exclusive scan of cnt[0..k) into start[0..k]; single block, any k.  Also zeroes cnt for the
@@ -854,7 +857,7 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(uint32_t *__restrict__
             if ((pad32 & 1u) && recs) {
                 const uint32_t real = cnt[i];
                 const bool additive = (pad32 & 4u) != 0;  // bit 2: tile images of the additive gate (start value -inf)
-                const uint32_t opld = opdw + 2, img = rq_img_dwords(opdw, additive);
+                const uint32_t opld = rq_img_opld(opdw, additive), img = rq_img_dwords(opdw, additive);
                 for (uint32_t at = st0 + real; at < st0 + v; ++at) {  // at most 31 rows
                     if (additive) {
                         recs[(uint64_t)(at >> 5) * img + 32 * opld + 32 * RQ_RECA_TAIL + (at & 31u)] = 0xFF800000u;
@@ -923,7 +926,7 @@ __device__ __forceinline__ void stage_fill_item(const PairScalars *__restrict__ 
     uint32_t *tdst = r + opdw;
     float *cdst = nullptr;  // additive gate: the row's accumulator start value
     if (tile_images) {
-        const uint32_t opld = opdw + 2, img = rq_img_dwords(opdw, tile_images == 2);
+        const uint32_t opld = rq_img_opld(opdw, tile_images == 2), img = rq_img_dwords(opdw, tile_images == 2);
         const uint32_t taild = tile_images == 2 ? RQ_RECA_TAIL : RQ_REC_TAIL;
         uint32_t *base = recs + (uint64_t)(at >> 5) * img;
         r = base + (at & 31u) * opld;
@@ -1062,7 +1065,7 @@ __global__ __launch_bounds__(256) void group_vrange_kernel(const uint32_t *__res
                                                            const uint32_t *__restrict__ grp_cnt, uint32_t opdw,
                                                            float4 *__restrict__ vref) {
     const uint32_t c = blockIdx.x, n = grp_cnt[c], st0 = grp_start[c];
-    const uint32_t opld = opdw + 2, img = rq_img_dwords(opdw, true);
+    const uint32_t opld = rq_img_opld(opdw, true), img = rq_img_dwords(opdw, true);
     const float inf = __builtin_inff();
     float lo[4] = {inf, inf, inf, inf}, hi[4] = {-inf, -inf, -inf, -inf};
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
@@ -1585,7 +1588,7 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
                                                            const ScanArgs a) {
     static_assert(!(ADD && ARENA), "the additive gate is built for the uniform survivor buffers only");
     constexpr uint32_t OPDW = 12 * W;            // operand dwords per record: dim fp6 fields
-    constexpr uint32_t OPLD = OPDW + 2;          // row stride (dwords) of the operand image: conflict-free ds_read_b64
+    constexpr uint32_t OPLD = rq_img_opld(OPDW, ADD);  // row stride (dwords) of the operand image: conflict-free ds_read_b64 (ADD at dim 128: ds_read_b128)
     constexpr uint32_t IMG_OP = 32 * OPLD;       // a query tile image: 32 operand rows ...
     constexpr uint32_t TAILD = ADD ? RQ_RECA_TAIL : RQ_REC_TAIL;
     constexpr uint32_t IMG = scan_mfma_img_dwords<W, ARENA, ADD>();  // ... + the 32 record tails (+ the 32 start values)
@@ -1901,7 +1904,13 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
             }
             return av;
         };
-        if constexpr (!STREAM_A) {
+        if constexpr (ADD && W == 2) {  // the lane's 12 dwords in three 16-byte reads
+#pragma unroll
+            for (int e = 0; e < 12; e += 4) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(&img[j * OPLD + 12 * h + e]);
+                (&aop[0][0])[e] = v.x, (&aop[0][0])[e + 1] = v.y, (&aop[0][0])[e + 2] = v.z, (&aop[0][0])[e + 3] = v.w;
+            }
+        } else if constexpr (!STREAM_A) {
 #pragma unroll
             for (int m = 0; m < W; ++m) {
                 const v8i32 av = load_a(m);
@@ -2005,7 +2014,7 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
                 mxi = mxi > ai[15] ? mxi : ai[15];
                 hot = __ballot(mxi >= gate_min) != 0ull;
             }
-            if (hot) {  // wave-uniform; everything below
+            if (__builtin_expect(hot, 0)) {  // wave-uniform; everything below (laid out off the hot path)
                 ++n_flag;
 #ifdef RQ_DEV_ABLATIONS
                 const unsigned long long tx0 = time_stat ? __builtin_readcyclecounter() : 0ull;

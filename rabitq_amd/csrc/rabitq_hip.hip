@@ -279,7 +279,6 @@ struct rq_index {
     FactorStats fstats{0, 0, 0, 0};
     std::atomic<uint32_t> cap_hint{0};  // survivor-buffer capacity learnt from earlier batches
     std::atomic<uint64_t> arena_hint{0};  // slots the largest arena stage of earlier batches needed (+ headroom)
-    std::atomic<uint32_t> early_cap_hint{0};  // the same for the stages before the final one (segmented passes size the final stage per query)
     std::atomic<uint32_t> big_dirs_hint{0};  // most long run directories (> 512 runs) a stage of a recent pass produced
     uint64_t pass_budget = 24ull << 30;  // bytes of survivor / run buffers one query pass may use (set by finish_index)
     // tile tables of the cluster-major scans: per tile size, one {list, first, list begin, list length} entry per
@@ -527,9 +526,12 @@ static bool scan_has_mfma(uint32_t W) {
         default: return false;
     }
 }
-static uint32_t scan_mfma_nt(uint32_t W) { return W == 2 ? 3 : (W >= 4 ? 2 : 4); }
+#ifndef RQ_ADD_NT2
+#define RQ_ADD_NT2 4  // sub-tiles per wave of the additive-gate instantiation at dim 128
+#endif
+static uint32_t scan_mfma_nt(uint32_t W, bool additive = false) { return W == 2 ? (additive ? RQ_ADD_NT2 : 3) : (W >= 4 ? 2 : 4); }
 static uint32_t scan_mfma_nw(uint32_t W, bool arena) { return W == 2 && !arena ? 8u : 4u; }  // scan_mfma_waves<W, ARENA>()
-static uint32_t scan_mfma_tile(uint32_t W, bool arena) { return 32 * scan_mfma_nw(W, arena) * scan_mfma_nt(W); }
+static uint32_t scan_mfma_tile(uint32_t W, bool arena, bool additive = false) { return 32 * scan_mfma_nw(W, arena) * scan_mfma_nt(W, additive); }
 static size_t scan_mfma_ring_bytes(uint32_t W, bool arena = false) {  // scan_mfma_ring_slots<W, ARENA>() tile images
     (void)arena;
     const uint64_t slots = W <= 2 ? 4ull : (W >= 16 ? 5ull : 3ull);
@@ -546,7 +548,7 @@ static void launch_scan_mfma_add(const ScanPtrs &p, const ScanArgs &args, uint32
     launch_scan_chunks(args, [&](const ScanArgs &a, dim3 g) {
         switch (W) {
             case 1: launch_scan_mfma_t<1, 4, false, true>(p, a, g, st); break;
-            case 2: launch_scan_mfma_t<2, 3, false, true>(p, a, g, st); break;
+            case 2: launch_scan_mfma_t<2, RQ_ADD_NT2, false, true>(p, a, g, st); break;
             default: break;
         }
     });
@@ -611,7 +613,7 @@ static hipError_t set_scan_mfma_attr() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_mfma_ring_bytes(W));
     if (e != hipSuccess) return e;
     if constexpr (W <= 2) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(scan_mfma_kernel<W, NT, false, true>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(scan_mfma_kernel<W, (W == 2 ? RQ_ADD_NT2 : NT), false, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_mfma_ring_bytes(W));
         if (e != hipSuccess) return e;
     }
@@ -741,7 +743,7 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
 }
 
 struct PassResult {
-    uint64_t rough = 0, precise = 0, overflowed = 0, max_need = 0, early_max = 0;
+    uint64_t rough = 0, precise = 0, overflowed = 0, max_need = 0;
 };
 
 // Second half of a pass: wait for the stream, read the totals, collect the profile.
@@ -754,7 +756,6 @@ static rq_status finish_pass(const rq_index *idx, Workspace &ws, PassResult *res
     res->precise = ws.h_totals[1];
     res->overflowed = ws.h_totals[2];
     res->max_need = ws.h_totals[4];
-    res->early_max = ws.h_totals[6];
     if (nq >= 256) const_cast<rq_index *>(idx)->big_dirs_hint.store((uint32_t)ws.h_totals[7]);
     // The additive gate is a looser test than the rank-5 threshold it replaces: an index / workload on which it sends more than
     // 3 % of the sub-tile steps down the exact path (each costs ~10 plain steps) goes back to the bf16 threshold MFMA for good
@@ -1106,7 +1107,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         sp.list_uref = idx->list_uref.p, sp.grp_vref = ws.grp_vref.p;
         a.cap = qp.cap;
         a.dbg = (uint32_t)g_scan_dbg.load();
-        const uint32_t stage_tile = use_mfma ? scan_mfma_tile(W, arena_stage) : tile;
+        const uint32_t stage_tile = use_mfma ? scan_mfma_tile(W, arena_stage, additive) : tile;
         a.tiles_per_group = ceil_div(std::min<uint64_t>(idx->max_list_len, sg.s_hi), stage_tile);
         sp.tile_table = nullptr;
         const uint64_t grid_blocks = (uint64_t)k * a.tiles_per_group, real_tiles = idx->n / stage_tile + k;
@@ -1145,7 +1146,11 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             uint32_t arena_rsub = 0;
             bool arena_retried = false;
             ws.arena_failed = true;  // (until the stage has its arena: an allocation failure or a give-up below returns from inside the loop)
-            if (g_seg_opt.load() == 3) return fail(RQ_ERR_OOM, "survivor arena: injected failure (test hook survivor_segments = 3)");
+            if (g_seg_opt.load() == 3) {  // test hook: the arena cannot be had -- through a REAL failing allocation (1 PiB), sticky error and all
+                DevBuf<SurvRec> never;
+                RQC(never.alloc(1ull << 46));
+                return fail(RQ_ERR_OOM, "survivor arena: injected failure (test hook survivor_segments = 3)");
+            }
             for (int attempt = 0;; ++attempt) {
                 want = std::min<uint64_t>(want, 0xFFFF0000ull);
                 RQC(ws.arena_recs.ensure(want));
@@ -1405,11 +1410,6 @@ static rq_status after_pass(rq_index *idx, Workspace *ws, const QueryParams &qp,
     const uint32_t len = qp.len, probe = qp.probe, topk = qp.topk;
     const bool heuristic = qp.heuristic;
     const uint32_t npb = std::min(probe, idx->k);
-    if (pr.early_max > RQ_DEFAULT_CAP) {  // the capacity the stages before the final one need (segmented passes use it as their uniform bound)
-        const uint32_t want = pow2_ceil((uint32_t)std::min<uint64_t>(pr.early_max + pr.early_max / 4, RQ_MAX_CAP_HINT));
-        uint32_t cur = idx->early_cap_hint.load();
-        while (cur < want && !idx->early_cap_hint.compare_exchange_weak(cur, want)) {}
-    }
     if (pr.max_need > qp.cap) {  // remember (with headroom) so that later batches do not overflow
         // ... but only up to RQ_MAX_CAP_HINT: survivor buffers are cap x 32 B for EVERY query of the pass, so one outlier
         // query (a loose threshold after an unlucky nearest list) must not shrink the passes of all later batches; beyond
@@ -1551,6 +1551,10 @@ static rq_status query_device(rq_index *idx, const float *d_q, uint32_t nq, uint
             // no room for the survivor arena (or it kept overflowing): the pass again on the uniform buffers, where a query that
             // overflows is simply re-run with the capacity it asks for -- slower, never wrong
             (void)hipStreamSynchronize(ws->stream);
+            // a failed hipMalloc leaves hipErrorOutOfMemory as the thread's last error (sticky on ROCm 7.2): the repeat's own
+            // hipGetLastError() check must not pick it up; the arena of earlier batches goes back to the pool the repeat allocates from
+            (void)hipGetLastError();
+            ws->arena_recs.release(), ws->arena_runs.release(), ws->scan_extra.release();
             ws->arena_failed = false;
             qp.seg_final = false;
             RQC(ws_prepare(idx, *ws, qp));
@@ -1610,6 +1614,8 @@ static rq_status query_device_begin(rq_index *idx, const float *d_q, uint32_t nq
         st = run_pass(idx, *t->ws, d_q, t->qp, nullptr, d_out_dist, d_out_id, d_out_n, &pr, &t->prof, nullptr, nullptr, true);
         if (st != RQ_OK && t->ws->arena_failed && t->qp.seg_final) {  // as in query_device: the pass again on the uniform buffers
             (void)hipStreamSynchronize(t->ws->stream);
+            (void)hipGetLastError();  // (a failed hipMalloc's sticky error, as in query_device)
+            t->ws->arena_recs.release(), t->ws->arena_runs.release(), t->ws->scan_extra.release();
             t->ws->arena_failed = false;
             t->qp.seg_final = false;
             st = ws_prepare(idx, *t->ws, t->qp);
@@ -2384,7 +2390,7 @@ static rq_status copy_base_rows(const rq_index *idx, uint64_t i0, uint64_t m, fl
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-const char *rq_version(void) { return "rabitq_hip 0.3.0 (gfx950, abi 3)"; }
+const char *rq_version(void) { return "rabitq_hip 0.4.0 (gfx950, abi 4)"; }
 uint32_t rq_abi_version(void) { return RQ_ABI_VERSION; }
 const char *rq_last_error(void) { return g_err.c_str(); }
 

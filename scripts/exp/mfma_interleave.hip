@@ -112,6 +112,103 @@ __global__ __launch_bounds__(1024) void k(float *out, unsigned long long *cyc, i
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0, cyc[1] = r1 - r0;
 }
 
+
+// Software-pipelined form (additive gate: no threshold MFMA): the two MFMAs of sub-tile t+1 are issued BEFORE the gate of
+// sub-tile t, so that the gate's vector instructions run in the shadow of the next sub-tile's matrix work (two accumulators).
+// XT = 1: the pipeline also runs across tile boundaries (the next tile's A / C fragments are loaded one tile ahead).
+template <int NTT, int XT>
+__global__ __launch_bounds__(1024) void kp(float *out, unsigned long long *cyc, int iters, float gate_h) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    for (uint32_t i = threadIdx.x; i < 4 * 32 * 48; i += blockDim.x) lds[i] = i * 2654435761u >> 27;
+    v8i b[2];
+    for (int m = 0; m < 2; ++m) {
+        for (int e = 0; e < 8; ++e) b[m][e] = (int)((threadIdx.x * 3 + e + m) & 0x22222222);
+        b[m][4] = b[m][5] = b[m][6] = b[m][7] = 0;
+    }
+    int flagged = 0;
+    const float hc = gate_h;
+    __syncthreads();
+    auto load_tile = [&](int i, v8i (&a)[2], v16f &c) {
+        const uint32_t *img = lds + (i & 3) * (32 * 48);
+        for (int e = 0; e < 12; e += 4) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(&img[j * 28 + 12 * h + e]);
+            if (e == 0) a[0][0] = v.x, a[0][1] = v.y, a[0][2] = v.z, a[0][3] = v.w;
+            if (e == 4) a[0][4] = v.x, a[0][5] = v.y, a[1][0] = v.z, a[1][1] = v.w;
+            if (e == 8) a[1][2] = v.x, a[1][3] = v.y, a[1][4] = v.z, a[1][5] = v.w;
+        }
+        a[0][6] = a[0][7] = a[1][6] = a[1][7] = 0;
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 cv = *reinterpret_cast<const float4 *>(&img[32 * 28 + 8 * g4 + 4 * h]);
+            c[4 * g4] = cv.x, c[4 * g4 + 1] = cv.y, c[4 * g4 + 2] = cv.z, c[4 * g4 + 3] = cv.w;
+        }
+    };
+    auto mm2 = [&](const v8i (&a)[2], const v16f &c0) {
+        OPAQUE(b[0][0]);
+        v16f c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b[0], c0, 2, 4, 0, 0, 0, 0);
+        OPAQUE(b[1][0]);
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[1], b[1], c, 2, 4, 0, 0, 0, 0);
+    };
+    auto gate = [&](const v16f &c) {
+        float mx = hc;
+#pragma unroll
+        for (int g = 0; g < 16; g += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, c[g]), c[g + 1]);
+        if (__builtin_expect(__ballot(mx > hc) != 0ull, 0)) {
+            ++flagged;
+            out[threadIdx.x] = c[3];
+        }
+    };
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    v8i a[2], an[2];
+    v16f ci, cn;
+    load_tile(0, a, ci);
+    v16f pend;  // the accumulator whose gate is still owed
+    bool have = false;
+    for (int i = 0; i < iters; ++i) {
+        if (XT) load_tile(i + 1, an, cn);  // one tile ahead
+#pragma unroll
+        for (int t = 0; t < NTT; ++t) {
+            const v16f cur = mm2(a, ci);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t > 0 || (XT && have)) gate(pend);
+            __builtin_amdgcn_sched_barrier(0);
+            pend = cur;
+        }
+        if (!XT) {
+            gate(pend);
+            load_tile(i + 1, a, ci);
+        } else {
+            have = true;
+            a[0] = an[0], a[1] = an[1], ci = cn;
+        }
+    }
+    if (XT) gate(pend);
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (float)flagged;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0, cyc[1] = r1 - r0;
+}
+template <int NTT, int XT>
+void runp(float *o, unsigned long long *c, int wps) {
+    unsigned long long h[2] = {0, 0};
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0), hipEventCreate(&e1);
+    float ms = 0;
+    const int iters = 4096;
+    hipFuncSetAttribute((const void *)kp<NTT, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    for (int r = 0; r < 3; ++r) {
+        hipEventRecord(e0, 0);
+        kp<NTT, XT><<<256, 256 * wps, 100 * 1024>>>(o, c, iters, 1.0e30f);
+        hipEventRecord(e1, 0);
+        hipDeviceSynchronize();
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    hipMemcpy(h, c, 16, hipMemcpyDeviceToHost);
+    const double steps_per_simd = (double)wps * iters * NTT;
+    printf("PIPELINED nt %d across-tiles %d waves/SIMD %d: %7.1f ns/step/SIMD  memtime/realtime = %.3f GHz  (%.2f ms)\n", NTT, XT, wps,
+           ms * 1e6 / steps_per_simd, (double)h[0] / ((double)h[1] * 10.0), ms);
+}
 template <int NACC, int THR, int BFMT, int SB = 0, int GATE = 8, int TREE = 0, int BR = 1>
 void run(float *o, unsigned long long *c, int wps) {
     unsigned long long h[2] = {0, 0};
@@ -138,20 +235,12 @@ int main() {
     unsigned long long *c;
     hipMalloc(&o, 256 * 1024 * 4);
     hipMalloc(&c, 16);
-    for (int wps = 2; wps <= 4; ++wps) {
-        run<1, 1, 2, 0, 8>(o, c, wps);
-        run<1, 1, 2, 0, 0>(o, c, wps);
-        run<1, 1, 2, 0, 2>(o, c, wps);
-        run<1, 1, 2, 0, 5>(o, c, wps);
-        run<1, 1, 2, 0, 8, 1>(o, c, wps);
-        run<1, 1, 2, 0, 8, 0, 0>(o, c, wps);
-        run<1, 1, 2, 0, 8, 1, 0>(o, c, wps);
-        run<3, 1, 2, 0, 0>(o, c, wps);
-        run<3, 1, 2, 0, 8, 1, 0>(o, c, wps);
-        run<3, 1, 2, 1, 8, 1, 0>(o, c, wps);
-        run<1, 0, 2, 0, 0>(o, c, wps);
-        run<3, 0, 2, 0, 0>(o, c, wps);
-        run<3, 0, 2, 0, 8, 1, 0>(o, c, wps);
+    for (int wps = 1; wps <= 4; ++wps) {
+        run<1, 0, 4, 0, 8, 0, 1>(o, c, wps);
+        runp<4, 0>(o, c, wps);
+        runp<4, 1>(o, c, wps);
+        runp<6, 0>(o, c, wps);
+        runp<6, 1>(o, c, wps);
     }
     return 0;
 }

@@ -1,3 +1,5 @@
+# needs the developer build: make -C rabitq_amd/csrc dev
+export RABITQ_HIP_SO=$PWD/rabitq_amd/librabitq_hip_dev.so
 # matrix-core scan launch time at 100M x 768 under timing ablations (results are WRONG with most of them)
 for o in 64 8256 66 68; do timeout -k 10 400 python bench.py --no-secondary --dim 768 --batch 32768 --steps 3 --warmup 2 --no-cpu-baseline --no-two-in-flight --small-batch 0 --gt-queries 10 --option scan_debug=$o > gpurun_out/b_abl768_$o.json 2> gpurun_out/b_abl768_$o.err; python - <<PY
 import json

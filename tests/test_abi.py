@@ -67,7 +67,7 @@ def test_sized_out_structs_are_never_overrun(L):
     struct_size is refused (rq_info_t / rq_profile_t grew without a version)."""
     import ctypes as C
     from rabitq_amd import _lib
-    assert L.rq_abi_version() == _lib.ABI_VERSION and b"abi 3" in L.rq_version()
+    assert L.rq_abi_version() == _lib.ABI_VERSION and b"abi 4" in L.rq_version()
     buf = (C.c_uint8 * 256)(*([0xAB] * 256))
     C.cast(buf, C.POINTER(C.c_uint32))[0] = 24                      # an "old" rq_profile_t of 24 bytes
     assert L.rq_last_profile(C.cast(buf, C.POINTER(_lib.ProfileT))) == 0

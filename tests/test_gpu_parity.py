@@ -182,6 +182,104 @@ def test_query_matches_golden(rq, path):
     idx.close()
 
 
+# ---- every value rq_set_option accepts in the SHIPPED library is result-neutral -------------------------------------
+# (the timing ablations -- results wrong -- exist in the developer build only; what the product accepts must
+# leave the golden results untouched, and may be changed while queries are in flight)
+OPTION_VALUES = {
+    "scan_impl": [0, 1, 2], "scan_gate": [0, 1, 2], "coarse_impl": [0, 1, 2], "group_rank": [0, 1, 2], "scan_tile_table": [0, 1, 2],
+    "dense_dir": [0, 1], "small_batch": [0, 1], "small_batch_span": [64, 2560, 100000], "stage_growth": [0, 2, 16],
+    "survivor_segments": [0, 1, 2, 3], "max_scan_blocks": [0, 1, 7], "shared_thresholds": [0, 1, 2], "assign_impl": [0, 1],
+    "rerank_shadow": [0, 1], "scan_debug": [0, 128, 512, 4096, 16384, 128 | 512 | 4096],
+}
+OPTION_DEFAULTS = {"scan_impl": 0, "scan_gate": 0, "coarse_impl": 0, "group_rank": 1, "scan_tile_table": 1, "dense_dir": 1,
+                   "small_batch": 0, "small_batch_span": 2560, "stage_growth": 0, "survivor_segments": 1, "max_scan_blocks": 0,
+                   "shared_thresholds": 1, "assign_impl": 0, "rerank_shadow": 1, "scan_debug": 0}
+
+
+def test_every_option_value_keeps_golden_results(rq):
+    from rabitq_amd import index as ix
+    g = np.load(GOLDEN[0])
+    probe, topk, heur = (int(v) for v in g["q0_cfg"])
+    want_n = g["q0_n"]
+
+    def check(idx, what):
+        d, ids, cnt = idx.query_batch(g["queries"], probe, topk, bool(heur))
+        assert np.array_equal(cnt, want_n), what
+        for qi in range(len(cnt)):
+            n = int(cnt[qi])
+            assert np.array_equal(ids[qi, :n], g["q0_ids"][qi, :n]), (what, qi)
+            assert_bits_equal(d[qi, :n], g["q0_dist"][qi, :n], f"{what}: distances")
+        res = idx.query(g["queries"][0], probe, topk, bool(heur))
+        assert [i for _, i in res] == g["q0_ids"][0, :int(want_n[0])].tolist(), what
+    try:
+        for name, values in OPTION_VALUES.items():
+            for v in values:
+                ix.set_option(name, v)
+                idx = rq.RaBitQ.build(g["base_in"], g["centroids_in"], g["orthogonal"])   # (some options act at build time)
+                check(idx, f"{name}={v}")
+                idx.close()
+            ix.set_option(name, OPTION_DEFAULTS[name])
+        # the result-changing developer bits are refused by the shipped library
+        for bad in (1, 2, 4, 64, 256, 1024, 8192, 128 | 64):
+            with pytest.raises(rq.RabitqError):
+                ix.set_option("scan_debug", bad)
+        for name, bad in (("scan_gate", 3), ("scan_impl", 3), ("coarse_impl", 3), ("scan_dense", 1)):
+            with pytest.raises(rq.RabitqError):
+                ix.set_option(name, bad)
+    finally:
+        for name, v in OPTION_DEFAULTS.items():
+            ix.set_option(name, v)
+
+
+def test_options_flipped_under_concurrent_queries(rq, oracle):
+    """Options are process-global; a pass reads the kernel-selecting ones once per stage, so flipping them while other threads
+    query the same handle changes which kernels run, never a result."""
+    import threading
+    from rabitq_amd import index as ix
+    n, d, k = 16000, 128, 20
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.8, seed=131, centre_scale=0.6)
+    P = synth.random_orthogonal(d, seed=132)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    gidx = rq.RaBitQ.build(x, centres, P)
+    queries, _, _ = synth.mixture(330, d, k, sigma=0.8, seed=133, centre_scale=0.6)
+    want = [oidx.query(q, 8, 10)[1].tolist() for q in queries]
+    stop = threading.Event()
+    errs = []
+
+    def flipper():
+        rng = np.random.default_rng(5)
+        names = ["scan_impl", "scan_gate", "group_rank", "scan_tile_table", "dense_dir", "small_batch", "stage_growth", "coarse_impl"]
+        while not stop.is_set():
+            name = names[int(rng.integers(len(names)))]
+            ix.set_option(name, int(rng.choice(OPTION_VALUES[name])))
+
+    def worker(t):
+        try:
+            for rep in range(3):
+                if t % 2:   # big batches (list-major / matrix-core stages) ...
+                    _, ids, cnt = gidx.query_batch(queries, 8, 10)
+                    got = [ids[i, :cnt[i]].tolist() for i in range(len(queries))]
+                    assert got == want
+                else:       # ... next to small ones (the small-batch path)
+                    for j in range(t, 60, 4):
+                        _, ids, cnt = gidx.query_batch(queries[j:j + 3], 8, 10)
+                        assert [ids[i, :cnt[i]].tolist() for i in range(len(ids))] == want[j:j + 3]
+        except BaseException as ex:  # noqa: BLE001
+            errs.append(ex)
+    fl = threading.Thread(target=flipper)
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    fl.start()
+    [t.start() for t in th]
+    [t.join() for t in th]
+    stop.set()
+    fl.join()
+    for name, v in OPTION_DEFAULTS.items():
+        ix.set_option(name, v)
+    assert not errs, errs
+    gidx.close()
+    oidx.close()
+
+
 def _compare_with_oracle(rq, oracle, oidx, gidx, queries, probe, topk, heur):
     rq.metrics_reset()
     d, ids, cnt = gidx.query_batch(queries, probe, topk, heur)
