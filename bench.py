@@ -39,15 +39,18 @@ def main():
                          "0.5-2 s that would otherwise land in the first timed step)")
     # workload (defaults = BASELINE.json configs[2], the configuration the metric is quoted on)
     ap.add_argument("--vectors", type=int, default=None,
-                    help="vectors per GPU (default 100M = BASELINE configs[2]; 125M when --gpus 8, so that the 8-GPU point is "
-                         "BASELINE configs[4]: 1B x 128 over 32 768 lists)")
+                    help="vectors per GPU (default 100M = BASELINE configs[2] at EVERY --gpus N, so that N = 1, 2, 4, 8 are one curve; "
+                         "the 8-GPU run then also measures BASELINE configs[4] -- 125M per GPU = 1B x 128 over 32 768 lists -- into "
+                         "`secondary.configs4_1Bx128`)")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--lists", type=int, default=4096, help="IVF lists per GPU")
     ap.add_argument("--nprobe", type=int, default=64)
     ap.add_argument("--topk", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=65536,
-                    help="queries per step (throughput grows with the batch: more queries share each list in the matrix-core "
-                         "scan; 10000 -> 1.6 M/s, 32768 -> 2.15 M/s, 65536 -> 2.34 M/s on one MI355X)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="queries per step over ALL GPUs (default 65536 x N: the lists grow with N -- 4096 per GPU --, so a fixed "
+                         "batch would leave every rank's matrix-core scan N times fewer queries per list; with the batch scaled, a "
+                         "rank's (query, list) pairs per step stay what they are on one GPU.  Throughput grows with the batch: "
+                         "more queries share each list)")
     ap.add_argument("--sigma", type=float, default=0.5)
     ap.add_argument("--distribution", choices=["easy", "hard"], default="easy",
                     help="easy = SURVEY.md 8(d) mixture with the true centres as centroids; hard = overlapping clusters, "
@@ -92,12 +95,16 @@ def main():
                     help="batches kept in flight in the timed loop (rq_query_batch_device_begin/_end); 1 = one blocking "
                          "call per step (default: per-kernel times are then clean); see --two-in-flight")
     args = ap.parse_args()
-    explicit_workload = args.vectors is not None or args.dim != 128 or args.distribution != "easy" or args.emulate_world > 1
+    explicit_workload = (args.vectors is not None or args.dim != 128 or args.distribution != "easy" or args.emulate_world > 1 or
+                         args.batch is not None)
     if args.emulate_world > 1:
         assert args.gpus == 1, "--emulate-world is a one-GPU rehearsal"
         args.sharded_path = True
     if args.vectors is None:
-        args.vectors = 125_000_000 if args.gpus == 8 else 100_000_000
+        args.vectors = 100_000_000
+    default_batch = args.batch is None
+    if args.batch is None:
+        args.batch = 65536 * max(1, args.gpus) * max(1, args.emulate_world)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) and wait.
@@ -159,6 +166,21 @@ def main():
                 traceback.print_exc()
                 sec[name] = {"error": f"{type(e).__name__}: {e}"}
         line["secondary"] = sec
+    if world == 8 and args.secondary and not explicit_workload:
+        # BASELINE configs[4] (1B x 128 over 8 GPUs; k is not given there: 32 768 = 4096 per GPU) next to the
+        # 100M-per-GPU point of the scaling curve: 125M vectors per GPU, same lists / batch, same process group
+        import copy
+        a2 = copy.copy(args)
+        a2.vectors, a2.steps, a2.warmup, a2.gt_queries = 125_000_000, min(args.steps, 5), 2, 256
+        try:
+            full = run_workload(a2, ctx, extras=False)
+            keep = ("value", "unit", "ms_per_step", "steps", "warmup", "config", "recall_at_10", "recall_queries", "build_seconds",
+                    "kernel_ms_per_step", "collective_path", "roofline", "rough_per_query", "precise_per_query")
+            line["secondary"] = {"configs4_1Bx128": {key: full[key] for key in keep if key in full}}
+        except Exception as e:   # must not cost the headline line (every rank takes the same path: the failure modes are collective)
+            import traceback
+            traceback.print_exc()
+            line["secondary"] = {"configs4_1Bx128": {"error": f"{type(e).__name__}: {e}"}}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
@@ -350,7 +372,7 @@ def run_workload(args, ctx, extras=True):
                                                                   "host-buffer collectives (gloo rehearsal)" if args.backend == "gloo" else "RCCL")
         else:
             log(f"C-ABI collective path unavailable ({why or 'another rank failed'}): falling back to torch.distributed")
-            if args.backend == "gloo":
+            if keep_alive and isinstance(keep_alive[0], sharding.HostCollectives):   # (also an EmulatedPeers table)
                 sharding.HostCollectives.uninstall()
     if sharded and collective_path is None:
         collective_path = "per-call entries + torch.distributed (" + args.backend + ")"
@@ -397,7 +419,7 @@ def run_workload(args, ctx, extras=True):
             ok, why = False, f"{type(e).__name__}: {e}"
         if not all_agree(ok):
             log(f"rq_query_batch_sharded_device failed in warm-up ({why or 'on another rank'}): falling back to torch.distributed")
-            if args.backend == "gloo":
+            if keep_alive and isinstance(keep_alive[0], sharding.HostCollectives):
                 sharding.HostCollectives.uninstall()
             collective_path = "per-call entries + torch.distributed (" + args.backend + "), after the C-ABI step failed: " + (why or "another rank")
             pc_local = torch.zeros((B, nprobe), device=dev, dtype=torch.int32)
@@ -477,12 +499,8 @@ def run_workload(args, ctx, extras=True):
             if key.startswith("ms_"):
                 breakdown[key[3:]] = round(breakdown.get(key[3:], 0.0) + v, 3)
     # share of the matrix-core scan's 32x32 sub-tile steps that were flagged by the integer gate and took the exact f32 path
-    # (one more untimed step with the counting hook on; results are unchanged by it)
-    rqi.set_option("scan_debug", 128)
-    step()
-    fence()
-    ep = rqi.last_profile()
-    rqi.set_option("scan_debug", 0)
+    # (always-on counters of the timed steps)
+    ep = {"matrix_exact_steps": prof.get("matrix_exact_steps", 0), "matrix_subtile_steps": prof.get("matrix_subtile_steps", 0)}
     exact_rate = ep["matrix_exact_steps"] / ep["matrix_subtile_steps"] if ep["matrix_subtile_steps"] else None
     rqi.set_profiling(2)
     if world > 1:
@@ -530,11 +548,14 @@ def run_workload(args, ctx, extras=True):
     if prof.get("matrix_launches", 0) > 0 and prof["ms_scan_matrix"] > 0:
         ml, mm, mp = prof["matrix_launches"], prof["ms_scan_matrix"] * 1e-3, prof["matrix_pairs"]
         flops = mp * 2.0 * idx.dim                       # USEFUL work only: the dim-long integer dot product of every pair
-        over = mp * 2.0 * 16                             # overhead: the 16-slot bf16 threshold MFMA per pair (not counted)
+        additive = prof.get("matrix_additive_launches", 0) >= ml > 0   # every matrix-core launch ran the additive gate
+        over = 0.0 if additive else mp * 2.0 * 16        # overhead: the 16-slot bf16 threshold MFMA per pair (not counted)
         mbytes = mp * (idx.dim / 8 + 16)
         roofline = {"bound": "mfma", "achieved": round(flops / mm / 1e12, 1), "peak": round(PEAK_FP6, 1), "unit": "TFLOP/s",
                     "frac": round(flops / mm / 1e12 / PEAK_FP6, 4), "traffic": dom_traffic, "traffic_source": traffic_src,
-                    "kernel": "scan_mfma_kernel<W,NT> (v_mfma_f32_32x32x64_f8f6f4 e2m3 x e2m3)",
+                    "kernel": ("scan_mfma_kernel<W,NT,ADD> (v_mfma_f32_32x32x64_f8f6f4 e2m3 x e2m1; additive gate S* >= B_q + G_c, no threshold MFMA)"
+                               if additive else "scan_mfma_kernel<W,NT> (v_mfma_f32_32x32x64_f8f6f4 e2m3 x e2m3 + bf16 threshold MFMA)"),
+                    "gate": "additive" if additive else "bf16 rank-5 threshold",
                     "launches": int(ml), "avg_launch_ms": round(mm / ml * 1e3, 4),
                     "algorithmic_flops_per_launch": int(flops / ml), "pairs_per_launch": int(mp / ml),
                     "overhead_flops_per_launch_threshold_mfma": int(over / ml),
@@ -568,11 +589,44 @@ def run_workload(args, ctx, extras=True):
                   "p50_ms": round(float(np.median(lat) * 1e3), 4), "p99_ms": round(float(np.quantile(lat, 0.99) * 1e3), 4),
                   "queries_per_s": round(len(lat) / float(lat.sum()), 1), "device_ms": round(rqi.last_profile()["ms_total"], 4)}
 
+    # ---- the drop-in signature: RaBitQ::query takes &[f32] from HOST memory (src/rabitq.rs:268-274).  rq_query_batch with host
+    # buffers = the timed step + PCIe both ways (B*len*4 bytes in, B*topk*8 + B*4 out), pageable and pinned ---------------------
+    host_entry = None
+    if rank == 0 and extras and not sharded:
+        from rabitq_amd import _lib as _l
+        import ctypes as C
+        host_entry = {}
+        for kind in ("pageable", "pinned"):
+            pin = kind == "pinned"
+            hq = torch.empty((B, d), dtype=torch.float32, pin_memory=pin)
+            hq.copy_(queries)
+            hd = torch.empty((B, topk), dtype=torch.float32, pin_memory=pin)
+            hi = torch.empty((B, topk), dtype=torch.int32, pin_memory=pin)
+            hn = torch.empty((B,), dtype=torch.int32, pin_memory=pin)
+            call = lambda: _l.check(_l.lib().rq_query_batch(idx._h, C.c_void_p(hq.data_ptr()), B, d, nprobe, topk, 0,   # noqa: E731
+                                                            C.c_void_p(hd.data_ptr()), C.c_void_p(hi.data_ptr()), C.c_void_p(hn.data_ptr())))
+            call()
+            hs = min(args.steps, 5)
+            th = time.perf_counter()
+            for _ in range(hs):
+                call()
+            eh = (time.perf_counter() - th) / hs
+            same = bool(torch.equal(hi.to(torch.int64) & 0xFFFFFFFF, res[1].cpu()))
+            host_entry[kind] = {"ms_per_step": round(eh * 1e3, 3), "queries_per_s": round(B / eh, 1), "steps": hs,
+                                "ids_equal_to_device_entry": same}
+            del hq, hd, hi, hn
+        host_entry["entry"] = "rq_query_batch (host pointers in and out; one blocking call per step)"
+        host_entry["bytes_in_out_per_step"] = [B * d * 4, B * topk * 8 + B * 4]
+
     size_txt = f"{n // 1_000_000}Mx{d}" if n % 1_000_000 == 0 else f"{n}x{d}"
     line = {"metric": f"queries/sec at recall@10>=0.95, {size_txt}; HBM GB/s on popcount scan", "value": round(qps, 1),
             "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak",   # per-GPU work is fixed: every rank indexes --vectors rows of its own (125M at 8 GPUs, else 100M)
+            "scaling": "weak",   # per-GPU work is fixed: every rank indexes --vectors rows and 4096 lists of its own, and the batch grows with N
+            "scaling_note": f"weak: {n // 1_000_000}M vectors and {k_local} lists per GPU at every N; one step answers {B} queries "
+                            f"(65536 x N by default) against ALL {k} lists, so a rank scans as many (query, list) pairs per step as "
+                            "one GPU does alone; the coarse ranking (queries x all lists, sliced by lists over the ranks) is the part "
+                            "whose per-rank work grows with N",
             "vs_baseline": None, "dtype": "exact integer dot (fp6 MFMA, v_dot8_u32_u4) + f32", "data": "synthetic",
             "engine_options": args.option, "collective_path": collective_path,
             "config": {"workload": f"{n // 1_000_000}Mx{d} synthetic mixture per GPU, {k_local} lists per GPU, "
@@ -583,7 +637,8 @@ def run_workload(args, ctx, extras=True):
                                    (f" -- REHEARSAL of one rank of a {args.emulate_world}-GPU run ({k} lists in all, this rank owns {k_local}; "
                                     f"coarse ranking unsliced, recall against this rank's own vectors only)" if getattr(args, "emulate_world", 1) > 1 else "") +
                                    (" (BASELINE.json configs[4]: 1B x 128; k is unspecified there: 32 768 = 4096 per GPU, SURVEY.md 8d)"
-                                    if (n, d, k_local, nprobe, world, args.distribution) == (125_000_000, 128, 4096, 64, 8, "easy") else ""),
+                                    if (n, d, k_local, nprobe, world, args.distribution) == (125_000_000, 128, 4096, 64, 8, "easy") else "") +
+                                   (f"; batch = 65536 x {world} GPUs" if world > 1 and B == 65536 * world else ""),
                        "batches_in_flight": depth,
                        "n_per_gpu": n, "dim": d, "lists_total": k, "nprobe": nprobe, "topk": topk, "batch": B,
                        "sigma": args.sigma, "centre_scale": centre_scale, "sharding": f"vectors x{world}",
@@ -602,7 +657,7 @@ def run_workload(args, ctx, extras=True):
             "segmented_passes_per_step": prof.get("segmented_passes", 0) / args.steps,
             "roofline": roofline, "roofline_scan_all_launches": scan_all,
             "roofline_rotation": rotation,
-            "scan_small_batch": small, "single_query": single, "two_batches_in_flight": overlap}
+            "scan_small_batch": small, "single_query": single, "two_batches_in_flight": overlap, "host_entry": host_entry}
 
     # ---- CPU baseline: the oracle (port of the reference's AVX2 path) on this box's host cores ------
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_queries > 0 and extras:
@@ -614,7 +669,7 @@ def run_workload(args, ctx, extras=True):
         else:
             line["cpu_baseline"] = cpu_baseline(idx, queries[:args.cpu_queries].cpu().numpy(), nprobe, topk, ri, d)
     # everything this workload holds on the device goes before the next one is built
-    if (args.backend == "gloo" or getattr(args, "emulate_world", 1) > 1) and keep_alive and sharded:
+    if keep_alive and isinstance(keep_alive[0], sharding.HostCollectives) and sharded:
         sharding.HostCollectives.uninstall()
     for obj in keep_alive:
         if hasattr(obj, "close"):
@@ -628,12 +683,14 @@ def run_workload(args, ctx, extras=True):
 def small_batch_regime(idx, queries, sb, d, nprobe, topk, out_d, out_i, out_n, n, k_local):
     """The scan kernel in its HBM-bound regime: a small batch, (almost) no list shared between queries."""
     from rabitq_amd import index as rqi
-    for _ in range(2):
-        idx.query_batch_device(queries.data_ptr(), sb, d, nprobe, topk, out_d.data_ptr(), out_i.data_ptr(), out_n.data_ptr())
-    sp = {}
+    nqs = queries.shape[0]
     reps = 10
+    for w in range(2):   # warm-up on queries the timed calls do not use (the tail of the batch), so no timed call finds its lists cached
+        qw = queries[max(0, nqs - (w + 1) * sb): max(sb, nqs - w * sb)]
+        idx.query_batch_device(qw.data_ptr(), sb, d, nprobe, topk, out_d.data_ptr(), out_i.data_ptr(), out_n.data_ptr())
+    sp = {}
     for r in range(reps):
-        q0 = (r * sb) % max(1, queries.shape[0] - sb + 1)      # different queries per call
+        q0 = (r * sb) % max(1, nqs - 3 * sb + 1)      # different queries per call, all before the warm-up slice
         idx.query_batch_device(queries[q0:q0 + sb].data_ptr(), sb, d, nprobe, topk, out_d.data_ptr(), out_i.data_ptr(),
                                out_n.data_ptr())
         for key, v in rqi.last_profile().items():
@@ -646,6 +703,9 @@ def small_batch_regime(idx, queries, sb, d, nprobe, topk, out_d, out_i, out_n, n
              "whole_call_algorithmic_GBps": round(sp["scan_bytes"] / (sp["ms_total"] * 1e-3) / 1e9, 1),
              "whole_call_frac_of_8TBps": round(sp["scan_bytes"] / (sp["ms_total"] * 1e-3) / 1e9 / 8000.0, 4),
              "path": "few-launch small-batch path (kernels_small.h)" if sp.get("small_batch_passes", 0) else "staged path",
+             "timing": "HIP events of the engine around its scan launches / the whole pass, fresh queries in every call (an event "
+                       "pair adds ~4 us to a launch: at batch 1 the 50 MB scan launch itself is ~7-10 us, see the kernel-trace "
+                       "figures under committed_profile)",
              "queries_per_s": round(sb * reps / (sp["ms_total"] * 1e-3), 1)}
     # physical HBM rate of the same regime: PMC FETCH_SIZE (x2) over kernel-trace durations, committed profile
     hp = next((os.path.join(ROOT, "profiles", f) for f in ("r03_hbm_regime.json", "r02_hbm_regime.json")

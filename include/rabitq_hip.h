@@ -327,8 +327,8 @@ typedef struct {
     float ms_scan_matrix;      /* device time of the scan_mfma_kernel launches           */
     uint32_t matrix_launches;
     uint64_t matrix_pairs;     /* (query, candidate) pairs they scored                   */
-    /* only with rq_set_option("scan_debug", 128) (a measurement hook; results unchanged): 32x32 (query x candidate)
-     * sub-tile steps of the matrix-core scan, and how many of them were flagged and took the exact f32 path */
+    /* 32x32 (query x candidate) sub-tile steps of the matrix-core scan, and how many of them were flagged by its gate and took
+     * the exact f32 path (always filled since ABI revision 4) */
     uint64_t matrix_subtile_steps, matrix_exact_steps;
     /* of rerank_candidates: survivors the fp16 shadow rows proved to be at or above their stage's threshold, whose
      * 4*dim-byte row was therefore never fetched (option "rerank_shadow"; large batches) */
@@ -341,7 +341,8 @@ typedef struct {
      * appended its survivors to the shared arena and scattered them into per-query segments sized by their exact counts,
      * instead of one capacity for every query */
     uint64_t survivor_workspace_bytes;
-    uint32_t segmented_passes, reserved2;
+    uint32_t segmented_passes;
+    uint32_t matrix_additive_launches; /* of matrix_launches: those that ran the additive gate (no threshold MFMA; option "scan_gate") */
 } rq_profile_t;
 /* level: 0 = off; 1 = every kernel group bracketed (each event costs a few microseconds of stream
  * time); 2 = only the scan launches and the whole pass (ms_scan, ms_total; the other fields stay 0). */

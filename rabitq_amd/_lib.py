@@ -68,7 +68,7 @@ class ProfileT(_Sized):
         ("ms_scan_matrix", C.c_float), ("matrix_launches", C.c_uint32), ("matrix_pairs", C.c_uint64),
         ("matrix_subtile_steps", C.c_uint64), ("matrix_exact_steps", C.c_uint64),
         ("rerank_shadow_rejects", C.c_uint64), ("ms_early", C.c_float), ("small_batch_passes", C.c_uint32),
-        ("survivor_workspace_bytes", C.c_uint64), ("segmented_passes", C.c_uint32), ("reserved2", C.c_uint32)]
+        ("survivor_workspace_bytes", C.c_uint64), ("segmented_passes", C.c_uint32), ("matrix_additive_launches", C.c_uint32)]
 
 
 def build(force: bool = False) -> str:

@@ -2014,8 +2014,12 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
                 mxi = mxi > ai[15] ? mxi : ai[15];
                 hot = __ballot(mxi >= gate_min) != 0ull;
             }
-            if (__builtin_expect(hot, 0)) {  // wave-uniform; everything below (laid out off the hot path)
+            // wave-uniform; everything below.  (Additive form: laid out off the hot path, +1.5 %; the wide instantiations spill with it.)
+            if (ADD ? __builtin_expect(hot, 0) : hot) {
                 ++n_flag;
+                // nothing of the cold branch may be scheduled ahead of it: hoisted into the tile loop its recomputation and LDS reads
+                // cost the wide instantiations 34 spilled registers (dim 768: 21.6 -> 28.4 ms per launch)
+                __builtin_amdgcn_sched_barrier(0);
 #ifdef RQ_DEV_ABLATIONS
                 const unsigned long long tx0 = time_stat ? __builtin_readcyclecounter() : 0ull;
 #endif

@@ -1231,6 +1231,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             pf.end();
         }
         if (use_mfma) ws.pend_matrix_stages++;
+        if (prof_acc && additive) prof_acc->matrix_additive_launches++;
         if (prof_acc) prof_acc->scan_launches++;
         if (prof_acc && use_mfma) {
             prof_acc->matrix_launches++;
@@ -3067,6 +3068,7 @@ static void profile_add(rq_profile_t &acc, const rq_profile_t &x) {
     acc.matrix_exact_steps += x.matrix_exact_steps, acc.rerank_shadow_rejects += x.rerank_shadow_rejects;
     acc.ms_early += x.ms_early, acc.small_batch_passes += x.small_batch_passes;
     acc.survivor_workspace_bytes = std::max(acc.survivor_workspace_bytes, x.survivor_workspace_bytes), acc.segmented_passes += x.segmented_passes;
+    acc.matrix_additive_launches += x.matrix_additive_launches;
 }
 
 // probe lists <-> merge keys (f32 distance bits << 32 | list id: distances are >= 0, so the bits order like the values;
@@ -3174,12 +3176,21 @@ static rq_status sharded_step(rq_index *mi, void *nccl_comm, uint32_t world, uin
         for (uint32_t v : {nq, len, probe, topk, world, (uint32_t)heuristic, (uint32_t)shared, mi->k, mi->dim}) h = (h ^ v) * 0x01000193u;
         const int32_t hs = (int32_t)(h & 0x3FFFFFFFu);
         const int32_t hand[4] = {hs, -hs, err != RQ_OK ? 1 : 0, 0};
-        HIPC(hipMemcpyAsync(ws->sh_flag.p, hand, sizeof hand, hipMemcpyHostToDevice, st));
+        // a local HIP failure here must not keep this rank out of the collective (its peers would block in it): it is folded into
+        // `err`, the all-reduce is issued regardless (the words then on the device make the peers' parameter check fail), and
+        // this rank returns its own error afterwards
+        {
+            const hipError_t he = hipMemcpyAsync(ws->sh_flag.p, hand, sizeof hand, hipMemcpyHostToDevice, st);
+            if (he != hipSuccess && err == RQ_OK) err = RQ_ERR_HIP, err_msg = std::string("hipMemcpyAsync (handshake): ") + hipGetErrorString(he);
+        }
         const int rc = api->all_reduce(ws->sh_flag.p, ws->sh_flag.p, 4, RQ_NCCL_INT32, RQ_NCCL_MAX, nccl_comm, st);
         if (rc != 0) return nccl_fail("ncclAllReduce (handshake)", rc);
-        int32_t got[4];
-        HIPC(hipMemcpyAsync(got, ws->sh_flag.p, sizeof got, hipMemcpyDeviceToHost, st));
-        HIPC(hipStreamSynchronize(st));
+        int32_t got[4] = {0, 0, 1, 0};
+        {
+            hipError_t he = hipMemcpyAsync(got, ws->sh_flag.p, sizeof got, hipMemcpyDeviceToHost, st);
+            if (he == hipSuccess) he = hipStreamSynchronize(st);
+            if (he != hipSuccess && err == RQ_OK) err = RQ_ERR_HIP, err_msg = std::string("handshake read-back: ") + hipGetErrorString(he);
+        }
         if (err != RQ_OK) return fail(err, err_msg);
         if (got[0] != -got[1])
             return fail(RQ_ERR_INVALID, "rq_query_batch_sharded_device: the ranks were called with different nq / len / probe / topk / world / ranker / shared_thresholds");

@@ -320,8 +320,11 @@ class HostCollectives:
             return 1
 
     def _user_rank(self, comm, out_rank):
-        out_rank[0] = dist.get_rank(self.group)
-        return 0
+        try:   # an exception inside a ctypes callback is swallowed (the call would return 0 with out_rank unset: rank 0's slice)
+            out_rank[0] = dist.get_rank(self.group)
+            return 0
+        except Exception:  # noqa: BLE001
+            return 1
 
 
 class EmulatedPeers(HostCollectives):
