@@ -273,6 +273,7 @@ struct rq_index {
     DevBuf<uint64_t> codes;
     DevBuf<float4> factors;
     DevBuf<float4> list_uref;  // per list: mean of u' = (1, cds, ., eb) / factor_ip over its regular vectors (additive gate of the matrix-core scan; derived)
+    uint32_t nonempty_lists = 0;  // lists with at least one vector (a shard of a multi-GPU index owns only some of the k lists)
     std::atomic<int> additive_loose{0};  // the additive gate flagged too many sub-tile steps on this index: later passes use the bf16 threshold
     std::mutex ws_mu;
     std::vector<std::unique_ptr<Workspace>> ws_pool;
@@ -635,6 +636,7 @@ static rq_status ensure_kernel_attributes() {
         set(reinterpret_cast<const void *>(coarse_dist_kernel<8>), 140 * 1024, "coarse_dist_kernel<8>");
         set(reinterpret_cast<const void *>(assign_generic_kernel<8>), 140 * 1024, "assign_generic_kernel<8>");
         set(reinterpret_cast<const void *>(merge_smallest_u64_kernel), 16384 * 8, "merge_smallest_u64_kernel");
+        set(reinterpret_cast<const void *>(group_rank_kernel), 32768 * 4, "group_rank_kernel");
         set(reinterpret_cast<const void *>(sb_front_kernel), 140 * 1024, "sb_front_kernel");
         set(reinterpret_cast<const void *>(sort_runs_mid_kernel), RQ_SORT_MID_LDS_WORDS * 8, "sort_runs_mid_kernel");  // (+ 34 KiB of static LDS)
         set(reinterpret_cast<const void *>(assign_approx_kernel<6, 1>), (int)assign_lds_bytes<6, 1>(), "assign_approx_kernel<6,1>");
@@ -684,6 +686,7 @@ struct QueryParams {
     // its survivors are scattered into per-query segments sized by their exact counts (the workspace then scales with the
     // sum of the survivors instead of nq x the worst query)
     bool seg_final = false;
+    bool ext_lists = false;  // the probe lists come from the caller: no coarse ranking in the pass (and no nq x k distance matrix)
 };
 
 #define RQ_DEFAULT_CAP 4096u
@@ -698,7 +701,7 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
     if (!ws.h_totals) HIPC(hipHostMalloc((void **)&ws.h_totals, 16 * sizeof(unsigned long long)));
     RQC(ws.qpad.ensure(nq * idx->dim));
     RQC(ws.y.ensure(nq * idx->dim));
-    RQC(ws.dist.ensure(nq * idx->k));
+    if (!qp.ext_lists) RQC(ws.dist.ensure(nq * idx->k));
     RQC(ws.probe_dist.ensure(npairs));
     RQC(ws.probe_cluster.ensure(npairs));
     RQC(ws.scal.ensure(npairs));
@@ -845,7 +848,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         std::vector<Stage> stages;
         const uint64_t total_max = std::min<uint64_t>((uint64_t)nprobe * idx->max_list_len, idx->n);
         uint64_t lo = 0, hi = first_hi;
-        const uint64_t avg = std::max<uint64_t>(1, idx->n / std::max<uint32_t>(k, 1));
+        const uint64_t avg = std::max<uint64_t>(1, idx->n / std::max<uint32_t>(idx->nonempty_lists, 1));  // (over the lists that exist here: a shard owns k / world of them)
         // the threshold has settled once a query has seen its whole nearest list; with unbalanced lists (Zipf sizes) the
         // nearest list of many queries is one of the long ones, so the bar is the LONGEST list (capped: a single
         // monster list must not push the whole batch through many thin stages)
@@ -977,7 +980,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         uint32_t *q6 = scan_has_mfma(W) && impl != 1 ? ws.qf6.p : nullptr;
 #define RQ_PREP_SMALL(LP, R, PPB, PP)                                                                              \
     prep_small_kernel<LP, R, PP><<<ceil_div(npairs, (PPB) * (PP)), 256, 0, st>>>(ws.y.p, idx->centroids.p, idx->offsets.p, probe_cluster, \
-                                                                    probe_dist, npairs, nprobe, ws.scal.p, qn, q6, k, 1u)
+                                                                    probe_dist, npairs, nprobe, ws.scal.p, qn, q6, k, idx->nonempty_lists * 2 < k ? 2u : 1u)
         if (dim == 128) RQ_PREP_SMALL(32, 1, 8, 4);  // 32 lanes per pair, two pairs per wave, four rounds of pairs per lane group
         else if (dim == 64) RQ_PREP_SMALL(16, 1, 16, 4);
         else if (dim == 256) RQ_PREP_SMALL(64, 1, 4, 4);
@@ -1027,7 +1030,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     const uint32_t big_hint = idx->big_dirs_hint.load();
     const uint32_t mid_blocks = big_hint == 0 ? 64u : std::min(4096u, std::max(256u, big_hint / 4));
     const uint32_t tile = scan_tile(W);
-    const uint64_t avg_len = std::max<uint64_t>(1, idx->n / std::max<uint32_t>(k, 1));
+    const uint64_t avg_len = std::max<uint64_t>(1, idx->n / std::max<uint32_t>(idx->nonempty_lists, 1));
     uint32_t stage_no = ~0u;
     for (const Stage &sg : stages) {
         ++stage_no;
@@ -1063,7 +1066,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             HIPC(hipMemsetAsync(ws.grp_cnt.p, 0, (size_t)((k + 4) & ~3u) * 4, st));  // 16-byte multiple: one fill kernel
             // big stages: places inside the groups come out of the counting pass (LDS histogram per block)
             const int rank_opt = g_group_rank.load();  // 0 never, 1 auto, 2 whenever the histogram fits LDS (tests)
-            ranked = k <= 12288 && (rank_opt == 2 || (rank_opt == 1 && stage_pairs >= 16 * RQ_RANK_ITEMS &&
+            ranked = k <= 32768 && (rank_opt == 2 || (rank_opt == 1 && stage_pairs >= 16 * RQ_RANK_ITEMS &&
                                                       stage_pairs / RQ_RANK_ITEMS >= k / 256));
             if (ranked) {
                 const uint32_t nblk = ceil_div(stage_pairs, RQ_RANK_ITEMS);
@@ -1391,16 +1394,22 @@ static uint32_t pass_capacity(const rq_index *idx, uint32_t remaining, bool seed
 
 // queries per pass: survivor / run buffers are 32 B per slot per query (keep one pass under ~24 GiB) and
 // (query, list) pairs per pass <= 2^22 (bounds the per-pair buffers and every launch size)
-static uint32_t pass_queries(const rq_index *idx, uint32_t remaining, uint32_t probe, uint32_t cap0, bool seg) {
+static uint32_t pass_queries(const rq_index *idx, uint32_t remaining, uint32_t probe, uint32_t cap0, bool seg, bool ext_lists = false) {
     // survivor records + run directory: 32 B per slot per query, 48 B when the pass also keeps the second directory buffer
     // (ws_prepare: capacities beyond the default, segmented passes, long directories); the budget is a third of the HBM that
     // was free once the index was resident (at least 4 GiB: an index that fills the HBM -- 100M x 768 -- still answers a
     // 32 768-query batch in ONE pass; split in two, every block of the matrix-core scan paid its start-up twice: a third
     // of that launch at dim 768)
     const uint64_t slot_bytes = cap0 > RQ_DEFAULT_CAP || seg || idx->big_dirs_hint.load() > 0 ? 48 : 32;
-    uint32_t step_nq = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(remaining, RQ_MAX_NQ_PER_PASS),
+    // Probe lists supplied by the caller = a shard of a multi-GPU deployment: most of a query's probed lists live on other ranks
+    // (empty here: skipped before any per-pair work), and the step's batch grows with the number of ranks so that a list still
+    // meets as many queries as on one GPU -- cut into passes of 65 536 queries, each pass of an 8-GPU step would bring a list
+    // 128 queries instead of 1024 and the matrix-core scan would run at half its rate (one-rank-of-eight rehearsal: 0.19 of
+    // peak).  Such passes may hold 16 x the queries / pairs (per-pair buffers: ~200 B per pair, 6.7 GB at 2^25 pairs).
+    const uint64_t max_nq = ext_lists ? 16ull * RQ_MAX_NQ_PER_PASS : RQ_MAX_NQ_PER_PASS, max_pairs = ext_lists ? (1ull << 26) : (1ull << 22);
+    uint32_t step_nq = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(remaining, max_nq),
                                                     std::max<uint64_t>(1, idx->pass_budget / ((uint64_t)cap0 * slot_bytes)));
-    return std::min<uint32_t>(step_nq, std::max<uint32_t>(1, (1u << 22) / std::min(probe, idx->k)));
+    return std::min<uint32_t>(step_nq, (uint32_t)std::max<uint64_t>(1, max_pairs / std::min(probe, idx->k)));
 }
 
 // After a finished pass: remember the capacity it needed and re-run exactly the queries whose survivor
@@ -1535,10 +1544,11 @@ static rq_status query_device(rq_index *idx, const float *d_q, uint32_t nq, uint
     for (uint32_t q0 = 0, step_nq = 0; q0 < nq; q0 += step_nq) {
         bool seg = false;
         const uint32_t cap0 = pass_capacity(idx, nq - q0, ext_thr != nullptr, &seg);
-        step_nq = pass_queries(idx, nq - q0, probe, cap0, seg);
+        step_nq = pass_queries(idx, nq - q0, probe, cap0, seg, ext_cluster != nullptr);
         QueryParams qp{step_nq, len, probe, topk, heuristic, cap0, std::max(cap0, std::max(RQ_DEFAULT_CAP, idx->cap_hint.load()))};
         qp.seg_final = seg && step_nq >= 256;
         qp.thr_init = ext_thr ? ext_thr + q0 : nullptr;
+        qp.ext_lists = ext_cluster != nullptr;
         RQC(ws_prepare(idx, *ws, qp));
         PassResult pr;
         const float *q_at = d_q + (uint64_t)q0 * len;
@@ -1691,6 +1701,8 @@ static rq_status finish_index(rq_index *idx) {
     RQC(derive_shadow_rows(idx));
     idx->h_offsets.resize((size_t)idx->k + 1);
     HIPC(hipMemcpy(idx->h_offsets.data(), idx->offsets.p, ((size_t)idx->k + 1) * 4, hipMemcpyDeviceToHost));
+    idx->nonempty_lists = 0;
+    for (uint32_t c = 0; c < idx->k; ++c) idx->nonempty_lists += idx->h_offsets[c + 1] > idx->h_offsets[c] ? 1u : 0u;
     {
         size_t free_b = 0, total_b = 0;
         HIPC(hipMemGetInfo(&free_b, &total_b));
@@ -2799,17 +2811,23 @@ rq_status rq_coarse_topk_device(const rq_index *idx, const float *d_queries, uin
     } rel{mi, ws};
     if (!ws->stream) HIPC(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
     hipStream_t st = ws->stream;
-    RQC(ws->y.ensure((uint64_t)nq * dim));
-    RQC(ws->dist.ensure((uint64_t)nq * std::max(kc, idx->k)));
-    const float *qp = d_queries;
-    if (len != dim) {
-        RQC(ws->qpad.ensure((uint64_t)nq * dim));
-        pad_rows_kernel<<<ceil_div((uint64_t)nq * dim, 256), 256, 0, st>>>(d_queries, ws->qpad.p, nq, len, dim);
-        qp = ws->qpad.p;
+    // the distance matrix is chunk x kc floats: queries go through in chunks of at most 2^31 cells (8 GiB), so that a
+    // multi-GPU batch (65536 x N queries) against tens of thousands of lists does not ask for one 70 GB buffer
+    const uint32_t chunk = (uint32_t)std::min<uint64_t>(nq, std::max<uint64_t>(1024, (1ull << 31) / std::max(kc, idx->k)));
+    RQC(ws->y.ensure((uint64_t)chunk * dim));
+    RQC(ws->dist.ensure((uint64_t)chunk * std::max(kc, idx->k)));
+    if (len != dim) RQC(ws->qpad.ensure((uint64_t)chunk * dim));
+    for (uint32_t q0 = 0; q0 < nq; q0 += chunk) {
+        const uint32_t m = std::min(chunk, nq - q0);
+        const float *qp = d_queries + (uint64_t)q0 * len;
+        if (len != dim) {
+            pad_rows_kernel<<<ceil_div((uint64_t)m * dim, 256), 256, 0, st>>>(qp, ws->qpad.p, m, len, dim);
+            qp = ws->qpad.p;
+        }
+        launch_rotate(qp, idx->P.p, ws->y.p, m, dim, m >= 32, st);
+        launch_coarse(idx->cent_t.p + list_lo, ws->y.p, ws->dist.p, kc, dim, m, idx->k, st);
+        launch_select(ws->dist.p, kc, np, d_out_cluster + (uint64_t)q0 * probe, d_out_dist + (uint64_t)q0 * probe, list_lo, probe, m, st);
     }
-    launch_rotate(qp, idx->P.p, ws->y.p, nq, dim, nq >= 32, st);
-    launch_coarse(idx->cent_t.p + list_lo, ws->y.p, ws->dist.p, kc, dim, nq, idx->k, st);
-    launch_select(ws->dist.p, kc, np, d_out_cluster, d_out_dist, list_lo, probe, nq, st);
     HIPC(hipStreamSynchronize(st));
     HIPC(hipGetLastError());
     return RQ_OK;
@@ -3105,9 +3123,9 @@ __global__ void gather_status_kernel(const unsigned long long *__restrict__ gath
 //   0  handshake: ONE ncclAllReduce(max) of three int32 {h, -h, error} with h = a hash of the call's parameters: a rank
 //      that failed validation or allocation, or was called with other parameters, makes EVERY rank return an error
 //      before any data collective is issued (mismatched counts would hang or corrupt the gather buffers);
-//   1  coarse ranking, sliced: rank r ranks lists [r k / world, (r+1) k / world) only (any disjoint cover works, the
-//      centroids are replicated), ONE all-gather of the nq x nprobe (distance, list) keys, merge: every rank holds the
-//      global probe lists and the ranking cost does not grow with the number of GPUs;
+//   1  coarse ranking, sliced by queries: rank r ranks queries [r nq / world, (r+1) nq / world) against ALL lists (the
+//      centroids are replicated), ONE all-gather of nq / world x nprobe (distance, list) keys per rank: every rank holds the
+//      global probe lists, each exactly the single-index ranking of its query;
 //   2  with shared thresholds (a shard's own threshold is looser than the reference's; a shard that does not hold a
 //      query's neighbourhood would re-rank most of what it scans):
 //        A  the nearest list alone (only its owner finds candidates): the usual staged pass;
@@ -3144,14 +3162,15 @@ static rq_status sharded_step(rq_index *mi, void *nccl_comm, uint32_t world, uin
     const uint64_t out_stride = (uint64_t)nq * width + 1;  // a rank's block of the final all-gather: keys + status word
     int my_rank = 0;
     rq_status err = validate_query(mi, d_queries, len, probe, topk, d_out_dist, d_out_id, d_out_n);
-    const bool sliced = api && world > 1 && (uint64_t)world * npb <= 16384;
+    const bool sliced = api && world > 1;
+    const uint64_t pchunk = (uint64_t)((nq + world - 1) / world) * npb;  // probe-list keys a rank contributes (query-sliced coarse ranking)
     auto alloc_all = [&]() -> rq_status {
         RQC(ws->sh_dist.ensure(cells));
         RQC(ws->sh_id.ensure(cells));
         RQC(ws->sh_n.ensure(nq));
-        RQC(ws->sh_packed.ensure(std::max<uint64_t>(out_stride, pcells)));
-        RQC(ws->sh_gathered.ensure(std::max<uint64_t>(out_stride, sliced ? pcells : 0) * world));
-        RQC(ws->sh_merged.ensure(std::max<uint64_t>(cells, sliced ? pcells : 0)));
+        RQC(ws->sh_packed.ensure(std::max<uint64_t>(out_stride, sliced ? pchunk : 0)));
+        RQC(ws->sh_gathered.ensure(std::max<uint64_t>(out_stride, sliced ? pchunk : 0) * world));
+        RQC(ws->sh_merged.ensure(cells));
         RQC(ws->sh_pc.ensure(2 * pcells + nq));
         RQC(ws->sh_pd.ensure(2 * pcells + nq));
         if (shared) {
@@ -3213,17 +3232,24 @@ static rq_status sharded_step(rq_index *mi, void *nccl_comm, uint32_t world, uin
     const bool need_lists = sliced || shared;  // the plain unsliced step ranks inside query_device
     if (need_lists) {
         if (sliced) {
-            const uint32_t lo = (uint32_t)((uint64_t)my_rank * mi->k / world), hi = (uint32_t)((uint64_t)(my_rank + 1) * mi->k / world);
-            note_hip(hipMemsetAsync(ws->sh_packed.p, 0xFF, pcells * 8, st), "hipMemsetAsync");  // an empty or failed slice: no list
-            if (err == RQ_OK && lo < hi) {
+            // The coarse ranking is sliced by QUERIES: rank r ranks queries [r * chunk, (r + 1) * chunk) against ALL k lists, one
+            // all-gather hands every rank every query's probe list.  (Until round 3 the slices were LISTS -- every rank ranked all
+            // queries against its k / world lists, all-gathered world x nprobe keys per query and merged them: with the batch
+            // growing with the world that is world x the keys on the wire -- 268 MB per rank at 8 x 65 536 queries -- plus a
+            // 512-key merge per query; by queries it is 33 MB per rank and no merge, the same distance flops, and the ranking of a
+            // query is literally the single-index ranking.)
+            const uint32_t chunk = (nq + world - 1) / world, q_lo = std::min<uint64_t>((uint64_t)my_rank * chunk, nq);
+            const uint32_t q_n = std::min<uint32_t>(chunk, nq - q_lo);
+            note_hip(hipMemsetAsync(ws->sh_packed.p, 0xFF, (uint64_t)chunk * npb * 8, st), "hipMemsetAsync");  // an empty or failed slice: no list
+            if (err == RQ_OK && q_n) {
                 note_hip(hipStreamSynchronize(st), "hipStreamSynchronize");
-                note(rq_coarse_topk_device(mi, d_queries, nq, len, lo, hi, npb, pc, pd));  // synchronous, on a pooled workspace
-                if (err == RQ_OK) pack_probe_keys_kernel<<<ceil_div(pcells, 256), 256, 0, st>>>(pc, pd, pcells, ws->sh_packed.p);
+                note(rq_coarse_topk_device(mi, d_queries + (uint64_t)q_lo * len, q_n, len, 0, mi->k, npb, pc, pd));  // synchronous, on a pooled workspace
+                if (err == RQ_OK) pack_probe_keys_kernel<<<ceil_div((uint64_t)q_n * npb, 256), 256, 0, st>>>(pc, pd, (uint64_t)q_n * npb, ws->sh_packed.p);
             }
-            const int rc = api->all_gather(ws->sh_packed.p, ws->sh_gathered.p, pcells, RQ_NCCL_UINT64, nccl_comm, st);
+            const int rc = api->all_gather(ws->sh_packed.p, ws->sh_gathered.p, (uint64_t)chunk * npb, RQ_NCCL_UINT64, nccl_comm, st);
             if (rc != 0) note(nccl_fail("ncclAllGather (probe lists)", rc));
-            merge_smallest_u64_kernel<<<nq, 256, (size_t)pow2_ceil(world * npb) * 8, st>>>(ws->sh_gathered.p, world, nq, npb, npb, ws->sh_merged.p, pcells);
-            unpack_probe_keys_kernel<<<ceil_div(pcells, 256), 256, 0, st>>>(ws->sh_merged.p, nq, npb, pc, pd, shared ? pc_a : nullptr, pd_a, pc_b, pd_b);
+            // the gathered blocks are the probe lists of queries 0 .. world * chunk in order (rows past nq are padding)
+            unpack_probe_keys_kernel<<<ceil_div(pcells, 256), 256, 0, st>>>(ws->sh_gathered.p, nq, npb, pc, pd, shared ? pc_a : nullptr, pd_a, pc_b, pd_b);
         } else if (err == RQ_OK) {
             note(rq_coarse_topk_device(mi, d_queries, nq, len, 0, mi->k, npb, pc, pd));
             if (shared) split_probe_kernel<<<ceil_div(pcells, 256), 256, 0, st>>>(pc, pd, nq, npb, pc_a, pd_a, pc_b, pd_b);

@@ -124,8 +124,9 @@ def main():
         res.update({f"{tag}_dist": od.cpu().numpy(), f"{tag}_ids": oi.cpu().numpy().view(np.uint32).astype(np.int64),
                     f"{tag}_cnt": on.cpu().numpy().astype(np.int64),
                     f"{tag}_local_rerank": np.array([rabitq_amd.index.last_profile()["rerank_candidates"]])})
-        want = ([("all_reduce", 4), ("all_gather", nq * probe), ("all_reduce", nq), ("all_gather", nq * 2 * topk + 1)] if shared else
-                [("all_reduce", 4), ("all_gather", nq * probe), ("all_gather", nq * topk + 1)])
+        per_rank = -(-nq // world) * probe   # the coarse ranking is sliced by queries: a rank contributes its queries' probe lists
+        want = ([("all_reduce", 4), ("all_gather", per_rank), ("all_reduce", nq), ("all_gather", nq * 2 * topk + 1)] if shared else
+                [("all_reduce", 4), ("all_gather", per_rank), ("all_gather", nq * topk + 1)])
         assert hc.calls == want, (hc.calls, want)
     rabitq_amd.index.set_option("shared_thresholds", 1)
     # a rank called with other parameters: the handshake makes EVERY rank fail, nobody blocks in a collective
