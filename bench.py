@@ -526,16 +526,21 @@ def run_workload(args, ctx, extras=True):
     # HBM bytes are NOT measured in this run (PMC counters need their own rocprofv3 pass): when the committed PMC summary
     # was taken on this exact workload its figures are quoted, labelled as such; otherwise traffic is null.
     traffic, dom_traffic, traffic_src = None, None, None
-    tr_path = os.path.join(ROOT, "profiles", "scan_traffic.json")
-    if os.path.exists(tr_path):
+    import glob as _glob
+    want_cfg = {"vectors": n, "dim": d, "lists": k_local, "nprobe": nprobe, "batch": B, "distribution": "hard" if hard else "easy"}
+    for tr_path in sorted(_glob.glob(os.path.join(ROOT, "profiles", "scan_traffic*.json"))):
         try:
             tj = json.load(open(tr_path))
-            if tj.get("config", {}) == {"vectors": n, "dim": d, "lists": k_local, "nprobe": nprobe, "batch": B}:  # same workload only
+            cfg_t = dict(tj.get("config", {}))
+            cfg_t.setdefault("distribution", "easy")
+            if cfg_t == want_cfg:  # a PMC pass of THIS workload only
                 traffic = tj.get("hbm_bytes_per_launch")
                 dom_traffic = tj.get("dominant_launch", {}).get("hbm_read_bytes")
-                traffic_src = "committed PMC pass profiles/scan_traffic.json (FETCH_SIZE x2, same workload), not measured in this run"
+                traffic_src = (f"committed PMC pass profiles/{os.path.basename(tr_path)} (FETCH_SIZE x2, same workload; its dominant launch: "
+                               f"{tj.get('dominant_launch', {}).get('kernel', '?')}), not measured in this run")
+                break
         except Exception:
-            traffic = None
+            continue
     scan_all = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "all scan launches of a batch: scan_kernel<W,CPL> (early stages) + scan_mfma_kernel<W,NT>",

@@ -536,8 +536,7 @@ static uint32_t scan_mfma_tile(uint32_t W, bool arena, bool additive = false) { 
 static size_t scan_mfma_ring_bytes(uint32_t W, bool arena = false) {  // scan_mfma_ring_slots<W, ARENA>() tile images
     (void)arena;
     const uint64_t slots = W <= 2 ? 4ull : (W >= 16 ? 5ull : 3ull);
-    static const size_t pad = getenv("RQ_EXP_MFMA_LDS_PAD_KB") ? (size_t)atoi(getenv("RQ_EXP_MFMA_LDS_PAD_KB")) * 1024 : 0;  // experiment: fewer blocks per CU
-    return slots * (32 * (12 * W + 2) + RQ_REC_TAIL * 32) * 4 + (W == 2 ? pad : 0);
+    return slots * (32 * (12 * W + 2) + RQ_REC_TAIL * 32) * 4;
 }
 template <int W, int NT, bool ARENA, bool ADD = false>
 static void launch_scan_mfma_t(const ScanPtrs &p, const ScanArgs &a, dim3 g, hipStream_t st) {

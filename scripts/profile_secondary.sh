@@ -15,7 +15,7 @@ import csv, glob, json
 f = glob.glob("gpurun_out/ksec_$tag/*/*kernel_stats.csv")[0]
 rows = [r for r in csv.DictReader(open(f)) if not any(t in r["Name"] for t in ("at::native", "Cijk_", "__amd_rocclr", "at::cuda", "rocprim", "hipcub"))]
 cfg = json.loads(open("gpurun_out/ksec_$tag.json").read().strip().splitlines()[-1])["config"]["workload"]
-with open("gpurun_out/profiles/r03_kernel_stats_$tag.csv", "w") as o:
+with open("gpurun_out/profiles/${R:-r04}_kernel_stats_$tag.csv", "w") as o:
     o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py $* --no-secondary --steps 3 --warmup 3 --no-cpu-baseline --no-two-in-flight --small-batch 0 --gt-queries 50\n")
     o.write(f"# ({cfg}; 3 warm-up + 3 timed + 2 breakdown batches and the streamed build); engine kernels only\n")
     w = csv.writer(o)
