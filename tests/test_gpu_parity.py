@@ -280,6 +280,38 @@ def test_options_flipped_under_concurrent_queries(rq, oracle):
     oidx.close()
 
 
+def test_additive_gate_falls_back_when_it_flags_too_much(rq, oracle):
+    """The additive gate of the matrix-core scan (dim 64 / 128) is looser than the rank-5 threshold it replaces; an index whose
+    batches send more than 3 % of the sub-tile steps down the exact path goes back to the bf16 threshold MFMA for good.  Queries
+    of two very different scales make the per-list range of v' (and with it the candidates' side of the bound) useless: the
+    first batch runs additive and flags nearly everything, later batches run the bf16 form -- with identical results throughout."""
+    from rabitq_amd import index as ix
+    n, d, k = 20000, 128, 8
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.8, seed=211, centre_scale=0.6)
+    P = synth.random_orthogonal(d, seed=212)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    gidx = rq.RaBitQ.build(x, centres, P)
+    queries, _, _ = synth.mixture(400, d, k, sigma=0.8, seed=213, centre_scale=0.6)
+    queries[::2] *= np.float32(40.0)          # every other query far outside the data: huge ycd, delta, v'
+    ix.set_option("scan_impl", 2)              # matrix cores wherever the kernel exists (the batch is small)
+    try:
+        seen = []
+        for rep in range(3):
+            _compare_with_oracle(rq, oracle, oidx, gidx, queries, k, 10, False)
+            pr = ix.last_profile()
+            seen.append((pr["matrix_launches"], pr["matrix_additive_launches"], pr["matrix_subtile_steps"], pr["matrix_exact_steps"]))
+        assert seen[0][1] > 0 and seen[0][3] * 32 > seen[0][2], seen        # first batch: additive, and it flagged > 3 %
+        assert seen[1][0] > 0 and seen[1][1] == 0 and seen[2][1] == 0, seen  # afterwards: the bf16 threshold
+        ix.set_option("scan_gate", 2)          # pinned additive: still the same answers
+        _compare_with_oracle(rq, oracle, oidx, gidx, queries, k, 10, False)
+        assert ix.last_profile()["matrix_additive_launches"] > 0
+    finally:
+        ix.set_option("scan_gate", 0)
+        ix.set_option("scan_impl", 0)
+    gidx.close()
+    oidx.close()
+
+
 def _compare_with_oracle(rq, oracle, oidx, gidx, queries, probe, topk, heur):
     rq.metrics_reset()
     d, ids, cnt = gidx.query_batch(queries, probe, topk, heur)
