@@ -560,10 +560,13 @@ __global__ __launch_bounds__(256) void list_uref_kernel(const float4 *__restrict
 // Here every (vector, centroid) distance is first APPROXIMATED as (|c|^2 + |x|^2) - 2 <c~, x~> with the inner products
 // from v_mfma_f32_32x32x16_bf16 (operands rounded to bf16, f32 accumulation: 16x the f32 MFMA rate), which is within
 //     m_x = (2^-8 + (2 dim + 64) 2^-24) 1.05 (Cmax + |x|)^2
-// of the reference's f32 value e_j (src/simd.rs:14-73):  |<x,c> - <x~,c~>| <= (2^-8 + 2^-17) |x||c| by the two operand
-// roundings (2^-9 relative each), (|x||c| <= (|x|+|c|)^2 / 4), the f32 accumulation of the 128-term products, the two
-// norms (a dim-long f32 fma chain each) and the reference's own chain ((dim/8 + 5) 2^-24 relative) are all inside the
-// second term; Cmax = the largest centroid norm.  So the exact minimiser j* (and every exact tie) has
+// of the reference's f32 value e_j (src/simd.rs:14-73).  bf16 keeps 8 significant bits: round-to-nearest is 2^-8 relative per
+// operand, so |<x,c> - <x~,c~>| <= (2^-7 + 2^-16) |x||c|, the term -2<x,c> of the distance is off by at most
+// (2^-6 + 2^-15) |x||c| <= (2^-8 + 2^-17) (|x|+|c|)^2   (|x||c| <= (|x|+|c|)^2 / 4): the first term of m_x, with its 2^-17
+// tail inside the factor 1.05 -- that factor is LOAD-BEARING (it is the only slack over the bf16 bound: do not tighten it).
+// The f32 accumulation of the 128-term products, the two norms (a dim-long f32 fma chain each) and the reference's own chain
+// ((dim/8 + 5) 2^-24 relative) are all inside the second term; Cmax = the largest centroid norm.  So the exact minimiser j*
+// (and every exact tie) has
 //     a_{j*} <= e_{j*} + m <= e_j + m <= a_j + 2 m   for every j,   in particular   a_{j*} <= a_min + 2 m:
 // pass 1 finds a_min per vector, pass 2 lists the lists with a <= a_min + 2 m (one on well separated data, a few on
 // overlapping clusters), assign_refine_kernel recomputes THOSE in the reference's lane order and takes the first
