@@ -1594,6 +1594,8 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
                                                            const float4 *__restrict__ list_uref /* ADD: U0 per list */,
                                                            const float4 *__restrict__ grp_vref /* ADD: V0, DV per list (two float4) */,
                                                            const ScanArgs a) {
+    // (an ADD + ARENA instantiation was built and measured in round 4: on the hard distribution -- overlapping clusters, hub lists with
+    // wide v' ranges -- the additive bound flags 95 % of the steps, 45 -> 131 ms per step: the arena stages keep the bf16 threshold)
     static_assert(!(ADD && ARENA), "the additive gate is built for the uniform survivor buffers only");
     constexpr uint32_t OPDW = 12 * W;            // operand dwords per record: dim fp6 fields
     constexpr uint32_t OPLD = rq_img_opld(OPDW, ADD);  // row stride (dwords) of the operand image: conflict-free ds_read_b64 (ADD at dim 128: ds_read_b128)

@@ -532,7 +532,7 @@ static bool scan_has_mfma(uint32_t W) {
 #endif
 static uint32_t scan_mfma_nt(uint32_t W, bool additive = false) { return W == 2 ? (additive ? RQ_ADD_NT2 : 3) : (W >= 4 ? 2 : 4); }
 static uint32_t scan_mfma_nw(uint32_t W, bool arena) { return W == 2 && !arena ? 8u : 4u; }  // scan_mfma_waves<W, ARENA>()
-static uint32_t scan_mfma_tile(uint32_t W, bool arena, bool additive = false) { return 32 * scan_mfma_nw(W, arena) * scan_mfma_nt(W, additive); }
+static uint32_t scan_mfma_tile(uint32_t W, bool arena, bool additive = false) { return 32 * scan_mfma_nw(W, arena) * scan_mfma_nt(W, additive && !arena); }
 static size_t scan_mfma_ring_bytes(uint32_t W, bool arena = false) {  // scan_mfma_ring_slots<W, ARENA>() tile images
     (void)arena;
     const uint64_t slots = W <= 2 ? 4ull : (W >= 16 ? 5ull : 3ull);
@@ -1177,7 +1177,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                 a.x = ws.scan_extra.p;
                 a.dense_dir = 0u;
                 pf.begin(use_mfma ? PF_SCAN_MATRIX : PF_SCAN);
-                if (use_mfma) launch_scan_mfma(sp, a, W, st, false);
+                if (use_mfma) launch_scan_mfma(sp, a, W, st, additive);  // (the kernel must match the record format stage_fill_kernel wrote)
                 else launch_scan(sp, a, W, st);
                 pf.end();
                 pf.begin(PF_GROUP);
