@@ -70,9 +70,10 @@ typedef struct {
 
 /* ---- library ------------------------------------------------------------------------------- */
 /* ABI revision of this header: bumped whenever a struct layout or the meaning of an entry point changes (3: sized
- * out-structs, rq_get_device_ptr refuses RQ_ARR_BASE on tiered indexes; options "scan_dense" and "coarse_impl" = 3 removed.
+ * out-structs, rq_get_device_ptr refuses RQ_ARR_BASE on tiered indexes; options "scan_dense" and the round-2 "coarse_impl" = 3 removed.
  * 4: rq_set_option("scan_debug") refuses the timing-ablation bits -- they exist in the developer build only --, the matrix-core
- * scan's step counters in rq_profile_t are always filled, new option "scan_gate").  A host checks rq_abi_version() ==
+ * scan's step counters in rq_profile_t are always filled, new option "scan_gate", "coarse_impl" = 3 is back with a new meaning,
+ * rq_profile_t.reserved became coarse_fallback_rows, .reserved2 matrix_additive_launches).  A host checks rq_abi_version() ==
  * RQ_ABI_VERSION once after loading the library. */
 #define RQ_ABI_VERSION 4
 uint32_t rq_abi_version(void);
@@ -315,7 +316,7 @@ rq_status rq_rerank(const rq_index *idx, const float *query_padded, const uint32
  * (sum over probed lists of len * (dim/8 + 16)) and the number of scan launches. */
 typedef struct {
     uint32_t struct_size;      /* in: sizeof(rq_profile_t) of the caller */
-    uint32_t reserved;
+    uint32_t coarse_fallback_rows; /* queries whose pre-filtered coarse ranking (option "coarse_impl") fell back to all-lists exact order */
     float ms_rotate, ms_coarse, ms_select, ms_prep, ms_group, ms_scan, ms_rerank, ms_sort, ms_replay,
         ms_total;
     uint64_t scan_bytes;       /* algorithmic bytes over all scan launches of the call */
@@ -358,8 +359,13 @@ rq_status rq_set_profiling(int level);
  * distance is at or above the stage's threshold (then the reference rejects it whatever its value).  0 = never.
  * Results are bit-identical either way.
  * "max_scan_blocks": test hook, blocks per scan launch (0 = hardware bound).
- * "coarse_impl": test hook, coarse-distance kernel: 0 = automatic (default), 1 = query rows through LDS, 2 = query
- * rows in scalar registers (what large batches use).
+ * "coarse_impl": coarse ranking (identical probe lists and distance bits for every value): 0 = automatic (default: batches of
+ * >= 2048 queries rank through the bf16 matrix-core pre-filter + exact-order refinement of the candidates within a proven margin
+ * of the nprobe-th approximate distance, where it applies -- dim/64 in {1, 2, 3, 4, 6, 8, 12}, <= 8192 lists, nprobe <= 64 --, else
+ * the exact-order distance kernels over all lists), 1 = exact-order kernel with the query rows through LDS, 2 = exact-order
+ * kernel with the query rows in scalar registers, 3 = the pre-filter wherever it applies (tests).  rq_profile_t.
+ * coarse_fallback_rows counts queries whose candidate set exceeded the refinement's 256 slots (near-equidistant centroids) or
+ * whose margin was not finite: they are ranked in exact order over all lists inside the same kernel.
  * "shared_thresholds": rq_query_batch_sharded_device: 1 (default) = with more than one shard the step runs the nearest
  * list first, all-reduces (min) the k-th best distances and seeds the rest of the probe list with them (see
  * rq_query_batch_device_seeded); 0 = every shard prunes with its own thresholds only; 2 = also with one shard (tests).

@@ -61,7 +61,7 @@ class BuildStatsT(_Sized):
 
 
 class ProfileT(_Sized):
-    _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_uint32)] + [(n, C.c_float) for n in ("ms_rotate", "ms_coarse", "ms_select", "ms_prep", "ms_group", "ms_scan",
+    _fields_ = [("struct_size", C.c_uint32), ("coarse_fallback_rows", C.c_uint32)] + [(n, C.c_float) for n in ("ms_rotate", "ms_coarse", "ms_select", "ms_prep", "ms_group", "ms_scan",
                                          "ms_rerank", "ms_sort", "ms_replay", "ms_total")] + [
         ("scan_bytes", C.c_uint64), ("scan_candidates", C.c_uint64), ("rerank_candidates", C.c_uint64),
         ("scan_launches", C.c_uint32), ("retries", C.c_uint32),

@@ -726,6 +726,92 @@ __global__ __launch_bounds__(256, (W <= 4 ? 2 : 1)) void assign_approx_kernel(co
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Coarse ranking through the same pre-filter (round 4; src/rabitq.rs:283-297: all k exact-order distances, select the nprobe
+// smallest, sort them).  coarse_approx_kernel writes, for every query, a'_j = |c_j|^2 - 2 <c~_j, y~> (the approximation above minus
+// the query's own |y|^2, a constant of the row) for every list; select_refine_wave_kernel (kernels_query.h) finds the nprobe-th
+// smallest a' of a row, lists the lists within 2 m_y above it (the true nprobe nearest are among them: the nprobe smallest-a' lists
+// all have e <= a' + |y|^2 + m, so the nprobe-th smallest exact distance is <= tau + m, and every list at or below it has
+// a' + |y|^2 <= e + m <= tau + 2 m), recomputes THOSE in the reference's lane order and selects / sorts on the exact values.
+// Roles are swapped against assign_approx_kernel (queries = A rows, lists = B columns), so that a wave's stores are 128-byte
+// runs of one query's row.
+// ------------------------------------------------------------------------------------------------
+template <int W, int NT>
+__global__ __launch_bounds__(256, (W <= 4 ? 2 : 1)) void coarse_approx_kernel(const float *__restrict__ y /* nq x dim, rotated queries */,
+                                                              const uint16_t *__restrict__ cent_bf /* k x dim bf16 */,
+                                                              const float *__restrict__ cnorm, uint32_t nq, uint32_t k,
+                                                              float *__restrict__ dist /* nq x k */) {
+    constexpr int DIM = 64 * W, NM = DIM / 16;
+    constexpr uint32_t ROWB = DIM * 2 + 16, TILEB = 32 * ROWB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char asg_lds[];  // 2 x (tile image | 32 norms), as assign_approx_kernel
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6, col = lane & 31, kh = lane >> 5;
+    const uint32_t v0 = (blockIdx.x * 4 + wave) * (32 * NT);
+    asg_bf16x8 afrag[NT][NM];  // k-elements 16 m + 8 kh .. + 7 of query v0 + 32 tile + col
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) {
+        const uint32_t v = v0 + 32 * tl + col;
+        const float *xp = y + (uint64_t)(v < nq ? v : (nq - 1)) * DIM + 8 * kh;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const float4 a = *reinterpret_cast<const float4 *>(xp + 16 * m), b = *reinterpret_cast<const float4 *>(xp + 16 * m + 4);
+            const uint4 pk = make_uint4(asg_bf16_pair(a.x, a.y), asg_bf16_pair(a.z, a.w), asg_bf16_pair(b.x, b.y), asg_bf16_pair(b.z, b.w));
+            afrag[tl][m] = __builtin_bit_cast(asg_bf16x8, pk);
+        }
+    }
+    const uint32_t ntile = (k + 31) / 32;
+    constexpr uint32_t PIECES = 32 * DIM * 2 / 16, NREG = (PIECES + 255) / 256;
+    auto stage = [&](uint32_t tile, uint4 (&regs)[NREG], float &cn) {  // global -> registers
+#pragma unroll
+        for (uint32_t i = 0; i < NREG; ++i) {
+            const uint32_t pc = t + 256 * i, row = pc / (DIM / 8), within = pc - row * (DIM / 8);
+            const uint32_t j = 32 * tile + row;
+            regs[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (pc < PIECES && j < k) regs[i] = *reinterpret_cast<const uint4 *>(cent_bf + (uint64_t)j * DIM + 8 * within);
+        }
+        cn = 0.0f;
+        if (t < 32 && 32 * tile + t < k) cn = cnorm[32 * tile + t];
+    };
+    auto land = [&](uint32_t buf, const uint4 (&regs)[NREG], float cn) {  // registers -> LDS
+        unsigned char *img = asg_lds + buf * (TILEB + 128);
+#pragma unroll
+        for (uint32_t i = 0; i < NREG; ++i) {
+            const uint32_t pc = t + 256 * i, row = pc / (DIM / 8), within = pc - row * (DIM / 8);
+            if (pc < PIECES) *reinterpret_cast<uint4 *>(img + row * ROWB + 16 * within) = regs[i];
+        }
+        if (t < 32) reinterpret_cast<float *>(img + TILEB)[t] = cn;
+    };
+    uint4 regs[NREG];
+    float cn_next;
+    stage(0, regs, cn_next);
+    land(0, regs, cn_next);
+    for (uint32_t tile = 0; tile < ntile; ++tile) {
+        __syncthreads();  // tile `tile` is in LDS; the other buffer is free
+        if (tile + 1 < ntile) stage(tile + 1, regs, cn_next);
+        const unsigned char *img = asg_lds + (tile & 1u) * (TILEB + 128);
+        const float cn = reinterpret_cast<const float *>(img + TILEB)[col];  // |c|^2 of this lane's list
+        asg_f32x16 acc[NT];
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) acc[tl] = asg_f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const asg_bf16x8 cf = *reinterpret_cast<const asg_bf16x8 *>(img + col * ROWB + (16 * m + 8 * kh) * 2);
+#pragma unroll
+            for (int tl = 0; tl < NT; ++tl) acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[tl][m], cf, acc[tl], 0, 0, 0);
+        }
+        const uint32_t j = 32 * tile + col;
+        if (j < k) {
+#pragma unroll
+            for (int tl = 0; tl < NT; ++tl)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {  // register r of lane half kh = query row (r & 3) + 8 (r >> 2) + 4 kh of the tile
+                    const uint32_t v = v0 + 32 * tl + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4 * kh;
+                    if (v < nq) dist[(uint64_t)v * k + j] = fmaf(-2.0f, acc[tl][r], cn);
+                }
+        }
+        if (tile + 1 < ntile) land((tile + 1) & 1u, regs, cn_next);
+    }
+}
+
 // exact-order distances (src/simd.rs:14-73) of every vector to its listed candidates, first minimum (smallest list id among
 // equal distances: kmeans_nearest_cluster's strict `<` over ascending j); two lanes per vector (lane half hf = AVX lanes
 // 4hf..4hf+3).  Vectors with 0 or more than RQ_ASSIGN_CAND candidates are appended to `redo` for the exact-order kernel.

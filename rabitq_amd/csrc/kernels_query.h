@@ -430,6 +430,216 @@ __global__ __launch_bounds__(256) void select_probe_wave_kernel(const float *__r
 }
 
 // ------------------------------------------------------------------------------------------------
+// Probe selection behind the matrix-core pre-filter of the coarse ranking (coarse_approx_kernel, kernels_build.h): `dist` holds
+// APPROXIMATE values a'_j = |c_j|^2 - 2 <c~_j, y~> (bf16 operands), each within m_y of e_j - |y|^2 (e_j = the reference's exact-order
+// f32 distance).  One wave per query:
+//   1. tau = the nprobe-th smallest a' of the row (the bisection of select_probe_wave);
+//   2. candidates = the lists with a' <= tau + 2 m_y: the true nprobe nearest -- and every exact tie with the nprobe-th -- are among
+//      them (kernels_build.h has the argument); typically nprobe + a few dozen;
+//   3. their EXACT distances in the reference's lane order (src/simd.rs:14-73: 8 GPU lanes = the 8 AVX lanes of one list, folded by
+//      reduce8_lanes), 8 lists per wave step;
+//   4. the nprobe smallest (distance, list id) keys of the candidates, ascending: exactly what select_probe_wave returns from a row of
+//      exact distances.
+// A row with more than RQ_COARSE_CAND candidates (near-equidistant centroids) or a margin that is not finite (NaN / inf input) is
+// ranked the plain way instead: the wave recomputes ALL k distances in exact order into the row and runs select_probe_wave on it.
+// ------------------------------------------------------------------------------------------------
+#define RQ_COARSE_CAND 256u
+template <int KPL>
+__global__ __launch_bounds__(256) void select_refine_wave_kernel(float *__restrict__ dist, const float *__restrict__ y,
+                                                                 const float *__restrict__ centroids, float cmax, uint32_t k, uint32_t dim,
+                                                                 uint32_t nprobe, uint32_t *__restrict__ out_cluster,
+                                                                 float *__restrict__ out_dist, uint32_t out_stride, uint32_t nq,
+                                                                 unsigned long long *__restrict__ fallback_rows /* counter, may be null */) {
+    __shared__ unsigned long long win[4][RQ_COARSE_CAND];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, b = blockIdx.x * 4 + wave;
+    if (b >= nq) return;
+    unsigned long long *wn = win[wave];
+    float *d = dist + (uint64_t)b * k;
+    const float *yr = y + (uint64_t)b * dim;
+    const uint32_t grp = lane >> 3, al = lane & 7;  // 8 lanes per list: AVX lane al of list slot grp
+    // exact-order distance of list j to the query (all 8 lanes of the group return it)
+    // (dim is a multiple of 64: eight AVX steps at a time, all sixteen loads of a chunk in flight before the first is used --
+    // one load per step, as a plain loop compiles to, made this kernel a chain of 256 dependent L2 round trips per query)
+    auto exact_dist4 = [&](const uint32_t (&jj)[4], float (&ee)[4]) {  // four lists at once: 40 loads in flight per 64 dimensions
+        const float *cp[4];
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cp[q] = centroids + (uint64_t)jj[q] * dim + al;
+        for (uint32_t e0 = 0; e0 < dim; e0 += 64) {
+            float vv[4][8], yv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                yv[i] = yr[e0 + 8 * i + al];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) vv[q][i] = cp[q][e0 + 8 * i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float df = vv[q][i] - yv[i];
+                    acc[q] = fmaf(df, df, acc[q]);
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ee[q] = reduce8_lanes(acc[q]);
+    };
+    uint32_t key[KPL];
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    auto list_of = [&](int i) { return 256u * (uint32_t)(i >> 2) + 4u * lane + (uint32_t)(i & 3); };
+    const bool vec4 = (k & 3u) == 0u;
+#pragma unroll
+    for (int i4 = 0; i4 < KPL; i4 += 4) {
+        const uint32_t j0 = list_of(i4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vec4 && j0 < k) {
+            v = *reinterpret_cast<const float4 *>(d + j0);
+        } else if (!vec4) {
+            if (j0 < k) v.x = d[j0];
+            if (j0 + 1 < k) v.y = d[j0 + 1];
+            if (j0 + 2 < k) v.z = d[j0 + 2];
+            if (j0 + 3 < k) v.w = d[j0 + 3];
+        }
+        const float ve[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = i4 + e;
+            key[i] = 0xFFFFFFFFu;
+            if (j0 + e < k) {
+                key[i] = ord32_biased(ve[e]);
+                kmin = key[i] < kmin ? key[i] : kmin;
+                kmax = key[i] > kmax ? key[i] : kmax;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const uint32_t a = __shfl_xor(kmin, o, 64), c = __shfl_xor(kmax, o, 64);
+        kmin = a < kmin ? a : kmin;
+        kmax = c > kmax ? c : kmax;
+    }
+    auto count_le = [&](uint32_t t) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) c += (uint32_t)__popcll(__ballot(key[i] <= t));
+        return c;
+    };
+    kmin = __builtin_amdgcn_readfirstlane(kmin), kmax = __builtin_amdgcn_readfirstlane(kmax);
+    // ANY T with count(key <= T) >= nprobe bounds the nprobe-th smallest a' from above, which is all the candidate rule needs: the
+    // bisection stops as soon as the count lands in [nprobe, nprobe + 12] (7-9 steps instead of the ~25 an exact threshold takes;
+    // the price is up to 12 more candidates)
+    uint32_t lo = kmin, hi = kmax;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        const uint32_t c = count_le(mid);
+        if (c >= nprobe) {
+            hi = mid;
+            if (c <= nprobe + 12) break;
+        } else {
+            lo = mid + 1;
+        }
+    }
+    const float tau = ord32_unbias(hi);
+    // the query's margin (kernels_build.h): |y| from an f32 sum (any order: its rounding is inside the factors below)
+    float yn = 0.0f;
+    for (uint32_t e = lane; e < dim; e += 64) yn = fmaf(yr[e], yr[e], yn);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) yn += __shfl_xor(yn, o, 64);
+    const float rad = cmax + sqrtf(yn) * 1.000001f;
+    const float mx = (0.00390625f + (float)(2 * dim + 64) * 5.9604645e-8f) * 1.05f * (rad * rad);
+    float thr2 = tau + 2.0f * mx;
+    thr2 = thr2 + fabsf(thr2) * 1.0e-6f;  // the comparison's own rounding
+    const bool fin = fabsf(thr2) < 3.0e38f && fabsf(tau) < 3.0e38f;  // false for NaN / inf
+    const uint32_t T2 = ord32_biased(thr2);
+    const uint32_t c2 = fin ? count_le(T2) : 0xFFFFFFFFu;
+    if (!(c2 <= RQ_COARSE_CAND) || c2 < nprobe) {  // (wave-uniform) the plain way: every distance in exact order, then the exact selection
+        for (uint32_t j0 = 0; j0 < k; j0 += 32) {
+            uint32_t jj[4];
+            float ee[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) jj[q] = j0 + 8 * q + grp < k ? j0 + 8 * q + grp : 0u;
+            exact_dist4(jj, ee);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (j0 + 8 * q + grp < k && al == 0) d[j0 + 8 * q + grp] = ee[q];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own stores: read back below by other lanes of the wave
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (fallback_rows && lane == 0) atomicAdd(fallback_rows, 1ull);
+        select_probe_wave<KPL>(dist, k, nprobe, out_cluster, out_dist, 0u, out_stride, b, wn);
+        return;
+    }
+    // candidate ids into LDS (low half of the slots), in register order
+    uint32_t base = 0;
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        const bool take = key[i] <= T2;
+        const uint64_t m = __ballot(take);
+        if (m) {  // wave-uniform
+            if (take) wn[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = list_of(i);
+            base += (uint32_t)__popcll(m);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    // exact keys, 8 candidates per step
+    for (uint32_t c0 = 0; c0 < c2; c0 += 32) {
+        uint32_t jj[4];
+        float ee[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) jj[q] = c0 + 8 * q + grp < c2 ? (uint32_t)wn[c0 + 8 * q + grp] : 0u;
+        exact_dist4(jj, ee);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (c0 + 8 * q + grp < c2 && al == 0) wn[c0 + 8 * q + grp] = ((unsigned long long)ord32_biased(ee[q]) << 32) | jj[q];
+    }
+    for (uint32_t i = c2 + lane; i < RQ_COARSE_CAND; i += 64) wn[i] = ~0ull;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    // bitonic sort of the RQ_COARSE_CAND slots, ascending: element index i = lane + 64 s (s = the lane's slot); at a step (size, stride)
+    // element i keeps the minimum of (i, i ^ stride) iff ((i & stride) == 0) == ((i & size) == 0)  (the last size ascends everywhere)
+    constexpr int NS = RQ_COARSE_CAND / 64;
+    unsigned long long vs[NS];
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) vs[sl] = wn[lane + 64 * sl];
+#pragma unroll
+    for (int size = 2; size <= 64 * NS; size <<= 1)
+#pragma unroll
+        for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+            if (stride >= 64) {  // the partner is another slot of the same lane
+                const int ss = stride / 64;
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl) {
+                    if (sl & ss) continue;
+                    const bool asc = size >= 64 * NS || ((64 * sl) & size) == 0;
+                    const unsigned long long a0 = vs[sl], b0 = vs[sl | ss];
+                    const unsigned long long mn = a0 < b0 ? a0 : b0, mxv = a0 < b0 ? b0 : a0;
+                    vs[sl] = asc ? mn : mxv, vs[sl | ss] = asc ? mxv : mn;
+                }
+            } else {
+                const bool lower = (lane & stride) == 0;
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl) {
+                    const unsigned long long o = __shfl_xor(vs[sl], stride, 64);
+                    const bool asc = size < 64 ? (lane & size) == 0 : (size >= 64 * NS || ((64 * sl) & size) == 0);
+                    const unsigned long long mn = o < vs[sl] ? o : vs[sl], mxv = o < vs[sl] ? vs[sl] : o;
+                    vs[sl] = lower == asc ? mn : mxv;
+                }
+            }
+        }
+    const unsigned long long v0 = vs[0];
+    // v0 of lane l = the l-th smallest key
+    if (lane < nprobe) {
+        out_cluster[(uint64_t)b * out_stride + lane] = (uint32_t)v0;
+        out_dist[(uint64_t)b * out_stride + lane] = ord32_unbias((uint32_t)(v0 >> 32));
+    }
+    for (uint32_t i = nprobe + lane; i < out_stride; i += 64) {  // fewer lists than requested: "no list"
+        out_cluster[(uint64_t)b * out_stride + i] = 0xFFFFFFFFu;
+        out_dist[(uint64_t)b * out_stride + i] = __builtin_inff();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Shard merge (multi-GPU fan-out): per query, the m_out smallest of the `world` x `width` u64 keys the ranks
 // contributed (all-gathered as in[world][nq][width], rows in any order), ascending.  Used for the probe lists
 // (key = distance bits << 32 | list id) and for the per-shard top-k (key = Ord32 image << 32 | global id).

@@ -225,6 +225,7 @@ struct Workspace {
     DevBuf<float4> grp_vref;  // additive gate: per list, centre and half-range of v' over the stage's pairs (group_vrange_kernel)
     bool pend_additive = false;  // the pass ran a matrix-core stage with the additive gate (finish_pass reads its flag rate)
     uint32_t pend_matrix_stages = 0;  // matrix-core stages of the pass
+    bool pend_prefiltered = false;    // the pass ranked its lists through the matrix-core pre-filter (totals[12] = rows that fell back)
     DevBuf<SurvRec> surv, arr;
     DevBuf<RunRec> runs, runs_tmp;
     bool use_runs_tmp = false;
@@ -273,6 +274,9 @@ struct rq_index {
     DevBuf<uint64_t> codes;
     DevBuf<float4> factors;
     DevBuf<float4> list_uref;  // per list: mean of u' = (1, cds, ., eb) / factor_ip over its regular vectors (additive gate of the matrix-core scan; derived)
+    DevBuf<uint16_t> cent_bf;  // k x dim bf16 image of the rotated centroids and their squared norms (coarse pre-filter; derived)
+    DevBuf<float> cent_sqnorm;
+    float cent_norm_max = INFINITY;  // largest centroid norm (inf: no pre-filter)
     uint32_t nonempty_lists = 0;  // lists with at least one vector (a shard of a multi-GPU index owns only some of the k lists)
     std::atomic<int> additive_loose{0};  // the additive gate flagged too many sub-tile steps on this index: later passes use the bf16 threshold
     std::mutex ws_mu;
@@ -390,7 +394,7 @@ __global__ void unpack_topk_keys_kernel(const unsigned long long *__restrict__ k
 }
 
 // coarse ranking distances (src/rabitq.rs:283-287), every query against the lists [first, first + k) of cent_t
-static std::atomic<int> g_coarse_impl{0};  // 0 auto, 1 LDS-broadcast kernels, 2 scalar-register kernel (test hook)
+static std::atomic<int> g_coarse_impl{0};  // 0 auto, 1 LDS-broadcast kernels, 2 scalar-register kernel, 3 bf16-MFMA pre-filter + exact refinement wherever it applies
 static std::atomic<int> g_scan_dbg{0};
 // the probe selection runs one wave per query (row in registers) for these shapes, one block per query otherwise
 static bool select_is_wave(uint32_t k, uint32_t nprobe, uint32_t nq) { return nprobe <= 64 && k <= 8192 && nq >= 8; }
@@ -405,6 +409,39 @@ static void launch_coarse(const float *cent_t, const float *y, float *dist, uint
     else
         coarse_dist_kernel<4><<<dim3(ceil_div(nq, 4), ceil_div(k, 256)), 256, 4 * dim * sizeof(float), st>>>(cent_t, y, dist, k, dim, nq,
                                                                                                     kstride);
+}
+
+// Coarse ranking of nq rotated queries against ALL k lists: the matrix-core pre-filter + exact-order refinement where it applies
+// (coarse_impl 3, or -- once measured faster -- auto for big batches), else the exact-order distance kernels + selection.
+static bool coarse_prefilter_has(uint32_t W) { return W == 1 || W == 2 || W == 3 || W == 4 || W == 6 || W == 8 || W == 12; }
+static bool coarse_prefilter_applies(const rq_index *idx, uint32_t nq, uint32_t nprobe) {
+    const int impl = g_coarse_impl.load();
+    return (impl == 3 || (impl == 0 && nq >= 2048)) && coarse_prefilter_has(idx->W) && std::isfinite(idx->cent_norm_max) &&
+           idx->cent_bf.p != nullptr && select_is_wave(idx->k, nprobe, nq) && idx->k >= 64 && nprobe >= 1;
+}
+static void launch_coarse_prefiltered(const rq_index *idx, const float *y, float *dist, uint32_t nq, uint32_t nprobe, uint32_t *out_cluster,
+                                      float *out_dist, uint32_t out_stride, unsigned long long *fallback_rows, hipStream_t st) {
+    const uint32_t k = idx->k, dim = idx->dim;
+#define RQ_CAP(WW, NT)                                                                                                      \
+    coarse_approx_kernel<WW, NT><<<ceil_div(nq, 128 * NT), 256, assign_lds_bytes<WW, NT>(), st>>>(y, idx->cent_bf.p, idx->cent_sqnorm.p, nq, \
+                                                                                                  k, dist)
+    switch (idx->W) {
+        case 1: RQ_CAP(1, 2); break;
+        case 2: RQ_CAP(2, 2); break;
+        case 3: RQ_CAP(3, 1); break;
+        case 4: RQ_CAP(4, 1); break;
+        case 6: RQ_CAP(6, 1); break;
+        case 8: RQ_CAP(8, 1); break;
+        default: RQ_CAP(12, 1); break;
+    }
+#undef RQ_CAP
+    const dim3 g(ceil_div(nq, 4)), b(256);
+    if (k <= 1024)
+        select_refine_wave_kernel<16><<<g, b, 0, st>>>(dist, y, idx->centroids.p, idx->cent_norm_max, k, dim, nprobe, out_cluster, out_dist, out_stride, nq, fallback_rows);
+    else if (k <= 4096)
+        select_refine_wave_kernel<64><<<g, b, 0, st>>>(dist, y, idx->centroids.p, idx->cent_norm_max, k, dim, nprobe, out_cluster, out_dist, out_stride, nq, fallback_rows);
+    else
+        select_refine_wave_kernel<128><<<g, b, 0, st>>>(dist, y, idx->centroids.p, idx->cent_norm_max, k, dim, nprobe, out_cluster, out_dist, out_stride, nq, fallback_rows);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -642,6 +679,9 @@ static rq_status ensure_kernel_attributes() {
         set(reinterpret_cast<const void *>(assign_approx_kernel<6, 1>), (int)assign_lds_bytes<6, 1>(), "assign_approx_kernel<6,1>");
         set(reinterpret_cast<const void *>(assign_approx_kernel<8, 1>), (int)assign_lds_bytes<8, 1>(), "assign_approx_kernel<8,1>");
         set(reinterpret_cast<const void *>(assign_approx_kernel<12, 1>), (int)assign_lds_bytes<12, 1>(), "assign_approx_kernel<12,1>");
+        set(reinterpret_cast<const void *>(coarse_approx_kernel<6, 1>), (int)assign_lds_bytes<6, 1>(), "coarse_approx_kernel<6,1>");
+        set(reinterpret_cast<const void *>(coarse_approx_kernel<8, 1>), (int)assign_lds_bytes<8, 1>(), "coarse_approx_kernel<8,1>");
+        set(reinterpret_cast<const void *>(coarse_approx_kernel<12, 1>), (int)assign_lds_bytes<12, 1>(), "coarse_approx_kernel<12,1>");
         set(reinterpret_cast<const void *>(sb_finish_kernel<true>), 104 * 1024, "sb_finish_kernel");   // (+ 33 KiB of static LDS)
         set(reinterpret_cast<const void *>(sb_finish_kernel<false>), 104 * 1024, "sb_finish_kernel");  // (+ 49 KiB of static LDS)
 #define RQ_SBQ_ATTR(WW)                                                                                  \
@@ -709,7 +749,7 @@ static rq_status ws_prepare(const rq_index *idx, Workspace &ws, const QueryParam
     RQC(ws.qnib.ensure(npairs * 8 * idx->W));
     RQC(ws.qf6.ensure(npairs * 12 * idx->W));
     RQC(ws.rough_cnt.ensure(nq));
-    RQC(ws.totals.ensure(8));
+    RQC(ws.totals.ensure(16));  // [0..7] the pass's totals, [12] rows of the pre-filtered coarse ranking that fell back to exact order
     RQC(ws.stat.ensure(256));
     // record-major (8W + tail per pair) or tile images (pairs padded to 32 per list, 12W + 2 + tail per slot)
     RQC(ws.recs.ensure((npairs + 32ull * idx->k + 32) * (12ull * idx->W + 2 + RQ_REC_TAIL)));
@@ -766,6 +806,7 @@ static rq_status finish_pass(const rq_index *idx, Workspace &ws, PassResult *res
     if (ws.pend_additive && ws.h_totals[8] >= 4096 && ws.h_totals[9] * 32 > ws.h_totals[8])
         const_cast<rq_index *>(idx)->additive_loose.store(1);
     if (prof_acc) prof_acc->matrix_subtile_steps += ws.h_totals[8], prof_acc->matrix_exact_steps += ws.h_totals[9];
+    if (prof_acc) prof_acc->coarse_fallback_rows += (uint32_t)std::min<unsigned long long>(ws.h_totals[10], 0xFFFFFFFFull);
     if (pf.on && prof_acc) {
         float ms[PF_N] = {0};
         pf.collect(ms);
@@ -828,6 +869,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     const uint32_t nq = qp.nq, nprobe = std::min(qp.probe, k), topk = qp.topk;
     const uint32_t npairs = nq * nprobe;
     hipStream_t st = ws.stream;
+    ws.pend_prefiltered = false;
     Prof &pf = ws.prof;
     pf.reset(g_profiling.load(), st);
     pf.begin(PF_TOTAL);
@@ -965,12 +1007,20 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         probe_cluster = ext_cluster;
         probe_dist = ext_dist;
     } else {
-        pf.begin(PF_COARSE);
-        launch_coarse(idx->cent_t.p, ws.y.p, ws.dist.p, k, dim, nq, k, st);
-        pf.end();
-        pf.begin(PF_SELECT);
-        launch_select(ws.dist.p, k, nprobe, ws.probe_cluster.p, ws.probe_dist.p, 0, nprobe, nq, st);
-        pf.end();
+        if (coarse_prefilter_applies(idx, nq, nprobe)) {
+            pf.begin(PF_COARSE);
+            HIPC(hipMemsetAsync(ws.totals.p + 12, 0, 8, st));
+            launch_coarse_prefiltered(idx, ws.y.p, ws.dist.p, nq, nprobe, ws.probe_cluster.p, ws.probe_dist.p, nprobe, ws.totals.p + 12, st);
+            ws.pend_prefiltered = true;
+            pf.end();
+        } else {
+            pf.begin(PF_COARSE);
+            launch_coarse(idx->cent_t.p, ws.y.p, ws.dist.p, k, dim, nq, k, st);
+            pf.end();
+            pf.begin(PF_SELECT);
+            launch_select(ws.dist.p, k, nprobe, ws.probe_cluster.p, ws.probe_dist.p, 0, nprobe, nq, st);
+            pf.end();
+        }
     }
 
     // 3. per-pair query quantisation (:304-317)
@@ -1335,7 +1385,8 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     pf.end();
     if (pf.on) (void)hipEventRecord(pf.spans[total_span].b, st);
     HIPC(hipMemcpyAsync(ws.h_totals, ws.totals.p, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    ws.h_totals[7] = 0, ws.h_totals[8] = 0, ws.h_totals[9] = 0;
+    ws.h_totals[7] = 0, ws.h_totals[8] = 0, ws.h_totals[9] = 0, ws.h_totals[10] = 0;
+    if (ws.pend_prefiltered) HIPC(hipMemcpyAsync(ws.h_totals + 10, ws.totals.p + 12, 8, hipMemcpyDeviceToHost, st));
     if (ws.pend_matrix_stages) {  // sub-tile steps of the matrix-core stages and how many of them took the exact path
         stat_fold_kernel<<<1, 64, 0, st>>>(ws.stat.p, ws.stat.p + 200);
         HIPC(hipMemcpyAsync(ws.h_totals + 8, ws.stat.p + 200, 16, hipMemcpyDeviceToHost, st));
@@ -1691,6 +1742,20 @@ static rq_status finish_index(rq_index *idx) {
         if (idx->n)
             factor_stats_kernel<<<(uint32_t)std::min<uint64_t>(ceil_div(idx->n, 256), 4096), 256>>>(idx->factors.p, idx->n, st4.p);
         HIPC(hipMemcpy(&idx->fstats, st4.p, 16, hipMemcpyDeviceToHost));
+    }
+    idx->cent_norm_max = INFINITY;
+    if (idx->k) {  // bf16 centroids + norms for the matrix-core pre-filter of the coarse ranking
+        const uint64_t cells = (uint64_t)idx->k * idx->dim;
+        DevBuf<uint32_t> mxb;
+        RQC(mxb.alloc(1));
+        HIPC(hipMemset(mxb.p, 0, 4));
+        RQC(idx->cent_bf.alloc(cells));
+        RQC(idx->cent_sqnorm.alloc(idx->k));
+        to_bf16_kernel<<<ceil_div(cells, 2048), 256>>>(idx->centroids.p, cells, idx->cent_bf.p);
+        row_sqnorm_kernel<<<ceil_div(idx->k, 256), 256>>>(idx->centroids.p, idx->k, idx->dim, idx->cent_sqnorm.p, mxb.p);
+        float m2 = 0.0f;
+        HIPC(hipMemcpy(&m2, mxb.p, 4, hipMemcpyDeviceToHost));
+        idx->cent_norm_max = std::isfinite(m2) && m2 < 1.0e30f ? std::sqrt(m2) * 1.000001f : INFINITY;
     }
     if (idx->k) {  // per-list reference of the candidates' side of the additive gate
         RQC(idx->list_uref.alloc(idx->k));
@@ -2825,6 +2890,10 @@ rq_status rq_coarse_topk_device(const rq_index *idx, const float *d_queries, uin
             qp = ws->qpad.p;
         }
         launch_rotate(qp, idx->P.p, ws->y.p, m, dim, m >= 32, st);
+        if (kc == idx->k && coarse_prefilter_applies(idx, m, np)) {
+            launch_coarse_prefiltered(idx, ws->y.p, ws->dist.p, m, np, d_out_cluster + (uint64_t)q0 * probe, d_out_dist + (uint64_t)q0 * probe, probe, nullptr, st);
+            continue;
+        }
         launch_coarse(idx->cent_t.p + list_lo, ws->y.p, ws->dist.p, kc, dim, m, idx->k, st);
         launch_select(ws->dist.p, kc, np, d_out_cluster + (uint64_t)q0 * probe, d_out_dist + (uint64_t)q0 * probe, list_lo, probe, m, st);
     }
@@ -3087,6 +3156,7 @@ static void profile_add(rq_profile_t &acc, const rq_profile_t &x) {
     acc.ms_early += x.ms_early, acc.small_batch_passes += x.small_batch_passes;
     acc.survivor_workspace_bytes = std::max(acc.survivor_workspace_bytes, x.survivor_workspace_bytes), acc.segmented_passes += x.segmented_passes;
     acc.matrix_additive_launches += x.matrix_additive_launches;
+    acc.coarse_fallback_rows += x.coarse_fallback_rows;
 }
 
 // probe lists <-> merge keys (f32 distance bits << 32 | list id: distances are >= 0, so the bits order like the values;
@@ -3380,7 +3450,7 @@ rq_status rq_set_option(const char *name, int value) {
         return RQ_OK;
     }
     if (std::string(name) == "coarse_impl") {  // test hook: coarse-distance kernel (0 auto, 1 LDS broadcast, 2 scalar registers)
-        if (value < 0 || value > 2) return fail(RQ_ERR_INVALID, "coarse_impl must be 0, 1 or 2");
+        if (value < 0 || value > 3) return fail(RQ_ERR_INVALID, "coarse_impl must be 0, 1, 2 or 3");
         g_coarse_impl = value;
         return RQ_OK;
     }

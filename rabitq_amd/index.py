@@ -325,7 +325,7 @@ def set_option(name: str, value: int) -> None:
 def last_profile() -> dict:
     p = ProfileT()
     check(lib().rq_last_profile(C.byref(p)))
-    return {name: getattr(p, name) for name, _ in ProfileT._fields_ if name not in ("struct_size", "reserved", "reserved2")}
+    return {name: getattr(p, name) for name, _ in ProfileT._fields_ if name != "struct_size"}
 
 
 def calculate_recall(truth, res, topk: int) -> float:

@@ -186,7 +186,7 @@ def test_query_matches_golden(rq, path):
 # (the timing ablations -- results wrong -- exist in the developer build only; what the product accepts must
 # leave the golden results untouched, and may be changed while queries are in flight)
 OPTION_VALUES = {
-    "scan_impl": [0, 1, 2], "scan_gate": [0, 1, 2], "coarse_impl": [0, 1, 2], "group_rank": [0, 1, 2], "scan_tile_table": [0, 1, 2],
+    "scan_impl": [0, 1, 2], "scan_gate": [0, 1, 2], "coarse_impl": [0, 1, 2, 3], "group_rank": [0, 1, 2], "scan_tile_table": [0, 1, 2],
     "dense_dir": [0, 1], "small_batch": [0, 1], "small_batch_span": [64, 2560, 100000], "stage_growth": [0, 2, 16],
     "survivor_segments": [0, 1, 2, 3], "max_scan_blocks": [0, 1, 7], "shared_thresholds": [0, 1, 2], "assign_impl": [0, 1],
     "rerank_shadow": [0, 1], "scan_debug": [0, 128, 512, 4096, 16384, 128 | 512 | 4096],
@@ -223,7 +223,7 @@ def test_every_option_value_keeps_golden_results(rq):
         for bad in (1, 2, 4, 64, 256, 1024, 8192, 128 | 64):
             with pytest.raises(rq.RabitqError):
                 ix.set_option("scan_debug", bad)
-        for name, bad in (("scan_gate", 3), ("scan_impl", 3), ("coarse_impl", 3), ("scan_dense", 1)):
+        for name, bad in (("scan_gate", 3), ("scan_impl", 3), ("coarse_impl", 4), ("scan_dense", 1)):
             with pytest.raises(rq.RabitqError):
                 ix.set_option(name, bad)
     finally:
@@ -310,6 +310,49 @@ def test_additive_gate_falls_back_when_it_flags_too_much(rq, oracle):
         ix.set_option("scan_impl", 0)
     gidx.close()
     oidx.close()
+
+
+@pytest.mark.parametrize("d,k,nq,probe,kind", [(128, 4096, 3000, 64, "mixture"), (128, 300, 2500, 64, "mixture"), (64, 1000, 2100, 33, "ties"),
+                                                  (256, 700, 2100, 64, "equidistant"), (768, 260, 2100, 20, "mixture"),
+                                                  (128, 5000, 2200, 64, "scaled"), (128, 130, 2100, 1, "nan")])
+def test_prefiltered_coarse_ranking_equals_exact_order_kernels(rq, d, k, nq, probe, kind):
+    """Coarse ranking through the bf16 matrix-core pre-filter + exact-order refinement (coarse_impl = 3; automatic for big batches)
+    against the plain exact-order kernel + selection (rq_coarse_rank): list ids and distance bits of every probe list.
+    ties: duplicate centroids (exact ties at the selection threshold); equidistant: centroids on a sphere around the queries (more
+    candidates than the refinement holds: the in-kernel exact fall-back); scaled: coordinates x 3e3; nan: a NaN query."""
+    import torch
+    from rabitq_amd import index as ix
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(d + k)
+    centres = rng.standard_normal((k, d)).astype(np.float32)
+    queries = (centres[rng.integers(0, k, nq)] + 0.5 * rng.standard_normal((nq, d))).astype(np.float32)
+    if kind == "ties":
+        centres[k // 2:] = centres[: k - k // 2]            # every centroid twice
+    elif kind == "equidistant":
+        centres /= np.linalg.norm(centres, axis=1, keepdims=True)
+        queries = (1e-3 * rng.standard_normal((nq, d))).astype(np.float32)   # all lists at distance ~1: hundreds within the margin
+    elif kind == "scaled":
+        centres *= np.float32(3e3)
+        queries *= np.float32(3e3)
+    elif kind == "nan":
+        queries[5, 3] = np.nan
+    x = centres[rng.integers(0, k, 4 * k)] + 0.1 * rng.standard_normal((4 * k, d)).astype(np.float32)
+    idx = rq.RaBitQ.build(x.astype(np.float32), centres, synth.random_orthogonal(d, seed=9))
+    _, want_cl, want_cd = rq.ops.coarse_rank(idx, queries, probe)          # the plain exact-order kernel + selection
+    q = torch.from_numpy(queries).to(dev)
+    try:
+        for impl in (3, 0):
+            ix.set_option("coarse_impl", impl)
+            pc = torch.zeros((nq, probe), device=dev, dtype=torch.int32)
+            pdd = torch.zeros((nq, probe), device=dev, dtype=torch.float32)
+            idx.coarse_topk_device(q.data_ptr(), nq, d, 0, k, probe, pc.data_ptr(), pdd.data_ptr())
+            got_cl, got_cd = pc.cpu().numpy().view(np.uint32), pdd.cpu().numpy()
+            rows = np.arange(nq) if kind != "nan" else np.delete(np.arange(nq), 5)     # (NaN inputs are not matched: INTEGRATION.md)
+            assert np.array_equal(got_cl[rows], want_cl[rows]), (impl, np.argwhere(got_cl[rows] != want_cl[rows])[:5])
+            assert np.array_equal(got_cd[rows].view(np.uint32), want_cd[rows].view(np.uint32)), impl
+    finally:
+        ix.set_option("coarse_impl", 0)
+    idx.close()
 
 
 def _compare_with_oracle(rq, oracle, oidx, gidx, queries, probe, topk, heur):
@@ -1063,7 +1106,7 @@ def test_begin_end_overflow_retry_matches_sync(rq):
     assert np.array_equal(res[0][0], res[1][0])
 
 
-@pytest.mark.parametrize("coarse_impl", [0, 2])
+@pytest.mark.parametrize("coarse_impl", [0, 2, 3])
 @pytest.mark.parametrize("k", [2000, 5000])
 def test_many_lists_probe_selection_matches_oracle(rq, oracle, k, coarse_impl):
     # the register-resident probe selection is instantiated per list-count bracket (<= 1024, <= 4096, <= 8192):
@@ -1104,7 +1147,7 @@ def test_coarse_distance_kernels_agree_bitwise(rq, oracle, d, k, nq):
     gidx = rq.RaBitQ.build(x, centres, P)
     queries, _, _ = synth.mixture(nq, d, k, sigma=0.9, seed=d + k + 1, centre_scale=0.8)
     try:
-        for impl in (1, 2):
+        for impl in (1, 2, 3):
             ix.set_option("coarse_impl", impl)
             _compare_with_oracle(rq, oracle, oidx, gidx, queries, min(k, 40), 10, False)
             _compare_with_oracle(rq, oracle, oidx, gidx, queries[:3], 7, 5, False)
