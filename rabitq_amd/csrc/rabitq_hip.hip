@@ -564,9 +564,6 @@ static bool scan_has_mfma(uint32_t W) {
         default: return false;
     }
 }
-#ifndef RQ_ADD_NT2
-#define RQ_ADD_NT2 4  // sub-tiles per wave of the additive-gate instantiation at dim 128
-#endif
 static uint32_t scan_mfma_nt(uint32_t W, bool additive = false) { return W == 2 ? (additive ? RQ_ADD_NT2 : 3) : (W >= 4 ? 2 : 4); }
 static uint32_t scan_mfma_nw(uint32_t W, bool arena) { return W == 2 && !arena ? 8u : 4u; }  // scan_mfma_waves<W, ARENA>()
 static uint32_t scan_mfma_tile(uint32_t W, bool arena, bool additive = false) { return 32 * scan_mfma_nw(W, arena) * scan_mfma_nt(W, additive && !arena); }
