@@ -155,40 +155,50 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
                 return;
             }
             if constexpr (ARENA) return;  // (unreachable: keeps the direct path out of the arena instantiation)
+            // Direct path.  The stages this kernel serves in a large batch are survivor-dense (nearly every 128-pair iteration
+            // gets here), so the emission is kept as short as the scoring: everything wave-uniform (query row, buffer base, run
+            // bases, counts) lives in scalar registers, the ranks come from v_mbcnt, and the run descriptors of both sub-tiles
+            // leave in ONE store (lane c writes run c).
             unsigned long long old = 0;
             if (lane == 0) old = atomicAdd(surv_cnt + b, ((unsigned long long)nruns << 32) | total);
             uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)old);
-            uint32_t rbase = __builtin_amdgcn_readfirstlane((uint32_t)(old >> 32));
-            const QSeg seg = scan_seg(a);
-            const uint64_t qat = seg.at(b);
-            const uint32_t qcap = seg.capof(b);
+            const uint32_t rbase = __builtin_amdgcn_readfirstlane((uint32_t)(old >> 32));
+            const uint32_t qcap = a.cap;  // (uniform geometry: query b owns slots [b * cap, (b + 1) * cap))
+            const uint64_t qat64 = (uint64_t)b * qcap;
+            const uint64_t qat = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(qat64 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)qat64);
             SurvRec *out = surv + qat;
+            uint32_t cn[CPL], cbase[CPL];
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
-                const uint32_t cntc = (uint32_t)__popcll(m[c]);
-                if ((m[c] >> lane) & 1ull) {
-                    uint32_t at = base + (uint32_t)__popcll(m[c] & ((1ull << lane) - 1ull));
-                    if (at < qcap) {
-                        SurvRec r;
-                        r.pos = pos[c];
-                        r.slot = slot;
-                        r.rough = rough[c];
-                        r.accurate = 0.0f;
-                        out[at] = r;
-                    }
+                cn[c] = (uint32_t)__popcll(m[c]);
+                cbase[c] = base;
+                const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m[c] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[c], 0u));
+                if (((m[c] >> lane) & 1ull) && at < qcap) {
+                    SurvRec r;
+                    r.pos = pos[c];
+                    r.slot = slot;
+                    r.rough = rough[c];
+                    r.accurate = 0.0f;
+                    out[at] = r;
                 }
-                // the run's descriptor: appended (sorted later), or straight into its cell of the dense directory
-                const uint32_t dcell = a.dense_dir ? t[RQ_REC_CELL0] + ((first + c * 256 + (threadIdx.x & ~63u)) >> 6) : rbase;
-                if (cntc && lane == 0 && dcell < qcap) {
+                base += cn[c];
+            }
+            if (lane < CPL) {  // lane c: the descriptor of sub-tile c's run -- appended (sorted later), or straight into its cell of the dense directory
+                uint32_t mycnt = cn[0], mybase = cbase[0], myr = rbase;
+#pragma unroll
+                for (int c = 1; c < CPL; ++c)
+                    if (lane == (uint32_t)c) mycnt = cn[c], mybase = cbase[c], myr = rbase + (cn[c - 1] ? 1u : 0u);
+                static_assert(CPL <= 2, "run slot of sub-tile c = rbase + non-empty sub-tiles before it");
+                const uint32_t p0 = first + lane * 256 + (threadIdx.x & ~63u);
+                const uint32_t dcell = a.dense_dir ? t[RQ_REC_CELL0] + (p0 >> 6) : myr;
+                if (mycnt && dcell < qcap) {
                     RunRec rr;
-                    rr.pos = list_begin + first + c * 256 + (threadIdx.x & ~63u);
+                    rr.pos = list_begin + p0;
                     rr.slot = slot;
-                    rr.base = base;
-                    rr.cnt = cntc;
+                    rr.base = mybase;
+                    rr.cnt = mycnt;
                     runs[qat + dcell] = rr;
                 }
-                base += cntc;
-                rbase += cntc ? 1u : 0u;
             }
         }
     };
