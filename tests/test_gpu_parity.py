@@ -649,6 +649,33 @@ def test_large_index_properties(rq, n, d, k, probe, hbm_mb):
     idx.close()
 
 
+def test_config1_sift_like_1m_matches_oracle(rq, oracle):
+    """BASELINE.json configs[1] at its own size: 1M x 128, 1024 lists, nprobe 32, top-10.  The SIFT files are not in this
+    image, so the data is SIFT-LIKE (non-negative integer coordinates 0..255 around 1024 centres); the oracle builds the
+    whole index itself (~10 s of one core), every array of the two builds is compared bit for bit, then 300 queries through
+    both rankers and a batch of one: ids in order, distance bits, rough / precise counters."""
+    n, d, k, probe = 1_000_000, 128, 1024, 32
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.8, seed=1001, centre_scale=0.7)
+    queries, _, _ = synth.mixture(300, d, k, sigma=0.8, seed=1002, centre_scale=0.7)
+    x, centres, queries = (np.rint(a * 40 + 128).clip(0, 255).astype(np.float32) for a in (x, centres, queries))
+    queries[3] = x[12345]                                   # a query that IS a base vector (distance 0 to itself)
+    P = synth.random_orthogonal(d, seed=1003)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    gidx = rq.RaBitQ.build(x, centres, P)
+    assert_bits_equal(gidx.centroids, oidx.centroids, "rotated centroids")
+    assert np.array_equal(gidx.offsets, oidx.offsets)
+    assert np.array_equal(gidx.map_ids, oidx.map_ids)
+    assert_bits_equal(gidx.codes, oidx.codes, "codes")
+    assert_bits_equal(gidx.factors, oidx.factors, "factors")
+    assert_bits_equal(gidx.base, x[oidx.map_ids], "base in cluster order")
+    _compare_with_oracle(rq, oracle, oidx, gidx, queries, probe, 10, False)
+    _compare_with_oracle(rq, oracle, oidx, gidx, queries[:64], probe, 10, True)
+    _compare_with_oracle(rq, oracle, oidx, gidx, queries[:1], probe, 10, False)     # the reference harness's one query per call
+    _compare_with_oracle(rq, oracle, oidx, gidx, queries[:40], probe, 100, False)
+    gidx.close()
+    oidx.close()
+
+
 @pytest.mark.parametrize("d", [64, 100, 192, 256, 384, 512, 768])
 def test_prefiltered_assignment_equals_exact_order_kernels(rq, oracle, d):
     """Nearest-list assignment through the matrix cores (assign_approx_kernel: bf16 MFMA approximation, candidates within
