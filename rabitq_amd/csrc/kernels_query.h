@@ -216,9 +216,10 @@ __global__ __launch_bounds__(256) void select_probe_kernel(const float *__restri
                                                            uint32_t nprobe,
                                                            uint32_t *__restrict__ out_cluster,
                                                            float *__restrict__ out_dist, uint32_t id_offset,
-                                                           uint32_t out_stride) {
+                                                           uint32_t out_stride, const uint32_t *__restrict__ only_rows = nullptr /* per row: 0 = skip */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem_raw);  // nprobe entries
+    if (only_rows && only_rows[blockIdx.x] == 0u) return;
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_sel, s_want, s_done, s_cnt;
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
@@ -445,6 +446,114 @@ __global__ __launch_bounds__(256) void select_probe_wave_kernel(const float *__r
 // ranked the plain way instead: the wave recomputes ALL k distances in exact order into the row and runs select_probe_wave on it.
 // ------------------------------------------------------------------------------------------------
 #define RQ_COARSE_CAND 256u
+// exact-order distance (src/simd.rs:14-73) of four lists per 8-lane group to the query row yr: lane al of a group carries AVX
+// lane al; all 8 lanes of the group return the folded sum.  dim is a multiple of 64: eight AVX steps at a time, all the loads
+// of a chunk in flight before the first is used (one load per step, as a plain loop compiles to, made the caller a chain of
+// 256 dependent L2 round trips per query).
+__device__ __forceinline__ void coarse_exact_dist4(const float *__restrict__ centroids, const float *__restrict__ yr, uint32_t dim,
+                                                   uint32_t al, const uint32_t (&jj)[4], float (&ee)[4]) {
+    const float *cp[4];
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cp[q] = centroids + (uint64_t)jj[q] * dim + al;
+    for (uint32_t e0 = 0; e0 < dim; e0 += 64) {
+        float vv[4][8], yv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            yv[i] = yr[e0 + 8 * i + al];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vv[q][i] = cp[q][e0 + 8 * i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float df = vv[q][i] - yv[i];
+                acc[q] = fmaf(df, df, acc[q]);
+            }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ee[q] = reduce8_lanes(acc[q]);
+}
+
+// The candidate lists wn[0 .. c2) (list ids; c2 <= RQ_COARSE_CAND, >= nprobe) of query row b: exact keys in the reference's lane
+// order, bitonic sort of the RQ_COARSE_CAND slots across the wave, the nprobe smallest written out in ascending order.
+__device__ __forceinline__ void coarse_refine_tail(unsigned long long *wn, uint32_t c2, const float *__restrict__ centroids,
+                                                   const float *__restrict__ yr, uint32_t dim, uint32_t nprobe, uint32_t b,
+                                                   uint32_t *__restrict__ out_cluster, float *__restrict__ out_dist, uint32_t out_stride) {
+    const uint32_t lane = threadIdx.x & 63, grp = lane >> 3, al = lane & 7;
+    // exact keys, 32 candidates per step
+    for (uint32_t c0 = 0; c0 < c2; c0 += 32) {
+        uint32_t jj[4];
+        float ee[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) jj[q] = c0 + 8 * q + grp < c2 ? (uint32_t)wn[c0 + 8 * q + grp] : 0u;
+        coarse_exact_dist4(centroids, yr, dim, al, jj, ee);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (c0 + 8 * q + grp < c2 && al == 0) wn[c0 + 8 * q + grp] = ((unsigned long long)ord32_biased(ee[q]) << 32) | jj[q];
+    }
+    for (uint32_t i = c2 + lane; i < RQ_COARSE_CAND; i += 64) wn[i] = ~0ull;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    // bitonic sort of the RQ_COARSE_CAND slots, ascending: element index i = lane + 64 s (s = the lane's slot); at a step (size, stride)
+    // element i keeps the minimum of (i, i ^ stride) iff ((i & stride) == 0) == ((i & size) == 0)  (the last size ascends everywhere)
+    constexpr int NS = RQ_COARSE_CAND / 64;
+    unsigned long long vs[NS];
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) vs[sl] = wn[lane + 64 * sl];
+#pragma unroll
+    for (int size = 2; size <= 64 * NS; size <<= 1)
+#pragma unroll
+        for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+            if (stride >= 64) {  // the partner is another slot of the same lane
+                const int ss = stride / 64;
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl) {
+                    if (sl & ss) continue;
+                    const bool asc = size >= 64 * NS || ((64 * sl) & size) == 0;
+                    const unsigned long long a0 = vs[sl], b0 = vs[sl | ss];
+                    const unsigned long long mn = a0 < b0 ? a0 : b0, mxv = a0 < b0 ? b0 : a0;
+                    vs[sl] = asc ? mn : mxv, vs[sl | ss] = asc ? mxv : mn;
+                }
+            } else {
+                const bool lower = (lane & stride) == 0;
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl) {
+                    const unsigned long long o = __shfl_xor(vs[sl], stride, 64);
+                    const bool asc = size < 64 ? (lane & size) == 0 : (size >= 64 * NS || ((64 * sl) & size) == 0);
+                    const unsigned long long mn = o < vs[sl] ? o : vs[sl], mxv = o < vs[sl] ? vs[sl] : o;
+                    vs[sl] = lower == asc ? mn : mxv;
+                }
+            }
+        }
+    const unsigned long long v0 = vs[0];
+    // v0 of lane l = the l-th smallest key
+    if (lane < nprobe) {
+        out_cluster[(uint64_t)b * out_stride + lane] = (uint32_t)v0;
+        out_dist[(uint64_t)b * out_stride + lane] = ord32_unbias((uint32_t)(v0 >> 32));
+    }
+    for (uint32_t i = nprobe + lane; i < out_stride; i += 64) {  // fewer lists than requested: "no list"
+        out_cluster[(uint64_t)b * out_stride + i] = 0xFFFFFFFFu;
+        out_dist[(uint64_t)b * out_stride + i] = __builtin_inff();
+    }
+}
+
+// the query's margin of the matrix-core pre-filter (kernels_build.h) -> the biased key of tau + 2 m (0xFFFFFFFF: not finite)
+__device__ __forceinline__ uint32_t coarse_margin_key(const float *__restrict__ yr, uint32_t dim, float cmax, float tau) {
+    const uint32_t lane = threadIdx.x & 63;
+    float yn = 0.0f;  // |y|^2 from an f32 sum (any order: its rounding is inside the factors below)
+    for (uint32_t e = lane; e < dim; e += 64) yn = fmaf(yr[e], yr[e], yn);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) yn += __shfl_xor(yn, o, 64);
+    const float rad = cmax + sqrtf(yn) * 1.000001f;
+    const float mx = (0.00390625f + (float)(2 * dim + 64) * 5.9604645e-8f) * 1.05f * (rad * rad);
+    float thr2 = tau + 2.0f * mx;
+    thr2 = thr2 + fabsf(thr2) * 1.0e-6f;  // the comparison's own rounding
+    const bool fin = fabsf(thr2) < 3.0e38f && fabsf(tau) < 3.0e38f;  // false for NaN / inf
+    return fin ? ord32_biased(thr2) : 0xFFFFFFFFu;
+}
+
 template <int KPL>
 __global__ __launch_bounds__(256) void select_refine_wave_kernel(float *__restrict__ dist, const float *__restrict__ y,
                                                                  const float *__restrict__ centroids, float cmax, uint32_t k, uint32_t dim,
@@ -458,33 +567,6 @@ __global__ __launch_bounds__(256) void select_refine_wave_kernel(float *__restri
     float *d = dist + (uint64_t)b * k;
     const float *yr = y + (uint64_t)b * dim;
     const uint32_t grp = lane >> 3, al = lane & 7;  // 8 lanes per list: AVX lane al of list slot grp
-    // exact-order distance of list j to the query (all 8 lanes of the group return it)
-    // (dim is a multiple of 64: eight AVX steps at a time, all sixteen loads of a chunk in flight before the first is used --
-    // one load per step, as a plain loop compiles to, made this kernel a chain of 256 dependent L2 round trips per query)
-    auto exact_dist4 = [&](const uint32_t (&jj)[4], float (&ee)[4]) {  // four lists at once: 40 loads in flight per 64 dimensions
-        const float *cp[4];
-        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) cp[q] = centroids + (uint64_t)jj[q] * dim + al;
-        for (uint32_t e0 = 0; e0 < dim; e0 += 64) {
-            float vv[4][8], yv[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                yv[i] = yr[e0 + 8 * i + al];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) vv[q][i] = cp[q][e0 + 8 * i];
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float df = vv[q][i] - yv[i];
-                    acc[q] = fmaf(df, df, acc[q]);
-                }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ee[q] = reduce8_lanes(acc[q]);
-    };
     uint32_t key[KPL];
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
     auto list_of = [&](int i) { return 256u * (uint32_t)(i >> 2) + 4u * lane + (uint32_t)(i & 3); };
@@ -541,17 +623,8 @@ __global__ __launch_bounds__(256) void select_refine_wave_kernel(float *__restri
         }
     }
     const float tau = ord32_unbias(hi);
-    // the query's margin (kernels_build.h): |y| from an f32 sum (any order: its rounding is inside the factors below)
-    float yn = 0.0f;
-    for (uint32_t e = lane; e < dim; e += 64) yn = fmaf(yr[e], yr[e], yn);
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) yn += __shfl_xor(yn, o, 64);
-    const float rad = cmax + sqrtf(yn) * 1.000001f;
-    const float mx = (0.00390625f + (float)(2 * dim + 64) * 5.9604645e-8f) * 1.05f * (rad * rad);
-    float thr2 = tau + 2.0f * mx;
-    thr2 = thr2 + fabsf(thr2) * 1.0e-6f;  // the comparison's own rounding
-    const bool fin = fabsf(thr2) < 3.0e38f && fabsf(tau) < 3.0e38f;  // false for NaN / inf
-    const uint32_t T2 = ord32_biased(thr2);
+    const uint32_t T2 = coarse_margin_key(yr, dim, cmax, tau);
+    const bool fin = T2 != 0xFFFFFFFFu;
     const uint32_t c2 = fin ? count_le(T2) : 0xFFFFFFFFu;
     if (!(c2 <= RQ_COARSE_CAND) || c2 < nprobe) {  // (wave-uniform) the plain way: every distance in exact order, then the exact selection
         for (uint32_t j0 = 0; j0 < k; j0 += 32) {
@@ -559,7 +632,7 @@ __global__ __launch_bounds__(256) void select_refine_wave_kernel(float *__restri
             float ee[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) jj[q] = j0 + 8 * q + grp < k ? j0 + 8 * q + grp : 0u;
-            exact_dist4(jj, ee);
+            coarse_exact_dist4(centroids, yr, dim, al, jj, ee);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (j0 + 8 * q + grp < k && al == 0) d[j0 + 8 * q + grp] = ee[q];
@@ -583,61 +656,148 @@ __global__ __launch_bounds__(256) void select_refine_wave_kernel(float *__restri
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    // exact keys, 8 candidates per step
-    for (uint32_t c0 = 0; c0 < c2; c0 += 32) {
-        uint32_t jj[4];
-        float ee[4];
+    coarse_refine_tail(wn, c2, centroids, yr, dim, nprobe, b, out_cluster, out_dist, out_stride);
+}
+
+
+// The same for MORE lists than a wave can hold in registers (k > 8192: the probe ranking of a multi-GPU deployment is over the
+// lists of ALL shards -- 32 768 at eight GPUs).  One sweep over the row of approximate distances leaves the minimum of every
+// TILE of 32 consecutive lists (k / 32 keys: 16 per lane at k = 32 768).  The nprobe-th smallest tile minimum bounds the row's
+// nprobe-th smallest a' from above (those nprobe minima are nprobe different lists), and tightly: the nearest lists of a query
+// rarely share a tile.  Only the tiles whose minimum is within the margin are read again for the candidates (a few dozen
+// 128-byte pieces instead of the row).  A row that cannot be handled (more than RQ_COARSE_CAND candidates, a margin that is not
+// finite) gets all its distances in exact order and its flag set: select_probe_kernel then selects those rows (redo_flag).
+// dynamic LDS: 4 x 64 TPL dwords (tile keys, then the flagged tiles, per wave)
+template <int TPL>
+__global__ __launch_bounds__(256) void select_refine_tiled_kernel(float *__restrict__ dist, const float *__restrict__ y,
+                                                                  const float *__restrict__ centroids, float cmax, uint32_t k, uint32_t dim,
+                                                                  uint32_t nprobe, uint32_t *__restrict__ out_cluster,
+                                                                  float *__restrict__ out_dist, uint32_t out_stride, uint32_t nq,
+                                                                  uint32_t *__restrict__ redo_flag,
+                                                                  unsigned long long *__restrict__ fallback_rows /* counter, may be null */) {
+    __shared__ unsigned long long win[4][RQ_COARSE_CAND];
+    extern __shared__ __attribute__((aligned(16))) uint32_t tile_lds[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, b = blockIdx.x * 4 + wave;
+    if (b >= nq) return;
+    unsigned long long *wn = win[wave];
+    uint32_t *tkeys = tile_lds + wave * (64 * TPL);
+    float *d = dist + (uint64_t)b * k;
+    const float *yr = y + (uint64_t)b * dim;
+    const uint32_t grp = lane >> 3, al = lane & 7;
+    const uint32_t ntile = (k + 31) / 32;  // <= 64 TPL (host)
+    const bool vec4 = (k & 3u) == 0u;
+    // sweep: 8 tiles (256 lists) per step, 4 lists per lane, the 8 lanes of a group fold one tile
+    for (uint32_t t0 = 0; t0 < ntile; t0 += 8) {
+        const uint32_t j0 = t0 * 32 + lane * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vec4 && j0 < k) {
+            v = *reinterpret_cast<const float4 *>(d + j0);
+        } else if (!vec4) {
+            if (j0 < k) v.x = d[j0];
+            if (j0 + 1 < k) v.y = d[j0 + 1];
+            if (j0 + 2 < k) v.z = d[j0 + 2];
+            if (j0 + 3 < k) v.w = d[j0 + 3];
+        }
+        const float ve[4] = {v.x, v.y, v.z, v.w};
+        uint32_t mn = 0xFFFFFFFFu;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) jj[q] = c0 + 8 * q + grp < c2 ? (uint32_t)wn[c0 + 8 * q + grp] : 0u;
-        exact_dist4(jj, ee);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t key = j0 + e < k ? ord32_biased(ve[e]) : 0xFFFFFFFFu;
+            mn = key < mn ? key : mn;
+        }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (c0 + 8 * q + grp < c2 && al == 0) wn[c0 + 8 * q + grp] = ((unsigned long long)ord32_biased(ee[q]) << 32) | jj[q];
+        for (int o = 4; o >= 1; o >>= 1) {
+            const uint32_t a = __shfl_xor(mn, o, 8);
+            mn = a < mn ? a : mn;
+        }
+        if (al == 0 && t0 + grp < 64 * TPL) tkeys[t0 + grp] = mn;  // (tiles past the last one come out as "no list")
     }
-    for (uint32_t i = c2 + lane; i < RQ_COARSE_CAND; i += 64) wn[i] = ~0ull;
+    for (uint32_t i = ((ntile + 7) & ~7u) + lane; i < 64 * TPL; i += 64) tkeys[i] = 0xFFFFFFFFu;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    // bitonic sort of the RQ_COARSE_CAND slots, ascending: element index i = lane + 64 s (s = the lane's slot); at a step (size, stride)
-    // element i keeps the minimum of (i, i ^ stride) iff ((i & stride) == 0) == ((i & size) == 0)  (the last size ascends everywhere)
-    constexpr int NS = RQ_COARSE_CAND / 64;
-    unsigned long long vs[NS];
+    uint32_t tk[TPL];  // tile lane + 64 i
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
 #pragma unroll
-    for (int sl = 0; sl < NS; ++sl) vs[sl] = wn[lane + 64 * sl];
+    for (int i = 0; i < TPL; ++i) {
+        tk[i] = tkeys[lane + 64 * i];
+        if (lane + 64 * i < ntile) {
+            kmin = tk[i] < kmin ? tk[i] : kmin;
+            kmax = tk[i] > kmax ? tk[i] : kmax;
+        }
+    }
 #pragma unroll
-    for (int size = 2; size <= 64 * NS; size <<= 1)
+    for (int o = 32; o >= 1; o >>= 1) {
+        const uint32_t a = __shfl_xor(kmin, o, 64), c = __shfl_xor(kmax, o, 64);
+        kmin = a < kmin ? a : kmin;
+        kmax = c > kmax ? c : kmax;
+    }
+    kmin = __builtin_amdgcn_readfirstlane(kmin), kmax = __builtin_amdgcn_readfirstlane(kmax);
+    auto count_le = [&](uint32_t t) {
+        uint32_t c = 0;
 #pragma unroll
-        for (int stride = size >> 1; stride >= 1; stride >>= 1) {
-            if (stride >= 64) {  // the partner is another slot of the same lane
-                const int ss = stride / 64;
+        for (int i = 0; i < TPL; ++i) c += (uint32_t)__popcll(__ballot(tk[i] <= t && lane + 64 * i < ntile));
+        return c;
+    };
+    uint32_t lo = kmin, hi = kmax;  // (ntile >= nprobe: count_le(kmax) = ntile >= nprobe)
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        const uint32_t c = count_le(mid);
+        if (c >= nprobe) {
+            hi = mid;
+            if (c <= nprobe + 12) break;
+        } else {
+            lo = mid + 1;
+        }
+    }
+    const uint32_t T2 = ntile >= nprobe ? coarse_margin_key(yr, dim, cmax, ord32_unbias(hi)) : 0xFFFFFFFFu;
+    bool ok = T2 != 0xFFFFFFFFu;
+    // the tiles that can hold a candidate, compacted over the tile keys (every lane has its keys in registers by now)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    uint32_t nf = 0;
+    if (ok) {
 #pragma unroll
-                for (int sl = 0; sl < NS; ++sl) {
-                    if (sl & ss) continue;
-                    const bool asc = size >= 64 * NS || ((64 * sl) & size) == 0;
-                    const unsigned long long a0 = vs[sl], b0 = vs[sl | ss];
-                    const unsigned long long mn = a0 < b0 ? a0 : b0, mxv = a0 < b0 ? b0 : a0;
-                    vs[sl] = asc ? mn : mxv, vs[sl | ss] = asc ? mxv : mn;
-                }
-            } else {
-                const bool lower = (lane & stride) == 0;
-#pragma unroll
-                for (int sl = 0; sl < NS; ++sl) {
-                    const unsigned long long o = __shfl_xor(vs[sl], stride, 64);
-                    const bool asc = size < 64 ? (lane & size) == 0 : (size >= 64 * NS || ((64 * sl) & size) == 0);
-                    const unsigned long long mn = o < vs[sl] ? o : vs[sl], mxv = o < vs[sl] ? vs[sl] : o;
-                    vs[sl] = lower == asc ? mn : mxv;
-                }
+        for (int i = 0; i < TPL; ++i) {
+            const bool take = tk[i] <= T2 && lane + 64 * i < ntile;
+            const uint64_t m = __ballot(take);
+            if (m) {
+                if (take) tkeys[nf + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = lane + 64 * i;
+                nf += (uint32_t)__popcll(m);
             }
         }
-    const unsigned long long v0 = vs[0];
-    // v0 of lane l = the l-th smallest key
-    if (lane < nprobe) {
-        out_cluster[(uint64_t)b * out_stride + lane] = (uint32_t)v0;
-        out_dist[(uint64_t)b * out_stride + lane] = ord32_unbias((uint32_t)(v0 >> 32));
     }
-    for (uint32_t i = nprobe + lane; i < out_stride; i += 64) {  // fewer lists than requested: "no list"
-        out_cluster[(uint64_t)b * out_stride + i] = 0xFFFFFFFFu;
-        out_dist[(uint64_t)b * out_stride + i] = __builtin_inff();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    uint32_t base = 0;
+    for (uint32_t s0 = 0; ok && s0 < nf; s0 += 2) {  // two flagged tiles per step: one per half-wave
+        const uint32_t ti = s0 + (lane >> 5);
+        const uint32_t j = ti < nf ? tkeys[ti] * 32 + (lane & 31) : 0xFFFFFFFFu;
+        const bool take = j < k && ord32_biased(d[j]) <= T2;
+        const uint64_t m = __ballot(take);
+        if (m) {  // wave-uniform
+            const uint32_t cnt = (uint32_t)__popcll(m);
+            if (base + cnt > RQ_COARSE_CAND) ok = false;
+            else if (take) wn[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = j;
+            base += cnt;
+        }
     }
+    if (!ok || base < nprobe) {  // (wave-uniform) the plain way: every distance in exact order; the block-per-query selection takes the row
+        for (uint32_t j0 = 0; j0 < k; j0 += 32) {
+            uint32_t jj[4];
+            float ee[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) jj[q] = j0 + 8 * q + grp < k ? j0 + 8 * q + grp : 0u;
+            coarse_exact_dist4(centroids, yr, dim, al, jj, ee);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (j0 + 8 * q + grp < k && al == 0) d[j0 + 8 * q + grp] = ee[q];
+        }
+        if (lane == 0) {
+            redo_flag[b] = 1u;
+            if (fallback_rows) atomicAdd(fallback_rows, 1ull);
+        }
+        return;
+    }
+    if (lane == 0) redo_flag[b] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    coarse_refine_tail(wn, base, centroids, yr, dim, nprobe, b, out_cluster, out_dist, out_stride);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -213,6 +213,7 @@ struct Workspace {
     DevBuf<float> retry_q, retry_pd, retry_pc;  // overflow re-runs: the affected queries (and their probe lists)
     DevBuf<uint32_t> retry_rows;
     DevBuf<uint32_t> q_hist, q_start, q_order;  // rerank order of a large batch (queries grouped by nearest list)
+    DevBuf<uint32_t> coarse_redo;               // pre-filtered coarse ranking over more than 8192 lists: rows left to the block-per-query selection
     DevBuf<uint32_t> pair_rank, rank_base;      // group_rank_kernel: places of a big stage's pairs inside their groups
     DevBuf<uint32_t> probe_cluster, recs, grp_cnt, grp_start, heap_len, heap_id, precise, need,
         nsurv, nshadow, win_count, arr_len, row_map, big_list;
@@ -394,7 +395,7 @@ __global__ void unpack_topk_keys_kernel(const unsigned long long *__restrict__ k
 }
 
 // coarse ranking distances (src/rabitq.rs:283-287), every query against the lists [first, first + k) of cent_t
-static std::atomic<int> g_coarse_impl{0};  // 0 auto, 1 LDS-broadcast kernels, 2 scalar-register kernel, 3 bf16-MFMA pre-filter + exact refinement wherever it applies
+static std::atomic<int> g_coarse_impl{0};  // 0 auto, 1 LDS-broadcast kernels, 2 scalar-register kernel, 3 bf16-MFMA pre-filter + exact refinement wherever it applies (row in registers up to 8192 lists), 4 the same with the tile-minima selection wherever it applies
 static std::atomic<int> g_scan_dbg{0};
 // the probe selection runs one wave per query (row in registers) for these shapes, one block per query otherwise
 static bool select_is_wave(uint32_t k, uint32_t nprobe, uint32_t nq) { return nprobe <= 64 && k <= 8192 && nq >= 8; }
@@ -413,14 +414,18 @@ static void launch_coarse(const float *cent_t, const float *y, float *dist, uint
 
 // Coarse ranking of nq rotated queries against ALL k lists: the matrix-core pre-filter + exact-order refinement where it applies
 // (coarse_impl 3, or -- once measured faster -- auto for big batches), else the exact-order distance kernels + selection.
+static std::atomic<int> g_coarse_tiled_from{4096};  // pre-filtered coarse ranking: list count from which the selection goes through tile minima (developer knob)
 static bool coarse_prefilter_has(uint32_t W) { return W == 1 || W == 2 || W == 3 || W == 4 || W == 6 || W == 8 || W == 12; }
+// (more lists than one wave holds in registers -- the ranking of a multi-GPU deployment is over the lists of ALL shards -- go through
+// the tile-minima selection, select_refine_tiled_kernel)
 static bool coarse_prefilter_applies(const rq_index *idx, uint32_t nq, uint32_t nprobe) {
     const int impl = g_coarse_impl.load();
-    return (impl == 3 || (impl == 0 && nq >= 2048)) && coarse_prefilter_has(idx->W) && std::isfinite(idx->cent_norm_max) &&
-           idx->cent_bf.p != nullptr && select_is_wave(idx->k, nprobe, nq) && idx->k >= 64 && nprobe >= 1;
+    return (impl == 3 || impl == 4 || (impl == 0 && nq >= 2048)) && coarse_prefilter_has(idx->W) && std::isfinite(idx->cent_norm_max) &&
+           idx->cent_bf.p != nullptr && nprobe <= 64 && nq >= 8 && idx->k >= 64 && nprobe >= 1 && idx->k <= 65536;
 }
+// redo: nq flags (only written / read when k > 8192)
 static void launch_coarse_prefiltered(const rq_index *idx, const float *y, float *dist, uint32_t nq, uint32_t nprobe, uint32_t *out_cluster,
-                                      float *out_dist, uint32_t out_stride, unsigned long long *fallback_rows, hipStream_t st) {
+                                      float *out_dist, uint32_t out_stride, unsigned long long *fallback_rows, uint32_t *redo, hipStream_t st) {
     const uint32_t k = idx->k, dim = idx->dim;
 #define RQ_CAP(WW, NT)                                                                                                      \
     coarse_approx_kernel<WW, NT><<<ceil_div(nq, 128 * NT), 256, assign_lds_bytes<WW, NT>(), st>>>(y, idx->cent_bf.p, idx->cent_sqnorm.p, nq, \
@@ -436,7 +441,24 @@ static void launch_coarse_prefiltered(const rq_index *idx, const float *y, float
     }
 #undef RQ_CAP
     const dim3 g(ceil_div(nq, 4)), b(256);
-    if (k <= 1024)
+    // the selection: tile minima (select_refine_tiled_kernel) wherever a row has at least nprobe tiles of 32 lists -- measured faster than
+    // the register-resident row from 4096 lists up, and the only form beyond 8192 --, else the row in registers
+    const uint32_t ntile = ceil_div(k, 32u);
+    const int impl = g_coarse_impl.load();
+    const bool tiled = redo != nullptr && ntile >= nprobe && (k > 8192 || impl == 4 || (impl != 3 && k >= (uint32_t)g_coarse_tiled_from.load()));
+    if (tiled) {
+#define RQ_TILED(TPL)                                                                                                             \
+    select_refine_tiled_kernel<TPL><<<g, b, 4 * 64 * (TPL) * 4, st>>>(dist, y, idx->centroids.p, idx->cent_norm_max, k, dim, nprobe, out_cluster, \
+                                                                    out_dist, out_stride, nq, redo, fallback_rows)
+        if (ntile <= 128) RQ_TILED(2);
+        else if (ntile <= 256) RQ_TILED(4);
+        else if (ntile <= 512) RQ_TILED(8);
+        else if (ntile <= 1024) RQ_TILED(16);
+        else RQ_TILED(32);
+#undef RQ_TILED
+        // rows the tiled kernel could not handle hold exact-order distances now: the block-per-query selection takes them (it exits at once for the others)
+        select_probe_kernel<<<nq, 256, (size_t)nprobe * 8, st>>>(dist, k, nprobe, out_cluster, out_dist, 0u, out_stride, redo);
+    } else if (k <= 1024)
         select_refine_wave_kernel<16><<<g, b, 0, st>>>(dist, y, idx->centroids.p, idx->cent_norm_max, k, dim, nprobe, out_cluster, out_dist, out_stride, nq, fallback_rows);
     else if (k <= 4096)
         select_refine_wave_kernel<64><<<g, b, 0, st>>>(dist, y, idx->centroids.p, idx->cent_norm_max, k, dim, nprobe, out_cluster, out_dist, out_stride, nq, fallback_rows);
@@ -1007,7 +1029,8 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         if (coarse_prefilter_applies(idx, nq, nprobe)) {
             pf.begin(PF_COARSE);
             HIPC(hipMemsetAsync(ws.totals.p + 12, 0, 8, st));
-            launch_coarse_prefiltered(idx, ws.y.p, ws.dist.p, nq, nprobe, ws.probe_cluster.p, ws.probe_dist.p, nprobe, ws.totals.p + 12, st);
+            RQC(ws.coarse_redo.ensure(nq));
+            launch_coarse_prefiltered(idx, ws.y.p, ws.dist.p, nq, nprobe, ws.probe_cluster.p, ws.probe_dist.p, nprobe, ws.totals.p + 12, ws.coarse_redo.p, st);
             ws.pend_prefiltered = true;
             pf.end();
         } else {
@@ -2888,7 +2911,9 @@ rq_status rq_coarse_topk_device(const rq_index *idx, const float *d_queries, uin
         }
         launch_rotate(qp, idx->P.p, ws->y.p, m, dim, m >= 32, st);
         if (kc == idx->k && coarse_prefilter_applies(idx, m, np)) {
-            launch_coarse_prefiltered(idx, ws->y.p, ws->dist.p, m, np, d_out_cluster + (uint64_t)q0 * probe, d_out_dist + (uint64_t)q0 * probe, probe, nullptr, st);
+            RQC(ws->coarse_redo.ensure(m));
+            launch_coarse_prefiltered(idx, ws->y.p, ws->dist.p, m, np, d_out_cluster + (uint64_t)q0 * probe, d_out_dist + (uint64_t)q0 * probe, probe, nullptr,
+                                      ws->coarse_redo.p, st);
             continue;
         }
         launch_coarse(idx->cent_t.p + list_lo, ws->y.p, ws->dist.p, kc, dim, m, idx->k, st);
@@ -3446,8 +3471,13 @@ rq_status rq_set_option(const char *name, int value) {
         g_max_scan_blocks = value == 0 ? RQ_MAX_BLOCKS_256 : std::min<uint32_t>((uint32_t)value, RQ_MAX_BLOCKS_256);
         return RQ_OK;
     }
+    if (std::string(name) == "coarse_tiled_from") {  // developer knob: list count from which the pre-filtered ranking selects through tile minima
+        if (value < 0) return fail(RQ_ERR_INVALID, "coarse_tiled_from must be >= 0");
+        g_coarse_tiled_from = value;
+        return RQ_OK;
+    }
     if (std::string(name) == "coarse_impl") {  // test hook: coarse-distance kernel (0 auto, 1 LDS broadcast, 2 scalar registers)
-        if (value < 0 || value > 3) return fail(RQ_ERR_INVALID, "coarse_impl must be 0, 1, 2 or 3");
+        if (value < 0 || value > 4) return fail(RQ_ERR_INVALID, "coarse_impl must be 0, 1, 2, 3 or 4");
         g_coarse_impl = value;
         return RQ_OK;
     }

@@ -97,7 +97,7 @@ def fuzz_round(rq, oracle, rng, it, nmax=12000):
     # engine knobs that must never change a result
     knobs = {"base_device_mb": int(rng.choice([-1, -1, 0, 1])), "max_scan_blocks": int(rng.choice([0, 0, 3, 40])),
              "scan_tile_table": int(rng.choice([0, 1, 2])), "group_rank": int(rng.choice([0, 1, 2])),
-             "rerank_shadow": int(rng.choice([0, 1, 1])), "coarse_impl": int(rng.choice([0, 1, 2, 3])),
+             "rerank_shadow": int(rng.choice([0, 1, 1])), "coarse_impl": int(rng.choice([0, 1, 2, 3, 4])),
              "dense_dir": int(rng.choice([0, 1, 1])), "small_batch": int(rng.choice([0, 0, 1])),
              "small_batch_span": int(rng.choice([100, 2560, 2560, 65536])), "stage_growth": int(rng.choice([0, 0, 2, 16])),
              "scan_impl": int(rng.choice([0, 1, 2])), "survivor_segments": int(rng.choice([1, 1, 2])),

@@ -186,12 +186,12 @@ def test_query_matches_golden(rq, path):
 # (the timing ablations -- results wrong -- exist in the developer build only; what the product accepts must
 # leave the golden results untouched, and may be changed while queries are in flight)
 OPTION_VALUES = {
-    "scan_impl": [0, 1, 2], "scan_gate": [0, 1, 2], "coarse_impl": [0, 1, 2, 3], "group_rank": [0, 1, 2], "scan_tile_table": [0, 1, 2],
+    "scan_impl": [0, 1, 2], "scan_gate": [0, 1, 2], "coarse_impl": [0, 1, 2, 3, 4], "coarse_tiled_from": [0, 4096, 1000000], "group_rank": [0, 1, 2], "scan_tile_table": [0, 1, 2],
     "dense_dir": [0, 1], "small_batch": [0, 1], "small_batch_span": [64, 2560, 100000], "stage_growth": [0, 2, 16],
     "survivor_segments": [0, 1, 2, 3], "max_scan_blocks": [0, 1, 7], "shared_thresholds": [0, 1, 2], "assign_impl": [0, 1],
     "rerank_shadow": [0, 1], "scan_debug": [0, 128, 512, 4096, 16384, 128 | 512 | 4096],
 }
-OPTION_DEFAULTS = {"scan_impl": 0, "scan_gate": 0, "coarse_impl": 0, "group_rank": 1, "scan_tile_table": 1, "dense_dir": 1,
+OPTION_DEFAULTS = {"scan_impl": 0, "scan_gate": 0, "coarse_impl": 0, "coarse_tiled_from": 4096, "group_rank": 1, "scan_tile_table": 1, "dense_dir": 1,
                    "small_batch": 0, "small_batch_span": 2560, "stage_growth": 0, "survivor_segments": 1, "max_scan_blocks": 0,
                    "shared_thresholds": 1, "assign_impl": 0, "rerank_shadow": 1, "scan_debug": 0}
 
@@ -223,7 +223,7 @@ def test_every_option_value_keeps_golden_results(rq):
         for bad in (1, 2, 4, 64, 256, 1024, 8192, 128 | 64):
             with pytest.raises(rq.RabitqError):
                 ix.set_option("scan_debug", bad)
-        for name, bad in (("scan_gate", 3), ("scan_impl", 3), ("coarse_impl", 4), ("scan_dense", 1)):
+        for name, bad in (("scan_gate", 3), ("scan_impl", 3), ("coarse_impl", 5), ("scan_dense", 1)):
             with pytest.raises(rq.RabitqError):
                 ix.set_option(name, bad)
     finally:
@@ -314,7 +314,12 @@ def test_additive_gate_falls_back_when_it_flags_too_much(rq, oracle):
 
 @pytest.mark.parametrize("d,k,nq,probe,kind", [(128, 4096, 3000, 64, "mixture"), (128, 300, 2500, 64, "mixture"), (64, 1000, 2100, 33, "ties"),
                                                   (256, 700, 2100, 64, "equidistant"), (768, 260, 2100, 20, "mixture"),
-                                                  (128, 5000, 2200, 64, "scaled"), (128, 130, 2100, 1, "nan")])
+                                                  (128, 5000, 2200, 64, "scaled"), (128, 130, 2100, 1, "nan"),
+                                                  # more lists than one wave holds in registers (the ranking of a multi-GPU deployment is over
+                                                  # all shards' lists): the tile-minima selection, its per-row fall-back included
+                                                  (128, 9000, 2100, 64, "mixture"), (64, 33000, 2050, 33, "mixture"), (128, 20000, 2100, 64, "ties"),
+                                                  (128, 10000, 2060, 64, "equidistant"), (128, 8300, 2100, 40, "nan"), (128, 16500, 2100, 64, "scaled"),
+                                                  (64, 40001, 2050, 64, "mixture")])
 def test_prefiltered_coarse_ranking_equals_exact_order_kernels(rq, d, k, nq, probe, kind):
     """Coarse ranking through the bf16 matrix-core pre-filter + exact-order refinement (coarse_impl = 3; automatic for big batches)
     against the plain exact-order kernel + selection (rq_coarse_rank): list ids and distance bits of every probe list.
@@ -341,7 +346,7 @@ def test_prefiltered_coarse_ranking_equals_exact_order_kernels(rq, d, k, nq, pro
     _, want_cl, want_cd = rq.ops.coarse_rank(idx, queries, probe)          # the plain exact-order kernel + selection
     q = torch.from_numpy(queries).to(dev)
     try:
-        for impl in (3, 0):
+        for impl in (3, 4, 0):
             ix.set_option("coarse_impl", impl)
             pc = torch.zeros((nq, probe), device=dev, dtype=torch.int32)
             pdd = torch.zeros((nq, probe), device=dev, dtype=torch.float32)
@@ -1133,11 +1138,12 @@ def test_begin_end_overflow_retry_matches_sync(rq):
     assert np.array_equal(res[0][0], res[1][0])
 
 
-@pytest.mark.parametrize("coarse_impl", [0, 2, 3])
-@pytest.mark.parametrize("k", [2000, 5000])
+@pytest.mark.parametrize("coarse_impl", [0, 2, 3, 4])
+@pytest.mark.parametrize("k", [2000, 5000, 9000])
 def test_many_lists_probe_selection_matches_oracle(rq, oracle, k, coarse_impl):
     # the register-resident probe selection is instantiated per list-count bracket (<= 1024, <= 4096, <= 8192):
-    # exercise the two larger ones (and many tiny / empty lists) against the oracle
+    # exercise the two larger ones (and many tiny / empty lists) against the oracle; beyond 8192 lists the block-per-query
+    # selection (coarse_impl 0 / 2) and the tile-minima pre-filtered selection (coarse_impl 3)
     n, d, nq = 30000, 64, 24
     x, _, _ = synth.mixture(n, d, 50, sigma=0.9, seed=k, centre_scale=0.8)
     rng = np.random.default_rng(k)
@@ -1174,7 +1180,7 @@ def test_coarse_distance_kernels_agree_bitwise(rq, oracle, d, k, nq):
     gidx = rq.RaBitQ.build(x, centres, P)
     queries, _, _ = synth.mixture(nq, d, k, sigma=0.9, seed=d + k + 1, centre_scale=0.8)
     try:
-        for impl in (1, 2, 3):
+        for impl in (1, 2, 3, 4):
             ix.set_option("coarse_impl", impl)
             _compare_with_oracle(rq, oracle, oidx, gidx, queries, min(k, 40), 10, False)
             _compare_with_oracle(rq, oracle, oidx, gidx, queries[:3], 7, 5, False)
