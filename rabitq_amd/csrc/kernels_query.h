@@ -766,16 +766,27 @@ __global__ __launch_bounds__(256) void select_refine_tiled_kernel(float *__restr
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     uint32_t base = 0;
-    for (uint32_t s0 = 0; ok && s0 < nf; s0 += 2) {  // two flagged tiles per step: one per half-wave
-        const uint32_t ti = s0 + (lane >> 5);
-        const uint32_t j = ti < nf ? tkeys[ti] * 32 + (lane & 31) : 0xFFFFFFFFu;
-        const bool take = j < k && ord32_biased(d[j]) <= T2;
-        const uint64_t m = __ballot(take);
-        if (m) {  // wave-uniform
-            const uint32_t cnt = (uint32_t)__popcll(m);
-            if (base + cnt > RQ_COARSE_CAND) ok = false;
-            else if (take) wn[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = j;
-            base += cnt;
+    for (uint32_t s0 = 0; ok && s0 < nf; s0 += 8) {  // eight flagged tiles per step (one per half-wave, four loads in flight per lane:
+                                                      // one at a time the loop was a chain of ~50 dependent L2 round trips per query)
+        uint32_t jv[4];
+        float dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t ti = s0 + 2 * u + (lane >> 5);
+            jv[u] = ti < nf ? tkeys[ti] * 32 + (lane & 31) : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dv[u] = jv[u] < k ? d[jv[u]] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool take = jv[u] < k && ord32_biased(dv[u]) <= T2;
+            const uint64_t m = __ballot(take);
+            if (m) {  // wave-uniform
+                const uint32_t cnt = (uint32_t)__popcll(m);
+                if (base + cnt > RQ_COARSE_CAND) ok = false;
+                else if (take) wn[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = jv[u];
+                base += cnt;
+            }
         }
     }
     if (!ok || base < nprobe) {  // (wave-uniform) the plain way: every distance in exact order; the block-per-query selection takes the row
