@@ -748,45 +748,79 @@ __global__ __launch_bounds__(256) void select_refine_tiled_kernel(float *__restr
             lo = mid + 1;
         }
     }
-    const uint32_t T2 = ntile >= nprobe ? coarse_margin_key(yr, dim, cmax, ord32_unbias(hi)) : 0xFFFFFFFFu;
-    bool ok = T2 != 0xFFFFFFFFu;
-    // the tiles that can hold a candidate, compacted over the tile keys (every lane has its keys in registers by now)
+    // every lane has its tile keys in registers by now: the LDS copy becomes the list of flagged tiles
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    uint32_t nf = 0;
-    if (ok) {
+    // the lists with a' <= T (key << 32 | list id into the candidate slots): only tiles whose minimum is <= T are read again.
+    // false: more than RQ_COARSE_CAND of them
+    uint32_t base = 0;
+    auto collect = [&](uint32_t T) -> bool {
+        uint32_t nf = 0;
 #pragma unroll
         for (int i = 0; i < TPL; ++i) {
-            const bool take = tk[i] <= T2 && lane + 64 * i < ntile;
+            const bool take = tk[i] <= T && lane + 64 * i < ntile;
             const uint64_t m = __ballot(take);
             if (m) {
                 if (take) tkeys[nf + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = lane + 64 * i;
                 nf += (uint32_t)__popcll(m);
             }
         }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    uint32_t base = 0;
-    for (uint32_t s0 = 0; ok && s0 < nf; s0 += 8) {  // eight flagged tiles per step (one per half-wave, four loads in flight per lane:
-                                                      // one at a time the loop was a chain of ~50 dependent L2 round trips per query)
-        uint32_t jv[4];
-        float dv[4];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        base = 0;
+        bool fits = true;
+        for (uint32_t s0 = 0; fits && s0 < nf; s0 += 8) {  // eight flagged tiles per step (one per half-wave, four loads in flight per lane:
+                                                            // one at a time the loop was a chain of ~50 dependent L2 round trips per query)
+            uint32_t jv[4];
+            float dv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t ti = s0 + 2 * u + (lane >> 5);
-            jv[u] = ti < nf ? tkeys[ti] * 32 + (lane & 31) : 0xFFFFFFFFu;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) dv[u] = jv[u] < k ? d[jv[u]] : 0.0f;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const bool take = jv[u] < k && ord32_biased(dv[u]) <= T2;
-            const uint64_t m = __ballot(take);
-            if (m) {  // wave-uniform
-                const uint32_t cnt = (uint32_t)__popcll(m);
-                if (base + cnt > RQ_COARSE_CAND) ok = false;
-                else if (take) wn[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = jv[u];
-                base += cnt;
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t ti = s0 + 2 * u + (lane >> 5);
+                jv[u] = ti < nf ? tkeys[ti] * 32 + (lane & 31) : 0xFFFFFFFFu;
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dv[u] = jv[u] < k ? d[jv[u]] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t key = ord32_biased(dv[u]);
+                const bool take = jv[u] < k && key <= T;
+                const uint64_t m = __ballot(take);
+                if (m) {  // wave-uniform
+                    const uint32_t cnt = (uint32_t)__popcll(m);
+                    if (base + cnt > RQ_COARSE_CAND) fits = false;
+                    else if (take) wn[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)key << 32) | jv[u];
+                    base += cnt;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        return fits;
+    };
+    // first with the bound the tile minima give (tight when the nearest lists sit in different tiles)
+    uint32_t T2 = ntile >= nprobe ? coarse_margin_key(yr, dim, cmax, ord32_unbias(hi)) : 0xFFFFFFFFu;
+    bool ok = T2 != 0xFFFFFFFFu;
+    if (ok && !collect(T2)) {
+        // too many lists within the margin of that bound (wide margins: high dimensions): the row's nprobe-th smallest a' itself --
+        // every list at or below the tile bound `hi` is collected (there are at least nprobe), bisection over those keys as the
+        // single-wave kernel does over the row -- and the margin from there
+        ok = collect(hi);
+        if (ok) {
+            uint32_t kk[RQ_COARSE_CAND / 64];
+#pragma unroll
+            for (int i = 0; i < (int)(RQ_COARSE_CAND / 64); ++i) kk[i] = lane + 64 * i < base ? (uint32_t)(wn[lane + 64 * i] >> 32) : 0xFFFFFFFFu;
+            uint32_t l2 = kmin, h2 = hi;
+            while (l2 < h2) {
+                const uint32_t mid = l2 + ((h2 - l2) >> 1);
+                uint32_t c = 0;
+#pragma unroll
+                for (int i = 0; i < (int)(RQ_COARSE_CAND / 64); ++i) c += (uint32_t)__popcll(__ballot(kk[i] <= mid));
+                if (c >= nprobe) {
+                    h2 = mid;
+                    if (c <= nprobe + 12) break;
+                } else {
+                    l2 = mid + 1;
+                }
+            }
+            T2 = coarse_margin_key(yr, dim, cmax, ord32_unbias(h2));
+            ok = T2 != 0xFFFFFFFFu && collect(T2);
         }
     }
     if (!ok || base < nprobe) {  // (wave-uniform) the plain way: every distance in exact order; the block-per-query selection takes the row
@@ -2256,6 +2290,210 @@ __global__ __launch_bounds__(256) void accurate_filtered_kernel(SurvRec *__restr
             if (hf == 0) recs[j].accurate = r;
             if (threadIdx.x == 0) qn = waiting - 128;
             __syncthreads();  // the queue's top 128 entries are free again, qn is set
+        }
+    }
+    const uint32_t waiting = qn;
+    if (pair < waiting) {
+        const uint32_t j = queue[pair];
+        const float r = exact_l2_pair(base + (uint64_t)recs[j].pos * dim + 4 * hf, acc_q, dim, hf);
+        if (hf == 0) recs[j].accurate = r;
+    }
+    uint32_t rj = hf == 0 ? rejected : 0u;  // per-query counter (one address per query: no hot spot)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) rj += __shfl_xor(rj, o, 64);
+    if ((threadIdx.x & 63) == 0 && rj) atomicAdd(&nshadow[b], rj);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The 8-bit shadow (round 4): one BYTE per dimension instead of the fp16 shadow's two.
+//
+// Every list c has an affine map of its own, x^_i = lo_c + s_c * code_i with lo_c = the smallest and lo_c + 255 s_c = the largest
+// coordinate of any of its rows (q8_range_kernel), so no coordinate clips and |x_i - x^_i| <= s_c / 2 up to rounding.  The bound
+// the pre-filter needs, ||x - x^|| over the rows of the list, is not derived but MEASURED while the codes are written
+// (q8_encode_kernel: the largest |x_i - fmaf(s_c, code_i, lo_c)| of the list, evaluated exactly as the re-ranker evaluates x^),
+// times sqrt(dim).  The test itself is accurate_filtered_kernel's: d^ = ||x^ - q|| in f32, t = d^ (1 - eps) - err, and a survivor is
+// dropped only if t^2 (1 - eps) still exceeds the stage's threshold -- the f32 row is then never read (128 instead of 256 shadow
+// bytes per survivor at dim 128; measured on the benchmark mixture: 86 % of the survivors rejected against the fp16 shadow's 92 %).
+// A list with a non-finite coordinate gets err = inf: nothing of it is ever rejected.
+// ------------------------------------------------------------------------------------------------
+// one block per list: lo, s (and the error accumulator cleared)
+__global__ __launch_bounds__(256) void q8_range_kernel(const float *__restrict__ base, const uint32_t *__restrict__ offsets, uint32_t dim,
+                                                       float4 *__restrict__ list_q8) {
+    __shared__ float smn[4], smx[4];
+    __shared__ uint32_t sbad[4];
+    const uint32_t c = blockIdx.x;
+    const uint64_t e0 = (uint64_t)offsets[c] * dim, e1 = (uint64_t)offsets[c + 1] * dim;
+    float mn = 3.402823466e+38f, mx = -3.402823466e+38f;
+    uint32_t bad = 0;
+    for (uint64_t e = e0 + threadIdx.x * 4ull; e < e1; e += 1024) {  // dim is a multiple of 64: rows are whole float4s
+        const float4 v = *reinterpret_cast<const float4 *>(base + e);
+        const float ve[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (!(fabsf(ve[i]) < 3.0e38f)) bad = 1;  // NaN / inf / huge
+            mn = ve[i] < mn ? ve[i] : mn;
+            mx = ve[i] > mx ? ve[i] : mx;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float a = __shfl_xor(mn, o, 64), b = __shfl_xor(mx, o, 64);
+        mn = a < mn ? a : mn, mx = b > mx ? b : mx;
+        bad |= __shfl_xor(bad, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) smn[threadIdx.x >> 6] = mn, smx[threadIdx.x >> 6] = mx, sbad[threadIdx.x >> 6] = bad;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) mn = smn[w] < mn ? smn[w] : mn, mx = smx[w] > mx ? smx[w] : mx, bad |= sbad[w];
+        float lo = mn, sc = (mx - mn) * (1.0f / 255.0f);
+        if (e1 == e0) lo = 0.0f, sc = 1.0f;
+        if (!(sc > 0.0f)) sc = 1.0f;                       // all coordinates equal (or an empty list): code 0 everywhere
+        if (!(sc < 3.0e38f) || !(fabsf(lo) < 3.0e38f)) bad = 1;
+        // .z: the largest |x_i - x^_i| of the list as the bits of a non-negative float (atomicMax by q8_encode_kernel); inf: never reject
+        list_q8[c] = make_float4(bad ? 0.0f : lo, bad ? 1.0f : sc, bad ? __builtin_inff() : 0.0f, 0.0f);
+    }
+}
+// grid (ceil(longest list / 256), k): 256 rows of one list per block; dim / 16 threads per row, 16 codes (one 16-byte store) each
+__global__ __launch_bounds__(256) void q8_encode_kernel(const float *__restrict__ base, const uint32_t *__restrict__ offsets, uint32_t dim,
+                                                        float4 *__restrict__ list_q8, uint8_t *__restrict__ out) {
+    __shared__ float smax[4];
+    const uint32_t c = blockIdx.y, r0 = offsets[c] + blockIdx.x * 256u, r1 = offsets[c + 1];
+    if (r0 >= r1) return;
+    const float4 par = list_q8[c];
+    const float lo = par.x, sc = par.y, inv = 1.0f / sc;
+    const uint32_t tpr = dim / 16, rows_per_pass = 256 / tpr;  // dim <= 4096
+    const uint32_t rr = threadIdx.x / tpr, g = threadIdx.x - rr * tpr;
+    float emax = 0.0f;
+    for (uint32_t r = r0 + rr; r < r1 && r < r0 + 256u && rr < rows_per_pass; r += rows_per_pass) {
+        const float *x = base + (uint64_t)r * dim + 16 * g;
+        uint32_t w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + 4 * u);
+            const float ve[4] = {v.x, v.y, v.z, v.w};
+            w[u] = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float t = rintf((ve[i] - lo) * inv);
+                t = t < 0.0f ? 0.0f : (t > 255.0f ? 255.0f : t);  // (NaN: a list with one has err = inf already)
+                const uint32_t code = (uint32_t)t;
+                const float e = fabsf(ve[i] - fmaf(sc, (float)code, lo));  // exactly the re-ranker's x^
+                emax = (e > emax || !(e < 3.0e38f)) ? (e < 3.0e38f ? e : __builtin_inff()) : emax;
+                w[u] |= code << (8 * i);
+            }
+        }
+        *reinterpret_cast<uint4 *>(out + (uint64_t)r * dim + 16 * g) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float a = __shfl_xor(emax, o, 64);
+        emax = a > emax ? a : emax;
+    }
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = emax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w2 = 1; w2 < 4; ++w2) emax = smax[w2] > emax ? smax[w2] : emax;
+        atomicMax(reinterpret_cast<unsigned int *>(&list_q8[c].z), __builtin_bit_cast(unsigned int, emax));  // non-negative floats order as their bits
+    }
+}
+
+// accurate_filtered_kernel with the 8-bit shadow: grid (gx, nq), block 256 = 256 survivors per round, two lanes each and two
+// survivors per lane pair (lane half hf takes the 16-dimension groups 2u + hf of a row; both survivors' pieces are requested
+// before either is used: a 128-byte row is four 16-byte loads per lane, too few in flight to keep the memory busy one row at a time)
+__global__ __launch_bounds__(256) void accurate_filtered8_kernel(SurvRec *__restrict__ surv,
+                                                                 const unsigned long long *__restrict__ surv_cnt,
+                                                                 const QSeg seg, const float *__restrict__ base,
+                                                                 const uint8_t *__restrict__ base_q8, const float4 *__restrict__ list_q8,
+                                                                 const float *__restrict__ qpad, uint32_t dim,
+                                                                 const uint32_t *__restrict__ order,
+                                                                 const float *__restrict__ thr_start,
+                                                                 const uint32_t *__restrict__ probe_cluster, uint32_t nprobe,
+                                                                 uint32_t *__restrict__ nshadow) {
+    extern __shared__ __attribute__((aligned(16))) float acc_q[];  // dim floats (the padded query)
+    __shared__ uint32_t queue[512];
+    __shared__ uint32_t qn;
+    const uint32_t b = order ? order[blockIdx.y] : blockIdx.y;
+    const uint32_t n = (uint32_t)surv_cnt[b];
+    if (n > seg.capof(b) || n == 0) return;  // overflowed: this query is re-run with a larger buffer
+    for (uint32_t c = threadIdx.x * 4; c < dim; c += 1024)
+        *reinterpret_cast<float4 *>(acc_q + c) = *reinterpret_cast<const float4 *>(qpad + (uint64_t)b * dim + c);
+    if (threadIdx.x == 0) qn = 0;
+    __syncthreads();
+    SurvRec *recs = surv + seg.at(b);
+    const uint32_t hf = threadIdx.x & 1, pair = threadIdx.x >> 1;
+    const float thr = thr_start[b];
+    const bool test = thr > 1e-30f && thr < 3.0e38f;  // a finite, normal threshold (false for NaN / inf: everything is exact)
+    const float eps = (float)(dim / 4 + 64) * 5.9604645e-8f, down = 1.0f - eps, up = 1.0f + eps;
+    const float sqd = sqrtf((float)dim) * 1.001f;
+    const uint32_t ngrp = dim / 16;
+    const uint32_t *pc = probe_cluster + (uint64_t)b * nprobe;
+    uint32_t rejected = 0;
+    for (uint32_t i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
+        uint32_t iv[2] = {i0 + pair, i0 + 128 + pair};
+        bool exact[2] = {iv[0] < n, iv[1] < n};
+        if (test) {
+            float4 par[2];
+            const uint8_t *x[2];
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const SurvRec r = recs[exact[v] ? iv[v] : 0u];
+                par[v] = list_q8[pc[r.slot]];  // lo, s, max |x_i - x^_i| of the list
+                x[v] = base_q8 + (uint64_t)r.pos * dim;
+            }
+            float d0[2] = {0.0f, 0.0f}, d1[2] = {0.0f, 0.0f};
+            for (uint32_t g0 = hf; g0 < ngrp; g0 += 8) {  // four 16-byte pieces of each row in flight per lane
+                uint4 cv[2][4];
+#pragma unroll
+                for (int v = 0; v < 2; ++v)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (g0 + 2 * u < ngrp) cv[v][u] = *reinterpret_cast<const uint4 *>(x[v] + 16 * (g0 + 2 * u));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (!(g0 + 2 * u < ngrp)) continue;
+                    const float *q = acc_q + 16 * (g0 + 2 * u);
+#pragma unroll
+                    for (int wi = 0; wi < 4; ++wi) {
+                        const float4 qa = *reinterpret_cast<const float4 *>(q + 4 * wi);
+#pragma unroll
+                        for (int v = 0; v < 2; ++v) {
+                            const uint32_t wv = wi == 0 ? cv[v][u].x : (wi == 1 ? cv[v][u].y : (wi == 2 ? cv[v][u].z : cv[v][u].w));
+                            const float e0 = fmaf(par[v].y, (float)(wv & 255u), par[v].x) - qa.x;
+                            const float e1 = fmaf(par[v].y, (float)((wv >> 8) & 255u), par[v].x) - qa.y;
+                            const float e2 = fmaf(par[v].y, (float)((wv >> 16) & 255u), par[v].x) - qa.z;
+                            const float e3 = fmaf(par[v].y, (float)(wv >> 24), par[v].x) - qa.w;
+                            d0[v] = fmaf(e0, e0, d0[v]), d1[v] = fmaf(e1, e1, d1[v]), d0[v] = fmaf(e2, e2, d0[v]), d1[v] = fmaf(e3, e3, d1[v]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                float dt = d0[v] + d1[v];
+                dt += __shfl_xor(dt, 1, 2);
+                const float err = (par[v].z * up) * sqd;  // >= sqrt(dim) max |x_i - x^_i| >= ||x - x^||   (inf: a list that is never rejected)
+                const float t = sqrtf(dt * down) * down - err * up;
+                if (exact[v] && t > 0.0f && (t * t) * (down * down) > thr) {  // false for NaN
+                    exact[v] = false;
+                    if (hf == 0) recs[iv[v]].accurate = __builtin_inff();
+                    ++rejected;
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+            if (exact[v] && hf == 0) queue[atomicAdd(&qn, 1u)] = iv[v];  // at most 127 waiting + 256 new
+        __syncthreads();
+        uint32_t waiting = qn;  // the same value in every thread: nobody touches qn before the next barrier
+        __syncthreads();
+        while (waiting >= 128) {  // block-uniform
+            const uint32_t j = queue[waiting - 128 + pair];
+            const float r = exact_l2_pair(base + (uint64_t)recs[j].pos * dim + 4 * hf, acc_q, dim, hf);
+            if (hf == 0) recs[j].accurate = r;
+            waiting -= 128;
+            __syncthreads();  // the queue's top 128 entries are free again
+            if (threadIdx.x == 0) qn = waiting;
+            __syncthreads();
         }
     }
     const uint32_t waiting = qn;

@@ -270,7 +270,9 @@ struct rq_index {
         if (base_host) (void)hipHostFree(base_host);
     }
     DevBuf<float> base, P, centroids, cent_t;
-    DevBuf<_Float16> base_h;  // fp16 shadow of `base` (rerank pre-filter, derived; untiered indexes with HBM to spare)
+    DevBuf<_Float16> base_h;  // fp16 shadow of `base` (rerank pre-filter, derived; untiered indexes with HBM to spare; option rerank_shadow = 1)
+    DevBuf<uint8_t> base_q8;  // 8-bit shadow of `base`, one affine map per list (the default pre-filter: half the fp16 shadow's bytes per survivor)
+    DevBuf<float4> list_q8;   //   per list: {lo, s, max |x_i - x^_i| over the list's rows, -}
     DevBuf<uint32_t> offsets, map_ids;
     DevBuf<uint64_t> codes;
     DevBuf<float4> factors;
@@ -445,7 +447,11 @@ static void launch_coarse_prefiltered(const rq_index *idx, const float *y, float
     // the register-resident row from 4096 lists up, and the only form beyond 8192 --, else the row in registers
     const uint32_t ntile = ceil_div(k, 32u);
     const int impl = g_coarse_impl.load();
-    const bool tiled = redo != nullptr && ntile >= nprobe && (k > 8192 || impl == 4 || (impl != 3 && k >= (uint32_t)g_coarse_tiled_from.load()));
+    // (not chosen automatically at dim 768 and beyond: measured on the 100M x 768 benchmark index the step's coarse ranking went from 2.5 to
+    // 22 ms with it -- no kernel got slower, the time sits between the launches behind coarse_approx_kernel<12,1>, the one kernel of the path
+    // that spills to scratch memory; the row-in-registers selection does not show it)
+    const bool tiled = redo != nullptr && ntile >= nprobe &&
+                       (k > 8192 || impl == 4 || (impl != 3 && k >= (uint32_t)g_coarse_tiled_from.load() && idx->W <= 8));
     if (tiled) {
 #define RQ_TILED(TPL)                                                                                                             \
     select_refine_tiled_kernel<TPL><<<g, b, 4 * 64 * (TPL) * 4, st>>>(dist, y, idx->centroids.p, idx->cent_norm_max, k, dim, nprobe, out_cluster, \
@@ -1356,7 +1362,11 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             pf.begin(PF_RERANK);
             const uint32_t gx = std::max(1u, std::min(16u, 4096u / std::max(nq, 1u)));
             // past the first stage the thresholds are finite: survivors go through the fp16 shadow rows first
-            if (idx->base_h.p && (stage_no > 0 || qp.thr_init) && !(g_scan_dbg & 512))
+            if (idx->base_q8.p && (stage_no > 0 || qp.thr_init) && !(g_scan_dbg & 512))
+                accurate_filtered8_kernel<<<dim3(gx, nq), 256, (size_t)dim * sizeof(float), st>>>(
+                    ws.surv.p, ws.surv_cnt.p, seg, idx->base.p, idx->base_q8.p, idx->list_q8.p, qpad, dim, rerank_order, ws.thr.p,
+                    probe_cluster, nprobe, ws.nshadow.p);
+            else if (idx->base_h.p && (stage_no > 0 || qp.thr_init) && !(g_scan_dbg & 512))
                 accurate_filtered_kernel<<<dim3(gx, nq), 256, (size_t)dim * sizeof(float), st>>>(
                     ws.surv.p, ws.surv_cnt.p, seg, idx->base.p, idx->base_h.p, qpad, dim, rerank_order, ws.thr.p,
                     ws.nshadow.p);
@@ -1736,7 +1746,7 @@ static rq_status query_device_end(rq_ticket *tk) {
 // fp16 shadow of the raw vectors (kernels_query.h: rerank pre-filter).  Only for untiered indexes, and only when the
 // 2*dim bytes per vector still leave the query workspaces their room; it costs one streaming pass over `base`.
 #define RQ_SHADOW_MIN_ROWS 1ull
-static std::atomic<int> g_rerank_shadow{1};  // fp16 shadow rows for the rerank pre-filter: 0 never, 1 when they fit
+static std::atomic<int> g_rerank_shadow{2};  // shadow rows for the rerank pre-filter: 0 never, 1 fp16 when they fit, 2 8-bit (one affine map per list) when they fit
 static rq_status derive_shadow_rows(rq_index *idx);
 static rq_status finish_index(rq_index *idx) {
     // derived state: transposed centroids, longest list
@@ -1798,11 +1808,34 @@ static rq_status finish_index(rq_index *idx) {
 
 static rq_status derive_shadow_rows(rq_index *idx) {
     idx->base_h.release();
-    if (!g_rerank_shadow.load() || idx->base_host != nullptr || idx->n < RQ_SHADOW_MIN_ROWS) return RQ_OK;
-    const uint64_t total = idx->n * idx->dim, bytes = total * 2;
+    idx->base_q8.release();
+    idx->list_q8.release();
+    const int kind = g_rerank_shadow.load();
+    if (!kind || idx->base_host != nullptr || idx->n < RQ_SHADOW_MIN_ROWS) return RQ_OK;
+    const uint64_t total = idx->n * idx->dim, bytes = total * (kind == 2 ? 1 : 2);
     size_t free_b = 0, total_b = 0;
     HIPC(hipMemGetInfo(&free_b, &total_b));
     if (free_b < bytes + (48ull << 30) && bytes > (1ull << 30)) return RQ_OK;  // keep the survivor buffers their share
+    if (kind == 2) {  // one byte per dimension, per-list affine map, measured error bound (kernels_query.h)
+        if (idx->dim > 4096 || idx->base_q8.alloc(total) != RQ_OK || idx->list_q8.alloc(std::max<uint32_t>(idx->k, 1)) != RQ_OK) {
+            (void)hipGetLastError();
+            idx->base_q8.release();
+            idx->list_q8.release();
+            return RQ_OK;  // no room: queries run without the pre-filter
+        }
+        std::vector<uint32_t> off((size_t)idx->k + 1);
+        HIPC(hipMemcpy(off.data(), idx->offsets.p, off.size() * 4, hipMemcpyDeviceToHost));
+        uint32_t longest = 0;
+        for (uint32_t c = 0; c < idx->k; ++c) longest = std::max(longest, off[c + 1] - off[c]);
+        q8_range_kernel<<<idx->k, 256>>>(idx->base.p, idx->offsets.p, idx->dim, idx->list_q8.p);
+        if (longest)
+            for (uint32_t c0 = 0; c0 < idx->k; c0 += 32768)  // (grid.y is limited to 65535)
+                q8_encode_kernel<<<dim3(ceil_div(longest, 256u), std::min(32768u, idx->k - c0)), 256>>>(
+                    idx->base.p, idx->offsets.p + c0, idx->dim, idx->list_q8.p + c0, idx->base_q8.p);
+        HIPC(hipDeviceSynchronize());
+        HIPC(hipGetLastError());
+        return RQ_OK;
+    }
     if (idx->base_h.alloc(total) != RQ_OK) {
         (void)hipGetLastError();
         return RQ_OK;  // no room: queries run without the pre-filter
@@ -3517,7 +3550,7 @@ rq_status rq_set_option(const char *name, int value) {
         return RQ_OK;
     }
     if (std::string(name) == "rerank_shadow") {  // fp16 shadow rows (rerank pre-filter) for indexes built / loaded from now on
-        if (value < 0 || value > 1) return fail(RQ_ERR_INVALID, "rerank_shadow must be 0 (never) or 1 (when they fit)");
+        if (value < 0 || value > 2) return fail(RQ_ERR_INVALID, "rerank_shadow must be 0 (never), 1 (fp16 rows when they fit) or 2 (8-bit rows when they fit)");
         g_rerank_shadow = value;
         return RQ_OK;
     }

@@ -9,9 +9,9 @@ import rabitq_amd as rq
 from rabitq_amd import index as ix
 from tests import synth
 dev = torch.device("cuda", 0)
-d, nq, probe = 128, 65536, 64
+d, nq, probe = int(os.environ.get("D", 128)), int(os.environ.get("NQ", 65536)), 64
 out = []
-for k in (2048, 4096, 8192, 16384, 32768):
+for k in [int(v) for v in os.environ.get("KLIST", "2048,4096,8192,16384,32768").split(",")]:
     g = torch.Generator(device=dev); g.manual_seed(k)
     centres = torch.randn(k, d, generator=g, device=dev)
     x = (centres[torch.randint(0, k, (4 * k,), generator=g, device=dev)] + 0.5 * torch.randn(4 * k, d, generator=g, device=dev)).contiguous()

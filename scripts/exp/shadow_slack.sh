@@ -1,0 +1,13 @@
+#!/bin/bash
+# Run ON THE GPU BOX (developer experiment): rejection rate of the rerank's shadow test when its error bound is inflated by a
+# constant (norm units) -- what a coarser shadow code (8 / 6 / 4 bits per dimension) would still reject.  Rebuilds the library
+# with -DRQ_EXP_SHADOW_SLACK=<x>.
+for x in "$@"; do
+  (cd rabitq_amd/csrc && touch rabitq_hip.hip && make FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Wall -Wno-unused-function -DRQ_EXP_SHADOW_SLACK=$x" build/rabitq_hip.o ../librabitq_hip.so > /dev/null 2>&1)
+  timeout -k 10 400 python bench.py --no-secondary --steps 3 --warmup 2 --no-cpu-baseline --no-two-in-flight --gt-queries 50 --small-batch 0 > gpurun_out/b_slack.json 2> gpurun_out/b_slack.err
+  python - <<PY
+import json
+d=json.loads(open("gpurun_out/b_slack.json").read().strip().splitlines()[-1])
+print("slack $x:", "survivors/query", round(d["rerank_candidates_per_query"],1), "rejected by the shadow", round(d["rerank_shadow_rejects_per_query"],1), "reference reranks", round(d["precise_per_query"],1))
+PY
+done

@@ -29,7 +29,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 KINDS = ["gauss", "gauss", "sift_u8", "sparse", "student_t", "tight", "near_ties"]
 SCALES = [1e-3, 1.0, 1.0, 40.0, 1e3, 3e4]
-KNOB_DEFAULTS = {"base_device_mb": -1, "max_scan_blocks": 0, "scan_tile_table": 1, "group_rank": 1, "rerank_shadow": 1,
+KNOB_DEFAULTS = {"base_device_mb": -1, "max_scan_blocks": 0, "scan_tile_table": 1, "group_rank": 1, "rerank_shadow": 2,
                  "coarse_impl": 0, "dense_dir": 1, "small_batch": 0, "scan_impl": 0, "small_batch_span": 2560, "stage_growth": 0,
                  "survivor_segments": 1, "scan_gate": 0}
 
@@ -97,7 +97,7 @@ def fuzz_round(rq, oracle, rng, it, nmax=12000):
     # engine knobs that must never change a result
     knobs = {"base_device_mb": int(rng.choice([-1, -1, 0, 1])), "max_scan_blocks": int(rng.choice([0, 0, 3, 40])),
              "scan_tile_table": int(rng.choice([0, 1, 2])), "group_rank": int(rng.choice([0, 1, 2])),
-             "rerank_shadow": int(rng.choice([0, 1, 1])), "coarse_impl": int(rng.choice([0, 1, 2, 3, 4])),
+             "rerank_shadow": int(rng.choice([0, 1, 2, 2])), "coarse_impl": int(rng.choice([0, 1, 2, 3, 4])),
              "dense_dir": int(rng.choice([0, 1, 1])), "small_batch": int(rng.choice([0, 0, 1])),
              "small_batch_span": int(rng.choice([100, 2560, 2560, 65536])), "stage_growth": int(rng.choice([0, 0, 2, 16])),
              "scan_impl": int(rng.choice([0, 1, 2])), "survivor_segments": int(rng.choice([1, 1, 2])),

@@ -44,7 +44,7 @@ def main(**over):
     chunk = max(262_144, min(4_000_000, (512 << 20) // d))
     # build-time knobs: BASE_MB = HBM budget of the raw vectors in MiB (the rest in pinned host memory), SHADOW=0 = no fp16 rows
     ix.set_option("base_device_mb", int(env.get("BASE_MB", -1)))
-    ix.set_option("rerank_shadow", int(env.get("SHADOW", 1)))
+    ix.set_option("rerank_shadow", int(env.get("SHADOW", 2)))
     b = rq.RaBitQ.builder(n, d, centres.data_ptr(), k, orthogonal=P)
     for ci, i0 in enumerate(range(0, n, chunk)):
         m = min(chunk, n - i0)
@@ -57,7 +57,7 @@ def main(**over):
         b.place_chunk(x.data_ptr(), i0, m)
     idx = b.finish()
     ix.set_option("base_device_mb", -1)
-    ix.set_option("rerank_shadow", 1)
+    ix.set_option("rerank_shadow", 2)
     del x
     idx_n_host = idx.n - idx.n_hbm
     torch.cuda.empty_cache()

@@ -189,11 +189,11 @@ OPTION_VALUES = {
     "scan_impl": [0, 1, 2], "scan_gate": [0, 1, 2], "coarse_impl": [0, 1, 2, 3, 4], "coarse_tiled_from": [0, 4096, 1000000], "group_rank": [0, 1, 2], "scan_tile_table": [0, 1, 2],
     "dense_dir": [0, 1], "small_batch": [0, 1], "small_batch_span": [64, 2560, 100000], "stage_growth": [0, 2, 16],
     "survivor_segments": [0, 1, 2, 3], "max_scan_blocks": [0, 1, 7], "shared_thresholds": [0, 1, 2], "assign_impl": [0, 1],
-    "rerank_shadow": [0, 1], "scan_debug": [0, 128, 512, 4096, 16384, 128 | 512 | 4096],
+    "rerank_shadow": [0, 1, 2], "scan_debug": [0, 128, 512, 4096, 16384, 128 | 512 | 4096],
 }
 OPTION_DEFAULTS = {"scan_impl": 0, "scan_gate": 0, "coarse_impl": 0, "coarse_tiled_from": 4096, "group_rank": 1, "scan_tile_table": 1, "dense_dir": 1,
                    "small_batch": 0, "small_batch_span": 2560, "stage_growth": 0, "survivor_segments": 1, "max_scan_blocks": 0,
-                   "shared_thresholds": 1, "assign_impl": 0, "rerank_shadow": 1, "scan_debug": 0}
+                   "shared_thresholds": 1, "assign_impl": 0, "rerank_shadow": 2, "scan_debug": 0}
 
 
 def test_every_option_value_keeps_golden_results(rq):
@@ -1575,15 +1575,19 @@ def test_long_run_directories_large_batch(rq, oracle, dense_dir):
     oidx.close()
 
 
+@pytest.mark.parametrize("shadow", [2, 1])
 @pytest.mark.parametrize("d,kind", [(128, "gauss"), (192, "gauss"), (128, "beyond_fp16"), (128, "fp16_subnormal"),
-                                    (128, "small_ints"), (64, "near_ties")])
-def test_rerank_shadow_rows_keep_results_exact(rq, oracle, d, kind, tmp_path):
-    """Large batches re-rank through the fp16 shadow rows (accurate_filtered_kernel): a survivor is dropped without its
-    f32 row being read only when the shadow PROVES accurate >= the stage's threshold.  Data the shadow represents badly
-    (elements beyond the fp16 range -> inf, fp16 subnormals, near-equal distances around the threshold) must still give
-    the oracle's ids and distances bit for bit; on ordinary data the test must actually reject rows."""
+                                    (128, "small_ints"), (64, "near_ties"), (128, "nan_row"), (768, "gauss")])
+def test_rerank_shadow_rows_keep_results_exact(rq, oracle, d, kind, shadow, tmp_path):
+    """Large batches re-rank through shadow rows -- 8-bit codes with one affine map per list and a measured error bound
+    (rerank_shadow = 2, the default: accurate_filtered8_kernel) or fp16 rows (1: accurate_filtered_kernel): a survivor is dropped
+    without its f32 row being read only when the shadow PROVES accurate >= the stage's threshold.  Data the shadow represents
+    badly (elements beyond the fp16 range -> inf / a list whose 8-bit step is huge, tiny scales, near-equal distances around
+    the threshold, a NaN coordinate: that list is never filtered) must still give the oracle's ids and distances bit for
+    bit; on ordinary data the test must actually reject rows."""
     from rabitq_amd import index as ix
-    n, k, nq = 40_000, 8, 300
+    ix.set_option("rerank_shadow", shadow)
+    n, k, nq = (40_000, 8, 300) if d < 768 else (12_000, 6, 280)
     rng = np.random.default_rng(d + len(kind))
     x, centres, _ = synth.mixture(n, d, k, sigma=0.7, seed=3 + d, centre_scale=0.6)
     queries, _, _ = synth.mixture(nq, d, k, sigma=0.7, seed=4 + d, centre_scale=0.6)
@@ -1600,6 +1604,8 @@ def test_rerank_shadow_rows_keep_results_exact(rq, oracle, d, kind, tmp_path):
         x[: n // 2] = x[:20].repeat(n // 40, axis=0) + 1e-4 * rng.standard_normal((n // 2, d))
         queries[:150] = x[rng.integers(0, n // 2, 150)] + 1e-4 * rng.standard_normal((150, d))
     x, centres, queries = (np.ascontiguousarray(a, np.float32) for a in (x, centres, queries))
+    if kind == "nan_row":
+        x[17, 5] = np.nan
     P = synth.random_orthogonal(d, seed=d)
     oidx = oracle.OracleIndex.build(x, centres, P)
     gidx = rq.RaBitQ.build(x, centres, P)
@@ -1613,7 +1619,7 @@ def test_rerank_shadow_rows_keep_results_exact(rq, oracle, d, kind, tmp_path):
                 assert pr["rerank_shadow_rejects"] > pr["rerank_candidates"] // 4, (pr["rerank_shadow_rejects"], pr["rerank_candidates"])
         ix.set_option("rerank_shadow", 0)      # the same index without shadow rows: the plain exact re-ranker
         plain = rq.RaBitQ.build(x, centres, P)
-        ix.set_option("rerank_shadow", 1)
+        ix.set_option("rerank_shadow", shadow)
         a, b = gidx.query_batch(queries, 8, 10, False), plain.query_batch(queries, 8, 10, False)
         assert ix.last_profile()["rerank_shadow_rejects"] == 0
         for u, v in zip(a, b):
@@ -1635,7 +1641,7 @@ def test_rerank_shadow_rows_keep_results_exact(rq, oracle, d, kind, tmp_path):
             shard.close()
     finally:
         ix.set_profiling(0)
-        ix.set_option("rerank_shadow", 1)
+        ix.set_option("rerank_shadow", 2)
     gidx.close()
     oidx.close()
 
