@@ -73,7 +73,8 @@ typedef struct {
  * out-structs, rq_get_device_ptr refuses RQ_ARR_BASE on tiered indexes; options "scan_dense" and the round-2 "coarse_impl" = 3 removed.
  * 4: rq_set_option("scan_debug") refuses the timing-ablation bits -- they exist in the developer build only --, the matrix-core
  * scan's step counters in rq_profile_t are always filled, new option "scan_gate", "coarse_impl" = 3 is back with a new meaning,
- * rq_profile_t.reserved became coarse_fallback_rows, .reserved2 matrix_additive_launches).  A host checks rq_abi_version() ==
+ * rq_profile_t.reserved became coarse_fallback_rows, .reserved2 matrix_additive_launches; later in revision 4, additions only: "coarse_impl" = 4,
+ * "coarse_tiled_from", "rerank_shadow" = 2 -- the new default).  A host checks rq_abi_version() ==
  * RQ_ABI_VERSION once after loading the library. */
 #define RQ_ABI_VERSION 4
 uint32_t rq_abi_version(void);
@@ -331,7 +332,7 @@ typedef struct {
     /* 32x32 (query x candidate) sub-tile steps of the matrix-core scan, and how many of them were flagged by its gate and took
      * the exact f32 path (always filled since ABI revision 4) */
     uint64_t matrix_subtile_steps, matrix_exact_steps;
-    /* of rerank_candidates: survivors the fp16 shadow rows proved to be at or above their stage's threshold, whose
+    /* of rerank_candidates: survivors the shadow rows (8-bit or fp16, option "rerank_shadow") proved to be at or above their stage's threshold, whose
      * 4*dim-byte row was therefore never fetched (option "rerank_shadow"; large batches) */
     uint64_t rerank_shadow_rejects;
     /* small-batch path (<= 64 queries: rotate + coarse in one launch, then one block per query doing probe selection, query
@@ -353,19 +354,23 @@ rq_status rq_set_profiling(int level);
  * settings return identical results; the option exists for tests and measurements.
  * "base_device_mb": HBM budget (MiB) of the raw vectors of indexes built / loaded from now on (-1 = automatic, the
  * default); vectors beyond it live in pinned host memory.  Results never depend on it.
- * "rerank_shadow": 1 (default) = indexes built / loaded from now on whose raw vectors are all in HBM also keep an fp16
- * shadow of them (2*dim bytes per vector, when that still leaves the query workspaces their room): the re-ranker of
- * large batches reads the shadow row first and fetches the f32 row only when the shadow cannot prove that the exact
- * distance is at or above the stage's threshold (then the reference rejects it whatever its value).  0 = never.
- * Results are bit-identical either way.
+ * "rerank_shadow": shadow rows of indexes built / loaded from now on whose raw vectors are all in HBM (when that still leaves
+ * the query workspaces their room): 2 (default) = 8-bit rows (dim bytes per vector; one affine map per list, error bound
+ * measured while the codes are written), 1 = fp16 rows (2*dim bytes per vector), 0 = none.  The re-ranker of large batches
+ * reads the shadow row first and fetches the f32 row only when the shadow cannot prove that the exact distance is at or
+ * above the stage's threshold (then the reference rejects it whatever its value).  Results are bit-identical for every value.
  * "max_scan_blocks": test hook, blocks per scan launch (0 = hardware bound).
  * "coarse_impl": coarse ranking (identical probe lists and distance bits for every value): 0 = automatic (default: batches of
  * >= 2048 queries rank through the bf16 matrix-core pre-filter + exact-order refinement of the candidates within a proven margin
- * of the nprobe-th approximate distance, where it applies -- dim/64 in {1, 2, 3, 4, 6, 8, 12}, <= 8192 lists, nprobe <= 64 --, else
- * the exact-order distance kernels over all lists), 1 = exact-order kernel with the query rows through LDS, 2 = exact-order
- * kernel with the query rows in scalar registers, 3 = the pre-filter wherever it applies (tests).  rq_profile_t.
- * coarse_fallback_rows counts queries whose candidate set exceeded the refinement's 256 slots (near-equidistant centroids) or
- * whose margin was not finite: they are ranked in exact order over all lists inside the same kernel.
+ * of the nprobe-th approximate distance, where it applies -- dim/64 in {1, 2, 3, 4, 6, 8, 12}, <= 65536 lists, nprobe <= 64; the
+ * nprobe-th approximate distance is bounded from the minima of 32-list tiles from 4096 lists up (dim <= 512) and always
+ * beyond 8192 lists, with the row in one wave's registers otherwise --, else the exact-order distance kernels over all lists),
+ * 1 = exact-order kernel with the query rows through LDS, 2 = exact-order kernel with the query rows in scalar registers,
+ * 3 = the pre-filter wherever it applies, row in registers up to 8192 lists (tests), 4 = the pre-filter with the tile-minima
+ * selection wherever a row has at least nprobe tiles (tests).  rq_profile_t.coarse_fallback_rows counts queries whose
+ * candidate set exceeded the refinement's 256 slots (near-equidistant centroids) or whose margin was not finite: they are
+ * ranked in exact order over all lists (per row).
+ * "coarse_tiled_from": developer knob, list count from which the automatic choice selects through tile minima (default 4096).
  * "shared_thresholds": rq_query_batch_sharded_device: 1 (default) = with more than one shard the step runs the nearest
  * list first, all-reduces (min) the k-th best distances and seeds the rest of the probe list with them (see
  * rq_query_batch_device_seeded); 0 = every shard prunes with its own thresholds only; 2 = also with one shard (tests).
@@ -393,7 +398,7 @@ rq_status rq_set_profiling(int level);
  * wherever it exists (test hook).
  * Developer knobs: "stage_growth" (geometric growth of the early stages, 0 = default; results are identical for every
  * value), "scan_debug": measurement hooks under which every result is UNCHANGED -- 128 (kept for older hosts: the sub-tile /
- * exact-path step counters of rq_profile_t are always on since ABI revision 4), 512 no fp16 shadow rows in the rerank,
+ * exact-path step counters of rq_profile_t are always on since ABI revision 4), 512 no shadow rows in the rerank,
  * 4096 the phases of the small-batch kernel, 16384 the stage list of every pass (stderr).  Any other bit is refused with
  * RQ_ERR_INVALID by this library: the TIMING ABLATIONS of the matrix-core scan (1, 2, 4, 64, 1024, 8192: results are WRONG) and
  * its in-kernel cycle counters (256) are compiled only into the developer build (make -C rabitq_amd/csrc dev ->
