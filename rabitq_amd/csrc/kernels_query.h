@@ -995,7 +995,8 @@ __device__ __forceinline__ void prep_small_pairs(const float *__restrict__ y, co
                                                  const float *__restrict__ pair_ycd, uint32_t npairs,
                                                  uint32_t pairs_per_row, PairScalars *__restrict__ scal,
                                                  uint32_t *__restrict__ qnib, uint32_t *__restrict__ qf6,
-                                                 uint32_t nlists, uint32_t skip_empty, uint32_t p0) {
+                                                 uint32_t nlists, uint32_t skip_empty, uint32_t p0,
+                                                 const uint32_t *__restrict__ live_list = nullptr /* compacted pair ids (pair_split_kernel): p0 indexes it */) {
     // dim = 4 * LP * R: LP lanes per pair, each owning 4 consecutive dimensions in each of R rounds of 4*LP
     // dimensions (R > 1 only with LP = 64: dim 512, 768, 1024).  Every lane group handles PP pairs: the kernel is a
     // chain of dependent gathers (probe list -> centroid row, list bounds), so the loads of all PP pairs are issued
@@ -1006,17 +1007,20 @@ __device__ __forceinline__ void prep_small_pairs(const float *__restrict__ y, co
     uint32_t cl[PP], lb[PP], ll[PP];
     float ycd_in[PP];
     bool live[PP];
+    uint32_t pid[PP];  // the pair each of the PP rounds works on
 #pragma unroll
     for (int pp = 0; pp < PP; ++pp) {
-        const uint32_t p = p0 + pp * PPW;
-        live[pp] = p < npairs;  // uniform over the pair's LP lanes
+        const uint32_t pi = p0 + pp * PPW;
+        live[pp] = pi < npairs;  // uniform over the pair's LP lanes
+        pid[pp] = live_list ? (live[pp] ? live_list[pi] : 0u) : pi;
+        const uint32_t p = pid[pp];
         cl[pp] = live[pp] ? pair_cluster[p] : 0xFFFFFFFFu;
         ycd_in[pp] = live[pp] ? pair_ycd[p] : 0.0f;
     }
     float4 cv[PP][R], yv[PP][R];
 #pragma unroll
     for (int pp = 0; pp < PP; ++pp) {
-        const uint32_t p = p0 + pp * PPW, c = cl[pp];
+        const uint32_t p = pid[pp], c = cl[pp];
         const bool in = live[pp] && c < nlists;
         lb[pp] = in ? offsets[c] : 0u;
         ll[pp] = in ? offsets[c + 1] - lb[pp] : 0u;
@@ -1037,7 +1041,7 @@ __device__ __forceinline__ void prep_small_pairs(const float *__restrict__ y, co
     }
 #pragma unroll
     for (int pp = 0; pp < PP; ++pp) {
-        const uint32_t p = p0 + pp * PPW;
+        const uint32_t p = pid[pp];
         if (!live[pp]) continue;
         const uint32_t row = p / pairs_per_row;
         if (ll[pp] == 0 && skip_empty) {  // nothing to scan for this pair (e.g. a list another shard owns)
@@ -1128,6 +1132,69 @@ __global__ __launch_bounds__(256) void prep_small_kernel(const float *__restrict
     const uint32_t p0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (PPW * PP) + (threadIdx.x & 63) / LP;
     prep_small_pairs<LP, R, PP>(y, centroids, offsets, pair_cluster, pair_ycd, npairs, pairs_per_row, scal, qnib, qf6, nlists,
                                 skip_empty, p0);
+}
+
+// Sharded passes (a rank of a multi-GPU deployment: most probed lists live on other ranks, i.e. are empty here): one THREAD
+// per pair writes the scalars of the pairs with nothing to scan and lists the others, and the quantisation kernel -- a lane
+// group per pair -- then runs over that list only (7 of 8 lane groups did nothing but find their list empty).
+__global__ __launch_bounds__(1024) void pair_split_kernel(const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ pair_cluster,
+                                                          const float *__restrict__ pair_ycd, uint32_t npairs, uint32_t pairs_per_row,
+                                                          uint32_t nlists, PairScalars *__restrict__ scal,
+                                                          uint32_t *__restrict__ live_list, uint32_t *__restrict__ live_count) {
+    // 4096 pairs per block, ONE reservation per block on the list's counter (a wave-level reservation each was half a million
+    // atomics on one address per pass: 3 ms)
+    __shared__ uint32_t wcnt[4][16], s_base;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool keep[4];
+    uint32_t rank[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t p = blockIdx.x * 4096 + u * 1024 + threadIdx.x;
+        keep[u] = false;
+        if (p < npairs) {
+            const uint32_t c = pair_cluster[p];
+            const uint32_t len = c < nlists ? offsets[c + 1] - offsets[c] : 0u;
+            keep[u] = len != 0;
+            if (!keep[u]) {  // exactly what prep_small_pairs writes for such a pair
+                PairScalars s;
+                s.lower = 0.0f, s.delta = 0.0f, s.sumq = 0.0f, s.ycd = pair_ycd[p], s.ycd_sqrt = 0.0f;
+                s.row = p / pairs_per_row, s.list_begin = 0, s.list_len = 0, s.stream_begin = 0, s.pad = 0;
+                scal[p] = s;
+            }
+        }
+        const uint64_t m = __ballot(keep[u]);
+        rank[u] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wcnt[u][wave] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int u = 0; u < 4; ++u)
+            for (int w = 0; w < 16; ++w) {
+                const uint32_t c = wcnt[u][w];
+                wcnt[u][w] = tot;
+                tot += c;
+            }
+        s_base = tot ? atomicAdd(live_count, tot) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (keep[u]) live_list[s_base + wcnt[u][wave] + rank[u]] = blockIdx.x * 4096 + u * 1024 + threadIdx.x;
+}
+template <int LP, int R, int PP>
+__global__ __launch_bounds__(256) void prep_small_listed_kernel(const float *__restrict__ y,
+                                                                const float *__restrict__ centroids,
+                                                                const uint32_t *__restrict__ offsets,
+                                                                const uint32_t *__restrict__ pair_cluster,
+                                                                const float *__restrict__ pair_ycd, const uint32_t *__restrict__ live_list,
+                                                                uint32_t nlive,
+                                                                uint32_t pairs_per_row, PairScalars *__restrict__ scal,
+                                                                uint32_t *__restrict__ qnib, uint32_t *__restrict__ qf6,
+                                                                uint32_t nlists) {
+    constexpr uint32_t PPW = 64 / LP;
+    const uint32_t p0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (PPW * PP) + (threadIdx.x & 63) / LP;
+    prep_small_pairs<LP, R, PP>(y, centroids, offsets, pair_cluster, pair_ycd, nlive, pairs_per_row, scal, qnib, qf6, nlists, 1u, p0, live_list);
 }
 
 // Position of every probed list in the query's candidate stream (the order the reference visits
@@ -1292,6 +1359,9 @@ __device__ __forceinline__ void stage_fill_item(const PairScalars *__restrict__ 
                                                 const uint32_t *__restrict__ blk_base, uint32_t k,
                                                 const float4 *__restrict__ list_uref /* tile_images == 2: U0 per list */) {
     const uint32_t sub = threadIdx.x & 15;                       // 16 lanes per pair
+    // (ranked placement: the counting pass has already decided which items are in the stage -- 7 of 8 are not when the pairs of
+    // seven other shards' lists ride along in a multi-GPU pass; they leave before their 40-byte scalars are fetched)
+    if (cluster_major && rank && rank[wi] == ~0u) return;
     const uint32_t wb = wi / slot_hi, p = wb * nprobe + (wi - wb * slot_hi);
     const PairScalars ps = scal[p];
     const bool in = pair_in_stage(ps, s_lo, s_hi);
@@ -1442,9 +1512,11 @@ __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__re
                                                          uint32_t tile_images,
                                                          const uint32_t *__restrict__ rank /* group_rank_kernel, or null */,
                                                          const uint32_t *__restrict__ blk_base, uint32_t k,
-                                                         const float4 *__restrict__ list_uref) {
-    const uint32_t wi = blockIdx.x * 16 + (threadIdx.x >> 4);  // work item: (query, slot < slot_hi)
+                                                         const float4 *__restrict__ list_uref,
+                                                         const uint32_t *__restrict__ items = nullptr /* the work items to visit (count of them), else all */) {
+    uint32_t wi = blockIdx.x * 16 + (threadIdx.x >> 4);  // work item: (query, slot < slot_hi)
     if (wi >= count) return;
+    if (items) wi = items[wi];
     stage_fill_item(scal, probe_cluster, operand, thr, wi, nprobe, slot_hi, opdw, s_lo, s_hi, cluster_major, grp_start, grp_cursor,
                     recs, fs, tile_images, rank, blk_base, k, list_uref);
 }

@@ -213,6 +213,7 @@ struct Workspace {
     DevBuf<float> retry_q, retry_pd, retry_pc;  // overflow re-runs: the affected queries (and their probe lists)
     DevBuf<uint32_t> retry_rows;
     DevBuf<uint32_t> q_hist, q_start, q_order;  // rerank order of a large batch (queries grouped by nearest list)
+    DevBuf<uint32_t> live_list;                 // sharded passes: the (query, list) pairs whose list has members here, + their count
     DevBuf<uint32_t> coarse_redo;               // pre-filtered coarse ranking over more than 8192 lists: rows left to the block-per-query selection
     DevBuf<uint32_t> pair_rank, rank_base;      // group_rank_kernel: places of a big stage's pairs inside their groups
     DevBuf<uint32_t> probe_cluster, recs, grp_cnt, grp_start, heap_len, heap_id, precise, need,
@@ -416,6 +417,7 @@ static void launch_coarse(const float *cent_t, const float *y, float *dist, uint
 
 // Coarse ranking of nq rotated queries against ALL k lists: the matrix-core pre-filter + exact-order refinement where it applies
 // (coarse_impl 3, or -- once measured faster -- auto for big batches), else the exact-order distance kernels + selection.
+static std::atomic<int> g_pair_split{1};  // sharded passes: pairs of empty lists settled by a thread each, quantisation over the listed others (0 = lane group per pair: test hook)
 static std::atomic<int> g_coarse_tiled_from{4096};  // pre-filtered coarse ranking: list count from which the selection goes through tile minima (developer knob)
 static bool coarse_prefilter_has(uint32_t W) { return W == 1 || W == 2 || W == 3 || W == 4 || W == 6 || W == 8 || W == 12; }
 // (more lists than one wave holds in registers -- the ranking of a multi-GPU deployment is over the lists of ALL shards -- go through
@@ -893,6 +895,8 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     const uint32_t dim = idx->dim, k = idx->k, W = idx->W;
     const uint32_t nq = qp.nq, nprobe = std::min(qp.probe, k), topk = qp.topk;
     const uint32_t npairs = nq * nprobe;
+    bool listed = false;  // sharded pass: the pairs whose list has members here are listed (ws.live_list, nlive of them)
+    uint32_t nlive = 0;
     hipStream_t st = ws.stream;
     ws.pend_prefiltered = false;
     Prof &pf = ws.prof;
@@ -1054,9 +1058,29 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     {
         uint32_t *qn = scan_is_fused(W) ? ws.qnib.p : nullptr;
         uint32_t *q6 = scan_has_mfma(W) && impl != 1 ? ws.qf6.p : nullptr;
+        // an index most of whose lists are empty (a shard of a multi-GPU deployment: the probe lists name the lists of every shard):
+        // the pairs with nothing to scan are settled by one thread each, the quantisation runs over the listed others
+        listed = idx->nonempty_lists * 2 < k && npairs >= 65536 && g_pair_split.load() != 0 &&
+                 (dim == 64 || dim == 128 || dim == 256 || dim == 512 || dim == 768 || dim == 1024);
+        if (listed) {
+            RQC(ws.live_list.ensure((size_t)npairs + 1));
+            HIPC(hipMemsetAsync(ws.live_list.p + npairs, 0, 4, st));
+            pair_split_kernel<<<ceil_div(npairs, 4096), 1024, 0, st>>>(idx->offsets.p, probe_cluster, probe_dist, npairs, nprobe, k, ws.scal.p,
+                                                                       ws.live_list.p, ws.live_list.p + npairs);
+            // the launches over the listed pairs are sized by their number: one small copy and a wait (tens of microseconds against
+            // the milliseconds that 7 of 8 idle lane groups cost)
+            HIPC(hipMemcpyAsync(&nlive, ws.live_list.p + npairs, 4, hipMemcpyDeviceToHost, st));
+            HIPC(hipStreamSynchronize(st));
+        }
 #define RQ_PREP_SMALL(LP, R, PPB, PP)                                                                              \
-    prep_small_kernel<LP, R, PP><<<ceil_div(npairs, (PPB) * (PP)), 256, 0, st>>>(ws.y.p, idx->centroids.p, idx->offsets.p, probe_cluster, \
-                                                                    probe_dist, npairs, nprobe, ws.scal.p, qn, q6, k, idx->nonempty_lists * 2 < k ? 2u : 1u)
+    do {                                                                                                           \
+        if (listed)                                                                                                \
+            prep_small_listed_kernel<LP, R, PP><<<std::max(1u, ceil_div(nlive, (PPB) * (PP))), 256, 0, st>>>(ws.y.p, idx->centroids.p, idx->offsets.p, probe_cluster, \
+                                                                    probe_dist, ws.live_list.p, nlive, nprobe, ws.scal.p, qn, q6, k); \
+        else                                                                                                       \
+            prep_small_kernel<LP, R, PP><<<ceil_div(npairs, (PPB) * (PP)), 256, 0, st>>>(ws.y.p, idx->centroids.p, idx->offsets.p, probe_cluster, \
+                                                                    probe_dist, npairs, nprobe, ws.scal.p, qn, q6, k, idx->nonempty_lists * 2 < k ? 2u : 1u); \
+    } while (0)
         if (dim == 128) RQ_PREP_SMALL(32, 1, 8, 4);  // 32 lanes per pair, two pairs per wave, four rounds of pairs per lane group
         else if (dim == 64) RQ_PREP_SMALL(16, 1, 16, 4);
         else if (dim == 256) RQ_PREP_SMALL(64, 1, 4, 4);
@@ -1161,12 +1185,17 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         // pack the stage's work records (query operand + scalars + current threshold + local range)
         const uint32_t *operand = fp6_records ? ws.qf6.p
                                               : (scan_is_fused(W) ? ws.qnib.p : reinterpret_cast<const uint32_t *>(ws.planes.p));
-        if (!(sb_filled && !cluster_major))  // (the small-batch kernel has written a pair-major final stage's records already)
-            stage_fill_kernel<<<ceil_div(stage_pairs, 16), 256, 0, st>>>(ws.scal.p, probe_cluster, operand, ws.thr.p, stage_pairs,
+        if (!(sb_filled && !cluster_major)) {  // (the small-batch kernel has written a pair-major final stage's records already)
+            // a sharded pass visits only the listed pairs when the stage's work items ARE the pairs (every slot can be in the stage)
+            const bool fill_listed = listed && ranked && cluster_major && slot_hi == nprobe;
+            const uint32_t fill_items = fill_listed ? nlive : stage_pairs;
+            if (fill_items)
+                stage_fill_kernel<<<ceil_div(fill_items, 16), 256, 0, st>>>(ws.scal.p, probe_cluster, operand, ws.thr.p, fill_items,
                                                                     nprobe, slot_hi, fp6_records ? 12 * W : 8 * W, sg.s_lo, sg.s_hi,
                                                                     a.cluster_major, ws.grp_start.p, ws.grp_cnt.p, ws.recs.p,
                                                                     idx->fstats, use_mfma ? (additive ? 2u : 1u) : 0u, ranked ? ws.pair_rank.p : nullptr,
-                                                                    ws.rank_base.p, k, idx->list_uref.p);
+                                                                    ws.rank_base.p, k, idx->list_uref.p, fill_listed ? ws.live_list.p : nullptr);
+        }
         if (additive) {  // the stage's v' ranges per list (the candidates' side of the additive bound is built from them in the scan)
             RQC(ws.grp_vref.ensure(2 * (size_t)k));
             group_vrange_kernel<<<k, 256, 0, st>>>(ws.recs.p, ws.grp_start.p, ws.grp_cnt.p, 12 * W, ws.grp_vref.p);
@@ -3502,6 +3531,11 @@ rq_status rq_set_option(const char *name, int value) {
     if (std::string(name) == "max_scan_blocks") {  // test hook: blocks per scan launch (0 = the hardware bound), forces chunked stages
         if (value < 0) return fail(RQ_ERR_INVALID, "max_scan_blocks must be >= 0");
         g_max_scan_blocks = value == 0 ? RQ_MAX_BLOCKS_256 : std::min<uint32_t>((uint32_t)value, RQ_MAX_BLOCKS_256);
+        return RQ_OK;
+    }
+    if (std::string(name) == "pair_split") {  // test hook: 1 (default) = sharded passes list their non-empty pairs before the query quantisation, 0 = never
+        if (value < 0 || value > 1) return fail(RQ_ERR_INVALID, "pair_split must be 0 or 1");
+        g_pair_split = value;
         return RQ_OK;
     }
     if (std::string(name) == "coarse_tiled_from") {  // developer knob: list count from which the pre-filtered ranking selects through tile minima

@@ -189,11 +189,11 @@ OPTION_VALUES = {
     "scan_impl": [0, 1, 2], "scan_gate": [0, 1, 2], "coarse_impl": [0, 1, 2, 3, 4], "coarse_tiled_from": [0, 4096, 1000000], "group_rank": [0, 1, 2], "scan_tile_table": [0, 1, 2],
     "dense_dir": [0, 1], "small_batch": [0, 1], "small_batch_span": [64, 2560, 100000], "stage_growth": [0, 2, 16],
     "survivor_segments": [0, 1, 2, 3], "max_scan_blocks": [0, 1, 7], "shared_thresholds": [0, 1, 2], "assign_impl": [0, 1],
-    "rerank_shadow": [0, 1, 2], "scan_debug": [0, 128, 512, 4096, 16384, 128 | 512 | 4096],
+    "rerank_shadow": [0, 1, 2], "pair_split": [0, 1], "scan_debug": [0, 128, 512, 4096, 16384, 128 | 512 | 4096],
 }
 OPTION_DEFAULTS = {"scan_impl": 0, "scan_gate": 0, "coarse_impl": 0, "coarse_tiled_from": 4096, "group_rank": 1, "scan_tile_table": 1, "dense_dir": 1,
                    "small_batch": 0, "small_batch_span": 2560, "stage_growth": 0, "survivor_segments": 1, "max_scan_blocks": 0,
-                   "shared_thresholds": 1, "assign_impl": 0, "rerank_shadow": 2, "scan_debug": 0}
+                   "shared_thresholds": 1, "assign_impl": 0, "rerank_shadow": 2, "pair_split": 1, "scan_debug": 0}
 
 
 def test_every_option_value_keeps_golden_results(rq):
@@ -861,6 +861,40 @@ def test_scan_implementations_match_oracle(rq, oracle, impl, gate, n, d, k, nq):
         ix.set_option("scan_gate", 0)
     gidx.close()
     oidx.close()
+
+
+def test_shard_pass_lists_its_nonempty_pairs(rq, oracle):
+    """A shard of a multi-GPU deployment ranks over the lists of ALL shards, so most of a pass's (query, list) pairs name
+    lists that are empty here.  Large passes settle those by one thread each and run the query quantisation over a
+    compacted list of the others (pair_split_kernel, prep_small_listed_kernel); ranked stage placement skips them before
+    their scalars are fetched.  A quarter shard (16 of 64 lists), 2100 queries x 32 probes = 67 200 pairs: both rankers,
+    option pair_split 1 against 0 bit for bit, and against the oracle on the shard's own arrays."""
+    from rabitq_amd import index as ix
+    n, d, k = 60000, 128, 64
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.8, seed=61, centre_scale=0.6)
+    gidx = rq.RaBitQ.build(x, centres, synth.random_orthogonal(d, seed=62))
+    owner, _ = gidx.partition_lists(4)
+    shard = gidx.shard(owner, 1)
+    assert int((np.diff(shard.offsets.astype(np.int64)) > 0).sum()) * 2 < k
+    queries, _, _ = synth.mixture(2100, d, k, sigma=0.8, seed=63, centre_scale=0.6)
+    ov = oracle.OracleIndex.view(shard.dim, base=shard.base, orthogonal=shard.orthogonal, centroids=shard.centroids, offsets=shard.offsets,
+                                 map_ids=shard.map_ids, codes=shard.codes, factors=shard.factors)
+    try:
+        got = {}
+        for split in (1, 0):
+            ix.set_option("pair_split", split)
+            got[split] = [shard.query_batch(queries, 32, 10, heur) for heur in (False, True)]
+        for a, b in zip(got[1], got[0]):
+            for u, v in zip(a, b):
+                assert_bits_equal(u, v, "pair_split 1 vs 0")
+        ix.set_option("pair_split", 1)
+        _compare_with_oracle(rq, oracle, ov, shard, queries, 32, 10, False)
+        _compare_with_oracle(rq, oracle, ov, shard, queries[:300], 40, 20, True)
+    finally:
+        ix.set_option("pair_split", 1)
+    shard.close()
+    gidx.close()
+    ov.close()
 
 
 # A stage whose grid exceeds the launch bound is issued as several launches over (group, tile) sub-ranges
