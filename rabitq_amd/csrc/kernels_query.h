@@ -686,33 +686,42 @@ __global__ __launch_bounds__(256) void select_refine_tiled_kernel(float *__restr
     const uint32_t grp = lane >> 3, al = lane & 7;
     const uint32_t ntile = (k + 31) / 32;  // <= 64 TPL (host)
     const bool vec4 = (k & 3u) == 0u;
-    // sweep: 8 tiles (256 lists) per step, 4 lists per lane, the 8 lanes of a group fold one tile
-    for (uint32_t t0 = 0; t0 < ntile; t0 += 8) {
-        const uint32_t j0 = t0 * 32 + lane * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (vec4 && j0 < k) {
-            v = *reinterpret_cast<const float4 *>(d + j0);
-        } else if (!vec4) {
-            if (j0 < k) v.x = d[j0];
-            if (j0 + 1 < k) v.y = d[j0 + 1];
-            if (j0 + 2 < k) v.z = d[j0 + 2];
-            if (j0 + 3 < k) v.w = d[j0 + 3];
-        }
-        const float ve[4] = {v.x, v.y, v.z, v.w};
-        uint32_t mn = 0xFFFFFFFFu;
+    // sweep: 32 tiles (1024 lists) per step -- four 16-byte loads in flight per lane --, 4 lists per lane and load, the 8 lanes of
+    // a group fold one tile
+    for (uint32_t t0 = 0; t0 < ntile; t0 += 32) {
+        float4 v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const uint32_t key = j0 + e < k ? ord32_biased(ve[e]) : 0xFFFFFFFFu;
-            mn = key < mn ? key : mn;
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t j0 = (t0 + 8 * u) * 32 + lane * 4;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (vec4 && j0 < k) {
+                v[u] = *reinterpret_cast<const float4 *>(d + j0);
+            } else if (!vec4) {
+                if (j0 < k) v[u].x = d[j0];
+                if (j0 + 1 < k) v[u].y = d[j0 + 1];
+                if (j0 + 2 < k) v[u].z = d[j0 + 2];
+                if (j0 + 3 < k) v[u].w = d[j0 + 3];
+            }
         }
 #pragma unroll
-        for (int o = 4; o >= 1; o >>= 1) {
-            const uint32_t a = __shfl_xor(mn, o, 8);
-            mn = a < mn ? a : mn;
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t j0 = (t0 + 8 * u) * 32 + lane * 4;
+            const float ve[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            uint32_t mn = 0xFFFFFFFFu;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t key = j0 + e < k ? ord32_biased(ve[e]) : 0xFFFFFFFFu;
+                mn = key < mn ? key : mn;
+            }
+#pragma unroll
+            for (int o = 4; o >= 1; o >>= 1) {
+                const uint32_t a = __shfl_xor(mn, o, 8);
+                mn = a < mn ? a : mn;
+            }
+            if (al == 0 && t0 + 8 * u + grp < 64 * TPL) tkeys[t0 + 8 * u + grp] = mn;  // (tiles past the last one come out as "no list")
         }
-        if (al == 0 && t0 + grp < 64 * TPL) tkeys[t0 + grp] = mn;  // (tiles past the last one come out as "no list")
     }
-    for (uint32_t i = ((ntile + 7) & ~7u) + lane; i < 64 * TPL; i += 64) tkeys[i] = 0xFFFFFFFFu;
+    for (uint32_t i = ((ntile + 31) & ~31u) + lane; i < 64 * TPL; i += 64) tkeys[i] = 0xFFFFFFFFu;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     uint32_t tk[TPL];  // tile lane + 64 i
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
