@@ -2353,7 +2353,11 @@ __global__ __launch_bounds__(256) void accurate_filtered_kernel(SurvRec *__restr
             }
             float dt = d0 + d1, nx = n0 + n1;
             dt += __shfl_xor(dt, 1, 2), nx += __shfl_xor(nx, 1, 2);
+#ifdef RQ_EXP_SHADOW_SLACK  // developer experiment (scripts/exp/shadow_slack.sh, rerank_shadow = 1): what a coarser shadow would still reject
+            const float err = (sqrtf(nx) * up) * 4.8877e-4f + abs_err + RQ_EXP_SHADOW_SLACK;
+#else
             const float err = (sqrtf(nx) * up) * 4.8877e-4f + abs_err;  // >= 2^-11 (1 + 2^-10) ||x~|| + sqrt(dim) 2^-25 >= ||x - x~||
+#endif
             const float t = sqrtf(dt * down) * down - err * up;
             if (t > 0.0f && (t * t) * (down * down) > thr) {  // false for NaN
                 exact = false;
