@@ -103,8 +103,27 @@ struct ScanExtra {
 // Reserve `nrec` records + `nrun` run descriptors of the arena for the calling lane's block: in the block's shard, or --
 // when that is full (few, heavy blocks) -- in the common area.  Returns false if neither has room (the overflow flag is
 // set: the host doubles the arena and repeats the stage).  rec_off / run_off: indices into arena_recs / arena_runs.
-__device__ __forceinline__ bool arena_reserve(const ScanExtra *xp, uint32_t nrec, uint32_t nrun, uint32_t *rec_off, uint32_t *run_off) {
-    const ScanExtra a = *xp;
+// The 64 bytes of a ScanExtra through ONE scalar load (the pointer is a kernel argument: wave-uniform).  Left to the compiler the
+// struct is fetched by lane 0 inside the survivor path with VECTOR loads -- into registers the matrix-core scan's tile loop also
+// uses, so that every LDS read of its exact path first waited for every outstanding memory operation of the wave (vmcnt(0)),
+// the in-flight query-tile copies included.
+__device__ __forceinline__ ScanExtra load_scan_extra(const ScanExtra *xp) {
+    typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+    static_assert(sizeof(ScanExtra) == 64, "one s_load_dwordx16");
+    u32x16 v;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(xp) : "memory");
+    auto ptr = [&](int i) { return ((unsigned long long)v[i + 1] << 32) | v[i]; };
+    ScanExtra e;
+    e.seg_base = reinterpret_cast<const unsigned long long *>(ptr(0));
+    e.seg_cap = reinterpret_cast<const uint32_t *>(ptr(2));
+    e.arena_recs = reinterpret_cast<SurvRec *>(ptr(4));
+    e.arena_runs = reinterpret_cast<uint4 *>(ptr(6));
+    e.arena_cur = reinterpret_cast<unsigned long long *>(ptr(8));
+    e.arena_fail = reinterpret_cast<unsigned int *>(ptr(10));
+    e.arena_sub = v[12], e.arena_rsub = v[13], e.arena_common = v[14], e.pad = v[15];
+    return e;
+}
+__device__ __forceinline__ bool arena_reserve(const ScanExtra &a, uint32_t nrec, uint32_t nrun, uint32_t *rec_off, uint32_t *run_off) {
     const uint32_t shard = blockIdx.x & (RQ_ARENA_SHARDS - 1u);
     const unsigned long long o = atomicAdd(a.arena_cur + shard, ((unsigned long long)nrun << 32) | nrec);
     const uint32_t ab = (uint32_t)o, rb = (uint32_t)(o >> 32);

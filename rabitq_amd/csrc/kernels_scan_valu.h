@@ -133,14 +133,15 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
             for (int c = 0; c < CPL; ++c) nruns += m[c] ? 1u : 0u;
             if constexpr (ARENA) {  // arena mode: count per query, append to this block's shard of the arena
                 uint32_t off = 0xFFFFFFFFu, roff = 0;
+                const ScanExtra xe = load_scan_extra(a.x);  // (one scalar load)
                 if (lane == 0) {
                     atomicAdd(surv_cnt + b, ((unsigned long long)nruns << 32) | total);
-                    if (!arena_reserve(a.x, total, nruns, &off, &roff)) off = 0xFFFFFFFFu;
+                    if (!arena_reserve(xe, total, nruns, &off, &roff)) off = 0xFFFFFFFFu;
                 }
                 off = __builtin_amdgcn_readfirstlane(off), roff = __builtin_amdgcn_readfirstlane(roff);
                 if (off == 0xFFFFFFFFu) return;
-                SurvRec *arecs = a.x->arena_recs;
-                uint4 *rdst = a.x->arena_runs + roff;
+                SurvRec *arecs = xe.arena_recs;
+                uint4 *rdst = xe.arena_runs + roff;
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
                     const uint32_t cntc = (uint32_t)__popcll(m[c]);
