@@ -2715,7 +2715,7 @@ __global__ __launch_bounds__(64) void replay_kernel(const SurvRec *__restrict__ 
 }
 
 // Segment sizing of an arena stage: query b's segment = its exact survivor count (surv_cnt low word, counted by the scan)
-// rounded up to 64 slots, at least floor_cap; the counter is cleared and becomes the scatter's cursor.
+// rounded up to 64 slots, at least floor_cap.
 __global__ void seg_exact_kernel(unsigned long long *__restrict__ surv_cnt, uint32_t nq, uint32_t floor_cap,
                                  uint32_t *__restrict__ q_cap) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2723,7 +2723,7 @@ __global__ void seg_exact_kernel(unsigned long long *__restrict__ surv_cnt, uint
     const uint32_t cnt = (uint32_t)surv_cnt[b];
     const uint32_t cap = cnt > floor_cap ? cnt : floor_cap;
     q_cap[b] = cap > 0xFFFFFF80u ? 0xFFFFFFC0u : ((cap + 63u) & ~63u);
-    surv_cnt[b] = 0ull;
+    // (the counter keeps its value: records | runs << 32 of the stage, what the kernels behind the scatter read)
 }
 // The arena's runs to their queries' segments.  A wave takes 64 runs of a shard at a time: lane r claims its run's place
 // with the per-query 64-bit counter (exactly the reservation the direct path makes) and writes the descriptor; the records
@@ -2733,7 +2733,7 @@ __global__ __launch_bounds__(256) void arena_scatter_kernel(const SurvRec *__res
                                                             const unsigned long long *__restrict__ arena_cur,
                                                             const unsigned int *__restrict__ arena_fail, uint32_t arena_rsub,
                                                             const unsigned long long *__restrict__ q_base,
-                                                            unsigned long long *__restrict__ surv_cnt, SurvRec *__restrict__ surv,
+                                                            const uint2 *__restrict__ arena_places, SurvRec *__restrict__ surv,
                                                             RunRec *__restrict__ runs) {
     __shared__ uint32_t s_pref[4][65], s_src[4][64];
     __shared__ unsigned long long s_dst[4][64];
@@ -2751,14 +2751,15 @@ __global__ __launch_bounds__(256) void arena_scatter_kernel(const SurvRec *__res
     }
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint4 *src = arena_runs + (uint64_t)shard * arena_rsub;
+    const uint2 *plc = arena_places + (uint64_t)shard * arena_rsub;
     const uint32_t col = common ? blockIdx.x - RQ_ARENA_SHARDS : 0u, ncol = common ? RQ_ARENA_COMMON_BLOCKS : 1u;
     for (uint32_t r0 = ((col * gridDim.y + blockIdx.y) * 4 + wave) * 64; r0 < nr; r0 += ncol * gridDim.y * 256) {
         uint32_t cnt = 0;
         if (r0 + lane < nr) {
             const uint4 d = src[r0 + lane];
             cnt = d.y >> 16;
-            const unsigned long long old = atomicAdd(surv_cnt + d.z, (1ull << 32) | cnt);
-            const uint32_t base = (uint32_t)old, rbase = (uint32_t)(old >> 32);
+            const uint2 pl = plc[r0 + lane];  // the run's place inside its query's segment, reserved by the scan
+            const uint32_t base = pl.x, rbase = pl.y;
             const unsigned long long qat = q_base[d.z];
             RunRec rr;
             rr.pos = d.x, rr.slot = d.y & 0xFFFFu, rr.base = base, rr.cnt = cnt;

@@ -81,15 +81,17 @@ struct ScanArgs {   // scalars only; pointers are explicit __restrict__ kernel p
     const struct ScanExtra *x;
 };
 // Survivor geometry beyond the uniform one.
-// Segments: query b owns seg_cap[b] slots from seg_base[b] (QSeg).
 // Arena mode (stages of a large batch that can exceed the uniform capacity): the survivors of a stage are first appended,
 // in no particular order, to ONE arena shared by all queries (RQ_ARENA_SHARDS shards, each with its own 64-bit cursor
 // -- records | runs << 32 --, chosen by block id: an append costs one more, uncontended atomic), while surv_cnt only
-// COUNTS per query; the exact counts then size a segment per query and arena_scatter_kernel moves every run to its
-// query's segment.  Nothing is sized for a worst query.
+// COUNTS per query -- and what that count returns is the run's place inside its query's future segment (arena_places); the
+// exact counts then size a segment per query and arena_scatter_kernel moves every run to its place.  Nothing is sized for a
+// worst query, and the scatter needs no atomics (one per run -- 2.5e8 per step on the hard benchmark distribution -- was
+// most of its time; issued from the scan's flushes they ride on a round trip the flush waits for anyway).
 struct ScanExtra {
-    const unsigned long long *seg_base;
-    const uint32_t *seg_cap;
+    uint2 *arena_places;        // per run descriptor: {first record, directory slot} of the run INSIDE its query's segment -- the value the
+                                // scan's per-query count returned, so that the scatter pass needs no reservation of its own
+    const uint32_t *reserved;
     SurvRec *arena_recs;        // nullptr: records go straight to the query's segment
     uint4 *arena_runs;          // {pos, slot | cnt << 16, query, record offset in the arena}
     unsigned long long *arena_cur;  // RQ_ARENA_SHARDS cursors, [SHARDS] overflow flag, [SHARDS + 1] (host), [SHARDS + 2] cursor of the common area
@@ -114,8 +116,8 @@ __device__ __forceinline__ ScanExtra load_scan_extra(const ScanExtra *xp) {
     asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(xp) : "memory");
     auto ptr = [&](int i) { return ((unsigned long long)v[i + 1] << 32) | v[i]; };
     ScanExtra e;
-    e.seg_base = reinterpret_cast<const unsigned long long *>(ptr(0));
-    e.seg_cap = reinterpret_cast<const uint32_t *>(ptr(2));
+    e.arena_places = reinterpret_cast<uint2 *>(ptr(0));
+    e.reserved = reinterpret_cast<const uint32_t *>(ptr(2));
     e.arena_recs = reinterpret_cast<SurvRec *>(ptr(4));
     e.arena_runs = reinterpret_cast<uint4 *>(ptr(6));
     e.arena_cur = reinterpret_cast<unsigned long long *>(ptr(8));

@@ -251,16 +251,19 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
         const QSeg seg = scan_seg(a);
         if constexpr (ARENA) {  // arena mode: count per query, ONE reservation for the whole queue in this block's shard
             const ScanExtra xe = load_scan_extra(a.x);  // (one scalar load: see there)
-            if (lane < nR) atomicAdd(surv_cnt + r_b[wave][lane], (1ull << 32) | r_cnt[wave][lane]);
+            unsigned long long place = 0;  // records | runs << 32 of the query before this run: its place in the query's segment
+            if (lane < nR) place = atomicAdd(surv_cnt + r_b[wave][lane], (1ull << 32) | r_cnt[wave][lane]);
             uint32_t off0 = 0xFFFFFFFFu, roff = 0;
             if (lane == 0 && nR && !arena_reserve(xe, nE, nR, &off0, &roff)) off0 = 0xFFFFFFFFu;
             off0 = __builtin_amdgcn_readfirstlane(off0), roff = __builtin_amdgcn_readfirstlane(roff);
             if (off0 != 0xFFFFFFFFu) {
                 SurvRec *arecs = xe.arena_recs;
                 uint4 *aruns = xe.arena_runs;
-                if (lane < nR)
+                if (lane < nR) {
                     aruns[roff + lane] =
                         make_uint4(r_pos[wave][lane], r_slot[wave][lane] | (r_cnt[wave][lane] << 16), r_b[wave][lane], off0 + r_off[wave][lane]);
+                    xe.arena_places[roff + lane] = make_uint2((uint32_t)place, (uint32_t)(place >> 32));
+                }
                 for (uint32_t e = lane; e < nE; e += 64) {
                     SurvRec sr;
                     sr.pos = q_pos[wave][e], sr.slot = r_slot[wave][q_run[wave][e]], sr.rough = q_rough[wave][e], sr.accurate = 0.0f;

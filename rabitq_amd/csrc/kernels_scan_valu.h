@@ -134,14 +134,17 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
             if constexpr (ARENA) {  // arena mode: count per query, append to this block's shard of the arena
                 uint32_t off = 0xFFFFFFFFu, roff = 0;
                 const ScanExtra xe = load_scan_extra(a.x);  // (one scalar load)
+                unsigned long long place = 0;  // the query's records | runs << 32 before these runs: their place in its segment
                 if (lane == 0) {
-                    atomicAdd(surv_cnt + b, ((unsigned long long)nruns << 32) | total);
+                    place = atomicAdd(surv_cnt + b, ((unsigned long long)nruns << 32) | total);
                     if (!arena_reserve(xe, total, nruns, &off, &roff)) off = 0xFFFFFFFFu;
                 }
                 off = __builtin_amdgcn_readfirstlane(off), roff = __builtin_amdgcn_readfirstlane(roff);
                 if (off == 0xFFFFFFFFu) return;
+                uint32_t pbase = (uint32_t)place, prun = (uint32_t)(place >> 32);  // (lane 0's values: it writes the descriptors)
                 SurvRec *arecs = xe.arena_recs;
                 uint4 *rdst = xe.arena_runs + roff;
+                uint2 *pdst = xe.arena_places + roff;
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
                     const uint32_t cntc = (uint32_t)__popcll(m[c]);
@@ -150,7 +153,11 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
                         r.pos = pos[c], r.slot = slot, r.rough = rough[c], r.accurate = 0.0f;
                         arecs[off + (uint32_t)__popcll(m[c] & ((1ull << lane) - 1ull))] = r;
                     }
-                    if (cntc && lane == 0) *rdst++ = make_uint4(list_begin + first + c * 256 + (threadIdx.x & ~63u), slot | (cntc << 16), b, off);
+                    if (cntc && lane == 0) {
+                        *rdst++ = make_uint4(list_begin + first + c * 256 + (threadIdx.x & ~63u), slot | (cntc << 16), b, off);
+                        *pdst++ = make_uint2(pbase, prun);
+                        pbase += cntc, ++prun;
+                    }
                     off += cntc;
                 }
                 return;

@@ -240,6 +240,7 @@ struct Workspace {
     DevBuf<unsigned long long> q_base;         // per query: first slot of its segment
     DevBuf<SurvRec> arena_recs;                // arena stages: survivors of all queries, unordered (256 shards)
     DevBuf<RunRec> arena_runs;                 //   their run descriptors as uint4 {pos, slot | cnt << 16, query, offset}
+    DevBuf<uint2> arena_places;                //   per descriptor: the run's place in its query's segment {first record, directory slot}
     DevBuf<unsigned long long> arena_cur;      //   RQ_ARENA_SHARDS shard cursors (records | runs << 32), overflow flag, total, cursor of the common area
     DevBuf<unsigned int> arena_fail;           //   per shard: first run index it turned away
     DevBuf<ScanExtra> scan_extra;              //   what the scan reads on its survivor path in arena mode
@@ -1268,7 +1269,8 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                 HIPC(hipMemsetAsync(ws.arena_cur.p, 0, (RQ_ARENA_SHARDS + 4) * 8, st));
                 HIPC(hipMemsetAsync(ws.arena_fail.p, 0xFF, RQ_ARENA_SHARDS * 4, st));
                 ScanExtra hx{};
-                hx.seg_base = nullptr, hx.seg_cap = nullptr;
+                RQC(ws.arena_places.ensure(want));
+                hx.arena_places = ws.arena_places.p, hx.reserved = nullptr;
                 hx.arena_recs = ws.arena_recs.p, hx.arena_runs = reinterpret_cast<uint4 *>(ws.arena_runs.p), hx.arena_cur = ws.arena_cur.p;
                 hx.arena_fail = ws.arena_fail.p;
                 {  // seven eighths of the arena in shards, the rest as the common area (what a full shard turns away: few, heavy blocks)
@@ -1296,13 +1298,14 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                 if (!(uint32_t)tail[0]) break;
                 pf.end();
                 if (attempt >= 6 || want >= 0xFFFF0000ull) return fail(RQ_ERR_OOM, "survivor arena kept overflowing");
-                // A shard AND the common area ran full: the stage again (the counters were cleared by seg_exact_kernel) with a
+                // A shard AND the common area ran full: the stage again (its per-query counters start from zero again) with a
                 // larger arena: the exact counts are known now.  A grid of at least 2048 blocks spreads over all the shards: twice
                 // the arena, at least the survivors + a quarter.  A SMALL grid uses only a few of the 2048 shards, so doubling
                 // alone could stay short for ever (found by the fuzz driver: 700 queries whose every candidate survives, on a
                 // 130-block grid): there the common area (an eighth of the arena) is made to hold ALL of the stage's survivors,
                 // which takes whatever the shards turn away
                 const uint64_t nblocks = a.use_table ? a.ngroups : (uint64_t)a.ngroups * a.tiles_per_group;
+                HIPC(hipMemsetAsync(ws.surv_cnt.p, 0, (size_t)nq * sizeof(unsigned long long), st));
                 want = std::max<uint64_t>(want * 2, 1u << 20);
                 if (nblocks < RQ_ARENA_SHARDS) want = std::max<uint64_t>(want, 8 * total_slots + (1u << 16)), arena_retried = true;
                 else want = std::max<uint64_t>(want, total_slots + total_slots / 4);
@@ -1321,7 +1324,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             }
             sp.surv = ws.surv.p, sp.runs = ws.runs.p;
             arena_scatter_kernel<<<dim3(RQ_ARENA_SHARDS + RQ_ARENA_COMMON_BLOCKS, 2), 256, 0, st>>>(ws.arena_recs.p, reinterpret_cast<const uint4 *>(ws.arena_runs.p), ws.arena_cur.p,
-                                                                              ws.arena_fail.p, arena_rsub, ws.q_base.p, ws.surv_cnt.p, ws.surv.p, ws.runs_tmp.p);
+                                                                              ws.arena_fail.p, arena_rsub, ws.q_base.p, ws.arena_places.p, ws.surv.p, ws.runs_tmp.p);
             runs_in_tmp = true;  // the ordering pass below writes the directory
             pf.end();
             seg = QSeg{ws.q_base.p, ws.q_cap.p, qp.cap};
