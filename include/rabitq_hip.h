@@ -370,6 +370,9 @@ rq_status rq_set_profiling(int level);
  * selection wherever a row has at least nprobe tiles (tests).  rq_profile_t.coarse_fallback_rows counts queries whose
  * candidate set exceeded the refinement's 256 slots (near-equidistant centroids) or whose margin was not finite: they are
  * ranked in exact order over all lists (per row).
+ * "pair_split": test hook, 1 (default) = passes over an index most of whose lists are empty (a shard: the probe lists name the lists
+ * of every shard) settle the (query, list) pairs with nothing to scan by one thread each and run the query quantisation and the final
+ * stage's record fill over a compacted list of the others, 0 = every pair takes the full path.  Identical results.
  * "coarse_tiled_from": developer knob, list count from which the automatic choice selects through tile minima (default 4096).
  * "shared_thresholds": rq_query_batch_sharded_device: 1 (default) = with more than one shard the step runs the nearest
  * list first, all-reduces (min) the k-th best distances and seeds the rest of the probe list with them (see
