@@ -863,6 +863,52 @@ def test_scan_implementations_match_oracle(rq, oracle, impl, gate, n, d, k, nq):
     oidx.close()
 
 
+def test_eight_shards_on_one_gpu_merge_to_the_single_index(rq, oracle):
+    """BASELINE.json configs[4] in small and in ONE process: an index cut into eight shards of whole lists
+    (rq_partition_lists / rq_shard_index, the partitioning of the 8-GPU run), every shard queried with the same 2100-query
+    batch -- its pass names the lists of all eight shards, 7 of 8 pairs are empty here -- and the eight top-k lists merged
+    by (Ord32 distance, id).  Every shard answers exactly as the oracle does on that shard's arrays (bit for bit); the
+    merged ids are the single index's except where a shard's own, looser threshold sequence re-ranks a candidate the
+    single sequential stream skipped (the reference's own approximation: a lower-bound violation on a true neighbour)."""
+    n, d, k, nq, probe, topk = 400_000, 128, 256, 2100, 32, 10
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.7, seed=71, centre_scale=0.7)
+    queries, _, _ = synth.mixture(nq, d, k, sigma=0.7, seed=72, centre_scale=0.7)
+    full = rq.RaBitQ.build(x, centres, synth.random_orthogonal(d, seed=73))
+    fd, fi, fn = full.query_batch(queries, probe, topk, False)
+    owner, load = full.partition_lists(8)
+    assert int(load.sum()) == n and load.min() > 0
+    md = np.full((nq, 8 * topk), np.inf, np.float32)
+    mi = np.full((nq, 8 * topk), 0xFFFFFFFF, np.uint32)
+    for r in range(8):
+        shard = full.shard(owner, r)
+        dist, ids, cnt = shard.query_batch(queries, probe, topk, False)
+        if r in (0, 5):   # the shard is a RaBitQ index of its own: the oracle on its arrays agrees bit for bit
+            ov = oracle.OracleIndex.view(shard.dim, base=shard.base, orthogonal=shard.orthogonal, centroids=shard.centroids,
+                                         offsets=shard.offsets, map_ids=shard.map_ids, codes=shard.codes, factors=shard.factors)
+            _compare_with_oracle(rq, oracle, ov, shard, queries[:120], probe, topk, False)
+            ov.close()
+        for qi in range(nq):
+            c = int(cnt[qi])
+            md[qi, r * topk:r * topk + c] = dist[qi, :c]
+            mi[qi, r * topk:r * topk + c] = ids[qi, :c]
+        shard.close()
+    order = np.lexsort((mi, md), axis=1)[:, :topk]          # by distance, ties by id
+    merged = np.take_along_axis(mi, order, axis=1)
+    same = sum(len(set(merged[qi].tolist()) & set(fi[qi, :fn[qi]].tolist())) for qi in range(nq))
+    total = int(fn.sum())
+    assert total == nq * topk and same >= total - total // 200, (same, total)   # >= 99.5 % of the ids identical
+    # and the merged lists are at least as good as the single index's where they differ (true distances, f64)
+    worse = 0
+    for qi in range(nq):
+        a, b = merged[qi], fi[qi, :topk]
+        if set(a.tolist()) != set(b.tolist()):
+            da = np.sort(((x[a].astype(np.float64) - queries[qi]) ** 2).sum(1))
+            db = np.sort(((x[b].astype(np.float64) - queries[qi]) ** 2).sum(1))
+            worse += int(da[-1] > db[-1] * (1 + 1e-9))
+    assert worse == 0, worse
+    full.close()
+
+
 def test_shard_pass_lists_its_nonempty_pairs(rq, oracle):
     """A shard of a multi-GPU deployment ranks over the lists of ALL shards, so most of a pass's (query, list) pairs name
     lists that are empty here.  Large passes settle those by one thread each and run the query quantisation over a
