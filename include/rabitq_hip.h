@@ -380,8 +380,10 @@ rq_status rq_set_profiling(int level);
  * "survivor_segments": 1 (default) = once an index has shown that its batches overflow the default survivor capacity, large
  * batches (>= 256 queries) size the survivor buffers of the stages that can exceed it PER QUERY (the scan appends to one shared
  * arena while counting per query; exact counts + prefix sum + a scatter pass) instead of giving every query the worst one's
- * capacity; 0 = never, 2 = every large batch (tests), 3 = as 2 with every arena stage failing (tests: a pass whose arena cannot be
- * had -- no memory, or it keeps overflowing -- is repeated on the uniform buffers).  Identical results.
+ * capacity; 0 = never, 2 = every large batch (tests).  A pass whose arena cannot be had -- no memory, or it keeps overflowing --
+ * is repeated on the uniform buffers; the failure injection that exercises this (value 3: as 2 with every arena stage failing
+ * through a real, oversized allocation) exists in the developer build only (`make dev`, -DRQ_DEV_ABLATIONS) and is refused
+ * here.  Identical results.
  * "small_batch": 0 (default) = batches of <= 64 queries (the reference's one-query-per-call loop included) run as a handful
  * of fat launches (kernels_small.h) whenever the shape allows (nprobe <= 64, <= 8192 lists, topk <= 256, dim in {64, 128,
  * 256, 512, 768, 1024}), 1 = never (test hook).  Identical results.

@@ -1,7 +1,10 @@
 """Benchmark harness with the reference CLI's behaviour (crates/cli/src/main.rs:11-83):
 
     python -m rabitq_amd.cli -b base.fvecs -c centroids.fvecs -q query.fvecs -t truth.ivecs \
-                             -s saved_dir [-p 100] [-k 10] [--heuristic-rank]
+                             -s saved_dir [-p 100] [-k 10] [-h | --heuristic-rank]
+
+* the flags are the reference's, letter for letter: `-h` is the heuristic re-ranker there (`#[argh(switch, short = 'h')]`,
+  main.rs:35-37), not help -- argh reserves only `--help` -- so a caller script written for the reference CLI runs unchanged;
 
 * if `--saved` is an existing directory the index is loaded from it, otherwise it is built from
   base + centroids and dumped there (main.rs:52-61);
@@ -22,8 +25,9 @@ import numpy as np
 from . import RaBitQ, calculate_recall, metrics_reset, metrics_str, vecs
 
 
-def main(argv=None) -> int:
-    ap = argparse.ArgumentParser(description="RaBitQ CLI args")
+def build_parser() -> argparse.ArgumentParser:
+    ap = argparse.ArgumentParser(description="RaBitQ CLI args", add_help=False)   # `-h` belongs to the reference's switch
+    ap.add_argument("--help", action="help", help="display usage information")
     ap.add_argument("-b", "--base", required=True, help="base path")
     ap.add_argument("-c", "--centroids", required=True, help="centroids path")
     ap.add_argument("-q", "--query", required=True, help="query path")
@@ -31,10 +35,14 @@ def main(argv=None) -> int:
     ap.add_argument("-p", "--probe", type=int, default=100)
     ap.add_argument("-k", "--topk", type=int, default=10)
     ap.add_argument("-s", "--saved", required=True, help="saved directory")
-    ap.add_argument("--heuristic-rank", action="store_true", help="heuristic re-rank (maybe faster when topk is large)")
+    ap.add_argument("-h", "--heuristic-rank", "--heuristic_rank", dest="heuristic_rank", action="store_true", help="heuristic re-rank (maybe faster when topk is large)")
     ap.add_argument("--batch", type=int, default=0, help="also time batches of this many queries")
     ap.add_argument("--seed", type=int, default=0, help="seed of the generated rotation when building")
-    args = ap.parse_args(argv)
+    return ap
+
+
+def main(argv=None) -> int:
+    args = build_parser().parse_args(argv)
 
     if os.path.isdir(args.saved):
         print(f"loading from {args.saved!r}...")

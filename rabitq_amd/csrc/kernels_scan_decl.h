@@ -10,7 +10,12 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS);
 
 // ---- matrix-core scan (kernels_scan_mfma.h) ----
 #ifndef RQ_ADD_NT2
-#define RQ_ADD_NT2 4  // sub-tiles per wave of the additive-gate instantiation at dim 128
+#define RQ_ADD_NT2 6  // sub-tiles per wave of the additive-gate instantiation at dim 128: every staged query tile (7 ds_read_b128 per lane)
+                      // serves six 32 x 32 steps (four in round 4: launch 6.0 -> 5.8 ms on the headline workload; seven / eight spill inside
+                      // the tile loop: 6.6 / 6.8 ms).  Its 33 spilled registers sit in the block's start-up and the cold path only.
+#endif
+#ifndef RQ_GATE_DEFER
+#define RQ_GATE_DEFER 1  // additive gate of the narrow instantiations: 1 = one branch per query tile (the cold path recomputes the flagged steps), 0 = one per step
 #endif
 // blocks per CU the register budget is cut for: the resident operands grow with W (6*W*NT dwords for the
 // candidates, 6*W for the query tile), so wide vectors run one block per CU with the full 512-register file

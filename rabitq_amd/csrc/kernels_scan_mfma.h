@@ -479,8 +479,122 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
                 for (int t = 0; t < NT; ++t) accs[t] = mm(av, get_b(t, m), accs[t]);
             }
         }
+        // the cold path of one 32 x 32 step whose gate fired: the accumulator registers with a flagged lane, s itself for them, the
+        // reference's f32 expression for those registers only, survivors into the wave's emit queue (t is a constant after unrolling)
+        auto cold_path = [&](const int t, const f32x16 acc) __attribute__((always_inline)) {
+            ++n_flag;
+            // nothing of the cold branch may be scheduled ahead of it: hoisted into the tile loop its recomputation and LDS reads
+            // cost the wide instantiations 34 spilled registers (dim 768: 21.6 -> 28.4 ms per launch)
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef RQ_DEV_ABLATIONS
+            const unsigned long long tx0 = time_stat ? __builtin_readcyclecounter() : 0ull;
+#endif
+            // lives inside this branch so that the common path carries no state of it (not even a zeroed tile)
+            uint32_t gmask = force_any ? 0xFFFFu : 0u;  // accumulator registers with at least one flagged lane
+            f32x16 sc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
+            for (int gq = 0; gq < 16; ++gq) {
+                if constexpr (ADD) gmask |= (__ballot(acc[gq] > hc[t]) != 0ull ? 1u : 0u) << gq;
+                else gmask |= (__ballot(acc[gq] > 0.0f) != 0ull ? 1u : 0u) << gq;
+            }
+            // the flagged cells need s itself: the same products again on a clean accumulator (exact)
+#pragma unroll
+            for (int m = 0; m < W; ++m) sc = mm(get_a(m), get_b(t, m), sc);
+            if (RQ_DBG(a, 1u)) gmask = 0;
+#ifdef RQ_DEV_ABLATIONS
+            if (time_stat) n_greg += (uint32_t)__popc(gmask);
+#endif
+            // exact evaluation + emit, for the flagged registers only
+            const float4 fc = facL[lpos[t] - first];
+            while (gmask) {
+                const uint32_t gq = (uint32_t)__builtin_ctz(gmask);
+                gmask &= gmask - 1;
+                const uint32_t row = (gq & 3) + 8 * (gq >> 2) + 4 * h;
+                const float sf = 2.0f * sc[gq];  // wave-uniform register index
+                // the row's scalars in two 16-byte LDS reads: lower delta sumq ycd | ycd_sqrt thr lo hi
+                const uint4 ta = *reinterpret_cast<const uint4 *>(&img[IMG_OP + row * TAILD]);
+                const uint4 tb = *reinterpret_cast<const uint4 *>(&img[IMG_OP + row * TAILD + 4]);
+                static_assert(RQ_REC_LOWER == 0 && RQ_REC_DELTA == 1 && RQ_REC_SUMQ == 2 && RQ_REC_YCD == 3 && RQ_REC_YCD_SQRT == 4 &&
+                                  RQ_REC_THR == 5 && RQ_REC_LO == 6 && RQ_REC_HI == 7, "tail layout read as two uint4");
+                // the reference's expression, left to right (src/rabitq.rs:352-363)
+                float tt = fc.w + __builtin_bit_cast(float, ta.w);
+                tt = tt + __builtin_bit_cast(float, ta.x) * fc.y;
+                const float u = (2.0f * sf - __builtin_bit_cast(float, ta.z)) * fc.x;
+                tt = tt + u * __builtin_bit_cast(float, ta.y);
+                const float rg = tt - fc.z * __builtin_bit_cast(float, tb.x);
+                bool pass = rg < __builtin_bit_cast(float, tb.y);  // src/rerank.rs:84
+                // a real query, and a list position inside its stage range
+                pass = pass && row < nvalid && lpos[t] >= tb.z && lpos[t] < tb.w;
+                const uint64_t m = __ballot(pass);
+                if (m == 0) continue;
+#ifdef RQ_DEV_ABLATIONS
+                if (time_stat) ++n_regs;
+#endif
+                if (nE + 64 > QE || nR + 2 > QR) {
+#ifdef RQ_DEV_ABLATIONS
+                    const unsigned long long tf0 = time_stat ? __builtin_readcyclecounter() : 0ull;
+#endif
+                    flush();
+#ifdef RQ_DEV_ABLATIONS
+                    if (time_stat) tm_flush += __builtin_readcyclecounter() - tf0, ++n_flush;
+#endif
+                }
+                // each half-wave is one run (one query x 32 consecutive positions); half 0 first
+                const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
+                const uint32_t c0 = (uint32_t)__popc(m0), c1 = (uint32_t)__popc(m1);
+                const uint32_t myrun = nR + ((h && c0) ? 1u : 0u), myoff = nE + (h ? c0 : 0u);
+                if (pass) {
+                    const uint32_t e = myoff + (uint32_t)__popc((h ? m1 : m0) & ((1u << j) - 1u));
+                    q_pos[wave][e] = list_begin + lpos[t];
+                    q_rough[wave][e] = rg;
+                    q_run[wave][e] = myrun;
+                }
+                if (j == 0 && (h ? c1 : c0)) {
+                    r_b[wave][myrun] = tail(RQ_REC_ROW, row);
+                    r_slot[wave][myrun] = tail(RQ_REC_SLOT, row);
+                    r_pos[wave][myrun] = list_begin + first + wave * (32 * NT) + t * 32;
+                    r_cnt[wave][myrun] = h ? c1 : c0;
+                    r_off[wave][myrun] = myoff;
+                }
+                nE += c0 + c1;
+                nR += (c0 ? 1u : 0u) + (c1 ? 1u : 0u);
+            }
+#ifdef RQ_DEV_ABLATIONS
+            if (time_stat) tm_exact += __builtin_readcyclecounter() - tx0;
+#endif
+        };
+        // Additive form, narrow vectors: ONE branch per query tile.  The NT steps run back to back, each leaving only its gate's
+        // verdict in a scalar mask (v_cmp into an SGPR pair, s_or); the tile's cold path -- 7.8e-4 of the steps on the benchmark
+        // mixture -- recomputes a step's accumulator tile (same instructions, same bits) before it looks at it.
+        constexpr bool DEFER = ADD && !SLAB_OUTER && (RQ_GATE_DEFER != 0);
+        if constexpr (DEFER) {
+            uint64_t anyhot = 0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f32x16 acc = cinit;
+#pragma unroll
+                for (int m = 0; m < W; ++m) acc = mm(get_a(m), get_b(t, m), acc);
+                float mx = hc[t];
+#pragma unroll
+                for (int gq = 0; gq < 16; gq += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, acc[gq]), acc[gq + 1]);
+                anyhot |= __ballot(mx > hc[t]);
+            }
+            if (__builtin_expect(anyhot != 0ull, 0)) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    f32x16 acc = cinit;
+#pragma unroll
+                    for (int m = 0; m < W; ++m) acc = mm(get_a(m), get_b(t, m), acc);
+                    float mx = hc[t];
+#pragma unroll
+                    for (int gq = 0; gq < 16; gq += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, acc[gq]), acc[gq + 1]);
+                    if (__ballot(mx > hc[t]) != 0ull) cold_path(t, acc);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < (DEFER ? 0 : NT); ++t) {
             f32x16 acc;
             if constexpr (SLAB_OUTER) {
                 acc = accs[t];
@@ -517,86 +631,7 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
             }
             // wave-uniform; everything below.  (Additive form: laid out off the hot path, +1.5 %; the wide instantiations spill with it.)
             if (ADD ? __builtin_expect(hot, 0) : hot) {
-                ++n_flag;
-                // nothing of the cold branch may be scheduled ahead of it: hoisted into the tile loop its recomputation and LDS reads
-                // cost the wide instantiations 34 spilled registers (dim 768: 21.6 -> 28.4 ms per launch)
-                __builtin_amdgcn_sched_barrier(0);
-#ifdef RQ_DEV_ABLATIONS
-                const unsigned long long tx0 = time_stat ? __builtin_readcyclecounter() : 0ull;
-#endif
-                // lives inside this branch so that the common path carries no state of it (not even a zeroed tile)
-                uint32_t gmask = force_any ? 0xFFFFu : 0u;  // accumulator registers with at least one flagged lane
-                f32x16 sc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                for (int gq = 0; gq < 16; ++gq) {
-                    if constexpr (ADD) gmask |= (__ballot(acc[gq] > hc[t]) != 0ull ? 1u : 0u) << gq;
-                    else gmask |= (__ballot(acc[gq] > 0.0f) != 0ull ? 1u : 0u) << gq;
-                }
-                // the flagged cells need s itself: the same products again on a clean accumulator (exact)
-#pragma unroll
-                for (int m = 0; m < W; ++m) sc = mm(get_a(m), get_b(t, m), sc);
-                if (RQ_DBG(a, 1u)) gmask = 0;
-#ifdef RQ_DEV_ABLATIONS
-                if (time_stat) n_greg += (uint32_t)__popc(gmask);
-#endif
-                // exact evaluation + emit, for the flagged registers only
-                const float4 fc = facL[lpos[t] - first];
-                while (gmask) {
-                    const uint32_t gq = (uint32_t)__builtin_ctz(gmask);
-                    gmask &= gmask - 1;
-                    const uint32_t row = (gq & 3) + 8 * (gq >> 2) + 4 * h;
-                    const float sf = 2.0f * sc[gq];  // wave-uniform register index
-                    // the row's scalars in two 16-byte LDS reads: lower delta sumq ycd | ycd_sqrt thr lo hi
-                    const uint4 ta = *reinterpret_cast<const uint4 *>(&img[IMG_OP + row * TAILD]);
-                    const uint4 tb = *reinterpret_cast<const uint4 *>(&img[IMG_OP + row * TAILD + 4]);
-                    static_assert(RQ_REC_LOWER == 0 && RQ_REC_DELTA == 1 && RQ_REC_SUMQ == 2 && RQ_REC_YCD == 3 && RQ_REC_YCD_SQRT == 4 &&
-                                      RQ_REC_THR == 5 && RQ_REC_LO == 6 && RQ_REC_HI == 7, "tail layout read as two uint4");
-                    // the reference's expression, left to right (src/rabitq.rs:352-363)
-                    float tt = fc.w + __builtin_bit_cast(float, ta.w);
-                    tt = tt + __builtin_bit_cast(float, ta.x) * fc.y;
-                    const float u = (2.0f * sf - __builtin_bit_cast(float, ta.z)) * fc.x;
-                    tt = tt + u * __builtin_bit_cast(float, ta.y);
-                    const float rg = tt - fc.z * __builtin_bit_cast(float, tb.x);
-                    bool pass = rg < __builtin_bit_cast(float, tb.y);  // src/rerank.rs:84
-                    // a real query, and a list position inside its stage range
-                    pass = pass && row < nvalid && lpos[t] >= tb.z && lpos[t] < tb.w;
-                    const uint64_t m = __ballot(pass);
-                    if (m == 0) continue;
-#ifdef RQ_DEV_ABLATIONS
-                    if (time_stat) ++n_regs;
-#endif
-                    if (nE + 64 > QE || nR + 2 > QR) {
-#ifdef RQ_DEV_ABLATIONS
-                        const unsigned long long tf0 = time_stat ? __builtin_readcyclecounter() : 0ull;
-#endif
-                        flush();
-#ifdef RQ_DEV_ABLATIONS
-                        if (time_stat) tm_flush += __builtin_readcyclecounter() - tf0, ++n_flush;
-#endif
-                    }
-                    // each half-wave is one run (one query x 32 consecutive positions); half 0 first
-                    const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
-                    const uint32_t c0 = (uint32_t)__popc(m0), c1 = (uint32_t)__popc(m1);
-                    const uint32_t myrun = nR + ((h && c0) ? 1u : 0u), myoff = nE + (h ? c0 : 0u);
-                    if (pass) {
-                        const uint32_t e = myoff + (uint32_t)__popc((h ? m1 : m0) & ((1u << j) - 1u));
-                        q_pos[wave][e] = list_begin + lpos[t];
-                        q_rough[wave][e] = rg;
-                        q_run[wave][e] = myrun;
-                    }
-                    if (j == 0 && (h ? c1 : c0)) {
-                        r_b[wave][myrun] = tail(RQ_REC_ROW, row);
-                        r_slot[wave][myrun] = tail(RQ_REC_SLOT, row);
-                        r_pos[wave][myrun] = list_begin + first + wave * (32 * NT) + t * 32;
-                        r_cnt[wave][myrun] = h ? c1 : c0;
-                        r_off[wave][myrun] = myoff;
-                    }
-                    nE += c0 + c1;
-                    nR += (c0 ? 1u : 0u) + (c1 ? 1u : 0u);
-                }
-#ifdef RQ_DEV_ABLATIONS
-                if (time_stat) tm_exact += __builtin_readcyclecounter() - tx0;
-#endif
+                cold_path(t, acc);
             }
         }
         slot = slot + 1 == scan_mfma_ring_slots<W, ARENA>() ? 0 : slot + 1;

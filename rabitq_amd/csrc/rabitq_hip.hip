@@ -579,6 +579,7 @@ static std::atomic<int> g_scan_impl{0};
 // shown that it flags too much), 1 = the bf16 rank-5 threshold MFMA always, 2 = additive wherever it exists (test hook)
 static std::atomic<int> g_scan_gate{0};
 static std::atomic<int> g_stage_growth{0};  // 0 = default schedule
+static std::atomic<int> g_stage_settle_pct{100};  // developer knob: where a large batch's early (VALU) stages end and the final (matrix-core) stage begins, in percent of the average list length
 static std::atomic<int> g_scan_tile_table{1};  // 0 = plain (list x tile) grids everywhere (test / measurement hook)
 static std::atomic<int> g_group_rank{1};  // group_rank_kernel for cluster-major stages: 0 never, 1 big stages, 2 always
 static std::atomic<int> g_shared_thr{1};  // rq_query_batch_sharded_device: thresholds shared between the shards (0 never, 1 world > 1, 2 always)
@@ -924,7 +925,8 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         // the threshold has settled once a query has seen its whole nearest list; with unbalanced lists (Zipf sizes) the
         // nearest list of many queries is one of the long ones, so the bar is the LONGEST list (capped: a single
         // monster list must not push the whole batch through many thin stages)
-        const uint64_t settle = std::min(settle_cap, std::max<uint64_t>(avg, std::min<uint64_t>(idx->max_list_len, 16 * avg)));
+        uint64_t settle = std::min(settle_cap, std::max<uint64_t>(avg, std::min<uint64_t>(idx->max_list_len, 16 * avg)));
+        if (nq >= 256) settle = std::max<uint64_t>(1, settle * (uint64_t)g_stage_settle_pct.load() / 100);
         while (lo < total_max) {
             // past the first two lists' worth of candidates the threshold is already tight: scan the rest of
             // the stream as ONE stage (every list then meets all its queries at once: full 32-query tiles)
@@ -1140,7 +1142,8 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         // matrix cores pay once many queries share each list AND survivors are rare, i.e. past the nearest list
         // (stages inside it leave hundreds of survivors per query: the exact path dominates there and the VALU
         // kernel wins, measured at any batch size)
-        const bool use_mfma = scan_has_mfma(W) && impl != 1 && (impl == 2 || (est_pairs >= 8ull * k && (sg.s_lo >= avg_len || one_stage)));
+        const bool use_mfma = scan_has_mfma(W) && impl != 1 &&
+                              (impl == 2 || (est_pairs >= 8ull * k && (sg.s_lo >= avg_len * (uint64_t)g_stage_settle_pct.load() / 100 || one_stage)));
         const bool cluster_major = use_mfma || (est_pairs >= k / 2 && est_pairs > 64);
         if (g_scan_dbg.load() & 16384)  // developer hook: the pass's stage list
             fprintf(stderr, "[rabitq_hip] stage %u: [%u, %u) span %llu est_pairs %llu %s\n", stage_no, sg.s_lo, sg.s_hi,
@@ -1255,11 +1258,13 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             uint32_t arena_rsub = 0;
             bool arena_retried = false;
             ws.arena_failed = true;  // (until the stage has its arena: an allocation failure or a give-up below returns from inside the loop)
-            if (g_seg_opt.load() == 3) {  // test hook: the arena cannot be had -- through a REAL failing allocation (1 PiB), sticky error and all
+#ifdef RQ_DEV_ABLATIONS
+            if (g_seg_opt.load() == 3) {  // developer build only (make dev): the arena cannot be had -- through a REAL failing allocation (1 PiB), sticky error and all
                 DevBuf<SurvRec> never;
                 RQC(never.alloc(1ull << 46));
-                return fail(RQ_ERR_OOM, "survivor arena: injected failure (test hook survivor_segments = 3)");
+                return fail(RQ_ERR_OOM, "survivor arena: injected failure (developer hook survivor_segments = 3)");
             }
+#endif
             for (int attempt = 0;; ++attempt) {
                 want = std::min<uint64_t>(want, 0xFFFF0000ull);
                 RQC(ws.arena_recs.ensure(want));
@@ -1678,7 +1683,7 @@ static rq_status query_device(rq_index *idx, const float *d_q, uint32_t nq, uint
             // a failed hipMalloc leaves hipErrorOutOfMemory as the thread's last error (sticky on ROCm 7.2): the repeat's own
             // hipGetLastError() check must not pick it up; the arena of earlier batches goes back to the pool the repeat allocates from
             (void)hipGetLastError();
-            ws->arena_recs.release(), ws->arena_runs.release(), ws->scan_extra.release();
+            ws->arena_recs.release(), ws->arena_runs.release(), ws->scan_extra.release(), ws->arena_places.release();
             ws->arena_failed = false;
             qp.seg_final = false;
             RQC(ws_prepare(idx, *ws, qp));
@@ -1739,7 +1744,7 @@ static rq_status query_device_begin(rq_index *idx, const float *d_q, uint32_t nq
         if (st != RQ_OK && t->ws->arena_failed && t->qp.seg_final) {  // as in query_device: the pass again on the uniform buffers
             (void)hipStreamSynchronize(t->ws->stream);
             (void)hipGetLastError();  // (a failed hipMalloc's sticky error, as in query_device)
-            t->ws->arena_recs.release(), t->ws->arena_runs.release(), t->ws->scan_extra.release();
+            t->ws->arena_recs.release(), t->ws->arena_runs.release(), t->ws->scan_extra.release(), t->ws->arena_places.release();
             t->ws->arena_failed = false;
             t->qp.seg_final = false;
             st = ws_prepare(idx, *t->ws, t->qp);
@@ -3515,6 +3520,11 @@ rq_status rq_set_option(const char *name, int value) {
         g_scan_impl = value;
         return RQ_OK;
     }
+    if (std::string(name) == "stage_settle_pct") {  // developer knob (results identical for every value): end of the early stages of a large batch, percent of the average list length
+        if (value < 1 || value > 400) return fail(RQ_ERR_INVALID, "stage_settle_pct must be in [1, 400]");
+        g_stage_settle_pct = value;
+        return RQ_OK;
+    }
     if (std::string(name) == "stage_growth") {  // geometric growth of the early stages (0 = default: 8, or 16 for small batches)
         if (value != 0 && (value < 2 || value > 64)) return fail(RQ_ERR_INVALID, "stage_growth must be 0 or in [2, 64]");
         g_stage_growth = value;
@@ -3551,8 +3561,13 @@ rq_status rq_set_option(const char *name, int value) {
         g_coarse_impl = value;
         return RQ_OK;
     }
-    if (std::string(name) == "survivor_segments") {  // 0 never, 1 automatic (default), 2 every batch of >= 256 queries (tests), 3 = 2 with every arena stage failing (tests: the fall-back)
+    if (std::string(name) == "survivor_segments") {  // 0 never, 1 automatic (default), 2 every batch of >= 256 queries (tests); developer build: 3 = 2 with every arena stage failing (the fall-back)
+#ifdef RQ_DEV_ABLATIONS
         if (value < 0 || value > 3) return fail(RQ_ERR_INVALID, "survivor_segments must be 0, 1, 2 or 3");
+#else
+        if (value == 3) return fail(RQ_ERR_INVALID, "survivor_segments = 3 (allocation-failure injection) exists in the developer build only (make dev)");
+        if (value < 0 || value > 2) return fail(RQ_ERR_INVALID, "survivor_segments must be 0, 1 or 2");
+#endif
         g_seg_opt = value;
         return RQ_OK;
     }

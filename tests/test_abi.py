@@ -191,3 +191,22 @@ def test_c_host_links_and_fails_loudly_without_device(L, tmp_path):
         pytest.skip("a GPU is present: tests/test_c_host_gpu.py runs the program")
     p = subprocess.run([exe, str(tmp_path / "idx")], capture_output=True, text=True)
     assert p.returncode == 2 and "no HIP device" in p.stderr, (p.returncode, p.stderr)
+
+
+def test_cli_flags_are_the_reference_clis():
+    """crates/cli/src/main.rs:11-38: -b -c -q -t -p -k -s and the SWITCH -h = heuristic_rank (argh keeps only --help for help),
+    defaults probe 100 / topk 10."""
+    from rabitq_amd import cli
+    ap = cli.build_parser()
+    base = ["-b", "b.fvecs", "-c", "c.fvecs", "-q", "q.fvecs", "-t", "t.ivecs", "-s", "saved"]
+    a = ap.parse_args(base)
+    assert (a.probe, a.topk, a.heuristic_rank) == (100, 10, False)
+    a = ap.parse_args(base + ["-h", "-p", "32", "-k", "100"])
+    assert (a.probe, a.topk, a.heuristic_rank) == (32, 100, True)
+    assert ap.parse_args(base + ["--heuristic-rank"]).heuristic_rank
+    long_form = ["--base", "b", "--centroids", "c", "--query", "q", "--truth", "t", "--saved", "s", "--probe", "7", "--topk", "3"]
+    a = ap.parse_args(long_form)
+    assert (a.base, a.centroids, a.query, a.truth, a.saved, a.probe, a.topk) == ("b", "c", "q", "t", "s", 7, 3)
+    with pytest.raises(SystemExit) as e:     # --help is the help flag, as with argh
+        ap.parse_args(["--help"])
+    assert e.value.code == 0

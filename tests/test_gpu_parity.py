@@ -188,7 +188,7 @@ def test_query_matches_golden(rq, path):
 OPTION_VALUES = {
     "scan_impl": [0, 1, 2], "scan_gate": [0, 1, 2], "coarse_impl": [0, 1, 2, 3, 4], "coarse_tiled_from": [0, 4096, 1000000], "group_rank": [0, 1, 2], "scan_tile_table": [0, 1, 2],
     "dense_dir": [0, 1], "small_batch": [0, 1], "small_batch_span": [64, 2560, 100000], "stage_growth": [0, 2, 16],
-    "survivor_segments": [0, 1, 2, 3], "max_scan_blocks": [0, 1, 7], "shared_thresholds": [0, 1, 2], "assign_impl": [0, 1],
+    "survivor_segments": [0, 1, 2], "max_scan_blocks": [0, 1, 7], "shared_thresholds": [0, 1, 2], "assign_impl": [0, 1],
     "rerank_shadow": [0, 1, 2], "pair_split": [0, 1], "scan_debug": [0, 128, 512, 4096, 16384, 128 | 512 | 4096],
 }
 OPTION_DEFAULTS = {"scan_impl": 0, "scan_gate": 0, "coarse_impl": 0, "coarse_tiled_from": 4096, "group_rank": 1, "scan_tile_table": 1, "dense_dir": 1,
@@ -1096,6 +1096,57 @@ def test_sharded_coarse_and_probed_query_equal_single(rq):
     idx.close()
 
 
+def test_one_sharded_pass_of_more_than_65536_queries(rq):
+    """A shard's pass (caller-supplied probe lists) may hold 16 x the queries of a plain pass -- the multi-GPU step scales its batch
+    with the number of ranks (524 288 queries at eight GPUs) -- so every launch sized by the query count (grid.y = nq of the exact-distance
+    kernels, one block per query of the ordering / replay kernels, the ranked placement's per-block histograms) runs beyond 65 536.
+    70 000 queries against one shard of four (most pairs name lists of other shards: the pair-split path) in ONE pass, both halves of the step (probed, then seeded with tight thresholds), compared
+    bit for bit with the same queries in two calls of 35 000 (passes that stay below 65 536)."""
+    import torch
+    from rabitq_amd import index as ix
+    dev = torch.device("cuda", 0)
+    n, d, k, nq, probe, topk = 40_000, 64, 32, 70_000, 6, 5
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.8, seed=91, centre_scale=0.6)
+    full = rq.RaBitQ.build(x, centres, synth.random_orthogonal(d, seed=92))
+    owner, _ = full.partition_lists(4)
+    shard = full.shard(owner, 0)
+    queries, _, _ = synth.mixture(nq, d, k, sigma=0.8, seed=93, centre_scale=0.6)
+    q = torch.from_numpy(queries).to(dev)
+    pc = torch.zeros((nq, probe), device=dev, dtype=torch.int32)
+    pdd = torch.zeros((nq, probe), device=dev, dtype=torch.float32)
+    full.coarse_topk_device(q.data_ptr(), nq, d, 0, k, probe, pc.data_ptr(), pdd.data_ptr())
+
+    def run(lo, hi, thr=None):
+        m = hi - lo
+        od = torch.zeros((m, topk), device=dev)
+        oi = torch.zeros((m, topk), device=dev, dtype=torch.int32)
+        on = torch.zeros(m, device=dev, dtype=torch.int32)
+        qq, cc, dd = q[lo:hi].contiguous(), pc[lo:hi].contiguous(), pdd[lo:hi].contiguous()
+        torch.cuda.synchronize()
+        if thr is None:
+            shard.query_batch_device_probed(qq.data_ptr(), m, d, cc.data_ptr(), dd.data_ptr(), probe, topk, od.data_ptr(), oi.data_ptr(), on.data_ptr())
+        else:
+            t = thr[lo:hi].contiguous()
+            shard.query_batch_device_seeded(qq.data_ptr(), m, d, cc.data_ptr(), dd.data_ptr(), probe, topk, t.data_ptr(), od.data_ptr(), oi.data_ptr(),
+                                            on.data_ptr())
+        torch.cuda.synchronize()
+        pr = ix.last_profile()
+        return od.cpu().numpy().view(np.uint32), oi.cpu().numpy().view(np.uint32), on.cpu().numpy().view(np.uint32), pr
+
+    for seeded in (False, True):
+        thr = None
+        if seeded:   # thresholds as the step's all-reduce would hand them over: a little above each query's k-th distance on this shard
+            kth = np.where(one[2] == topk, one[0].view(np.float32).max(axis=1), np.finfo(np.float32).max).astype(np.float32)
+            thr = torch.from_numpy(kth * np.float32(1.001)).to(dev)
+        one = run(0, nq, thr)
+        halves = [run(0, nq // 2, thr), run(nq // 2, nq, thr)]
+        for a in range(3):
+            assert np.array_equal(one[a], np.concatenate([h[a] for h in halves])), ("seeded" if seeded else "probed", a)
+        assert (one[2] > 0).any()
+    shard.close()
+    full.close()
+
+
 @pytest.mark.parametrize("nq", [40, 300])
 def test_seeded_probed_query(rq, nq):
     """rq_query_batch_device_seeded (the multi-GPU step's second call): the ranker starts from a per-query threshold and
@@ -1614,15 +1665,27 @@ def test_segmented_final_stage_matches_oracle(rq, oracle):
             _compare_with_oracle(rq, oracle, oidx, gidx, queries, k, 100, False)
             uni = ix.last_profile()
             assert uni["segmented_passes"] == 0 and seg_bytes <= uni["survivor_workspace_bytes"]
-            ix.set_option("survivor_segments", 3)        # every arena stage fails: the pass is repeated on the uniform buffers
-            _compare_with_oracle(rq, oracle, oidx, gidx, queries, k, 100, False)
-            assert ix.last_profile()["segmented_passes"] == 0
-            _compare_with_oracle(rq, oracle, oidx, gidx, queries, 3, 10, True)
             gidx.close()
     finally:
         ix.set_option("survivor_segments", 1)
         ix.set_option("scan_impl", 0)
     oidx.close()
+
+
+def test_arena_allocation_failure_falls_back_to_uniform_buffers(rq):
+    """A pass whose survivor arena cannot be had (out of memory) is repeated on the uniform buffers, results unchanged.  The
+    allocation-failure injection is not in the shipped library (rq_set_option refuses it there): this runs the same workload in a
+    child process on the developer build (librabitq_hip_dev.so, `make dev`; tests/dev_hooks_worker.py)."""
+    from rabitq_amd import index as ix, _lib
+    with pytest.raises(_lib.RabitqError):
+        ix.set_option("survivor_segments", 3)             # the shipped library carries no failure injection
+    dev = os.path.join(os.path.dirname(_lib.SO_PATH), "librabitq_hip_dev.so")
+    assert os.path.exists(dev), "the developer build must be in the tree (__graft_entry__.build() makes it)"
+    import subprocess, sys
+    env = dict(os.environ, RABITQ_HIP_SO=dev)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "dev_hooks_worker.py"), "arena_failure"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "DEV_HOOK_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
 @pytest.mark.parametrize("dense_dir", [0, 1])
