@@ -2485,7 +2485,11 @@ __global__ __launch_bounds__(256) void q8_encode_kernel(const float *__restrict_
 // accurate_filtered_kernel with the 8-bit shadow: grid (gx, nq), block 256 = 256 survivors per round, two lanes each and two
 // survivors per lane pair (lane half hf takes the 16-dimension groups 2u + hf of a row; both survivors' pieces are requested
 // before either is used: a 128-byte row is four 16-byte loads per lane, too few in flight to keep the memory busy one row at a time)
-__global__ __launch_bounds__(256) void accurate_filtered8_kernel(SurvRec *__restrict__ surv,
+#ifndef RQ_ACC8_WAVES
+#define RQ_ACC8_WAVES 4  // waves per SIMD the register budget is cut for (round 4: 132 registers, three waves; four: rerank 4.76 -> 4.35 ms per step)
+#endif
+#define RQ_ACC8_LDS_PROBES 1024u  // probe lists whose maps are staged in LDS (16 B each)
+__global__ __launch_bounds__(256, RQ_ACC8_WAVES) void accurate_filtered8_kernel(SurvRec *__restrict__ surv,
                                                                  const unsigned long long *__restrict__ surv_cnt,
                                                                  const QSeg seg, const float *__restrict__ base,
                                                                  const uint8_t *__restrict__ base_q8, const float4 *__restrict__ list_q8,
@@ -2494,36 +2498,51 @@ __global__ __launch_bounds__(256) void accurate_filtered8_kernel(SurvRec *__rest
                                                                  const float *__restrict__ thr_start,
                                                                  const uint32_t *__restrict__ probe_cluster, uint32_t nprobe,
                                                                  uint32_t *__restrict__ nshadow) {
-    extern __shared__ __attribute__((aligned(16))) float acc_q[];  // dim floats (the padded query)
+    extern __shared__ __attribute__((aligned(16))) float acc_q[];  // dim floats (the padded query), then -- when they fit -- the nprobe lists' (lo, s, err)
     __shared__ uint32_t queue[512];
     __shared__ uint32_t qn;
     const uint32_t b = order ? order[blockIdx.y] : blockIdx.y;
     const uint32_t n = (uint32_t)surv_cnt[b];
     if (n > seg.capof(b) || n == 0) return;  // overflowed: this query is re-run with a larger buffer
-    for (uint32_t c = threadIdx.x * 4; c < dim; c += 1024)
-        *reinterpret_cast<float4 *>(acc_q + c) = *reinterpret_cast<const float4 *>(qpad + (uint64_t)b * dim + c);
-    if (threadIdx.x == 0) qn = 0;
-    __syncthreads();
     SurvRec *recs = surv + seg.at(b);
     const uint32_t hf = threadIdx.x & 1, pair = threadIdx.x >> 1;
+    // The kernel is a chain of dependent gathers (survivor record -> its list's map and its shadow row -> the f32 row of the few that
+    // stay), i.e. bound by how many of them are in flight: the first round's records are requested before anything else, every later
+    // round's while the current one is being worked on, and the lists' maps are staged in LDS once per block (one dependent round
+    // trip less per round: probe list -> map was two)
+    const uint32_t i_first = blockIdx.x * 256;
+    SurvRec nxt[2];
+    nxt[0] = recs[i_first + pair < n ? i_first + pair : 0u], nxt[1] = recs[i_first + 128 + pair < n ? i_first + 128 + pair : 0u];
+    const uint32_t *pc = probe_cluster + (uint64_t)b * nprobe;
+    float4 *lpar = reinterpret_cast<float4 *>(acc_q + dim);
+    const bool par_lds = nprobe <= RQ_ACC8_LDS_PROBES;  // (launch: LDS for them only then)
+    for (uint32_t c = threadIdx.x * 4; c < dim; c += 1024)
+        *reinterpret_cast<float4 *>(acc_q + c) = *reinterpret_cast<const float4 *>(qpad + (uint64_t)b * dim + c);
+    if (par_lds)
+        for (uint32_t sl = threadIdx.x; sl < nprobe; sl += 256) lpar[sl] = list_q8[pc[sl]];
+    if (threadIdx.x == 0) qn = 0;
+    __syncthreads();
     const float thr = thr_start[b];
     const bool test = thr > 1e-30f && thr < 3.0e38f;  // a finite, normal threshold (false for NaN / inf: everything is exact)
     const float eps = (float)(dim / 4 + 64) * 5.9604645e-8f, down = 1.0f - eps, up = 1.0f + eps;
     const float sqd = sqrtf((float)dim) * 1.001f;
     const uint32_t ngrp = dim / 16;
-    const uint32_t *pc = probe_cluster + (uint64_t)b * nprobe;
     uint32_t rejected = 0;
-    for (uint32_t i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
+    for (uint32_t i0 = i_first; i0 < n; i0 += gridDim.x * 256) {
         uint32_t iv[2] = {i0 + pair, i0 + 128 + pair};
         bool exact[2] = {iv[0] < n, iv[1] < n};
+        const SurvRec cur[2] = {nxt[0], nxt[1]};
+        {  // the next round's records (clamped: the last prefetch re-reads record 0)
+            const uint32_t j0 = i0 + gridDim.x * 256 + pair, j1 = j0 + 128;
+            nxt[0] = recs[j0 < n ? j0 : 0u], nxt[1] = recs[j1 < n ? j1 : 0u];
+        }
         if (test) {
             float4 par[2];
             const uint8_t *x[2];
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
-                const SurvRec r = recs[exact[v] ? iv[v] : 0u];
-                par[v] = list_q8[pc[r.slot]];  // lo, s, max |x_i - x^_i| of the list
-                x[v] = base_q8 + (uint64_t)r.pos * dim;
+                par[v] = par_lds ? lpar[cur[v].slot] : list_q8[pc[cur[v].slot]];  // lo, s, max |x_i - x^_i| of the list
+                x[v] = base_q8 + (uint64_t)cur[v].pos * dim;
             }
             float d0[2] = {0.0f, 0.0f}, d1[2] = {0.0f, 0.0f};
             for (uint32_t g0 = hf; g0 < ngrp; g0 += 8) {  // four 16-byte pieces of each row in flight per lane
@@ -2550,6 +2569,9 @@ __global__ __launch_bounds__(256) void accurate_filtered8_kernel(SurvRec *__rest
                             d0[v] = fmaf(e0, e0, d0[v]), d1[v] = fmaf(e1, e1, d1[v]), d0[v] = fmaf(e2, e2, d0[v]), d1[v] = fmaf(e3, e3, d1[v]);
                         }
                     }
+                    // (the query pieces of the later groups are read when their turn comes: hoisted, the sixteen 16-byte LDS reads of
+                    // a round held 64 registers and cost the kernel a wave per SIMD)
+                    asm volatile("" ::: "memory");
                 }
             }
 #pragma unroll

@@ -1400,7 +1400,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             const uint32_t gx = std::max(1u, std::min(16u, 4096u / std::max(nq, 1u)));
             // past the first stage the thresholds are finite: survivors go through the fp16 shadow rows first
             if (idx->base_q8.p && (stage_no > 0 || qp.thr_init) && !(g_scan_dbg & 512))
-                accurate_filtered8_kernel<<<dim3(gx, nq), 256, (size_t)dim * sizeof(float), st>>>(
+                accurate_filtered8_kernel<<<dim3(gx, nq), 256, (size_t)dim * sizeof(float) + (nprobe <= RQ_ACC8_LDS_PROBES ? (size_t)nprobe * 16 : 0), st>>>(
                     ws.surv.p, ws.surv_cnt.p, seg, idx->base.p, idx->base_q8.p, idx->list_q8.p, qpad, dim, rerank_order, ws.thr.p,
                     probe_cluster, nprobe, ws.nshadow.p);
             else if (idx->base_h.p && (stage_no > 0 || qp.thr_init) && !(g_scan_dbg & 512))
