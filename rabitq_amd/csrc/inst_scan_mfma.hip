@@ -10,12 +10,12 @@
     template __global__ void scan_mfma_kernel<W, NT, false, false>(RQ_MFMA_PARAMS);                                                  \
     template __global__ void scan_mfma_kernel<W, NT, true, false>(RQ_MFMA_PARAMS);
 RQ_INST(1, 4)
-RQ_INST(2, 3)
+RQ_INST(2, RQ_NT_W2)
 RQ_INST(3, 4)
 RQ_INST(4, 2)
 RQ_INST(6, 2)
 RQ_INST(8, 2)
-RQ_INST(12, 2)
+RQ_INST(12, RQ_NT_W12)
 RQ_INST(16, 2)
 #undef RQ_INST
 // the additive-gate instantiations (dim 64 / 128, uniform survivor buffers)

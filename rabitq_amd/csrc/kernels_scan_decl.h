@@ -14,6 +14,12 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS);
                       // serves six 32 x 32 steps (four in round 4: launch 6.0 -> 5.8 ms on the headline workload; seven / eight spill inside
                       // the tile loop: 6.6 / 6.8 ms).  Its 33 spilled registers sit in the block's start-up and the cold path only.
 #endif
+#ifndef RQ_NT_W2
+#define RQ_NT_W2 3   // sub-tiles per wave at dim 128, bf16-threshold form (uniform and arena instantiations)
+#endif
+#ifndef RQ_NT_W12
+#define RQ_NT_W12 2  // sub-tiles per wave at dim 768
+#endif
 #ifndef RQ_GATE_DEFER
 #define RQ_GATE_DEFER 1  // additive gate of the narrow instantiations: 1 = one branch per query tile (the cold path recomputes the flagged steps), 0 = one per step
 #endif

@@ -95,8 +95,11 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
     constexpr uint32_t NI = (WQ4 + 63) / 64;     // LDS-DMA instructions per wave per tile
     static_assert(IMG % (4 * NW) == 0, "tile image must split into NW 16-byte-aligned shares");
     constexpr uint32_t TILE = 32 * NW * NT;
-    constexpr uint32_t BDW = ADD ? 4 : 6;        // candidate operand dwords per 32 dimensions: fp4 / fp6 fields
-    __shared__ __attribute__((aligned(16))) uint2 lut[256];
+    // candidate operand: fp4 e2m1 fields (a code bit = 1.0 = 0b0010), 4 dwords per 32 dimensions, in EVERY instantiation since round 5
+    // (rounds <= 4: fp6 e2m3, 6 dwords, outside the additive form) -- same matrix rate, same exact products, a third fewer resident
+    // registers: 12 per wave at dim 128 / three sub-tiles, 48 at dim 768
+    constexpr uint32_t BDW = 4;
+    __shared__ __attribute__((aligned(16))) uint32_t lut[256];
     extern __shared__ __attribute__((aligned(16))) uint32_t ring[];  // scan_mfma_ring_slots<W, ARENA>() x IMG dwords: query tiles in flight (LDS-DMA targets)
     __shared__ __attribute__((aligned(16))) float4 facL[TILE];      // the tile's factors, for the exact path
     // per-wave emit queue: survivors are parked here and written out in bulk (one atomic round trip per flush)
@@ -166,16 +169,11 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
     }
     if (tid < 256) {
         const uint32_t b = tid;
-        if constexpr (ADD) {  // byte -> 8 fp4 fields (bit e -> 1.0 = 0b0010 at bits 4e .. 4e+3)
+        {  // byte -> 8 fp4 fields (bit e -> 1.0 = 0b0010 at bits 4e .. 4e+3)
             uint32_t f = 0;
 #pragma unroll
             for (int e = 0; e < 8; ++e) f |= ((b >> e) & 1u) << (4 * e + 1);
-            lut[b] = make_uint2(f, 0u);
-        } else {  // byte -> 8 fp6 fields (bit e -> 1.0 = 0b001000 at bits 6e .. 6e+5)
-            uint64_t f = 0;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f |= (uint64_t)((b >> e) & 1u) << (6 * e + 3);
-            lut[b] = make_uint2((uint32_t)f, (uint32_t)(f >> 32));
+            lut[b] = f;
         }
     }
 
@@ -319,18 +317,8 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
 #pragma unroll
         for (int m = 0; m < W; ++m) {
             const uint32_t c = craw[t][m];
-            if constexpr (ADD) {
-                bexp[t][m][0] = lut[c & 0xFFu].x, bexp[t][m][1] = lut[(c >> 8) & 0xFFu].x;
-                bexp[t][m][2] = lut[(c >> 16) & 0xFFu].x, bexp[t][m][3] = lut[c >> 24].x;
-            } else {
-                const uint2 p0 = lut[c & 0xFFu], p1 = lut[(c >> 8) & 0xFFu], p2 = lut[(c >> 16) & 0xFFu], p3 = lut[c >> 24];
-                bexp[t][m][0] = p0.x;
-                bexp[t][m][1] = p0.y | (p1.x << 16);
-                bexp[t][m][2] = (p1.x >> 16) | (p1.y << 16);
-                bexp[t][m][3] = p2.x;
-                bexp[t][m][4] = p2.y | (p3.x << 16);
-                bexp[t][m][BDW - 1] = (p3.x >> 16) | (p3.y << 16);
-            }
+            bexp[t][m][0] = lut[c & 0xFFu], bexp[t][m][1] = lut[(c >> 8) & 0xFFu];
+            bexp[t][m][2] = lut[(c >> 16) & 0xFFu], bexp[t][m][3] = lut[c >> 24];
         }
 
     // always-on statistic (results unchanged, nothing in the hot loop): 32x32 sub-tile steps taken = NT per tile, and how many of
@@ -428,19 +416,12 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
             }
         };
         auto get_b = [&](int t, int m) {
-            if constexpr (ADD) {
-                const v8i32 bv = {(int)bexp[t][m][0], (int)bexp[t][m][1], (int)bexp[t][m][2], (int)bexp[t][m][3], 0, 0, 0, 0};
-                return bv;
-            } else {
-                const v8i32 bv = {(int)bexp[t][m][0], (int)bexp[t][m][1], (int)bexp[t][m][2], (int)bexp[t][m][3],
-                                  (int)bexp[t][m][4], (int)bexp[t][m][BDW - 1], 0, 0};
-                return bv;
-            }
+            const v8i32 bv = {(int)bexp[t][m][0], (int)bexp[t][m][1], (int)bexp[t][m][2], (int)bexp[t][m][3], 0, 0, 0, 0};
+            return bv;
         };
         // one 32 x 32 x 64 product block on top of c: A fp6 (e2m3) x B fp6 / fp4 (e2m1), exact in f32
         auto mm = [&](const v8i32 av, const v8i32 bv, const f32x16 c) {
-            if constexpr (ADD) return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 2 /*A e2m3*/, 4 /*B e2m1*/, 0, 0, 0, 0);
-            else return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 2 /*A e2m3*/, 2 /*B e2m3*/, 0, 0, 0, 0);
+            return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 2 /*A e2m3*/, 4 /*B e2m1*/, 0, 0, 0, 0);
         };
         // bf16 form: A operand of the threshold MFMA, slots 8h .. 8h+7 of query row j
         // (rows past the list's last query carry the "no query" operand written by group_scan_kernel: -S* = -inf)

@@ -596,7 +596,7 @@ static bool scan_has_mfma(uint32_t W) {
         default: return false;
     }
 }
-static uint32_t scan_mfma_nt(uint32_t W, bool additive = false) { return W == 2 ? (additive ? RQ_ADD_NT2 : 3) : (W >= 4 ? 2 : 4); }
+static uint32_t scan_mfma_nt(uint32_t W, bool additive = false) { return W == 2 ? (additive ? RQ_ADD_NT2 : RQ_NT_W2) : (W == 12 ? RQ_NT_W12 : (W >= 4 ? 2 : 4)); }
 static uint32_t scan_mfma_nw(uint32_t W, bool arena) { return W == 2 && !arena ? 8u : 4u; }  // scan_mfma_waves<W, ARENA>()
 static uint32_t scan_mfma_tile(uint32_t W, bool arena, bool additive = false) { return 32 * scan_mfma_nw(W, arena) * scan_mfma_nt(W, additive && !arena); }
 static size_t scan_mfma_ring_bytes(uint32_t W, bool arena = false) {  // scan_mfma_ring_slots<W, ARENA>() tile images
@@ -626,12 +626,12 @@ static void launch_scan_mfma_a(const ScanPtrs &p, const ScanArgs &args, uint32_t
     launch_scan_chunks(args, [&](const ScanArgs &a, dim3 g) {
         switch (W) {
             case 1: launch_scan_mfma_t<1, 4, ARENA>(p, a, g, st); break;
-            case 2: launch_scan_mfma_t<2, 3, ARENA>(p, a, g, st); break;
+            case 2: launch_scan_mfma_t<2, RQ_NT_W2, ARENA>(p, a, g, st); break;
             case 3: launch_scan_mfma_t<3, 4, ARENA>(p, a, g, st); break;
             case 4: launch_scan_mfma_t<4, 2, ARENA>(p, a, g, st); break;
             case 6: launch_scan_mfma_t<6, 2, ARENA>(p, a, g, st); break;
             case 8: launch_scan_mfma_t<8, 2, ARENA>(p, a, g, st); break;
-            case 12: launch_scan_mfma_t<12, 2, ARENA>(p, a, g, st); break;
+            case 12: launch_scan_mfma_t<12, RQ_NT_W12, ARENA>(p, a, g, st); break;
             case 16: launch_scan_mfma_t<16, 2, ARENA>(p, a, g, st); break;
             default: break;
         }
@@ -728,12 +728,12 @@ static rq_status ensure_kernel_attributes() {
             if (err == hipSuccess && e != hipSuccess) err = e, what = name;
         };
         chk(set_scan_mfma_attr<1, 4>(), "scan_mfma_kernel<1,4>");
-        chk(set_scan_mfma_attr<2, 3>(), "scan_mfma_kernel<2,3>");
+        chk(set_scan_mfma_attr<2, RQ_NT_W2>(), "scan_mfma_kernel<2,NT>");
         chk(set_scan_mfma_attr<3, 4>(), "scan_mfma_kernel<3,4>");
         chk(set_scan_mfma_attr<4, 2>(), "scan_mfma_kernel<4,2>");
         chk(set_scan_mfma_attr<6, 2>(), "scan_mfma_kernel<6,2>");
         chk(set_scan_mfma_attr<8, 2>(), "scan_mfma_kernel<8,2>");
-        chk(set_scan_mfma_attr<12, 2>(), "scan_mfma_kernel<12,2>");
+        chk(set_scan_mfma_attr<12, RQ_NT_W12>(), "scan_mfma_kernel<12,NT>");
         chk(set_scan_mfma_attr<16, 2>(), "scan_mfma_kernel<16,2>");
     });
     if (err != hipSuccess)
