@@ -740,7 +740,8 @@ template <int W, int NT>
 __global__ __launch_bounds__(256, (W <= 4 ? 2 : 1)) void coarse_approx_kernel(const float *__restrict__ y /* nq x dim, rotated queries */,
                                                               const uint16_t *__restrict__ cent_bf /* k x dim bf16 */,
                                                               const float *__restrict__ cnorm, uint32_t nq, uint32_t k,
-                                                              float *__restrict__ dist /* nq x k */) {
+                                                              float *__restrict__ dist /* nq x k */,
+                                                              const uint16_t *__restrict__ y_bf /* nq x dim bf16 (to_bf16_kernel of y), or null */) {
     constexpr int DIM = 64 * W, NM = DIM / 16;
     constexpr uint32_t ROWB = DIM * 2 + 16, TILEB = 32 * ROWB;
     extern __shared__ __attribute__((aligned(16))) unsigned char asg_lds[];  // 2 x (tile image | 32 norms), as assign_approx_kernel
@@ -750,12 +751,24 @@ __global__ __launch_bounds__(256, (W <= 4 ? 2 : 1)) void coarse_approx_kernel(co
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) {
         const uint32_t v = v0 + 32 * tl + col;
-        const float *xp = y + (uint64_t)(v < nq ? v : (nq - 1)) * DIM + 8 * kh;
+        const uint64_t vr = v < nq ? v : (nq - 1);
+        if constexpr (NM > 32) {
+            // dim > 512: the fragments come pre-rounded (to_bf16_kernel over the query rows, the rounding of asg_bf16_pair), one 16-byte
+            // load per slab straight into its place.  Converted here, the f32 loads of all dim / 16 slabs were in flight beside the
+            // fragments (384 + 192 registers at dim 768): 142 registers went to scratch memory in round 4 -- the only kernel of the
+            // query path that needed any, and a dispatch that needs more scratch than the queue holds is set up and torn down around
+            // the launch by the runtime (the 20 ms that appeared BETWEEN launches behind this kernel)
+            const uint16_t *xb = y_bf + vr * DIM + 8 * kh;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) afrag[tl][m] = __builtin_bit_cast(asg_bf16x8, *reinterpret_cast<const uint4 *>(xb + 16 * m));
+        } else {
+        const float *xp = y + vr * DIM + 8 * kh;
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
             const float4 a = *reinterpret_cast<const float4 *>(xp + 16 * m), b = *reinterpret_cast<const float4 *>(xp + 16 * m + 4);
             const uint4 pk = make_uint4(asg_bf16_pair(a.x, a.y), asg_bf16_pair(a.z, a.w), asg_bf16_pair(b.x, b.y), asg_bf16_pair(b.z, b.w));
             afrag[tl][m] = __builtin_bit_cast(asg_bf16x8, pk);
+        }
         }
     }
     const uint32_t ntile = (k + 31) / 32;

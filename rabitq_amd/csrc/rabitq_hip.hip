@@ -429,12 +429,15 @@ static bool coarse_prefilter_applies(const rq_index *idx, uint32_t nq, uint32_t 
            idx->cent_bf.p != nullptr && nprobe <= 64 && nq >= 8 && idx->k >= 64 && nprobe >= 1 && idx->k <= 65536;
 }
 // redo: nq flags (only written / read when k > 8192)
+// y_bf: room for nq x dim bf16 (the query rows pre-rounded for the wide instantiation; any workspace buffer that is free at this point)
 static void launch_coarse_prefiltered(const rq_index *idx, const float *y, float *dist, uint32_t nq, uint32_t nprobe, uint32_t *out_cluster,
-                                      float *out_dist, uint32_t out_stride, unsigned long long *fallback_rows, uint32_t *redo, hipStream_t st) {
+                                      float *out_dist, uint32_t out_stride, unsigned long long *fallback_rows, uint32_t *redo, hipStream_t st,
+                                      uint16_t *y_bf) {
     const uint32_t k = idx->k, dim = idx->dim;
+    if (idx->W > 8) to_bf16_kernel<<<ceil_div((uint64_t)nq * dim / 8, 256), 256, 0, st>>>(y, (uint64_t)nq * dim, y_bf);
 #define RQ_CAP(WW, NT)                                                                                                      \
     coarse_approx_kernel<WW, NT><<<ceil_div(nq, 128 * NT), 256, assign_lds_bytes<WW, NT>(), st>>>(y, idx->cent_bf.p, idx->cent_sqnorm.p, nq, \
-                                                                                                  k, dist)
+                                                                                                  k, dist, y_bf)
     switch (idx->W) {
         case 1: RQ_CAP(1, 2); break;
         case 2: RQ_CAP(2, 2); break;
@@ -450,9 +453,10 @@ static void launch_coarse_prefiltered(const rq_index *idx, const float *y, float
     // the register-resident row from 4096 lists up, and the only form beyond 8192 --, else the row in registers
     const uint32_t ntile = ceil_div(k, 32u);
     const int impl = g_coarse_impl.load();
-    // (not chosen automatically at dim 768 and beyond: measured on the 100M x 768 benchmark index the step's coarse ranking went from 2.5 to
-    // 22 ms with it -- no kernel got slower, the time sits between the launches behind coarse_approx_kernel<12,1>, the one kernel of the path
-    // that spills to scratch memory; the row-in-registers selection does not show it)
+    // (dim 768 and beyond stay on the row in registers below 8192 lists: 2.45 against 2.77 ms per 32 768 queries on the 100M x 768 index --
+    // the margin of the pre-filter grows with the dimension, so more tiles are read again.  Round 4 saw 22 ms here: the time sat between
+    // the launches behind coarse_approx_kernel<12,1>, which then spilled 142 registers -- a dispatch that needs more scratch than the queue
+    // holds is set up and torn down around the launch -- and needs no scratch any more.)
     const bool tiled = redo != nullptr && ntile >= nprobe &&
                        (k > 8192 || impl == 4 || (impl != 3 && k >= (uint32_t)g_coarse_tiled_from.load() && idx->W <= 8));
     if (tiled) {
@@ -1043,7 +1047,9 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             pf.begin(PF_COARSE);
             HIPC(hipMemsetAsync(ws.totals.p + 12, 0, 8, st));
             RQC(ws.coarse_redo.ensure(nq));
-            launch_coarse_prefiltered(idx, ws.y.p, ws.dist.p, nq, nprobe, ws.probe_cluster.p, ws.probe_dist.p, nprobe, ws.totals.p + 12, ws.coarse_redo.p, st);
+            RQC(ws.qf6.ensure((size_t)nq * dim / 2 + 16));  // (room for the pre-rounded query rows of the wide instantiation)
+            launch_coarse_prefiltered(idx, ws.y.p, ws.dist.p, nq, nprobe, ws.probe_cluster.p, ws.probe_dist.p, nprobe, ws.totals.p + 12, ws.coarse_redo.p, st,
+                                      reinterpret_cast<uint16_t *>(ws.qf6.p));  // (the fp6 images are written later: prep)
             ws.pend_prefiltered = true;
             pf.end();
         } else {
@@ -2982,8 +2988,9 @@ rq_status rq_coarse_topk_device(const rq_index *idx, const float *d_queries, uin
         launch_rotate(qp, idx->P.p, ws->y.p, m, dim, m >= 32, st);
         if (kc == idx->k && coarse_prefilter_applies(idx, m, np)) {
             RQC(ws->coarse_redo.ensure(m));
+            RQC(ws->qf6.ensure((size_t)m * dim / 2 + 16));
             launch_coarse_prefiltered(idx, ws->y.p, ws->dist.p, m, np, d_out_cluster + (uint64_t)q0 * probe, d_out_dist + (uint64_t)q0 * probe, probe, nullptr,
-                                      ws->coarse_redo.p, st);
+                                      ws->coarse_redo.p, st, reinterpret_cast<uint16_t *>(ws->qf6.p));
             continue;
         }
         launch_coarse(idx->cent_t.p + list_lo, ws->y.p, ws->dist.p, kc, dim, m, idx->k, st);
