@@ -214,6 +214,10 @@ def run_workload(args, ctx, extras=True):
     my_lo = rank * k_local                   # this rank's points come from its own k_local centres
     qweights = None if weights is None else weights.repeat(world) / world
     queries = synth.device_queries(centres, B, args.sigma, dev, weights=qweights)
+    # the timed steps rotate over FOUR distinct query batches (set 0 = `queries`: warm-up, ground truth, every extra leg): what the
+    # warm-up learns about set 0 -- survivor capacities, the arena's size -- has to hold for batches the engine has never seen
+    query_sets = [queries] + [synth.device_queries(centres, B, args.sigma, dev, seed=7 + 1000 * i, weights=qweights) for i in (1, 2, 3)]
+    qsel = [0]   # the set the next step answers
     P = synth.random_orthogonal(d, seed=99)
     chunk = max(262_144, min(4_000_000, (512 << 20) // d))     # rows per generated chunk (4M at d = 128)
     chunks = [(ci, i0, min(chunk, n - i0)) for ci, i0 in enumerate(range(0, n, chunk))]
@@ -382,7 +386,7 @@ def run_workload(args, ctx, extras=True):
 
     def step_torch():
         # each rank ranks only the lists it owns; one all-gather merges the per-rank nearest lists
-        idx.coarse_topk_device(queries.data_ptr(), B, d, rank * k_local, (rank + 1) * k_local, nprobe,
+        idx.coarse_topk_device(query_sets[qsel[0]].data_ptr(), B, d, rank * k_local, (rank + 1) * k_local, nprobe,
                                pc_local.data_ptr(), pd_local.data_ptr())
         pcl, pdl = (pc_local.cpu(), pd_local.cpu()) if args.backend == "gloo" else (pc_local, pd_local)
         pc, pdist = sharding.merge_probe_lists(pcl, pdl, nprobe)
@@ -390,7 +394,7 @@ def run_workload(args, ctx, extras=True):
         # thresholds shared between the shards (sharding.SeededShardQuery): the nearest list alone, one
         # all-reduce(min) of the k-th best distances found there, then the other lists seeded with it -- a shard that
         # does not hold a query's neighbourhood would otherwise re-rank most of what it scans
-        seeded.run(idx, queries.data_ptr(), d, pc, pdist, cpu_collectives=args.backend == "gloo")
+        seeded.run(idx, query_sets[qsel[0]].data_ptr(), d, pc, pdist, cpu_collectives=args.backend == "gloo")
         extra_prof.append(seeded.profile_a)
         pay = seeded.payload(rank * n)
         if args.backend == "gloo":
@@ -398,13 +402,13 @@ def run_workload(args, ctx, extras=True):
         return sharding.merge_shard_topk(pay, topk, id_bound=world * n)
 
     def step_c_abi():
-        idx.query_batch_sharded_device(comm_handle, world, rank * n, queries.data_ptr(), B, d, nprobe, topk, out_d.data_ptr(),
+        idx.query_batch_sharded_device(comm_handle, world, rank * n, query_sets[qsel[0]].data_ptr(), B, d, nprobe, topk, out_d.data_ptr(),
                                        out_i.data_ptr(), out_n.data_ptr())
         return out_d, out_i.to(torch.int64) & 0xFFFFFFFF, out_n
 
     def step():
         if not sharded:
-            idx.query_batch_device(queries.data_ptr(), B, d, nprobe, topk, out_d.data_ptr(), out_i.data_ptr(),
+            idx.query_batch_device(query_sets[qsel[0]].data_ptr(), B, d, nprobe, topk, out_d.data_ptr(), out_i.data_ptr(),
                                    out_n.data_ptr())
             return out_d, out_i.to(torch.int64) & 0xFFFFFFFF, out_n
         return step_c_abi() if seeded is None else step_torch()
@@ -433,12 +437,14 @@ def run_workload(args, ctx, extras=True):
 
     prof = {}
 
-    def run_steps(count, record, depth=depth):
+    def run_steps(count, record, depth=depth, rotate=False):
         """`count` steps; with depth > 1 a step's batch is begun before the previous one is ended, so consecutive
-        batches overlap on the device (each owns a workspace, a stream and an output slot)."""
+        batches overlap on the device (each owns a workspace, a stream and an output slot).  rotate: step i answers query set i mod 4
+        (otherwise set 0)."""
         res = None
         if depth == 1:
-            for _ in range(count):
+            for it in range(count):
+                qsel[0] = it % len(query_sets) if rotate else 0
                 extra_prof.clear()
                 ts = time.perf_counter()
                 res = step()
@@ -455,7 +461,7 @@ def run_workload(args, ctx, extras=True):
         for i in range(count + depth - 1):
             if i < count:
                 od, oi, on = outs[i % depth]
-                pending.append((idx.query_batch_device_begin(queries.data_ptr(), B, d, nprobe, topk, od.data_ptr(),
+                pending.append((idx.query_batch_device_begin(query_sets[i % len(query_sets) if rotate else 0].data_ptr(), B, d, nprobe, topk, od.data_ptr(),
                                                              oi.data_ptr(), on.data_ptr()), i % depth))
             if i >= depth - 1:
                 tk, slot = pending.pop(0)
@@ -472,16 +478,17 @@ def run_workload(args, ctx, extras=True):
     fence()
     rabitq_amd.metrics_reset()
     t1 = time.perf_counter()
-    res = run_steps(args.steps, True)
+    run_steps(args.steps, True, rotate=True)
     fence()
     elapsed = time.perf_counter() - t1
+    qsel[0] = 0
     # the same loop with two batches in flight: one batch's HBM-bound stages overlap the other's compute-bound scan
     overlap = None
     if not sharded and args.two_in_flight and extras:
         run_steps(2, False, 2)
         fence()
         t2 = time.perf_counter()
-        run_steps(args.steps, False, 2)
+        run_steps(args.steps, False, 2, rotate=True)
         fence()
         e2 = time.perf_counter() - t2
         overlap = {"batches_in_flight": 2, "value": round(B * args.steps / e2, 1), "unit": "queries/s",
@@ -491,7 +498,8 @@ def run_workload(args, ctx, extras=True):
     # per-kernel-group breakdown from ONE extra, untimed step (an event pair per group costs ~10 us of stream time each)
     rqi.set_profiling(1)
     extra_prof.clear()
-    step()
+    qsel[0] = 0
+    res = step()   # (set 0: also the batch whose first `ngt` queries have a ground truth)
     fence()
     breakdown = {}
     for pr in [rqi.last_profile()] + extra_prof:   # a multi-GPU step is two engine calls
@@ -558,6 +566,9 @@ def run_workload(args, ctx, extras=True):
         mbytes = mp * (idx.dim / 8 + 16)
         roofline = {"bound": "mfma", "achieved": round(flops / mm / 1e12, 1), "peak": round(PEAK_FP6, 1), "unit": "TFLOP/s",
                     "frac": round(flops / mm / 1e12 / PEAK_FP6, 4), "traffic": dom_traffic, "traffic_source": traffic_src,
+                    # fabric bytes of the launch (FETCH_SIZE x2: incl. Infinity-Cache hits) over the bytes of the index it reads once
+                    # (codes + factors of every vector): what the per-XCD L2s fetch more than once, plus the query tile images
+                    "traffic_over_unique_index_bytes": None if not dom_traffic else round(dom_traffic / (idx.n * (idx.dim / 8 + 16)), 2),
                     "kernel": ("scan_mfma_kernel<W,NT,ADD> (v_mfma_f32_32x32x64_f8f6f4 e2m3 x e2m1; additive gate S* >= B_q + G_c, no threshold MFMA)"
                                if additive else "scan_mfma_kernel<W,NT> (v_mfma_f32_32x32x64_f8f6f4 e2m3 x e2m3 + bf16 threshold MFMA)"),
                     "gate": "additive" if additive else "bf16 rank-5 threshold",
@@ -623,6 +634,11 @@ def run_workload(args, ctx, extras=True):
         host_entry["entry"] = "rq_query_batch (host pointers in and out; one blocking call per step)"
         host_entry["bytes_in_out_per_step"] = [B * d * 4, B * topk * 8 + B * 4]
 
+    # ---- between the small-batch regimes and the headline batch: what a service's request sizes would see -------------------
+    sweep = None
+    if rank == 0 and extras and not sharded:
+        sweep = batch_sweep(idx, centres, qweights, args.sigma, dev, d, nprobe, topk, [b for b in (128, 512, 2048, 8192, 16384) if b < B])
+
     size_txt = f"{n // 1_000_000}Mx{d}" if n % 1_000_000 == 0 else f"{n}x{d}"
     line = {"metric": f"queries/sec at recall@10>=0.95, {size_txt}; HBM GB/s on popcount scan", "value": round(qps, 1),
             "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -630,8 +646,9 @@ def run_workload(args, ctx, extras=True):
             "scaling": "weak",   # per-GPU work is fixed: every rank indexes --vectors rows and 4096 lists of its own, and the batch grows with N
             "scaling_note": f"weak: {n // 1_000_000}M vectors and {k_local} lists per GPU at every N; one step answers {B} queries "
                             f"(65536 x N by default) against ALL {k} lists, so a rank scans as many (query, list) pairs per step as "
-                            "one GPU does alone; the coarse ranking (queries x all lists, sliced by lists over the ranks) is the part "
-                            "whose per-rank work grows with N",
+                            "one GPU does alone; the coarse ranking is sliced by QUERIES over the ranks (rank r ranks queries "
+                            "[r B/N, (r+1) B/N) against ALL lists: (B/N) x k distances per rank, i.e. per-rank coarse work grows with N "
+                            "through k only; one all-gather carries B/N x nprobe (distance, list) keys per rank)",
             "vs_baseline": None, "dtype": "exact integer dot (fp6 MFMA, v_dot8_u32_u4) + f32", "data": "synthetic",
             "engine_options": args.option, "collective_path": collective_path,
             "config": {"workload": f"{n // 1_000_000}Mx{d} synthetic mixture per GPU, {k_local} lists per GPU, "
@@ -658,11 +675,14 @@ def run_workload(args, ctx, extras=True):
             "rerank_shadow_rejects_per_query": prof["rerank_shadow_rejects"] / (B * args.steps),
             "matrix_exact_path_rate": None if exact_rate is None else round(exact_rate, 5),
             "retries": int(prof["retries"]),
+            "query_batches": {"distinct_batches_in_timed_steps": len(query_sets),
+                              "note": "warm-up on batch 0 only; timed step i answers batch i mod 4 (fresh draws from the same mixture); "
+                                      "`retries` = queries re-run in the timed steps because a survivor capacity learnt on batch 0 did not hold"},
             "survivor_workspace_GB": round(prof.get("survivor_workspace_bytes_max", 0) / 1e9, 2),
             "segmented_passes_per_step": prof.get("segmented_passes", 0) / args.steps,
             "roofline": roofline, "roofline_scan_all_launches": scan_all,
             "roofline_rotation": rotation,
-            "scan_small_batch": small, "single_query": single, "two_batches_in_flight": overlap, "host_entry": host_entry}
+            "scan_small_batch": small, "batch_sweep": sweep, "single_query": single, "two_batches_in_flight": overlap, "host_entry": host_entry}
 
     # ---- CPU baseline: the oracle (port of the reference's AVX2 path) on this box's host cores ------
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_queries > 0 and extras:
@@ -680,9 +700,41 @@ def run_workload(args, ctx, extras=True):
         if hasattr(obj, "close"):
             obj.close()
     idx.close()
-    del outs, out_d, out_i, out_n, queries, res, rd, rn
+    del outs, out_d, out_i, out_n, queries, query_sets, res, rd, rn
     torch.cuda.empty_cache()
     return line
+
+
+def batch_sweep(idx, centres, qweights, sigma, dev, d, nprobe, topk, sizes):
+    """Queries per call between the small-batch path and the headline batch (crates/service/src/main.rs:36-44 answers whatever a
+    request brings): every call answers queries the engine has not seen (six distinct draws per size, one of them as warm-up)."""
+    import torch
+    from rabitq_amd import index as rqi
+    from tests import synth
+    rows = []
+    for b in sizes:
+        sets = [synth.device_queries(centres, b, sigma, dev, seed=50_000 + 17 * b + i, weights=qweights) for i in range(6)]
+        od = torch.empty((b, topk), device=dev, dtype=torch.float32)
+        oi = torch.zeros((b, topk), device=dev, dtype=torch.int32)
+        on = torch.zeros((b,), device=dev, dtype=torch.int32)
+        idx.query_batch_device(sets[0].data_ptr(), b, d, nprobe, topk, od.data_ptr(), oi.data_ptr(), on.data_ptr())
+        torch.cuda.synchronize()
+        retries, small_passes, matrix = 0, 0, 0
+        t0 = time.perf_counter()
+        for q in sets[1:]:
+            idx.query_batch_device(q.data_ptr(), b, d, nprobe, topk, od.data_ptr(), oi.data_ptr(), on.data_ptr())
+            pr = rqi.last_profile()
+            retries += pr["retries"]
+            small_passes += pr["small_batch_passes"]
+            matrix += pr["matrix_launches"]
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / (len(sets) - 1)
+        rows.append({"batch": b, "ms_per_call": round(el * 1e3, 3), "queries_per_s": round(b / el, 1), "retries": int(retries),
+                     "path": "small-batch kernels" if small_passes else ("staged: VALU early stages + matrix-core final stage" if matrix else "staged: VALU scan only")})
+        del sets, od, oi, on
+    for a, c in zip(rows, rows[1:]):
+        c["queries_per_s_vs_previous_size"] = round(c["queries_per_s"] / a["queries_per_s"], 2)
+    return rows
 
 
 def small_batch_regime(idx, queries, sb, d, nprobe, topk, out_d, out_i, out_n, n, k_local):
@@ -713,7 +765,8 @@ def small_batch_regime(idx, queries, sb, d, nprobe, topk, out_d, out_i, out_n, n
                        "figures under committed_profile)",
              "queries_per_s": round(sb * reps / (sp["ms_total"] * 1e-3), 1)}
     # physical HBM rate of the same regime: PMC FETCH_SIZE (x2) over kernel-trace durations, committed profile
-    hp = next((os.path.join(ROOT, "profiles", f) for f in ("r03_hbm_regime.json", "r02_hbm_regime.json")
+    # (the newest committed pass; its round is part of `source`: a pass taken on an earlier round's kernels must say so)
+    hp = next((os.path.join(ROOT, "profiles", f) for f in ("r05_hbm_regime.json", "r04_hbm_regime.json", "r03_hbm_regime.json", "r02_hbm_regime.json")
                if os.path.exists(os.path.join(ROOT, "profiles", f))), "")
     if hp:
         try:
@@ -724,8 +777,11 @@ def small_batch_regime(idx, queries, sb, d, nprobe, topk, out_d, out_i, out_n, n
                         if rg["batch"] == sb:   # NOT measured in this run: kept apart from the in-run figures above
                             small["committed_profile"] = {
                                 "source": os.path.basename(hp) + " (rocprofv3 --pmc FETCH_SIZE x2 / kernel-trace time)",
-                                "physical_GBps_all_scan_launches": round(rg["physical_GBps"], 1),
-                                "physical_frac_of_8TBps_all_scan_launches": round(rg["physical_frac_of_8TBps"], 4)}
+                                "source_round": os.path.basename(hp)[:3],
+                                "fabric_GBps_all_scan_launches": round(rg["physical_GBps"], 1),
+                                "fabric_frac_of_8TBps_all_scan_launches": round(rg["physical_frac_of_8TBps"], 4),
+                                "label": "fabric bytes: FETCH_SIZE includes Infinity-Cache hits, so this can exceed what HBM itself "
+                                         "delivers (~6.3 TB/s); x2 applied because the scan's loads are 16 B / lane, coalesced"}
         except Exception:
             pass
     return small
@@ -745,9 +801,33 @@ def self_launch(n: int) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for pr in procs:
-        rc = max(rc, abs(pr.wait()))
+    # Watchdog: a rank stuck in communicator set-up (ncclCommInitRank waits for every rank) or behind a rank that died must not hold
+    # the run until somebody else's limit.  On expiry -- or as soon as one rank has failed -- the children are terminated (then
+    # killed) and the parent exits non-zero; nothing is ever re-exec'd from a process that touched the GPU.
+    deadline = time.time() + float(os.environ.get("RQ_BENCH_DEADLINE_S", "1500"))
+    rc, live = 0, list(procs)
+    while live:
+        for pr in list(live):
+            code = pr.poll()
+            if code is not None:
+                live.remove(pr)
+                rc = max(rc, abs(code))
+        if not live:
+            break
+        if rc != 0 or time.time() > deadline:
+            why = "a rank failed" if rc != 0 else "deadline (RQ_BENCH_DEADLINE_S) passed"
+            print(f"[bench] {why}: terminating {len(live)} rank process(es)", file=sys.stderr, flush=True)
+            for pr in live:
+                pr.terminate()
+            t_end = time.time() + 20
+            for pr in live:
+                try:
+                    pr.wait(timeout=max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    pr.kill()
+                    pr.wait()
+            return rc or 124
+        time.sleep(0.2)
     return rc
 
 

@@ -583,6 +583,9 @@ static std::atomic<int> g_scan_impl{0};
 // shown that it flags too much), 1 = the bf16 rank-5 threshold MFMA always, 2 = additive wherever it exists (test hook)
 static std::atomic<int> g_scan_gate{0};
 static std::atomic<int> g_stage_growth{0};  // 0 = default schedule
+static std::atomic<int> g_large_from{256};  // queries from which a batch runs the large-batch form of the stages (full-chip rerank / ordering / replay launches, thin early stages, dense run directories, survivor arena); below: one fused launch per stage
+static bool rq_large_batch(uint32_t nq) { return nq >= (uint32_t)g_large_from.load(); }
+static std::atomic<int> g_cluster_major_div{32};  // a VALU stage goes list-major once its (query, list) pairs reach k / this
 static std::atomic<int> g_stage_settle_pct{100};  // developer knob: where a large batch's early (VALU) stages end and the final (matrix-core) stage begins, in percent of the average list length
 static std::atomic<int> g_scan_tile_table{1};  // 0 = plain (list x tile) grids everywhere (test / measurement hook)
 static std::atomic<int> g_group_rank{1};  // group_rank_kernel for cluster-major stages: 0 never, 1 big stages, 2 always
@@ -832,7 +835,7 @@ static rq_status finish_pass(const rq_index *idx, Workspace &ws, PassResult *res
     res->precise = ws.h_totals[1];
     res->overflowed = ws.h_totals[2];
     res->max_need = ws.h_totals[4];
-    if (nq >= 256) const_cast<rq_index *>(idx)->big_dirs_hint.store((uint32_t)ws.h_totals[7]);
+    if (rq_large_batch(nq)) const_cast<rq_index *>(idx)->big_dirs_hint.store((uint32_t)ws.h_totals[7]);
     // The additive gate is a looser test than the rank-5 threshold it replaces: an index / workload on which it sends more than
     // 3 % of the sub-tile steps down the exact path (each costs ~10 plain steps) goes back to the bf16 threshold MFMA for good
     // (results do not depend on the choice; option scan_gate pins it)
@@ -930,7 +933,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         // nearest list of many queries is one of the long ones, so the bar is the LONGEST list (capped: a single
         // monster list must not push the whole batch through many thin stages)
         uint64_t settle = std::min(settle_cap, std::max<uint64_t>(avg, std::min<uint64_t>(idx->max_list_len, 16 * avg)));
-        if (nq >= 256) settle = std::max<uint64_t>(1, settle * (uint64_t)g_stage_settle_pct.load() / 100);
+        if (rq_large_batch(nq)) settle = std::max<uint64_t>(1, settle * (uint64_t)g_stage_settle_pct.load() / 100);
         while (lo < total_max) {
             // past the first two lists' worth of candidates the threshold is already tight: scan the rest of
             // the stream as ONE stage (every list then meets all its queries at once: full 32-query tiles)
@@ -1104,7 +1107,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                                                              qn, q6, nullptr, k, 1u);
     }
     pair_prefix_kernel<<<ceil_div(nq, 4), 256, 0, st>>>(ws.scal.p, nq, nprobe, ws.rough_cnt.p);
-    if (nq >= 256) {  // large batch: rerank queries of the same nearest list back to back (cache locality of the row gather)
+    if (rq_large_batch(nq)) {  // large batch: rerank queries of the same nearest list back to back (cache locality of the row gather)
         HIPC(hipMemsetAsync(ws.q_hist.p, 0, (size_t)(k + 2) * 4, st));
         order_count_kernel<<<ceil_div(nq, 256), 256, 0, st>>>(probe_cluster, nprobe, nq, k, ws.q_hist.p);
         group_scan_kernel<<<1, 1024, 0, st>>>(ws.q_hist.p, k + 1, ws.q_start.p, 0u, nullptr, 0u);  // also zeroes the histogram: cursor
@@ -1125,11 +1128,11 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     } else {
         // small batches are launch-bound (coarser stages), large ones rerank-bound (tighter thresholds)
         const int gopt = g_stage_growth.load();
-        const uint64_t growth = gopt >= 2 ? (uint64_t)gopt : (nq >= 256 ? 8 : 16);
+        const uint64_t growth = gopt >= 2 ? (uint64_t)gopt : (rq_large_batch(nq) ? 8 : 16);
         // the first stage runs with threshold f32::MAX (everything survives) until the ranker's heap is full; in a large
         // batch it also takes what would be the next stage (whose threshold -- the worst of the first topk -- lets most
         // of it through anyway): one stage of launches less for ~1 % more exact distances
-        stages = build_stages((uint64_t)std::max<uint32_t>(topk, 1) * (nq >= 256 ? growth : 1), growth, ~0ull);
+        stages = build_stages((uint64_t)std::max<uint32_t>(topk, 1) * (rq_large_batch(nq) ? growth : 1), growth, ~0ull);
     }
     }  // !small
     ws.pend_matrix_ranges.clear();
@@ -1150,13 +1153,17 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         // kernel wins, measured at any batch size)
         const bool use_mfma = scan_has_mfma(W) && impl != 1 &&
                               (impl == 2 || (est_pairs >= 8ull * k && (sg.s_lo >= avg_len * (uint64_t)g_stage_settle_pct.load() / 100 || one_stage)));
-        const bool cluster_major = use_mfma || (est_pairs >= k / 2 && est_pairs > 64);
+        // list-major once the stage's pairs reach k / 32 (k / 2 up to round 4, and still on the small-batch path, whose kernels decide with
+        // that rule): a pair-major EARLY stage launches a block for every (query, probe slot, tile) although only the first slots are in
+        // it -- at 512 queries the early stages took 1.06 ms pair-major against 0.3 list-major (batch 256: 1.43 -> 1.12 ms per call,
+        // 512: 2.42 -> 1.62)
+        const bool cluster_major = use_mfma || (est_pairs >= k / (small ? 2u : (uint32_t)g_cluster_major_div.load()) && est_pairs > 64);
         if (g_scan_dbg.load() & 16384)  // developer hook: the pass's stage list
             fprintf(stderr, "[rabitq_hip] stage %u: [%u, %u) span %llu est_pairs %llu %s\n", stage_no, sg.s_lo, sg.s_hi,
                     (unsigned long long)span, (unsigned long long)est_pairs, use_mfma ? "matrix cores" : (cluster_major ? "VALU, list-major" : "VALU, pair-major"));
         const bool fp6_records = use_mfma;
         // (an arena stage, below: a stage that can exceed the uniform survivor capacity; its scan instantiation has its own tile)
-        const bool arena_stage = qp.seg_final && span > qp.cap && scan_is_fused(W) && nq >= 256;
+        const bool arena_stage = qp.seg_final && span > qp.cap && scan_is_fused(W) && rq_large_batch(nq);
         const int gate_opt = g_scan_gate.load();
         const bool additive = use_mfma && !arena_stage && scan_has_additive(W) && idx->list_uref.p != nullptr && gate_opt != 1 &&
                               (gate_opt == 2 || !idx->additive_loose.load());
@@ -1242,7 +1249,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         // large batches, VALU-kernel stages: the run descriptors go into a dense directory indexed by stream position
         // (stage_fill_kernel: RQ_REC_CELL0), so the stage needs no sort of its run directory
         uint32_t dense_cells = 0;
-        if (nq >= 256 && !use_mfma && scan_is_fused(W) && g_dense_dir.load() && sg.s_hi != 0xFFFFFFFFu &&
+        if (rq_large_batch(nq) && !use_mfma && scan_is_fused(W) && g_dense_dir.load() && sg.s_hi != 0xFFFFFFFFu &&
             !(qp.seg_final && span > qp.cap)) {  // (an arena stage appends its runs: they are placed by the scatter pass)
             const uint64_t cells = (uint64_t)((sg.s_hi - 1) >> 6) - (sg.s_lo >> 6) + 2ull * slot_hi + 2;
             if (cells <= qp.cap) dense_cells = (uint32_t)cells;
@@ -1362,7 +1369,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         // small batch: one fused launch per stage (launch-bound regime) -- unless the survivor buffers are large (queries
         // re-run after an overflow: tens of thousands of survivors each): one block per query would rerank and order
         // those alone, the large-batch kernels spread them over the chip
-        if (nq < 256 && qp.cap <= 4 * RQ_DEFAULT_CAP) {
+        if (!rq_large_batch(nq) && qp.cap <= 4 * RQ_DEFAULT_CAP) {
             pf.begin(PF_RERANK);
             const uint32_t fin_threads = nq <= 16 ? 1024u : 256u;  // a handful of queries: more lanes on each one's rerank
             // survivor buffers beyond the default mean this index / these queries leave long run directories (overflow
@@ -1464,7 +1471,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         stat_fold_kernel<<<1, 64, 0, st>>>(ws.stat.p, ws.stat.p + 200);
         HIPC(hipMemcpyAsync(ws.h_totals + 8, ws.stat.p + 200, 16, hipMemcpyDeviceToHost, st));
     }
-    if (nq >= 256)  // (the long-directory hint only sizes launches of large batches: a small batch saves the copy's round trip)
+    if (rq_large_batch(nq))  // (the long-directory hint only sizes launches of large batches: a small batch saves the copy's round trip)
         HIPC(hipMemcpyAsync(ws.h_totals + 7, ws.big_list.p + nq + 2, 4, hipMemcpyDeviceToHost, st));
     ws.pend_total_span = total_span;
     ws.pend_nq = nq;
@@ -1511,7 +1518,7 @@ static rq_status validate_query(const rq_index *idx, const float *d_q, uint32_t 
 static uint32_t pass_capacity(const rq_index *idx, uint32_t remaining, bool seeded, bool *seg) {
     const uint32_t hint = idx->cap_hint.load();
     const int opt = g_seg_opt.load();
-    *seg = !seeded && remaining >= 256 && scan_is_fused(idx->W) && (opt >= 2 || (opt == 1 && hint > RQ_DEFAULT_CAP));
+    *seg = !seeded && rq_large_batch(remaining) && scan_is_fused(idx->W) && (opt >= 2 || (opt == 1 && hint > RQ_DEFAULT_CAP));
     if (*seg) return RQ_DEFAULT_CAP;  // stages that cannot exceed it stay uniform, the others are segmented
     return std::max(RQ_DEFAULT_CAP, hint);
 }
@@ -1670,7 +1677,7 @@ static rq_status query_device(rq_index *idx, const float *d_q, uint32_t nq, uint
         const uint32_t cap0 = pass_capacity(idx, nq - q0, ext_thr != nullptr, &seg);
         step_nq = pass_queries(idx, nq - q0, probe, cap0, seg, ext_cluster != nullptr);
         QueryParams qp{step_nq, len, probe, topk, heuristic, cap0, std::max(cap0, std::max(RQ_DEFAULT_CAP, idx->cap_hint.load()))};
-        qp.seg_final = seg && step_nq >= 256;
+        qp.seg_final = seg && rq_large_batch(step_nq);
         qp.thr_init = ext_thr ? ext_thr + q0 : nullptr;
         qp.ext_lists = ext_cluster != nullptr;
         RQC(ws_prepare(idx, *ws, qp));
@@ -1739,7 +1746,7 @@ static rq_status query_device_begin(rq_index *idx, const float *d_q, uint32_t nq
         return RQ_OK;
     }
     t->qp = QueryParams{nq, len, probe, topk, heuristic, cap0, std::max(cap0, std::max(RQ_DEFAULT_CAP, idx->cap_hint.load()))};
-    t->qp.seg_final = seg && nq >= 256;
+    t->qp.seg_final = seg && rq_large_batch(nq);
     t->d_q = d_q, t->d_out_dist = d_out_dist, t->d_out_id = d_out_id, t->d_out_n = d_out_n;
     t->ws = ws_acquire(idx);
     rq_status st = ws_prepare(idx, *t->ws, t->qp);
@@ -1853,14 +1860,15 @@ static rq_status derive_shadow_rows(rq_index *idx) {
     idx->base_h.release();
     idx->base_q8.release();
     idx->list_q8.release();
-    const int kind = g_rerank_shadow.load();
+    int kind = g_rerank_shadow.load();
+    if (kind == 2 && idx->dim > 4096) kind = 1;  // (the 8-bit encoder handles rows of up to 4096 dimensions: wider vectors take the fp16 rows)
     if (!kind || idx->base_host != nullptr || idx->n < RQ_SHADOW_MIN_ROWS) return RQ_OK;
     const uint64_t total = idx->n * idx->dim, bytes = total * (kind == 2 ? 1 : 2);
     size_t free_b = 0, total_b = 0;
     HIPC(hipMemGetInfo(&free_b, &total_b));
     if (free_b < bytes + (48ull << 30) && bytes > (1ull << 30)) return RQ_OK;  // keep the survivor buffers their share
     if (kind == 2) {  // one byte per dimension, per-list affine map, measured error bound (kernels_query.h)
-        if (idx->dim > 4096 || idx->base_q8.alloc(total) != RQ_OK || idx->list_q8.alloc(std::max<uint32_t>(idx->k, 1)) != RQ_OK) {
+        if (idx->base_q8.alloc(total) != RQ_OK || idx->list_q8.alloc(std::max<uint32_t>(idx->k, 1)) != RQ_OK) {
             (void)hipGetLastError();
             idx->base_q8.release();
             idx->list_q8.release();
@@ -3525,6 +3533,16 @@ rq_status rq_set_option(const char *name, int value) {
     if (std::string(name) == "scan_impl") {
         if (value < 0 || value > 2) return fail(RQ_ERR_INVALID, "scan_impl must be 0 (auto), 1 (valu) or 2 (mfma)");
         g_scan_impl = value;
+        return RQ_OK;
+    }
+    if (std::string(name) == "cluster_major_div") {  // developer knob (results identical for every value)
+        if (value < 1 || value > 4096) return fail(RQ_ERR_INVALID, "cluster_major_div must be in [1, 4096]");
+        g_cluster_major_div = value;
+        return RQ_OK;
+    }
+    if (std::string(name) == "large_batch_from") {  // developer knob (results identical for every value): queries from which a batch takes the large-batch form of the stages
+        if (value < 2 || value > (1 << 20)) return fail(RQ_ERR_INVALID, "large_batch_from must be in [2, 2^20]");
+        g_large_from = value;
         return RQ_OK;
     }
     if (std::string(name) == "stage_settle_pct") {  // developer knob (results identical for every value): end of the early stages of a large batch, percent of the average list length

@@ -29,6 +29,27 @@ def _use_engine(t: torch.Tensor, world: int, width: int) -> bool:
     return t.is_cuda and world * width <= 16384 and torch.cuda.current_stream(t.device).cuda_stream == 0
 
 
+def partition_lists(offsets, world: int):
+    """The partitioning rule of rq_partition_lists restated on the host (numpy only): whole lists to shards, greedy by list
+    length -- longest first (ties: lower list id first), each to the least-loaded shard (ties: lower shard first).  Deterministic,
+    so every rank computes the same owner table on its own.  -> (owner u32[k], load u64[world])"""
+    import heapq
+    import numpy as np
+    off = np.asarray(offsets, dtype=np.int64)
+    lens = np.diff(off)
+    k = lens.size
+    owner = np.zeros(k, dtype=np.uint32)
+    heap = [(0, r) for r in range(world)]
+    for c in sorted(range(k), key=lambda c: (-int(lens[c]), c)):
+        load, r = heapq.heappop(heap)
+        owner[c] = r
+        heapq.heappush(heap, (load + int(lens[c]), r))
+    load = np.zeros(world, dtype=np.uint64)
+    for c in range(k):
+        load[owner[c]] += np.uint64(lens[c])
+    return owner, load
+
+
 def pack_topk(dist_t: torch.Tensor, ids_t: torch.Tensor, counts: torch.Tensor, id_offset: int) -> torch.Tensor:
     """(nq, topk) f32 distances + u32/i64 local ids + valid counts -> (nq, topk, 2) i64 payload of
     (monotone distance key, global id); invalid entries get the maximum key."""

@@ -3,6 +3,7 @@
 # per workload one plain run (HIP-event timings), one --kernel-trace --stats pass and one --pmc FETCH_SIZE pass
 # (counters in their own pass, with --kernel-trace only).  Summaries: scripts/pmc_hbm_summary.py -> profiles/.
 set -e
+R=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 run() {  # tag, args...
@@ -22,5 +23,5 @@ run d128 --vectors 100000000 --dim 128 --batches 64,16,1 --reps 20
 run d768 --vectors 30000000 --dim 768 --batches 64,16,1 --reps 10
 # the big per-dispatch traces are not needed back home: keep the csv files only
 find gpurun_out -name '*.db' -delete 2>/dev/null || true
-RQ_PROFILE_OUT=$PWD/gpurun_out/profiles python3 scripts/pmc_hbm_summary.py r03 > gpurun_out/hbm_summary.log 2>&1 || true
+RQ_PROFILE_OUT=$PWD/gpurun_out/profiles python3 scripts/pmc_hbm_summary.py $R > gpurun_out/hbm_summary.log 2>&1 || true
 tail -c 3000 gpurun_out/hbm_summary.log

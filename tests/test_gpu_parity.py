@@ -352,9 +352,11 @@ def test_prefiltered_coarse_ranking_equals_exact_order_kernels(rq, d, k, nq, pro
             pdd = torch.zeros((nq, probe), device=dev, dtype=torch.float32)
             idx.coarse_topk_device(q.data_ptr(), nq, d, 0, k, probe, pc.data_ptr(), pdd.data_ptr())
             got_cl, got_cd = pc.cpu().numpy().view(np.uint32), pdd.cpu().numpy()
-            rows = np.arange(nq) if kind != "nan" else np.delete(np.arange(nq), 5)     # (NaN inputs are not matched: INTEGRATION.md)
-            assert np.array_equal(got_cl[rows], want_cl[rows]), (impl, np.argwhere(got_cl[rows] != want_cl[rows])[:5])
-            assert np.array_equal(got_cd[rows].view(np.uint32), want_cd[rows].view(np.uint32)), impl
+            # (the NaN row included: its margin is not finite, so the pre-filter hands the row to the exact-order kernels + the
+            # block-per-query selection -- the very kernels `want` came from; the REFERENCE's behaviour on NaN input is not matched,
+            # INTEGRATION.md, only the engine's own paths agree with each other)
+            assert np.array_equal(got_cl, want_cl), (impl, np.argwhere(got_cl != want_cl)[:5])
+            assert np.array_equal(got_cd.view(np.uint32), want_cd.view(np.uint32)), impl
     finally:
         ix.set_option("coarse_impl", 0)
     idx.close()
@@ -919,7 +921,12 @@ def test_shard_pass_lists_its_nonempty_pairs(rq, oracle):
     n, d, k = 60000, 128, 64
     x, centres, _ = synth.mixture(n, d, k, sigma=0.8, seed=61, centre_scale=0.6)
     gidx = rq.RaBitQ.build(x, centres, synth.random_orthogonal(d, seed=62))
-    owner, _ = gidx.partition_lists(4)
+    owner, load = gidx.partition_lists(4)
+    from rabitq_amd import sharding
+    for w in (2, 4, 8):   # the host restatement of the rule (what the two-rank gloo test partitions with) == rq_partition_lists
+        o_c, l_c = gidx.partition_lists(w)
+        o_n, l_n = sharding.partition_lists(gidx.offsets, w)
+        assert np.array_equal(o_c, o_n) and np.array_equal(l_c, l_n), w
     shard = gidx.shard(owner, 1)
     assert int((np.diff(shard.offsets.astype(np.int64)) > 0).sum()) * 2 < k
     queries, _, _ = synth.mixture(2100, d, k, sigma=0.8, seed=63, centre_scale=0.6)
