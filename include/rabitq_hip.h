@@ -187,7 +187,12 @@ rq_status rq_query_batch_device(const rq_index *idx, const float *d_queries, uin
  * waits for it, performs the (rare) survivor-buffer re-runs and the counter updates, reports the
  * call's status and frees the ticket.  Queries and outputs must stay valid and untouched in between.
  * Batches begun back to back overlap on the device: one batch's HBM-bound stages (exact rerank) run
- * beside another's compute-bound scan.  Every begun ticket must be ended exactly once. */
+ * beside another's compute-bound scan.  Every begun ticket must be ended exactly once.
+ * Exceptions to "returns at once": (i) a batch that needs several passes (more queries than one pass holds) runs all but its last
+ * pass inside _begin; (ii) on a shard-like index -- fewer than half of its lists have members, i.e. a shard carved by
+ * rq_shard_index -- a pass of >= 65 536 (query, list) pairs sizes its launches by the number of pairs whose list lives here, which
+ * it reads back once: _begin then returns after rotate, coarse ranking and that split have run (tens of microseconds of device
+ * work), so two such batches overlap from the query quantisation on. */
 typedef struct rq_ticket rq_ticket;
 rq_status rq_query_batch_device_begin(const rq_index *idx, const float *d_queries, uint32_t nq,
                                       uint32_t len, uint32_t probe, uint32_t topk, int heuristic_rank,

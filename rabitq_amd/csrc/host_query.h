@@ -334,8 +334,14 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                                                                        ws.live_list.p, ws.live_list.p + npairs);
             // the launches over the listed pairs are sized by their number: one small copy and a wait (tens of microseconds against
             // the milliseconds that 7 of 8 idle lane groups cost)
-            HIPC(hipMemcpyAsync(&nlive, ws.live_list.p + npairs, 4, hipMemcpyDeviceToHost, st));
+            // (into the workspace's pinned block, not a pageable stack word; the wait is the price of sizing the launches below by the
+            // count -- rq_query_batch_device_begin on a shard-like index therefore returns only once rotate, coarse ranking and this
+            // split have run: include/rabitq_hip.h says so)
+            unsigned long long *h_live = ws.h_totals + 15;
+            *h_live = 0;
+            HIPC(hipMemcpyAsync(h_live, ws.live_list.p + npairs, 4, hipMemcpyDeviceToHost, st));
             HIPC(hipStreamSynchronize(st));
+            nlive = (uint32_t)*h_live;
         }
 #define RQ_PREP_SMALL(LP, R, PPB, PP)                                                                              \
     do {                                                                                                           \

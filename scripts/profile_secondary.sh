@@ -25,3 +25,4 @@ with open("gpurun_out/profiles/${R:-r04}_kernel_stats_$tag.csv", "w") as o:
 print("$tag:", len(rows), "kernels")
 PY
 done
+rm -rf gpurun_out/ksec_hard gpurun_out/ksec_768

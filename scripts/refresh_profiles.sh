@@ -28,4 +28,6 @@ done
 timeout -k 10 900 python3 bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.log
 RQ_PROFILE_OUT=$PWD/gpurun_out/profiles python3 scripts/make_profiles.py $R > gpurun_out/make_profiles.log 2>&1 || tail -5 gpurun_out/make_profiles.log
 find gpurun_out/kstats gpurun_out/pmc_fetch gpurun_out/pmc_fetch_hard gpurun_out/pmc_fetch_768 -name "*.db" -delete 2>/dev/null || true
+# only the summaries travel home (gpurun copies back at most 64 MiB): the raw per-dispatch tables stay on the box
+rm -rf gpurun_out/kstats gpurun_out/pmc_fetch gpurun_out/pmc_fetch_hard gpurun_out/pmc_fetch_768
 tail -c 600 gpurun_out/bench_final.json
