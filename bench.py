@@ -636,8 +636,10 @@ def run_workload(args, ctx, extras=True):
 
     # ---- between the small-batch regimes and the headline batch: what a service's request sizes would see -------------------
     sweep = None
+    default_sweep_beyond = (n, d, args.distribution) == (100_000_000, 128, "easy") and B == 65536   # (also two sizes beyond the headline batch)
     if rank == 0 and extras and not sharded:
-        sweep = batch_sweep(idx, centres, qweights, args.sigma, dev, d, nprobe, topk, [b for b in (128, 512, 2048, 8192, 16384) if b < B])
+        sweep = batch_sweep(idx, centres, qweights, args.sigma, dev, d, nprobe, topk,
+                            [b for b in (128, 512, 2048, 8192, 16384) if b < B] + ([2 * B, 4 * B] if default_sweep_beyond else []))
 
     size_txt = f"{n // 1_000_000}Mx{d}" if n % 1_000_000 == 0 else f"{n}x{d}"
     line = {"metric": f"queries/sec at recall@10>=0.95, {size_txt}; HBM GB/s on popcount scan", "value": round(qps, 1),
