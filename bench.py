@@ -86,6 +86,10 @@ def main():
                     help="after the timed region (whose steps run one batch at a time, so that every launch runs alone and "
                          "per-kernel times from HIP events and rocprofv3 --stats stay comparable), also measure the throughput "
                          "with two batches in flight (rq_query_batch_device_begin/_end) and report it as an extra field")
+    ap.add_argument("--batch-sweep", action=argparse.BooleanOptionalAction, default=True,
+                    help="headline run: also time batches of 128 ... 16384 (and 2x / 4x the headline batch) on the same index, fresh "
+                         "queries per call (`batch_sweep`); the profiling passes switch it off so that every launch of the dominant "
+                         "kernel in their tables is a full-batch launch")
     ap.add_argument("--emulate-world", type=int, default=1,
                     help="one-GPU rehearsal of ONE rank of a W-GPU run: W x --lists centroids of which this process owns the first "
                          "--lists (its vectors come from them), queries drawn over all of them, the C-ABI multi-GPU step with a "
@@ -637,7 +641,7 @@ def run_workload(args, ctx, extras=True):
     # ---- between the small-batch regimes and the headline batch: what a service's request sizes would see -------------------
     sweep = None
     default_sweep_beyond = (n, d, args.distribution) == (100_000_000, 128, "easy") and B == 65536   # (also two sizes beyond the headline batch)
-    if rank == 0 and extras and not sharded:
+    if rank == 0 and extras and not sharded and args.batch_sweep:
         sweep = batch_sweep(idx, centres, qweights, args.sigma, dev, d, nprobe, topk,
                             [b for b in (128, 512, 2048, 8192, 16384) if b < B] + ([2 * B, 4 * B] if default_sweep_beyond else []))
 

@@ -406,8 +406,11 @@ rq_status rq_set_profiling(int level);
  * where it exists (dim 64 / 128, stages on the uniform survivor buffers: no threshold MFMA) until an index shows that it sends
  * more than 3 % of the sub-tile steps down the exact path, 1 = the bf16 rank-5 threshold MFMA always, 2 = the additive bound
  * wherever it exists (test hook).
- * Developer knobs: "stage_growth" (geometric growth of the early stages, 0 = default; results are identical for every
- * value), "scan_debug": measurement hooks under which every result is UNCHANGED -- 128 (kept for older hosts: the sub-tile /
+ * Developer knobs (results are identical for every value): "stage_growth" (geometric growth of the early stages, 0 = default),
+ * "large_batch_from" (queries from which a batch takes the large-batch form of the stages -- full-chip rerank / ordering / replay
+ * launches, thin early stages, dense run directories, survivor arena; default 256), "cluster_major_div" (a VALU stage goes
+ * list-major once its (query, list) pairs reach k / this; default 32), "stage_settle_pct" (where a large batch's early stages end,
+ * in percent of the average list length; default 100), "scan_debug": measurement hooks under which every result is UNCHANGED -- 128 (kept for older hosts: the sub-tile /
  * exact-path step counters of rq_profile_t are always on since ABI revision 4), 512 no shadow rows in the rerank,
  * 4096 the phases of the small-batch kernel, 16384 the stage list of every pass (stderr).  Any other bit is refused with
  * RQ_ERR_INVALID by this library: the TIMING ABLATIONS of the matrix-core scan (1, 2, 4, 64, 1024, 8192: results are WRONG) and

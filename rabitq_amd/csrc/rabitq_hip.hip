@@ -39,7 +39,7 @@
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-const char *rq_version(void) { return "rabitq_hip 0.4.0 (gfx950, abi 4)"; }
+const char *rq_version(void) { return "rabitq_hip 0.5.0 (gfx950, abi 4)"; }
 uint32_t rq_abi_version(void) { return RQ_ABI_VERSION; }
 const char *rq_last_error(void) { return g_err.c_str(); }
 

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 K=$PWD/gpurun_out/kstats; rm -rf $K
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $K -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-two-in-flight --no-secondary --small-batch 0 --gt-queries 100 "$@" \
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $K -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-two-in-flight --no-secondary --no-batch-sweep --small-batch 0 --gt-queries 100 "$@" \
     > gpurun_out/bench_prof.json 2> gpurun_out/bench_prof.log
 find gpurun_out/kstats -name "*.db" -delete 2>/dev/null
 python3 - <<'PY'

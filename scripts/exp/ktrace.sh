@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 K=$PWD/gpurun_out/ktrace; rm -rf $K
-timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d $K -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-two-in-flight --no-secondary --small-batch 0 --gt-queries 100 "$@" \
+timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d $K -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-two-in-flight --no-secondary --no-batch-sweep --small-batch 0 --gt-queries 100 "$@" \
     > gpurun_out/bench_ktrace.json 2> gpurun_out/bench_ktrace.log
 find $K -name "*.db" -delete 2>/dev/null
 python3 - <<'PY'

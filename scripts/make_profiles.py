@@ -28,10 +28,10 @@ shutil.copy(stats, os.path.join(OUT, f"{ROUND}_kernel_stats_full.csv"))
 ours = [r for r in rows if not any(t in r["Name"] for t in ("at::native", "Cijk_", "__amd_rocclr", "at::cuda", "rocprim", "hipcub"))]
 with open(os.path.join(OUT, f"{ROUND}_kernel_stats.csv"), "w") as f:
     bcfg = json.load(open(newest("bench_final.json")))["config"]
-    f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-two-in-flight\n")
-    f.write(f"# ({bcfg['workload']}: 2 warm-up + 3 timed + 1 breakdown query batches, every launch alone on the device,\n")
-    f.write("#  small batches, 68 single queries, one streamed 100M build); engine kernels only, torch data-generation / ground-truth\n")
-    f.write("#  kernels are in the _full file\n")
+    f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-two-in-flight --no-secondary --no-batch-sweep --small-batch 0\n")
+    f.write(f"# ({bcfg['workload']}: 2 warm-up + 3 timed + 1 breakdown query batches -- every scan_mfma_kernel launch in this table is a\n")
+    f.write("#  full-batch launch, every launch alone on the device --, 68 single queries, one streamed 100M build); engine kernels only,\n")
+    f.write("#  torch data-generation / ground-truth kernels are in the _full file\n")
     w = csv.writer(f)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs"])
     for r in ours:
