@@ -25,3 +25,4 @@ run d768 --vectors 30000000 --dim 768 --batches 64,16,1 --reps 10
 find gpurun_out -name '*.db' -delete 2>/dev/null || true
 RQ_PROFILE_OUT=$PWD/gpurun_out/profiles python3 scripts/pmc_hbm_summary.py $R > gpurun_out/hbm_summary.log 2>&1 || true
 tail -c 3000 gpurun_out/hbm_summary.log
+rm -rf gpurun_out/hbm_d128_kt gpurun_out/hbm_d128_pmc gpurun_out/hbm_d768_kt gpurun_out/hbm_d768_pmc   # (only the summaries travel home)
