@@ -216,16 +216,28 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS) {
         // compiler every iteration was load -> wait -> compute (two dependent round trips: first the stage range, then
         // the operands), and the stage ran at 58 % VALU occupancy with 5-7 waves per SIMD.
         typedef uint32_t qv_t __attribute__((ext_vector_type(8 * W)));
-        typedef uint32_t tv_t __attribute__((ext_vector_type(16)));  // 12 of the RQ_REC_TAIL = 20 tail dwords are used here
+        typedef uint32_t t8_t __attribute__((ext_vector_type(8)));
+        typedef uint32_t t4_t __attribute__((ext_vector_type(4)));
+        // the 13 tail dwords this kernel reads (RQ_REC_LOWER .. RQ_REC_CELL0) as 8 + 4 + 1 scalar registers instead of a 16-dword
+        // tuple: two records in flight then fit 96 scalar registers -- the eighth wave per SIMD (102 were seven)
+        struct Tail {
+            t8_t a;
+            t4_t b;
+            uint32_t c;
+            __device__ __forceinline__ uint32_t operator[](int i) const { return i < 8 ? a[i] : (i < 12 ? b[i - 8] : c); }
+        };
+        static_assert(RQ_REC_CELL0 == 12 && RQ_REC_SLOT < 12, "tail fields read through the 8 + 4 + 1 split");
         qv_t qa, qb;
-        tv_t ta, tb;
+        Tail ta, tb;
 #define RQ_SLOAD(Q, T, PTR)                                                                                   \
     do {                                                                                                      \
         if constexpr (W == 1) asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(Q) : "s"(PTR));               \
         else asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(Q) : "s"(PTR));                                \
-        asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(T) : "s"(PTR), "i"(8 * W * 4));                      \
+        asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(T.a) : "s"(PTR), "i"(8 * W * 4));                     \
+        asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(T.b) : "s"(PTR), "i"(8 * W * 4 + 32));                \
+        asm volatile("s_load_dword %0, %1, %2" : "=s"(T.c) : "s"(PTR), "i"(8 * W * 4 + 48));                  \
     } while (0)
-#define RQ_SWAIT(Q, T) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(Q), "+s"(T))
+#define RQ_SWAIT(Q, T) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(Q), "+s"(T.a), "+s"(T.b), "+s"(T.c))
         RQ_SLOAD(qa, ta, rec);
         uint32_t i = pb;
         while (true) {
