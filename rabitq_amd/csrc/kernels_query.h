@@ -1353,6 +1353,7 @@ __device__ __forceinline__ uint32_t bf16_rne(float x) {
 __device__ __forceinline__ float bf16_to_f32(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
 
 // work item wi = (query, slot < slot_hi), handled by the 16 lanes threadIdx.x & ~15 .. | 15; thr_b: the query's threshold
+template <int LPP = 16 /* lanes per work item: 16, or 8 for the additive tile images (16-byte aligned operand rows) */>
 __device__ __forceinline__ void stage_fill_item(const PairScalars *__restrict__ scal,
                                                 const uint32_t *__restrict__ probe_cluster,
                                                 const uint32_t *__restrict__ operand /* opdw dwords per pair */,
@@ -1367,7 +1368,7 @@ __device__ __forceinline__ void stage_fill_item(const PairScalars *__restrict__ 
                                                 const uint32_t *__restrict__ rank /* group_rank_kernel, or null */,
                                                 const uint32_t *__restrict__ blk_base, uint32_t k,
                                                 const float4 *__restrict__ list_uref /* tile_images == 2: U0 per list */) {
-    const uint32_t sub = threadIdx.x & 15;                       // 16 lanes per pair
+    const uint32_t sub = threadIdx.x & (LPP - 1);                // LPP lanes per pair
     // (ranked placement: the counting pass has already decided which items are in the stage -- 7 of 8 are not when the pairs of
     // seven other shards' lists ride along in a multi-GPU pass; they leave before their 40-byte scalars are fetched)
     if (cluster_major && rank && rank[wi] == ~0u) return;
@@ -1385,7 +1386,7 @@ __device__ __forceinline__ void stage_fill_item(const PairScalars *__restrict__ 
         } else {
             uint32_t a = 0;
             if (sub == 0) a = atomicAdd(&grp_cursor[c], 1u);
-            at = grp_start[c] + __shfl(a, 0, 16);
+            at = grp_start[c] + __shfl(a, 0, LPP);
         }
     }
     // record-major: record `at` = opdw operand dwords + RQ_REC_TAIL tail dwords.  tile images (matrix-core
@@ -1403,7 +1404,11 @@ __device__ __forceinline__ void stage_fill_item(const PairScalars *__restrict__ 
         tdst = base + 32 * opld + (at & 31u) * taild;
         if (tile_images == 2) cdst = reinterpret_cast<float *>(base + 32 * opld + 32 * taild + (at & 31u));
     }
-    {  // operand rows are 8-byte aligned in both layouts (opdw, the record stride and the image row stride are even)
+    if constexpr (LPP == 8) {  // record-major records (stride opdw + 20 dwords) and additive tile images (rows of opdw + 4 dwords): 16-byte aligned like the operand itself (opdw = 8 W or 12 W)
+        const uint4 *src = reinterpret_cast<const uint4 *>(operand + (uint64_t)p * opdw);
+        uint4 *dst = reinterpret_cast<uint4 *>(r);
+        for (uint32_t i = sub; i < opdw / 4; i += 8) dst[i] = src[i];
+    } else {  // operand rows are 8-byte aligned in both layouts (opdw, the record stride and the image row stride are even)
         const uint2 *src = reinterpret_cast<const uint2 *>(operand + (uint64_t)p * opdw);
         uint2 *dst = reinterpret_cast<uint2 *>(r);
         for (uint32_t i = sub; i < opdw / 2; i += 16) dst[i] = src[i];
@@ -1508,6 +1513,7 @@ __device__ __forceinline__ void stage_fill_item(const PairScalars *__restrict__ 
         if (sub < 5) *reinterpret_cast<uint4 *>(tdst + 4 * sub) = piece;
     }
 }
+template <int LPP = 16>
 __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__restrict__ scal,
                                                          const uint32_t *__restrict__ probe_cluster,
                                                          const uint32_t *__restrict__ operand /* opdw dwords per pair */,
@@ -1523,10 +1529,10 @@ __global__ __launch_bounds__(256) void stage_fill_kernel(const PairScalars *__re
                                                          const uint32_t *__restrict__ blk_base, uint32_t k,
                                                          const float4 *__restrict__ list_uref,
                                                          const uint32_t *__restrict__ items = nullptr /* the work items to visit (count of them), else all */) {
-    uint32_t wi = blockIdx.x * 16 + (threadIdx.x >> 4);  // work item: (query, slot < slot_hi)
+    uint32_t wi = blockIdx.x * (256 / LPP) + threadIdx.x / LPP;  // work item: (query, slot < slot_hi)
     if (wi >= count) return;
     if (items) wi = items[wi];
-    stage_fill_item(scal, probe_cluster, operand, thr, wi, nprobe, slot_hi, opdw, s_lo, s_hi, cluster_major, grp_start, grp_cursor,
+    stage_fill_item<LPP>(scal, probe_cluster, operand, thr, wi, nprobe, slot_hi, opdw, s_lo, s_hi, cluster_major, grp_start, grp_cursor,
                     recs, fs, tile_images, rank, blk_base, k, list_uref);
 }
 
