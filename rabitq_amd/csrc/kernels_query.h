@@ -1010,7 +1010,7 @@ __device__ __forceinline__ void prep_small_pairs(const float *__restrict__ y, co
     // dimensions (R > 1 only with LP = 64: dim 512, 768, 1024).  Every lane group handles PP pairs: the kernel is a
     // chain of dependent gathers (probe list -> centroid row, list bounds), so the loads of all PP pairs are issued
     // before any of them is consumed.
-    static_assert(R == 1 || LP == 64, "several rounds only with a full wave per pair");
+    static_assert(R >= 1 && (LP == 16 || LP == 32 || LP == 64), "lane groups of 16 / 32 / 64; a round = 4 LP dimensions (the packing's neighbour exchanges stay inside a round)");
     constexpr uint32_t DIM = 4 * LP * R, W = DIM / 64, PPW = 64 / LP;
     const uint32_t lane = threadIdx.x & 63, sub = lane % LP;
     uint32_t cl[PP], lb[PP], ll[PP];
