@@ -160,8 +160,8 @@ enum { RQ_ARR_BASE = 0, RQ_ARR_ORTHOGONAL, RQ_ARR_CENTROIDS, RQ_ARR_OFFSETS, RQ_
 rq_status rq_get_array(const rq_index *idx, int which, void *dst, uint64_t dst_bytes);
 /* Device pointer of one array (valid until rq_free); for zero-copy hand-over to a caller that
  * already lives on the GPU.  RQ_ARR_BASE: every row at its position -- only when n_hbm == n; on a tiered index (list
- * tails in pinned host memory) there is no single device array and the call returns RQ_ERR_UNSUPPORTED (use
- * rq_get_array for a host copy of the whole array). */
+ * tails in pinned host memory) or one that stores its raw vectors as split rows (option "split_rows") there is no single f32
+ * device array and the call returns RQ_ERR_UNSUPPORTED (use rq_get_array for a host copy of the whole array). */
 rq_status rq_get_device_ptr(const rq_index *idx, int which, const void **out_ptr, uint64_t *out_bytes);
 
 /* ---- query: RaBitQ::query, src/rabitq.rs:268-333 --------------------------------------------- */
@@ -359,6 +359,13 @@ rq_status rq_set_profiling(int level);
  * settings return identical results; the option exists for tests and measurements.
  * "base_device_mb": HBM budget (MiB) of the raw vectors of indexes built / loaded from now on (-1 = automatic, the
  * default); vectors beyond it live in pinned host memory.  Results never depend on it.
+ * "split_rows": indexes built / loaded from now on whose raw vectors leave no room for shadow rows -- tiered ones (both tiers),
+ * and untiered ones where the shadow of "rerank_shadow" would not fit -- keep each raw vector as two 16-bit planes inside its own
+ * 4*dim bytes (1, default: the upper halves of the f32 words rounded to nearest, then the lower halves; every word is restored
+ * exactly), or as plain f32 (0); 2 = split rows always (test hook).  The re-ranker of large batches reads the first plane alone
+ * and fetches the second one only for survivors the first cannot prove out of the top-k.  Such an index has no f32 device array
+ * of its raw vectors (rq_get_device_ptr(RQ_ARR_BASE) -> RQ_ERR_UNSUPPORTED; rq_get_array restores them).  Results are
+ * bit-identical for every value.
  * "rerank_shadow": shadow rows of indexes built / loaded from now on whose raw vectors are all in HBM (when that still leaves
  * the query workspaces their room): 2 (default) = 8-bit rows (dim bytes per vector; one affine map per list, error bound
  * measured while the codes are written), 1 = fp16 rows (2*dim bytes per vector), 0 = none.  The re-ranker of large batches

@@ -125,19 +125,56 @@ struct ListTier {  // one per list
     uint32_t hbm_base;   // HBM rows of the lists before this one
     uint32_t host_base;  // host rows of the lists before this one
 };
+// Split rows (round 5): where no shadow rows fit beside the raw vectors (tiered indexes, and untiered ones that fill most of the
+// HBM) every raw vector is stored as TWO 16-bit planes inside the row's own 4*dim bytes --
+// first the dim upper halves of the f32 words rounded to nearest (h = (bits + 0x8000) >> 16: a bf16 image of the row with relative
+// error <= 2^-8 per element), then the dim lower halves unchanged -- so that bits = (h << 16) + sext16(lo) restores every word
+// exactly.  The re-ranker reads the first plane alone (half the bytes), proves most survivors out of the top-k with it
+// (accurate_split_kernel, kernels_query.h) and fetches the second plane only for the rest.  Both tiers use the layout: over the
+// host link the first plane alone is half the bytes as well.
+struct RowRef {
+    const float *p;  // the row's 4*dim bytes
+    bool split;      // stored as two 16-bit planes
+};
+__host__ __device__ __forceinline__ uint32_t rq_split_join(uint32_t h16, uint32_t lo16) {
+    return (h16 << 16) + (uint32_t)(int32_t)(int16_t)lo16;
+}
+// element e of a row / its store (cold paths: placement, dumps, shards, rq_rerank)
+__host__ __device__ __forceinline__ float rq_row_get(const RowRef r, uint32_t dim, uint32_t e) {
+    if (!r.split) return r.p[e];
+    const uint16_t *h = reinterpret_cast<const uint16_t *>(r.p);
+    return __builtin_bit_cast(float, rq_split_join(h[e], h[dim + e]));
+}
+__host__ __device__ __forceinline__ void rq_row_put(const RowRef r, uint32_t dim, uint32_t e, float v) {
+    float *w = const_cast<float *>(r.p);
+    if (!r.split) {
+        w[e] = v;
+        return;
+    }
+    const uint32_t bits = __builtin_bit_cast(uint32_t, v);
+    uint16_t *h = reinterpret_cast<uint16_t *>(w);
+    h[e] = (uint16_t)((bits + 0x8000u) >> 16), h[dim + e] = (uint16_t)bits;
+}
 struct BaseView {
     const float *dev;    // HBM tier
     const float *host;   // device-visible address of the pinned host tier; nullptr = every row is in HBM, at its position
     const ListTier *lt;  // k entries (tiered indexes only)
     uint32_t k;
+    uint32_t split;      // the rows (of both tiers) are split rows
     // row of position p that belongs to list c
-    __host__ __device__ __forceinline__ const float *row_in_list(uint64_t p, const ListTier &t, uint32_t dim) const {
+    __host__ __device__ __forceinline__ RowRef row_in_list(uint64_t p, const ListTier &t, uint32_t dim) const {
         const uint64_t local = p - t.off;
-        return local < t.h ? dev + ((uint64_t)t.hbm_base + local) * dim : host + ((uint64_t)t.host_base + (local - t.h)) * dim;
+        if (local < t.h) return RowRef{dev + ((uint64_t)t.hbm_base + local) * dim, split != 0};
+        return RowRef{host + ((uint64_t)t.host_base + (local - t.h)) * dim, split != 0};
+    }
+    // row of position p whose list is probe_row[slot] (the re-rankers: a survivor record names its slot)
+    __device__ __forceinline__ RowRef row_of_slot(uint64_t p, const uint32_t *__restrict__ probe_row, uint32_t slot, uint32_t dim) const {
+        if (!host) return RowRef{dev + p * dim, split != 0};
+        return row_in_list(p, lt[probe_row[slot]], dim);
     }
     // row of position p, list unknown: bisection over the lists (cold paths: placement, dumps, shards, rq_rerank)
-    __host__ __device__ __forceinline__ const float *row(uint64_t p, uint32_t dim) const {
-        if (!host) return dev + p * dim;
+    __host__ __device__ __forceinline__ RowRef row(uint64_t p, uint32_t dim) const {
+        if (!host) return RowRef{dev + p * dim, split != 0};
         uint32_t lo = 0, hi = k;  // largest c with lt[c].off <= p (empty lists share their start with the next one)
         while (hi - lo > 1) {
             const uint32_t mid = lo + ((hi - lo) >> 1);
@@ -145,8 +182,5 @@ struct BaseView {
             else hi = mid;
         }
         return row_in_list(p, lt[lo], dim);
-    }
-    __host__ __device__ __forceinline__ float *row_mut(uint64_t p, uint32_t dim) const {
-        return const_cast<float *>(row(p, dim));
     }
 };

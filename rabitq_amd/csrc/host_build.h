@@ -73,7 +73,7 @@ static rq_status derive_shadow_rows(rq_index *idx) {
     idx->list_q8.release();
     int kind = g_rerank_shadow.load();
     if (kind == 2 && idx->dim > 4096) kind = 1;  // (the 8-bit encoder handles rows of up to 4096 dimensions: wider vectors take the fp16 rows)
-    if (!kind || idx->base_host != nullptr || idx->n < RQ_SHADOW_MIN_ROWS) return RQ_OK;
+    if (!kind || idx->base_host != nullptr || idx->split_rows || idx->n < RQ_SHADOW_MIN_ROWS) return RQ_OK;
     const uint64_t total = idx->n * idx->dim, bytes = total * (kind == 2 ? 1 : 2);
     size_t free_b = 0, total_b = 0;
     HIPC(hipMemGetInfo(&free_b, &total_b));
@@ -241,6 +241,7 @@ static rq_status launch_assign_prefiltered(const float *xrot, const rq_index *id
 // builder's argument).  The rest goes to pinned, device-mapped host memory.
 // ------------------------------------------------------------------------------------------------
 static std::atomic<int64_t> g_base_device_mb{-1};  // -1 = automatic
+static std::atomic<int> g_split_rows{1};           // indexes built from now on with no room for shadow rows keep their raw vectors as split rows (0: plain f32, the round-4 layout; 2: always)
 #define RQ_HBM_RESERVE_BYTES (12ull << 30)
 // h_offsets: the k+1 list offsets on the host (the split is per list)
 static rq_status alloc_base_tiers(rq_index *idx, uint64_t budget_bytes, const uint32_t *h_offsets) {
@@ -260,6 +261,17 @@ static rq_status alloc_base_tiers(rq_index *idx, uint64_t budget_bytes, const ui
     const uint64_t budget_rows = cap == ~0ull ? idx->n : std::min<uint64_t>(idx->n, cap / row);
     if (budget_rows >= idx->n) {  // everything in HBM, rows at their positions
         idx->n_dev = idx->n;
+        // Will shadow rows fit beside them (derive_shadow_rows' rule, asked before the rows are placed)?  If not, the rows are stored
+        // as split rows (common.h) and their own first plane is the re-ranker's pre-filter.  (2: always -- test hook.)
+        const int sr = g_split_rows.load(), kind = g_rerank_shadow.load();
+        if (sr == 2) {
+            idx->split_rows = true;
+        } else if (sr == 1 && kind != 0) {
+            size_t free_b = 0, total_b = 0;
+            HIPC(hipMemGetInfo(&free_b, &total_b));
+            const uint64_t shadow = idx->n * idx->dim * (kind == 2 && idx->dim <= 4096 ? 1ull : 2ull);
+            idx->split_rows = shadow > (1ull << 30) && free_b < want + shadow + (48ull << 30);
+        }
         RQC(idx->base.alloc(idx->n * idx->dim));
         return RQ_OK;
     }
@@ -274,6 +286,7 @@ static rq_status alloc_base_tiers(rq_index *idx, uint64_t budget_bytes, const ui
         hbm += h, host += len - h;
     }
     idx->n_dev = hbm;
+    idx->split_rows = g_split_rows.load() != 0;  // both tiers as split rows (common.h): the re-ranker's pre-filter where no shadow fits
     RQC(idx->base.alloc(hbm * idx->dim));
     RQC(idx->list_tier.alloc(k));
     HIPC(hipMemcpy(idx->list_tier.p, idx->h_list_tier.data(), (size_t)k * sizeof(ListTier), hipMemcpyHostToDevice));
@@ -740,10 +753,26 @@ struct JsonIn {
 // (to_index = false: index -> buf; true: buf -> index)
 static rq_status copy_base_rows(const rq_index *idx, uint64_t i0, uint64_t m, float *buf, bool to_index) {
     const uint64_t dim = idx->dim, i1 = i0 + m;
+    std::vector<uint32_t> planes;  // split rows (common.h): transcoded here, on the host -- this is the dump / load path
     auto dev_copy = [&](uint64_t dev_row, uint64_t rows, float *hp) -> rq_status {
         if (!rows) return RQ_OK;
-        if (to_index) HIPC(hipMemcpy(idx->base.p + dev_row * dim, hp, rows * dim * 4, hipMemcpyHostToDevice));
-        else HIPC(hipMemcpy(hp, idx->base.p + dev_row * dim, rows * dim * 4, hipMemcpyDeviceToHost));
+        if (!idx->split_rows) {
+            if (to_index) HIPC(hipMemcpy(idx->base.p + dev_row * dim, hp, rows * dim * 4, hipMemcpyHostToDevice));
+            else HIPC(hipMemcpy(hp, idx->base.p + dev_row * dim, rows * dim * 4, hipMemcpyDeviceToHost));
+            return RQ_OK;
+        }
+        planes.resize(rows * dim);
+        if (to_index) {
+            for (uint64_t r = 0; r < rows; ++r)
+                for (uint32_t e = 0; e < dim; ++e)
+                    rq_row_put(RowRef{reinterpret_cast<const float *>(planes.data() + r * dim), true}, (uint32_t)dim, e, hp[r * dim + e]);
+            HIPC(hipMemcpy(idx->base.p + dev_row * dim, planes.data(), rows * dim * 4, hipMemcpyHostToDevice));
+        } else {
+            HIPC(hipMemcpy(planes.data(), idx->base.p + dev_row * dim, rows * dim * 4, hipMemcpyDeviceToHost));
+            for (uint64_t r = 0; r < rows; ++r)
+                for (uint32_t e = 0; e < dim; ++e)
+                    hp[r * dim + e] = rq_row_get(RowRef{reinterpret_cast<const float *>(planes.data() + r * dim), true}, (uint32_t)dim, e);
+        }
         return RQ_OK;
     };
     if (!idx->base_host) return dev_copy(i0, m, buf);
@@ -771,8 +800,17 @@ static rq_status copy_base_rows(const rq_index *idx, uint64_t i0, uint64_t m, fl
         if (e > split) {
             const uint64_t a2 = std::max(a, split);
             float *hrow = idx->base_host + ((uint64_t)lt[c].host_base + (a2 - split)) * dim;
-            if (to_index) memcpy(hrow, buf + (a2 - i0) * dim, (e - a2) * dim * 4);
-            else memcpy(buf + (a2 - i0) * dim, hrow, (e - a2) * dim * 4);
+            float *brow = buf + (a2 - i0) * dim;
+            if (!idx->split_rows) {
+                if (to_index) memcpy(hrow, brow, (e - a2) * dim * 4);
+                else memcpy(brow, hrow, (e - a2) * dim * 4);
+            } else {
+                for (uint64_t r = 0; r < e - a2; ++r)
+                    for (uint32_t el = 0; el < dim; ++el) {
+                        if (to_index) rq_row_put(RowRef{hrow + r * dim, true}, (uint32_t)dim, el, brow[r * dim + el]);
+                        else brow[r * dim + el] = rq_row_get(RowRef{hrow + r * dim, true}, (uint32_t)dim, el);
+                    }
+            }
         }
     }
     return RQ_OK;

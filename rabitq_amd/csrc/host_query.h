@@ -694,6 +694,9 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                 accurate_filtered_kernel<<<dim3(gx, nq), 256, (size_t)dim * sizeof(float), st>>>(
                     ws.surv.p, ws.surv_cnt.p, seg, idx->base.p, idx->base_h.p, qpad, dim, rerank_order, ws.thr.p,
                     ws.nshadow.p);
+            else if (idx->split_rows && (stage_no > 0 || qp.thr_init) && !(g_scan_dbg & 512))  // tiered: the rows' own first plane is the pre-filter
+                accurate_split_kernel<<<dim3(gx, nq), 256, (size_t)dim * sizeof(float) + (nprobe <= RQ_ACC8_LDS_PROBES ? (size_t)nprobe * 16 : 0), st>>>(
+                    ws.surv.p, ws.surv_cnt.p, seg, idx->view(), qpad, dim, rerank_order, ws.thr.p, probe_cluster, nprobe, ws.nshadow.p);
             else
                 accurate_kernel<<<dim3(gx, nq), 256, (size_t)dim * sizeof(float), st>>>(ws.surv.p, ws.surv_cnt.p, seg, idx->view(), qpad, dim,
                                                                                         rerank_order, probe_cluster, nprobe);

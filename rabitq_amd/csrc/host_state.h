@@ -238,7 +238,8 @@ struct rq_index {
     float *base_host_dev = nullptr;  // the same memory as the kernels address it
     DevBuf<ListTier> list_tier;      // k entries, tiered indexes only
     std::vector<ListTier> h_list_tier;
-    BaseView view() const { return BaseView{base.p, base_host_dev, list_tier.p, k}; }
+    bool split_rows = false;         // the raw vectors are split rows (common.h; set with the tiers, tiered indexes only)
+    BaseView view() const { return BaseView{base.p, base_host_dev, list_tier.p, k, split_rows ? 1u : 0u}; }
     ~rq_index() {
         if (base_host) (void)hipHostFree(base_host);
     }
@@ -304,9 +305,8 @@ __global__ __launch_bounds__(256) void shard_gather_kernel(const uint32_t *__res
             else hi = mid;
         }
         const uint64_t src = (uint64_t)old_off[lo] + (p - new_off[lo]);
-        const float *srow = base_in.row(src, dim);
-        float *drow = base_out.row_mut(p, dim);
-        for (uint32_t e = lane; e < dim; e += 64) drow[e] = srow[e];
+        const RowRef srow = base_in.row(src, dim), drow = base_out.row(p, dim);
+        for (uint32_t e = lane; e < dim; e += 64) rq_row_put(drow, dim, e, rq_row_get(srow, dim, e));
         for (uint32_t w = lane; w < W; w += 64) codes_out[p * W + w] = codes_in[src * W + w];
         if (lane == 0) {
             factors_out[p] = factors_in[src];

@@ -429,9 +429,20 @@ __global__ __launch_bounds__(256) void place_rows_kernel(const float *__restrict
                                                          const BaseView out) {
     const uint32_t lane = threadIdx.x & 63;
     for (uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < m; r += (uint64_t)gridDim.x * 4) {
-        float *dst = out.row_mut(pos_of_id[i0 + r], dim);
+        const RowRef dst = out.row(pos_of_id[i0 + r], dim);
         const float *src = rows + r * d;
-        for (uint32_t e = lane; e < dim; e += 64) dst[e] = e < d ? src[e] : 0.0f;
+        if (!dst.split) {
+            float *w = const_cast<float *>(dst.p);
+            for (uint32_t e = lane; e < dim; e += 64) w[e] = e < d ? src[e] : 0.0f;
+        } else {  // two elements per lane: one 4-byte store into each plane (dim is a multiple of 64)
+            uint32_t *hp = reinterpret_cast<uint32_t *>(const_cast<float *>(dst.p)), *lp = hp + dim / 2;
+            for (uint32_t e = 2 * lane; e < dim; e += 128) {
+                const uint32_t b0 = __builtin_bit_cast(uint32_t, e < d ? src[e] : 0.0f);
+                const uint32_t b1 = __builtin_bit_cast(uint32_t, e + 1 < d ? src[e + 1] : 0.0f);
+                hp[e / 2] = ((b0 + 0x8000u) >> 16) | ((b1 + 0x8000u) & 0xFFFF0000u);
+                lp[e / 2] = (b0 & 0xFFFFu) | (b1 << 16);
+            }
+        }
     }
 }
 

@@ -9,6 +9,9 @@
 //     survivors; exact f32 distances are computed for survivors only; an ordered replay of the
 //     reference's heap logic over (rough, accurate) pairs reproduces its result id-for-id.
 #pragma once
+#ifndef RQ_COLLECT_UNROLL
+#define RQ_COLLECT_UNROLL 8  // 16 tiles per step: coarse 1.07 -> 1.03 ms per step (4: the round-4 form; 16 no better)
+#endif
 #include "common.h"
 #include "kernels_scan_common.h"
 
@@ -776,19 +779,20 @@ __global__ __launch_bounds__(256) void select_refine_tiled_kernel(float *__restr
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         base = 0;
         bool fits = true;
-        for (uint32_t s0 = 0; fits && s0 < nf; s0 += 8) {  // eight flagged tiles per step (one per half-wave, four loads in flight per lane:
-                                                            // one at a time the loop was a chain of ~50 dependent L2 round trips per query)
-            uint32_t jv[4];
-            float dv[4];
+        constexpr int CU_ = RQ_COLLECT_UNROLL;
+        for (uint32_t s0 = 0; fits && s0 < nf; s0 += 2 * CU_) {  // 2 CU_ flagged tiles per step (one per half-wave, CU_ loads in flight per lane:
+                                                                 // one at a time the loop was a chain of ~50 dependent L2 round trips per query)
+            uint32_t jv[CU_];
+            float dv[CU_];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < CU_; ++u) {
                 const uint32_t ti = s0 + 2 * u + (lane >> 5);
                 jv[u] = ti < nf ? tkeys[ti] * 32 + (lane & 31) : 0xFFFFFFFFu;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) dv[u] = jv[u] < k ? d[jv[u]] : 0.0f;
+            for (int u = 0; u < CU_; ++u) dv[u] = jv[u] < k ? d[jv[u]] : 0.0f;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < CU_; ++u) {
                 const uint32_t key = ord32_biased(dv[u]);
                 const bool take = jv[u] < k && key <= T;
                 const uint64_t m = __ballot(take);
@@ -1694,10 +1698,10 @@ __global__ __launch_bounds__(256) void accurate_flat_kernel(const uint32_t *__re
     const uint32_t l = threadIdx.x & 7;
     uint32_t i = blockIdx.x * 32 + (threadIdx.x >> 3);
     if (i >= m) return;
-    const float *x = base.row(pos[i], dim);
+    const RowRef x = base.row(pos[i], dim);
     float acc = 0.0f;
     for (uint32_t c = 0; c < dim; c += 8) {
-        float d = x[c + l] - q[c + l];
+        float d = rq_row_get(x, dim, c + l) - q[c + l];
         acc = fmaf(d, d, acc);
     }
     acc = reduce8_lanes(acc);
@@ -2152,6 +2156,33 @@ __device__ __forceinline__ void replay_wave(const SurvRec *__restrict__ recs, co
     }
 }
 
+// exact f32 L2 of one SPLIT row (common.h: two 16-bit planes) against the query in LDS by a pair of lanes: the words are restored
+// exactly, the arithmetic is accurate_rows' (lane half hf = AVX lanes 4hf..4hf+3, chunks of 64 dimensions in order)
+__device__ __forceinline__ float exact_l2_pair_split(const float *__restrict__ row, const float *q_lds, uint32_t dim, uint32_t hf) {
+    const uint16_t *hp = reinterpret_cast<const uint16_t *>(row) + 4 * hf, *lp = hp + dim;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    for (uint32_t c = 0; c < dim; c += 64) {
+        uint2 hv[8], lv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) hv[u] = *reinterpret_cast<const uint2 *>(hp + c + 8 * u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) lv[u] = *reinterpret_cast<const uint2 *>(lp + c + 8 * u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 qv = *reinterpret_cast<const float4 *>(q_lds + c + 8 * u + 4 * hf);
+            const float x0 = __builtin_bit_cast(float, (hv[u].x << 16) + (uint32_t)(int32_t)(int16_t)lv[u].x);
+            const float x1 = __builtin_bit_cast(float, (hv[u].x & 0xFFFF0000u) + (uint32_t)((int32_t)lv[u].x >> 16));
+            const float x2 = __builtin_bit_cast(float, (hv[u].y << 16) + (uint32_t)(int32_t)(int16_t)lv[u].y);
+            const float x3 = __builtin_bit_cast(float, (hv[u].y & 0xFFFF0000u) + (uint32_t)((int32_t)lv[u].y >> 16));
+            const float d0 = x0 - qv.x, d1 = x1 - qv.y, d2 = x2 - qv.z, d3 = x3 - qv.w;
+            a0 = fmaf(d0, d0, a0), a1 = fmaf(d1, d1, a1), a2 = fmaf(d2, d2, a2), a3 = fmaf(d3, d3, a3);
+        }
+    }
+    const float c0 = a0 + __shfl_xor(a0, 1, 2), c1 = a1 + __shfl_xor(a1, 1, 2);
+    const float c2 = a2 + __shfl_xor(a2, 1, 2), c3 = a3 + __shfl_xor(a3, 1, 2);
+    return (c0 + c1) + (c2 + c3);
+}
+
 // Exact f32 L2 of survivors recs[first], recs[first + step], ... against the query held in LDS
 // (src/rerank.rs:85-90; lane order of src/simd.rs:14-73).  TWO lanes per candidate: lane half hf carries
 // AVX lanes 4hf..4hf+3 (elements 8c + 4hf + 0..3, one 16-byte load per chunk); the fold
@@ -2164,11 +2195,16 @@ __device__ __forceinline__ void accurate_rows(SurvRec *__restrict__ recs, uint32
     const uint32_t hf = threadIdx.x & 1;
     for (uint32_t i = first; i < n; i += step) {
         const float *x;
-        if (base.host == nullptr) {
+        if (base.host == nullptr && !base.split) {
             x = base.dev + (uint64_t)recs[i].pos * dim + 4 * hf;
         } else {  // tiered: the survivor's slot names its list, the list's tier record places the row (HBM or host link)
-            const ListTier t = base.lt[probe_row[recs[i].slot]];
-            x = base.row_in_list(recs[i].pos, t, dim) + 4 * hf;
+            const RowRef rr = base.row_of_slot(recs[i].pos, probe_row, recs[i].slot, dim);
+            if (rr.split) {  // (a pair of lanes shares its survivor: the branch does not split the pair)
+                const float r = exact_l2_pair_split(rr.p, q_lds, dim, hf);
+                if (hf == 0) recs[i].accurate = r;
+                continue;
+            }
+            x = rr.p + 4 * hf;
         }
         float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
         for (uint32_t c = 0; c < dim; c += 64) {  // dim is a multiple of 64
@@ -2395,6 +2431,126 @@ __global__ __launch_bounds__(256) void accurate_filtered_kernel(SurvRec *__restr
     if ((threadIdx.x & 63) == 0 && rj) atomicAdd(&nshadow[b], rj);
 }
 
+#define RQ_ACC8_LDS_PROBES 1024u  // probe lists whose maps / tier records the re-rankers stage in LDS (16 B each)
+// ------------------------------------------------------------------------------------------------
+// Rerank over SPLIT rows (common.h: indexes whose raw vectors leave no room for shadow rows -- tiered ones, and untiered ones that
+// fill most of the HBM): the
+// first plane of a split row IS one: x^ = the row rounded to bf16, ||x - x^|| <= 2^-8 / (1 - 2^-8) ||x^|| (+ 2^-134 per subnormal
+// element).  Same test as accurate_filtered_kernel's with that error term; a survivor it cannot reject has its second plane fetched
+// and the words restored exactly, so results are bit-identical to the plain layout's.  Host-tier rows are split rows too (half
+// the bytes over the host link for the ones the test rejects).  2*dim bytes per survivor instead of 4*dim for the ones the test rejects.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void accurate_split_kernel(SurvRec *__restrict__ surv,
+                                                             const unsigned long long *__restrict__ surv_cnt,
+                                                             const QSeg seg, const BaseView base,
+                                                             const float *__restrict__ qpad, uint32_t dim,
+                                                             const uint32_t *__restrict__ order,
+                                                             const float *__restrict__ thr_start,
+                                                             const uint32_t *__restrict__ probe_cluster, uint32_t nprobe,
+                                                             uint32_t *__restrict__ nshadow) {
+    extern __shared__ __attribute__((aligned(16))) float acc_q[];  // dim floats (the padded query), then -- when they fit -- the nprobe lists' tier records
+    __shared__ uint32_t queue[256];
+    __shared__ uint32_t qn;
+    const uint32_t b = order ? order[blockIdx.y] : blockIdx.y;
+    const uint32_t n = (uint32_t)surv_cnt[b];
+    if (n > seg.capof(b) || n == 0) return;  // overflowed: this query is re-run with a larger buffer
+    SurvRec *recs = surv + seg.at(b);
+    const uint32_t *probe_row = probe_cluster + (uint64_t)b * nprobe;
+    const uint32_t hf = threadIdx.x & 1, pair = threadIdx.x >> 1;
+    // a chain of dependent gathers (survivor record -> its list's tier record -> the row): the first round's records are requested
+    // before anything else, every later round's while the current one is worked on, the tier records are staged in LDS once per block
+    const uint32_t i_first = blockIdx.x * 128;
+    SurvRec nxt = recs[i_first + pair < n ? i_first + pair : 0u];
+    ListTier *ltl = reinterpret_cast<ListTier *>(acc_q + dim);
+    const bool lt_lds = base.host != nullptr && nprobe <= RQ_ACC8_LDS_PROBES;  // (launch: LDS for them only then; an untiered index has no tier records)
+    for (uint32_t c = threadIdx.x * 4; c < dim; c += 1024)
+        *reinterpret_cast<float4 *>(acc_q + c) = *reinterpret_cast<const float4 *>(qpad + (uint64_t)b * dim + c);
+    if (lt_lds)
+        for (uint32_t sl = threadIdx.x; sl < nprobe; sl += 256) ltl[sl] = base.lt[probe_row[sl]];
+    if (threadIdx.x == 0) qn = 0;
+    __syncthreads();
+    const float thr = thr_start ? thr_start[b] : __builtin_inff();
+    const bool test = thr > 1e-30f && thr < 3.0e38f;  // a finite, normal threshold (false for NaN / inf: everything is exact)
+    const float eps = (float)(dim / 4 + 64) * 5.9604645e-8f, down = 1.0f - eps, up = 1.0f + eps;
+    auto row_of = [&](const SurvRec &r) { return lt_lds ? base.row_in_list(r.pos, ltl[r.slot], dim) : base.row_of_slot(r.pos, probe_row, r.slot, dim); };
+    auto exact_of = [&](uint32_t j) {
+        const RowRef rr = row_of(recs[j]);
+        const float r = rr.split ? exact_l2_pair_split(rr.p, acc_q, dim, hf) : exact_l2_pair(rr.p + 4 * hf, acc_q, dim, hf);
+        if (hf == 0) recs[j].accurate = r;
+    };
+    uint32_t rejected = 0;
+    for (uint32_t i0 = i_first; i0 < n; i0 += gridDim.x * 128) {
+        const uint32_t i = i0 + pair;
+        bool exact = i < n;
+        const SurvRec cur = nxt;
+        {  // the next round's record (clamped: the last prefetch re-reads record 0)
+            const uint32_t jn = i + gridDim.x * 128;
+            nxt = recs[jn < n ? jn : 0u];
+        }
+        if (exact && test) {
+            const RowRef rr = row_of(cur);
+#ifdef RQ_EXP_COUNT_HOST  // developer experiment: the counter reports the host-tier survivors instead of the rejected ones
+            if (!rr.split) ++rejected;
+#endif
+            if (rr.split) {
+                const uint16_t *x = reinterpret_cast<const uint16_t *>(rr.p) + 8 * hf;
+                float d0 = 0.0f, d1 = 0.0f, n0 = 0.0f, n1 = 0.0f;
+                for (uint32_t c = 0; c < dim; c += 128) {  // 256 bytes of the plane: 8 x 16 bytes per lane in flight
+                    uint4 xv[8];
+                    const bool full = dim - c >= 128;  // dim is a multiple of 64: the last chunk may be a half one
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (u < 4 || full) xv[u] = *reinterpret_cast<const uint4 *>(x + c + 16 * u);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (!(u < 4 || full)) continue;
+                        const float4 qa = *reinterpret_cast<const float4 *>(acc_q + c + 16 * u + 8 * hf);
+                        const float4 qb = *reinterpret_cast<const float4 *>(acc_q + c + 16 * u + 8 * hf + 4);
+                        const float x0 = __builtin_bit_cast(float, xv[u].x << 16), x1 = __builtin_bit_cast(float, xv[u].x & 0xFFFF0000u);
+                        const float x2 = __builtin_bit_cast(float, xv[u].y << 16), x3 = __builtin_bit_cast(float, xv[u].y & 0xFFFF0000u);
+                        const float x4 = __builtin_bit_cast(float, xv[u].z << 16), x5 = __builtin_bit_cast(float, xv[u].z & 0xFFFF0000u);
+                        const float x6 = __builtin_bit_cast(float, xv[u].w << 16), x7 = __builtin_bit_cast(float, xv[u].w & 0xFFFF0000u);
+                        const float e0 = x0 - qa.x, e1 = x1 - qa.y, e2 = x2 - qa.z, e3 = x3 - qa.w;
+                        const float e4 = x4 - qb.x, e5 = x5 - qb.y, e6 = x6 - qb.z, e7 = x7 - qb.w;
+                        d0 = fmaf(e0, e0, d0), d1 = fmaf(e1, e1, d1), d0 = fmaf(e2, e2, d0), d1 = fmaf(e3, e3, d1);
+                        d0 = fmaf(e4, e4, d0), d1 = fmaf(e5, e5, d1), d0 = fmaf(e6, e6, d0), d1 = fmaf(e7, e7, d1);
+                        n0 = fmaf(x0, x0, n0), n1 = fmaf(x1, x1, n1), n0 = fmaf(x2, x2, n0), n1 = fmaf(x3, x3, n1);
+                        n0 = fmaf(x4, x4, n0), n1 = fmaf(x5, x5, n1), n0 = fmaf(x6, x6, n0), n1 = fmaf(x7, x7, n1);
+                    }
+                }
+                float dt = d0 + d1, nx = n0 + n1;
+                dt += __shfl_xor(dt, 1, 2), nx += __shfl_xor(nx, 1, 2);
+                // >= 2^-8 / (1 - 2^-8) ||x^|| + sqrt(dim) 2^-134 >= ||x - x^||  (3.9216e-3 > 2^-8 / (1 - 2^-8) = 3.92157e-3; an
+                // x^ with an infinite element makes err infinite and t NaN or -inf: no rejection)
+                const float err = (sqrtf(nx) * up) * 3.9216e-3f + 1.0e-37f;
+                const float t = sqrtf(dt * down) * down - err * up;
+                if (t > 0.0f && (t * t) * (down * down) > thr) {  // false for NaN
+                    exact = false;
+                    if (hf == 0) recs[i].accurate = __builtin_inff();
+#ifndef RQ_EXP_COUNT_HOST
+                    ++rejected;
+#endif
+                }
+            }
+        }
+        if (exact && hf == 0) queue[atomicAdd(&qn, 1u)] = i;  // at most 127 waiting + 128 new
+        __syncthreads();
+        const uint32_t waiting = qn;  // the same value in every thread: nobody touches qn before the next barrier
+        __syncthreads();
+        if (waiting >= 128) {
+            exact_of(queue[waiting - 128 + pair]);
+            if (threadIdx.x == 0) qn = waiting - 128;
+            __syncthreads();  // the queue's top 128 entries are free again, qn is set
+        }
+    }
+    const uint32_t waiting = qn;
+    if (pair < waiting) exact_of(queue[pair]);
+    uint32_t rj = hf == 0 ? rejected : 0u;  // per-query counter (one address per query: no hot spot)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) rj += __shfl_xor(rj, o, 64);
+    if ((threadIdx.x & 63) == 0 && rj) atomicAdd(&nshadow[b], rj);
+}
+
 // ------------------------------------------------------------------------------------------------
 // The 8-bit shadow (round 4): one BYTE per dimension instead of the fp16 shadow's two.
 //
@@ -2494,7 +2650,6 @@ __global__ __launch_bounds__(256) void q8_encode_kernel(const float *__restrict_
 #ifndef RQ_ACC8_WAVES
 #define RQ_ACC8_WAVES 4  // waves per SIMD the register budget is cut for (round 4: 132 registers, three waves; four: rerank 4.76 -> 4.35 ms per step)
 #endif
-#define RQ_ACC8_LDS_PROBES 1024u  // probe lists whose maps are staged in LDS (16 B each)
 __global__ __launch_bounds__(256, RQ_ACC8_WAVES) void accurate_filtered8_kernel(SurvRec *__restrict__ surv,
                                                                  const unsigned long long *__restrict__ surv_cnt,
                                                                  const QSeg seg, const float *__restrict__ base,

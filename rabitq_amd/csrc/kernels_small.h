@@ -287,11 +287,16 @@ __device__ __forceinline__ void sb_accurate_rows(SurvRec *recs, uint32_t n, cons
     const uint32_t hf = threadIdx.x & 1;
     for (uint32_t i = threadIdx.x >> 1; i < n; i += 512) {
         const float *x;
-        if (base.host == nullptr) {
+        if (base.host == nullptr && !base.split) {
             x = base.dev + (uint64_t)recs[i].pos * dim + 4 * hf;
         } else {
-            const ListTier tr = base.lt[probe_row[recs[i].slot]];
-            x = base.row_in_list(recs[i].pos, tr, dim) + 4 * hf;
+            const RowRef rr = base.row_of_slot(recs[i].pos, probe_row, recs[i].slot, dim);
+            if (rr.split) {
+                const float r = exact_l2_pair_split(rr.p, q_lds, dim, hf);
+                if (hf == 0) recs[i].accurate = r;
+                continue;
+            }
+            x = rr.p + 4 * hf;
         }
         float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
         auto chunk = [&](const float4 (&xv)[8], uint32_t c) {

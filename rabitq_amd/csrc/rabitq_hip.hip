@@ -400,6 +400,8 @@ rq_status rq_get_device_ptr(const rq_index *idx, int which, const void **out_ptr
         case RQ_ARR_BASE:
             if (idx->n_dev < idx->n)  // tiered: the HBM tier holds packed list heads, not rows at their positions
                 return fail(RQ_ERR_UNSUPPORTED, "the raw vectors of this index are tiered (HBM + pinned host memory): no single device array; use rq_get_array");
+            if (idx->split_rows)  // (common.h) not an array of f32 rows
+                return fail(RQ_ERR_UNSUPPORTED, "the raw vectors of this index are stored as split rows (two 16-bit planes per row): no f32 device array; use rq_get_array");
             *out_ptr = idx->base.p, *out_bytes = idx->n_dev * idx->dim * 4;
             break;
         case RQ_ARR_ORTHOGONAL: *out_ptr = idx->P.p, *out_bytes = (uint64_t)idx->dim * idx->dim * 4; break;
@@ -416,7 +418,7 @@ rq_status rq_get_device_ptr(const rq_index *idx, int which, const void **out_ptr
 rq_status rq_get_array(const rq_index *idx, int which, void *dst, uint64_t dst_bytes) {
     const void *p;
     uint64_t bytes;
-    if (idx && which == RQ_ARR_BASE && idx->n_dev < idx->n) {  // both tiers
+    if (idx && which == RQ_ARR_BASE && (idx->n_dev < idx->n || idx->split_rows)) {  // both tiers / split rows
         if (!dst || dst_bytes < idx->n * idx->dim * 4) return fail(RQ_ERR_INVALID, "destination too small");
         return copy_base_rows(idx, 0, idx->n, static_cast<float *>(dst), false);
     }
@@ -650,6 +652,11 @@ rq_status rq_set_option(const char *name, int value) {
                                                   // -1 = automatic (default), else MiB; the rest goes to pinned host memory
         if (value < -1) return fail(RQ_ERR_INVALID, "base_device_mb must be >= -1");
         g_base_device_mb = value;
+        return RQ_OK;
+    }
+    if (std::string(name) == "split_rows") {  // tiered indexes built / loaded from now on: raw vectors as two 16-bit planes (1, default) or plain f32 (0)
+        if (value < 0 || value > 2) return fail(RQ_ERR_INVALID, "split_rows must be 0, 1 or 2");
+        g_split_rows = value;
         return RQ_OK;
     }
     if (std::string(name) == "scan_tile_table") {  // full-list stages launch one block per existing (list, tile): 0 never, 1 auto, 2 always

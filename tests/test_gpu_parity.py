@@ -1725,6 +1725,129 @@ def test_long_run_directories_large_batch(rq, oracle, dense_dir):
     oidx.close()
 
 
+@pytest.mark.parametrize("tiered", [True, False])
+@pytest.mark.parametrize("d,kind", [(128, "gauss"), (768, "gauss"), (128, "subnormal"), (128, "small_ints"), (64, "near_ties"), (128, "nan_row")])
+def test_split_rows_keep_results_exact(rq, oracle, d, kind, tiered, tmp_path):
+    """Indexes whose raw vectors leave no room for shadow rows (tiered ones; untiered ones that fill most of the HBM -- forced here
+    with split_rows = 2) keep each row as two 16-bit planes: the upper halves of the f32 words
+    rounded to nearest, then the lower halves.  Large batches re-rank through the first plane (accurate_split_kernel) and fetch the
+    second one only when the first cannot PROVE accurate >= the stage's threshold; every word is restored exactly.  Ids, order and
+    distances equal the oracle's bit for bit on data the first plane represents badly too (subnormal elements, near-equal
+    distances, a NaN coordinate); the raw vectors read back unchanged; on ordinary data the test must reject rows; the plain layout
+    (split_rows = 0) gives the same bits."""
+    from rabitq_amd import index as ix
+    n, k, nq = (40_000, 8, 300) if d < 768 else (12_000, 6, 280)
+    rng = np.random.default_rng(7 * d + len(kind))
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.7, seed=3 + d, centre_scale=0.6)
+    queries, _, _ = synth.mixture(nq, d, k, sigma=0.7, seed=4 + d, centre_scale=0.6)
+    if kind == "subnormal":      # tiny scales, and a twentieth of the elements subnormal f32 words
+        x, centres, queries = x * 1e-6, centres * 1e-6, queries * 1e-6
+        x = np.ascontiguousarray(x, np.float32)
+        sub = rng.random(x.shape) < 0.05
+        x.view(np.uint32)[sub] = (rng.integers(0, 1 << 23, int(sub.sum())) | (rng.integers(0, 2, int(sub.sum())) << 31)).astype(np.uint32)
+    elif kind == "small_ints":
+        x, centres, queries = np.rint(x * 40 + 128).clip(0, 255), np.rint(centres * 40 + 128), np.rint(queries * 40 + 128).clip(0, 255)
+    elif kind == "near_ties":
+        x[: n // 2] = x[:20].repeat(n // 40, axis=0) + 1e-4 * rng.standard_normal((n // 2, d))
+        queries[:150] = x[rng.integers(0, n // 2, 150)] + 1e-4 * rng.standard_normal((150, d))
+    x, centres, queries = (np.ascontiguousarray(a, np.float32) for a in (x, centres, queries))
+    if kind == "nan_row":
+        x[17, 5] = np.nan
+    P = synth.random_orthogonal(d, seed=d)
+    oidx = oracle.OracleIndex.build(x, centres, P)
+    budget_mb = (n * d * 4 * 4 // 5) >> 20      # about four fifths of every list in HBM, the tails in pinned host memory
+    ix.set_option("base_device_mb", budget_mb if tiered else -1)
+    ix.set_option("split_rows", 1 if tiered else 2)
+    ix.set_profiling(1)
+    try:
+        gidx = rq.RaBitQ.build(x, centres, P)
+        assert (0 < gidx.n_hbm < n) if tiered else gidx.n_hbm == n
+        with pytest.raises(rq.RabitqError) as e:   # no f32 device array of split rows
+            gidx.device_ptr(0)
+        assert e.value.status == -6
+        assert_bits_equal(gidx.base, oidx.base, "raw vectors read back through the planes")
+        for probe, topk, heur in [(8, 10, False), (3, 50, False), (8, 10, True)]:
+            _compare_with_oracle(rq, oracle, oidx, gidx, queries, probe, topk, heur)
+            pr = ix.last_profile()
+            assert pr["rerank_shadow_rejects"] <= pr["rerank_candidates"]
+            if kind in ("gauss", "small_ints") and not heur:
+                assert pr["rerank_shadow_rejects"] > pr["rerank_candidates"] // 4, (pr["rerank_shadow_rejects"], pr["rerank_candidates"])
+        _compare_with_oracle(rq, oracle, oidx, gidx, queries[:40], 8, 10, False)    # small batch: the fused finish restores the words too
+        ix.set_option("split_rows", 0)
+        ix.set_option("rerank_shadow", 0)
+        plain = rq.RaBitQ.build(x, centres, P)
+        ix.set_option("rerank_shadow", 2)
+        ix.set_option("split_rows", 1 if tiered else 2)
+        a, b = gidx.query_batch(queries, 8, 10, False), plain.query_batch(queries, 8, 10, False)
+        assert ix.last_profile()["rerank_shadow_rejects"] == 0
+        for u, v in zip(a, b):
+            assert_bits_equal(u, v, "split / plain rows")
+        plain.close()
+        if kind == "gauss" and d == 128:   # dump -> load and a carved shard go through the planes as well
+            gidx.dump_to_dir(str(tmp_path / "idx"))
+            oidx.dump_to_dir(str(tmp_path / "o"))
+            assert (tmp_path / "idx" / "base.fvecs").read_bytes() == (tmp_path / "o" / "base.fvecs").read_bytes()
+            loaded = rq.RaBitQ.load_from_dir(str(tmp_path / "idx"))
+            assert (0 < loaded.n_hbm < n) if tiered else loaded.n_hbm == n
+            c = loaded.query_batch(queries, 8, 10, False)
+            assert ix.last_profile()["rerank_shadow_rejects"] > 0
+            owner, _ = gidx.partition_lists(1)
+            shard = gidx.shard(owner, 0)
+            e = shard.query_batch(queries, 8, 10, False)
+            for u, v, w in zip(a, c, e):
+                assert_bits_equal(u, v, "loaded index")
+                assert_bits_equal(u, w, "shard of everything")
+            assert_bits_equal(shard.base, oidx.base, "shard rows")
+            loaded.close()
+            shard.close()
+    finally:
+        ix.set_profiling(0)
+        ix.set_option("base_device_mb", -1)
+        ix.set_option("split_rows", 1)
+        ix.set_option("rerank_shadow", 2)
+    gidx.close()
+    oidx.close()
+
+
+def test_split_rows_restore_every_bit_pattern(rq, oracle):
+    """The two planes of a split row restore ANY 32-bit word: NaN payloads, infinities, subnormals, the words whose upper half
+    rounds up into the next binade / to inf / wraps (0x7F7F8000.., 0xFFFF8000..).  An index loaded from arrays (no arithmetic on
+    the raw vectors) with a third of every list in HBM reads back bit for bit; rq_rerank restores the words on the fly."""
+    from rabitq_amd import index as ix
+    n, d, k = 6000, 128, 6
+    rng = np.random.default_rng(11)
+    words = rng.integers(0, 1 << 32, (n, d), dtype=np.uint64).astype(np.uint32)
+    special = np.array([0x7F7F8000, 0x7F7FFFFF, 0xFF7FC000, 0x7F800000, 0xFF800000, 0x7FC00001, 0xFFFF8000, 0xFFFFFFFF, 0x00007FFF,
+                        0x00008000, 0x8000FFFF, 0x00000000, 0x80000000, 0x3F7F8000, 0x3F7F7FFF, 0x007F8000], np.uint32)
+    words[:, :16] = special[rng.integers(0, 16, (n, 16))]
+    base = words.view(np.float32)
+    offsets = np.linspace(0, n, k + 1).astype(np.uint32)
+    P = synth.random_orthogonal(d, seed=3)
+    centres = np.zeros((k, d), np.float32)
+    ix.set_option("base_device_mb", 1)       # 2048 of the 6000 rows stay in HBM
+    try:
+        idx = rq.RaBitQ.from_arrays(base, P, centres, offsets, np.arange(n, dtype=np.uint32), np.zeros((n, d // 64), np.uint64),
+                                    np.ones((n, 4), np.float32))
+    finally:
+        ix.set_option("base_device_mb", -1)
+    assert 0 < idx.n_hbm < n
+    assert_bits_equal(idx.base, base, "every word through the planes")
+    fin = np.zeros((n, d), np.float32)
+    fin[:] = rng.standard_normal((n, d)).astype(np.float32) * np.float32(3.0)
+    idx.close()
+    ix.set_option("base_device_mb", 1)
+    try:
+        idx = rq.RaBitQ.from_arrays(fin, P, centres, offsets, np.arange(n, dtype=np.uint32), np.zeros((n, d // 64), np.uint64),
+                                    np.ones((n, 4), np.float32))
+    finally:
+        ix.set_option("base_device_mb", -1)
+    q = rng.standard_normal(d).astype(np.float32)
+    pos = np.arange(0, n, 7, dtype=np.uint32)
+    want = np.array([oracle.l2_squared_distance(fin[p], q) for p in pos], np.float32)
+    assert_bits_equal(rq.ops.rerank(idx, q, pos), want, "rq_rerank over split rows")
+    idx.close()
+
+
 @pytest.mark.parametrize("shadow", [2, 1])
 @pytest.mark.parametrize("d,kind", [(128, "gauss"), (192, "gauss"), (128, "beyond_fp16"), (128, "fp16_subnormal"),
                                     (128, "small_ints"), (64, "near_ties"), (128, "nan_row"), (768, "gauss")])
