@@ -2557,12 +2557,19 @@ __global__ __launch_bounds__(256) void accurate_split_kernel(SurvRec *__restrict
 // Every list c has an affine map of its own, x^_i = lo_c + s_c * code_i with lo_c = the smallest and lo_c + 255 s_c = the largest
 // coordinate of any of its rows (q8_range_kernel), so no coordinate clips and |x_i - x^_i| <= s_c / 2 up to rounding.  The bound
 // the pre-filter needs, ||x - x^|| over the rows of the list, is not derived but MEASURED while the codes are written
-// (q8_encode_kernel: the largest |x_i - fmaf(s_c, code_i, lo_c)| of the list, evaluated exactly as the re-ranker evaluates x^),
-// times sqrt(dim).  The test itself is accurate_filtered_kernel's: d^ = ||x^ - q|| in f32, t = d^ (1 - eps) - err, and a survivor is
+// (q8_encode_kernel: the largest row norm of x - fmaf(s_c, code, lo_c) over the list, x^ evaluated exactly as the re-ranker evaluates
+// it -- round 5; for dimensions whose rows do not map onto a power-of-two thread group: the largest |x_i - x^_i| times sqrt(dim)).
+// The test itself is accurate_filtered_kernel's: d^ = ||x^ - q|| in f32, t = d^ (1 - eps) - err, and a survivor is
 // dropped only if t^2 (1 - eps) still exceeds the stage's threshold -- the f32 row is then never read (128 instead of 256 shadow
 // bytes per survivor at dim 128; measured on the benchmark mixture: 86 % of the survivors rejected against the fp16 shadow's 92 %).
 // A list with a non-finite coordinate gets err = inf: nothing of it is ever rejected.
 // ------------------------------------------------------------------------------------------------
+// whether q8_encode_kernel measures row norms of the error (list_q8[c].w) for this dimension: its dim / 16 threads per row must be
+// a power-of-two group inside one wave
+__host__ __device__ __forceinline__ bool q8_row_norms(uint32_t dim) {
+    const uint32_t tpr = dim / 16;
+    return tpr >= 1 && tpr <= 64 && (tpr & (tpr - 1)) == 0;
+}
 // one block per list: lo, s (and the error accumulator cleared)
 __global__ __launch_bounds__(256) void q8_range_kernel(const float *__restrict__ base, const uint32_t *__restrict__ offsets, uint32_t dim,
                                                        float4 *__restrict__ list_q8) {
@@ -2597,21 +2604,23 @@ __global__ __launch_bounds__(256) void q8_range_kernel(const float *__restrict__
         if (!(sc > 0.0f)) sc = 1.0f;                       // all coordinates equal (or an empty list): code 0 everywhere
         if (!(sc < 3.0e38f) || !(fabsf(lo) < 3.0e38f)) bad = 1;
         // .z: the largest |x_i - x^_i| of the list as the bits of a non-negative float (atomicMax by q8_encode_kernel); inf: never reject
-        list_q8[c] = make_float4(bad ? 0.0f : lo, bad ? 1.0f : sc, bad ? __builtin_inff() : 0.0f, 0.0f);
+        list_q8[c] = make_float4(bad ? 0.0f : lo, bad ? 1.0f : sc, bad ? __builtin_inff() : 0.0f, bad ? __builtin_inff() : 0.0f);  // .w: the largest row norm of the error, likewise
     }
 }
 // grid (ceil(longest list / 256), k): 256 rows of one list per block; dim / 16 threads per row, 16 codes (one 16-byte store) each
 __global__ __launch_bounds__(256) void q8_encode_kernel(const float *__restrict__ base, const uint32_t *__restrict__ offsets, uint32_t dim,
                                                         float4 *__restrict__ list_q8, uint8_t *__restrict__ out) {
-    __shared__ float smax[4];
+    __shared__ float smax[4], snorm[4];
     const uint32_t c = blockIdx.y, r0 = offsets[c] + blockIdx.x * 256u, r1 = offsets[c + 1];
     if (r0 >= r1) return;
     const float4 par = list_q8[c];
     const float lo = par.x, sc = par.y, inv = 1.0f / sc;
     const uint32_t tpr = dim / 16, rows_per_pass = 256 / tpr;  // dim <= 4096
     const uint32_t rr = threadIdx.x / tpr, g = threadIdx.x - rr * tpr;
-    float emax = 0.0f;
+    const bool row_norms = q8_row_norms(dim);  // the tpr threads of a row are an aligned power-of-two group of one wave
+    float emax = 0.0f, nmax = 0.0f;
     for (uint32_t r = r0 + rr; r < r1 && r < r0 + 256u && rr < rows_per_pass; r += rows_per_pass) {
+        float e2 = 0.0f;
         const float *x = base + (uint64_t)r * dim + 16 * g;
         uint32_t w[4];
 #pragma unroll
@@ -2626,21 +2635,29 @@ __global__ __launch_bounds__(256) void q8_encode_kernel(const float *__restrict_
                 const uint32_t code = (uint32_t)t;
                 const float e = fabsf(ve[i] - fmaf(sc, (float)code, lo));  // exactly the re-ranker's x^
                 emax = (e > emax || !(e < 3.0e38f)) ? (e < 3.0e38f ? e : __builtin_inff()) : emax;
+                e2 = fmaf(e, e, e2);
                 w[u] |= code << (8 * i);
             }
         }
         *reinterpret_cast<uint4 *>(out + (uint64_t)r * dim + 16 * g) = make_uint4(w[0], w[1], w[2], w[3]);
+        if (row_norms) {  // ||x - x^||^2 of the row: the group's partial sums folded (every thread of the group is in this iteration)
+            for (uint32_t o = tpr >> 1; o >= 1; o >>= 1) e2 += __shfl_xor(e2, (int)o, 64);
+            nmax = (e2 > nmax || !(e2 < 3.0e38f)) ? (e2 < 3.0e38f ? e2 : __builtin_inff()) : nmax;
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
-        const float a = __shfl_xor(emax, o, 64);
-        emax = a > emax ? a : emax;
+        const float a = __shfl_xor(emax, o, 64), b = __shfl_xor(nmax, o, 64);
+        emax = a > emax ? a : emax, nmax = b > nmax ? b : nmax;
     }
-    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = emax;
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = emax, snorm[threadIdx.x >> 6] = nmax;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w2 = 1; w2 < 4; ++w2) emax = smax[w2] > emax ? smax[w2] : emax;
+        for (int w2 = 1; w2 < 4; ++w2) emax = smax[w2] > emax ? smax[w2] : emax, nmax = snorm[w2] > nmax ? snorm[w2] : nmax;
         atomicMax(reinterpret_cast<unsigned int *>(&list_q8[c].z), __builtin_bit_cast(unsigned int, emax));  // non-negative floats order as their bits
+        // .w: the largest ||x - x^|| over the list's rows, rounded up past the f32 evaluation above (dim fused multiply-adds + a sqrt)
+        const float nrm = sqrtf(nmax) * (1.0f + (float)(dim + 8) * 6.0e-8f);
+        if (row_norms) atomicMax(reinterpret_cast<unsigned int *>(&list_q8[c].w), __builtin_bit_cast(unsigned int, nrm));
     }
 }
 
@@ -2687,6 +2704,7 @@ __global__ __launch_bounds__(256, RQ_ACC8_WAVES) void accurate_filtered8_kernel(
     const bool test = thr > 1e-30f && thr < 3.0e38f;  // a finite, normal threshold (false for NaN / inf: everything is exact)
     const float eps = (float)(dim / 4 + 64) * 5.9604645e-8f, down = 1.0f - eps, up = 1.0f + eps;
     const float sqd = sqrtf((float)dim) * 1.001f;
+    const bool rown = q8_row_norms(dim);
     const uint32_t ngrp = dim / 16;
     uint32_t rejected = 0;
     for (uint32_t i0 = i_first; i0 < n; i0 += gridDim.x * 256) {
@@ -2739,7 +2757,9 @@ __global__ __launch_bounds__(256, RQ_ACC8_WAVES) void accurate_filtered8_kernel(
             for (int v = 0; v < 2; ++v) {
                 float dt = d0[v] + d1[v];
                 dt += __shfl_xor(dt, 1, 2);
-                const float err = (par[v].z * up) * sqd;  // >= sqrt(dim) max |x_i - x^_i| >= ||x - x^||   (inf: a list that is never rejected)
+                // >= ||x - x^||: the largest row norm of the error measured over the list (dimensions q8_encode_kernel measures it for),
+                // else sqrt(dim) max |x_i - x^_i|   (inf: a list that is never rejected)
+                const float err = rown ? par[v].w * up : (par[v].z * up) * sqd;
                 const float t = sqrtf(dt * down) * down - err * up;
                 if (exact[v] && t > 0.0f && (t * t) * (down * down) > thr) {  // false for NaN
                     exact[v] = false;
