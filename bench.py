@@ -574,7 +574,7 @@ def run_workload(args, ctx, extras=True):
                     # (codes + factors of every vector): what the per-XCD L2s fetch more than once, plus the query tile images
                     "traffic_over_unique_index_bytes": None if not dom_traffic else round(dom_traffic / (idx.n * (idx.dim / 8 + 16)), 2),
                     "kernel": ("scan_mfma_kernel<W,NT,ADD> (v_mfma_f32_32x32x64_f8f6f4 e2m3 x e2m1; additive gate S* >= B_q + G_c, no threshold MFMA)"
-                               if additive else "scan_mfma_kernel<W,NT> (v_mfma_f32_32x32x64_f8f6f4 e2m3 x e2m3 + bf16 threshold MFMA)"),
+                               if additive else "scan_mfma_kernel<W,NT> (v_mfma_f32_32x32x64_f8f6f4 e2m3 x e2m1 + bf16 threshold MFMA)"),
                     "gate": "additive" if additive else "bf16 rank-5 threshold",
                     "launches": int(ml), "avg_launch_ms": round(mm / ml * 1e3, 4),
                     "algorithmic_flops_per_launch": int(flops / ml), "pairs_per_launch": int(mp / ml),

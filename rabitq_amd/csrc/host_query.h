@@ -197,7 +197,9 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             hi = std::min<uint64_t>(hi * growth, 0xFFFFFFF0ull);
             // the geometric step must not carry an early (VALU) stage over many lists when lists are short:
             // past two lists' worth the rest belongs to the final stage
-            if (lo < 2 * avg && hi > 2 * avg) hi = 2 * avg;
+            // (a step that ends within a factor two BELOW that mark is carried up to it: the hard distribution ran a thin matrix-core
+            // stage [40960, 48828) behind [5120, 40960) -- 4.5 ms of launches for 8 000 stream positions)
+            if (lo < 2 * avg && 2 * hi > 2 * avg) hi = 2 * avg;
             // ... and the last early stage ends exactly where the threshold has settled: everything beyond belongs to the
             // final (matrix-core) stage, where a list meets all its queries at once
             if (lo < settle && hi > settle) hi = settle;

@@ -2956,14 +2956,26 @@ __global__ __launch_bounds__(256) void arena_scatter_kernel(const SurvRec *__res
     const uint4 *src = arena_runs + (uint64_t)shard * arena_rsub;
     const uint2 *plc = arena_places + (uint64_t)shard * arena_rsub;
     const uint32_t col = common ? blockIdx.x - RQ_ARENA_SHARDS : 0u, ncol = common ? RQ_ARENA_COMMON_BLOCKS : 1u;
-    for (uint32_t r0 = ((col * gridDim.y + blockIdx.y) * 4 + wave) * 64; r0 < nr; r0 += ncol * gridDim.y * 256) {
+    // (a chain of dependent gathers per chunk -- descriptor -> the query's segment start -> the writes; records -> their copies --
+    // so the next chunk's descriptors, places and segment starts are requested while this chunk's records move)
+    const uint32_t rstep = ncol * gridDim.y * 256, rfirst = ((col * gridDim.y + blockIdx.y) * 4 + wave) * 64;
+    uint4 d_n = make_uint4(0, 0, 0, 0);
+    uint2 pl_n = make_uint2(0, 0);
+    unsigned long long qat_n = 0;
+    if (rfirst + lane < nr) {
+        d_n = src[rfirst + lane], pl_n = plc[rfirst + lane];
+        qat_n = q_base[d_n.z];
+    }
+    for (uint32_t r0 = rfirst; r0 < nr; r0 += rstep) {
         uint32_t cnt = 0;
+        const uint4 d = d_n;
+        const uint2 pl = pl_n;  // the run's place inside its query's segment, reserved by the scan
+        const unsigned long long qat = qat_n;
+        const bool more = r0 + rstep + lane < nr && r0 + rstep >= r0;
+        if (more) d_n = src[r0 + rstep + lane], pl_n = plc[r0 + rstep + lane];
         if (r0 + lane < nr) {
-            const uint4 d = src[r0 + lane];
             cnt = d.y >> 16;
-            const uint2 pl = plc[r0 + lane];  // the run's place inside its query's segment, reserved by the scan
             const uint32_t base = pl.x, rbase = pl.y;
-            const unsigned long long qat = q_base[d.z];
             RunRec rr;
             rr.pos = d.x, rr.slot = d.y & 0xFFFFu, rr.base = base, rr.cnt = cnt;
             runs[qat + rbase] = rr;
@@ -2979,14 +2991,28 @@ __global__ __launch_bounds__(256) void arena_scatter_kernel(const SurvRec *__res
         s_pref[wave][lane + 1] = incl;
         if (lane == 0) s_pref[wave][0] = 0;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (more) qat_n = q_base[d_n.z];
         const uint32_t total = __shfl(incl, 63, 64);
-        for (uint32_t e = lane; e < total; e += 64) {
-            uint32_t lo = 0;  // largest r with s_pref[r] <= e
+        for (uint32_t e0 = 0; e0 < total; e0 += 128) {  // two records per lane in flight
+            SurvRec rec[2];
+            unsigned long long dst[2];
 #pragma unroll
-            for (int step = 32; step >= 1; step >>= 1)
-                if (lo + step < 64 && s_pref[wave][lo + step] <= e) lo += step;
-            const uint32_t i = e - s_pref[wave][lo];
-            surv[s_dst[wave][lo] + i] = arena_recs[s_src[wave][lo] + i];
+            for (int v = 0; v < 2; ++v) {
+                const uint32_t e = e0 + 64 * v + lane;
+                dst[v] = ~0ull;
+                if (e < total) {
+                    uint32_t lo = 0;  // largest r with s_pref[r] <= e
+#pragma unroll
+                    for (int step = 32; step >= 1; step >>= 1)
+                        if (lo + step < 64 && s_pref[wave][lo + step] <= e) lo += step;
+                    const uint32_t i = e - s_pref[wave][lo];
+                    rec[v] = arena_recs[s_src[wave][lo] + i];
+                    dst[v] = s_dst[wave][lo] + i;
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+                if (dst[v] != ~0ull) surv[dst[v]] = rec[v];
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the chunk's LDS rows are free again
     }
