@@ -20,6 +20,9 @@ __global__ __launch_bounds__(256) void scan_kernel(SCAN_PARAMS);
 #ifndef RQ_NT_W12
 #define RQ_NT_W12 2  // sub-tiles per wave at dim 768
 #endif
+#ifndef RQ_A_RING
+#define RQ_A_RING 3  // query fragments the slab-outer streamed form requests ahead of their use (1: the compiler's own schedule)
+#endif
 #ifndef RQ_GATE_DEFER
 #define RQ_GATE_DEFER 1  // additive gate of the narrow instantiations: 1 = one branch per query tile (the cold path recomputes the flagged steps), 0 = one per step
 #endif

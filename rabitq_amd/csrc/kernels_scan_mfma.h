@@ -453,11 +453,32 @@ __global__ __launch_bounds__((64 * scan_mfma_waves<W, ARENA>()), scan_mfma_block
                 const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ua), __builtin_bit_cast(bf16x8, ubv), z, 0, 0, 0);
             }
+            if constexpr (STREAM_A && RQ_A_RING > 1) {
+                // A fragments RQ_A_RING slabs ahead of their use: left to itself the compiler requests a fragment one slab (two matrix
+                // instructions, 64 cycles) before it is needed -- less than an LDS round trip under load -- and these instantiations
+                // hold two waves per SIMD (SQ counters at dim 768: matrix pipe 0.475 busy, 0.46 of the wave-cycles waiting on an
+                // instruction's operands).  The scheduling barriers pin the order written here; the waits land at the uses.
+                constexpr int RING = RQ_A_RING < W ? RQ_A_RING : W;
+                v8i32 af[RING];
 #pragma unroll
-            for (int m = 0; m < W; ++m) {
-                const v8i32 av = get_a(m);
+                for (int m = 0; m < RING; ++m) af[m] = load_a(m);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) accs[t] = mm(av, get_b(t, m), accs[t]);
+                for (int m = 0; m < W; ++m) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const v8i32 av = af[m % RING];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) accs[t] = mm(av, get_b(t, m), accs[t]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (m + RING < W) af[m % RING] = load_a(m + RING);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+#pragma unroll
+                for (int m = 0; m < W; ++m) {
+                    const v8i32 av = get_a(m);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) accs[t] = mm(av, get_b(t, m), accs[t]);
+                }
             }
         }
         // the cold path of one 32 x 32 step whose gate fired: the accumulator registers with a flagged lane, s itself for them, the
