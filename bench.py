@@ -162,7 +162,7 @@ def main():
             try:
                 full = run_workload(a2, ctx, extras=False)
                 keep = ("value", "unit", "ms_per_step", "steps", "warmup", "config", "recall_at_10", "recall_queries", "build_seconds",
-                        "build", "kernel_ms_per_step", "matrix_exact_path_rate", "rerank_candidates_per_query", "retries",
+                        "build", "kernel_ms_per_step", "matrix_exact_path_rate", "rerank_candidates_per_query", "rerank_shadow_rejects_per_query", "retries",
                         "rough_per_query", "precise_per_query", "roofline", "roofline_rotation", "survivor_workspace_GB")
                 sec[name] = {key: full[key] for key in keep if key in full}
             except Exception as e:   # a secondary failure must not cost the headline line
@@ -315,7 +315,7 @@ def run_workload(args, ctx, extras=True):
                 "GBps_in_plus_out": round(2 * n * idx.dim * 4 / (rot_ms * 1e-3) / 1e9, 1),
                 "note": "every row of the build, HIP events around the kernel on its launch stream, summed over chunks"}
     build_info = {"assign_ms": round(bstats["ms_assign"], 1), "quantize_ms": round(bstats["ms_quantize"], 1),
-                  "rotate_ms": round(rot_ms, 1), "assign_rows_redone_in_exact_order": bstats.get("rows_exact_redo"), "rows_in_hbm": idx.n_hbm, "rows_in_pinned_host_memory": idx.n - idx.n_hbm,
+                  "rotate_ms": round(rot_ms, 1), "assign_rows_redone_in_exact_order": bstats.get("rows_exact_redo"), "rows_in_hbm": idx.n_hbm, "rows_in_pinned_host_memory": idx.n - idx.n_hbm, "raw_vectors_as_split_rows": idx.split_rows,
                   "centroid_training_seconds": None if kmeans_s is None else round(kmeans_s, 1)}
     log(f"index built in {build_s:.1f}s of engine time: n={idx.n} dim={idx.dim} k={idx.k} max_list_len={idx.max_list_len} "
         f"rows in HBM {idx.n_hbm} / host {idx.n - idx.n_hbm}")

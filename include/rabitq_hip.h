@@ -66,6 +66,8 @@ typedef struct {
     uint32_t max_list_len; /* longest IVF list */
     uint64_t n;            /* number of vectors */
     uint64_t n_hbm;        /* raw vectors resident in HBM; the other n - n_hbm (list tails) are in pinned host memory */
+    uint32_t split_rows;   /* 1: the raw vectors are stored as split rows (option "split_rows"); appended in 0.5.0 */
+    uint32_t reserved0;
 } rq_info_t;
 
 /* ---- library ------------------------------------------------------------------------------- */
@@ -74,7 +76,8 @@ typedef struct {
  * 4: rq_set_option("scan_debug") refuses the timing-ablation bits -- they exist in the developer build only --, the matrix-core
  * scan's step counters in rq_profile_t are always filled, new option "scan_gate", "coarse_impl" = 3 is back with a new meaning,
  * rq_profile_t.reserved became coarse_fallback_rows, .reserved2 matrix_additive_launches; later in revision 4, additions only: "coarse_impl" = 4,
- * "coarse_tiled_from", "rerank_shadow" = 2 -- the new default).  A host checks rq_abi_version() ==
+ * "coarse_tiled_from", "rerank_shadow" = 2 -- the new default; 0.5.0: option "split_rows", rq_info_t.split_rows appended, RQ_ARR_BASE
+ * refused for split rows as for tiers).  A host checks rq_abi_version() ==
  * RQ_ABI_VERSION once after loading the library. */
 #define RQ_ABI_VERSION 4
 uint32_t rq_abi_version(void);

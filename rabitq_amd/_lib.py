@@ -47,7 +47,7 @@ class _Sized(C.Structure):
 
 class Info(_Sized):
     _fields_ = [("struct_size", C.c_uint32), ("dim", C.c_uint32), ("k", C.c_uint32), ("max_list_len", C.c_uint32),
-                ("n", C.c_uint64), ("n_hbm", C.c_uint64)]
+                ("n", C.c_uint64), ("n_hbm", C.c_uint64), ("split_rows", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class MetricsT(C.Structure):

@@ -391,6 +391,7 @@ rq_status rq_info(const rq_index *idx, rq_info_t *out) {
     if (!idx || !out) return fail(RQ_ERR_INVALID, "null argument");
     rq_info_t full{};
     full.dim = idx->dim, full.k = idx->k, full.n = idx->n, full.max_list_len = idx->max_list_len, full.n_hbm = idx->n_dev;
+    full.split_rows = idx->split_rows ? 1u : 0u;
     return copy_out_sized(out, full);
 }
 

@@ -34,6 +34,7 @@ class RaBitQ:
         check(lib().rq_info(self._h, C.byref(info)))
         self.dim, self.k, self.n, self.max_list_len = int(info.dim), int(info.k), int(info.n), int(info.max_list_len)
         self.n_hbm = int(info.n_hbm)      # raw vectors in HBM; the other n - n_hbm live in pinned host memory
+        self.split_rows = bool(info.split_rows)   # raw vectors stored as two 16-bit planes per row (option "split_rows")
 
     # ---- RaBitQ::from_path (src/rabitq.rs:159) ------------------------------------------------
     @classmethod

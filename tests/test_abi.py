@@ -31,7 +31,7 @@ def test_struct_layouts_match_reference():
     from rabitq_amd import _lib
     import ctypes as C
     assert C.sizeof(_lib.MetricsT) == 32            # 4 x u64, src/metrics.rs:7-18
-    assert C.sizeof(_lib.Info) == 32            # rq_info_t: struct_size, dim, k, max_list_len, n, n_hbm
+    assert C.sizeof(_lib.Info) == 40            # rq_info_t: struct_size, dim, k, max_list_len, n, n_hbm, split_rows, reserved0
     # Factor is repr(C) 4 x f32 (src/rabitq.rs:21-32): (n, 4) f32 arrays are passed as rq_factor_t*
     assert np.dtype(np.float32).itemsize * 4 == 16
 

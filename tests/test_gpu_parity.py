@@ -1762,6 +1762,7 @@ def test_split_rows_keep_results_exact(rq, oracle, d, kind, tiered, tmp_path):
     try:
         gidx = rq.RaBitQ.build(x, centres, P)
         assert (0 < gidx.n_hbm < n) if tiered else gidx.n_hbm == n
+        assert gidx.split_rows
         with pytest.raises(rq.RabitqError) as e:   # no f32 device array of split rows
             gidx.device_ptr(0)
         assert e.value.status == -6
@@ -1776,6 +1777,7 @@ def test_split_rows_keep_results_exact(rq, oracle, d, kind, tiered, tmp_path):
         ix.set_option("split_rows", 0)
         ix.set_option("rerank_shadow", 0)
         plain = rq.RaBitQ.build(x, centres, P)
+        assert not plain.split_rows
         ix.set_option("rerank_shadow", 2)
         ix.set_option("split_rows", 1 if tiered else 2)
         a, b = gidx.query_batch(queries, 8, 10, False), plain.query_batch(queries, 8, 10, False)
