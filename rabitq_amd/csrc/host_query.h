@@ -218,6 +218,16 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     const float *probe_dist = ws.probe_dist.p;
     const uint32_t *rerank_order = nullptr;
     const bool one_stage = qp.thr_init != nullptr && d_row_map == nullptr;  // thresholds are already tight: nothing to learn in early stages
+    // matrix cores pay once many queries share each list AND survivors are rare, i.e. past the nearest list
+    // (stages inside it leave hundreds of survivors per query: the exact path dominates there and the VALU
+    // kernel wins, measured at any batch size)
+    auto stage_on_matrix = [&](const Stage &sg) {
+        const uint64_t avg_len = std::max<uint64_t>(1, idx->n / std::max<uint32_t>(idx->nonempty_lists, 1));
+        const uint64_t span = (uint64_t)std::min<uint64_t>(sg.s_hi, (uint64_t)nprobe * idx->max_list_len) - sg.s_lo;
+        const uint64_t est_pairs = (uint64_t)nq * std::min<uint64_t>(nprobe, span / avg_len + 2);
+        return scan_has_mfma(W) && impl != 1 &&
+               (impl == 2 || (est_pairs >= 8ull * k && (sg.s_lo >= avg_len * (uint64_t)g_stage_settle_pct.load() / 100 || one_stage)));
+    };
 
     // ---- small batches: few, fat launches (kernels_small.h) -------------------------------------------------------
     const bool sb_w = W == 1 || W == 2 || W == 4 || W == 8 || W == 12 || W == 16;
@@ -320,11 +330,34 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         }
     }
 
+    // the pass's stages, planned before the quantisation (which writes the VALU scans' operand only for the probe slots an early
+    // stage can reach)
+    if (one_stage) {
+        stages.push_back({0u, 0xFFFFFFFFu});
+    } else {
+        // small batches are launch-bound (coarser stages), large ones rerank-bound (tighter thresholds)
+        const int gopt = g_stage_growth.load();
+        const uint64_t growth = gopt >= 2 ? (uint64_t)gopt : (rq_large_batch(nq) ? 8 : 16);
+        // the first stage runs with threshold f32::MAX (everything survives) until the ranker's heap is full; in a large
+        // batch it also takes what would be the next stage (whose threshold -- the worst of the first topk -- lets most
+        // of it through anyway): one stage of launches less for ~1 % more exact distances
+        stages = build_stages((uint64_t)std::max<uint32_t>(topk, 1) * (rq_large_batch(nq) ? growth : 1), growth, ~0ull);
+    }
     // 3. per-pair query quantisation (:304-317)
     pf.begin(PF_PREP);
     {
         uint32_t *qn = scan_is_fused(W) ? ws.qnib.p : nullptr;
         uint32_t *q6 = scan_has_mfma(W) && impl != 1 ? ws.qf6.p : nullptr;
+        // The 4-bit operand (64 of a pair's ~210 bytes at dim 128) is read by the VALU scans only, and a VALU stage that ends at stream
+        // position s_hi cannot reach probe slot s_hi / (shortest list) or beyond: the matrix-core stages' pairs are written without it.
+        uint32_t qn_slots = nprobe;
+        if (qn && q6 && !ext_cluster && idx->min_list_len > 0) {
+            uint32_t reach = 0;
+            for (const Stage &sg : stages)
+                if (!stage_on_matrix(sg))
+                    reach = std::max<uint32_t>(reach, sg.s_hi == 0xFFFFFFFFu ? nprobe : (uint32_t)std::min<uint64_t>(nprobe, (uint64_t)(sg.s_hi - 1) / idx->min_list_len + 1));
+            qn_slots = reach;
+        }
         // an index most of whose lists are empty (a shard of a multi-GPU deployment: the probe lists name the lists of every shard):
         // the pairs with nothing to scan are settled by one thread each, the quantisation runs over the listed others
         listed = idx->nonempty_lists * 2 < k && npairs >= 65536 && g_pair_split.load() != 0 &&
@@ -352,7 +385,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
                                                                     probe_dist, ws.live_list.p, nlive, nprobe, ws.scal.p, qn, q6, k); \
         else                                                                                                       \
             prep_small_kernel<LP, R, PP><<<ceil_div(npairs, (PPB) * (PP)), 256, 0, st>>>(ws.y.p, idx->centroids.p, idx->offsets.p, probe_cluster, \
-                                                                    probe_dist, npairs, nprobe, ws.scal.p, qn, q6, k, idx->nonempty_lists * 2 < k ? 2u : 1u); \
+                                                                    probe_dist, npairs, nprobe, ws.scal.p, qn, q6, k, idx->nonempty_lists * 2 < k ? 2u : 1u, qn_slots); \
     } while (0)
         // dim 128: 16 lanes per pair, two rounds of 64 dimensions, two pairs per lane group in flight (round 4: 32 lanes, one round, four
         // pairs: the min / max / sum reductions over the pair's lanes are half of the kernel's vector work, and half the lanes do a
@@ -386,18 +419,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     HIPC(hipMemsetAsync(ws.stat.p, 0, 256 * sizeof(unsigned long long), st));  // the matrix-core scan's step counters (+ developer hooks)
     pf.end();
 
-    // 5. stages
-    if (one_stage) {
-        stages.push_back({0u, 0xFFFFFFFFu});
-    } else {
-        // small batches are launch-bound (coarser stages), large ones rerank-bound (tighter thresholds)
-        const int gopt = g_stage_growth.load();
-        const uint64_t growth = gopt >= 2 ? (uint64_t)gopt : (rq_large_batch(nq) ? 8 : 16);
-        // the first stage runs with threshold f32::MAX (everything survives) until the ranker's heap is full; in a large
-        // batch it also takes what would be the next stage (whose threshold -- the worst of the first topk -- lets most
-        // of it through anyway): one stage of launches less for ~1 % more exact distances
-        stages = build_stages((uint64_t)std::max<uint32_t>(topk, 1) * (rq_large_batch(nq) ? growth : 1), growth, ~0ull);
-    }
+    // 5. stages: planned above
     }  // !small
     ws.pend_matrix_ranges.clear();
     ws.pend_seg_slots = 0;
@@ -415,8 +437,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
         // matrix cores pay once many queries share each list AND survivors are rare, i.e. past the nearest list
         // (stages inside it leave hundreds of survivors per query: the exact path dominates there and the VALU
         // kernel wins, measured at any batch size)
-        const bool use_mfma = scan_has_mfma(W) && impl != 1 &&
-                              (impl == 2 || (est_pairs >= 8ull * k && (sg.s_lo >= avg_len * (uint64_t)g_stage_settle_pct.load() / 100 || one_stage)));
+        const bool use_mfma = stage_on_matrix(sg);
         // list-major once the stage's pairs reach k / 32 (k / 2 up to round 4, and still on the small-batch path, whose kernels decide with
         // that rule): a pair-major EARLY stage launches a block for every (query, probe slot, tile) although only the first slots are in
         // it -- at 512 queries the early stages took 1.06 ms pair-major against 0.3 list-major (batch 256: 1.43 -> 1.12 ms per call,

@@ -1009,7 +1009,8 @@ __device__ __forceinline__ void prep_small_pairs(const float *__restrict__ y, co
                                                  uint32_t pairs_per_row, PairScalars *__restrict__ scal,
                                                  uint32_t *__restrict__ qnib, uint32_t *__restrict__ qf6,
                                                  uint32_t nlists, uint32_t skip_empty, uint32_t p0,
-                                                 const uint32_t *__restrict__ live_list = nullptr /* compacted pair ids (pair_split_kernel): p0 indexes it */) {
+                                                 const uint32_t *__restrict__ live_list = nullptr /* compacted pair ids (pair_split_kernel): p0 indexes it */,
+                                                 uint32_t qn_slots = 0xFFFFFFFFu /* the 4-bit operand is written for probe slots below this only */) {
     // dim = 4 * LP * R: LP lanes per pair, each owning 4 consecutive dimensions in each of R rounds of 4*LP
     // dimensions (R > 1 only with LP = 64: dim 512, 768, 1024).  Every lane group handles PP pairs: the kernel is a
     // chain of dependent gathers (probe list -> centroid row, list bounds), so the loads of all PP pairs are issued
@@ -1102,7 +1103,7 @@ __device__ __forceinline__ void prep_small_pairs(const float *__restrict__ y, co
             const uint32_t dsub = LP * rd + sub;  // this lane's 4-dimension group among the dim/4 of the vector
             {  // qnib: dword m <-> dims 8m..8m+7 = groups 2m (low half), 2m+1 (high half)
                 const uint32_t other = __shfl_xor(nib16, 1, LP);
-                if (qnib && (sub & 1) == 0) qnib[(uint64_t)p * 8 * W + (dsub >> 1)] = nib16 | (other << 16);
+                if (qnib && (sub & 1) == 0 && p - row * pairs_per_row < qn_slots) qnib[(uint64_t)p * 8 * W + (dsub >> 1)] = nib16 | (other << 16);
             }
             {  // qf6: group t = dsub % 8 of a 32-dimension block holds stream bits [24t, 24t+24) of its 6 dwords
                 const uint32_t nxt = __shfl_down(f24, 1, LP);
@@ -1140,11 +1141,11 @@ __global__ __launch_bounds__(256) void prep_small_kernel(const float *__restrict
                                                          const float *__restrict__ pair_ycd, uint32_t npairs,
                                                          uint32_t pairs_per_row, PairScalars *__restrict__ scal,
                                                          uint32_t *__restrict__ qnib, uint32_t *__restrict__ qf6,
-                                                         uint32_t nlists, uint32_t skip_empty) {
+                                                         uint32_t nlists, uint32_t skip_empty, uint32_t qn_slots) {
     constexpr uint32_t PPW = 64 / LP;
     const uint32_t p0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (PPW * PP) + (threadIdx.x & 63) / LP;
     prep_small_pairs<LP, R, PP>(y, centroids, offsets, pair_cluster, pair_ycd, npairs, pairs_per_row, scal, qnib, qf6, nlists,
-                                skip_empty, p0);
+                                skip_empty, p0, nullptr, qn_slots);
 }
 
 // Sharded passes (a rank of a multi-GPU deployment: most probed lists live on other ranks, i.e. are empty here): one THREAD

@@ -31,7 +31,7 @@ KINDS = ["gauss", "gauss", "sift_u8", "sparse", "student_t", "tight", "near_ties
 SCALES = [1e-3, 1.0, 1.0, 40.0, 1e3, 3e4]
 KNOB_DEFAULTS = {"base_device_mb": -1, "max_scan_blocks": 0, "scan_tile_table": 1, "group_rank": 1, "rerank_shadow": 2,
                  "coarse_impl": 0, "dense_dir": 1, "small_batch": 0, "scan_impl": 0, "small_batch_span": 2560, "stage_growth": 0,
-                 "survivor_segments": 1, "scan_gate": 0}
+                 "survivor_segments": 1, "scan_gate": 0, "split_rows": 1}
 
 
 def make_case(rng, it, nmax):
@@ -101,7 +101,7 @@ def fuzz_round(rq, oracle, rng, it, nmax=12000):
              "dense_dir": int(rng.choice([0, 1, 1])), "small_batch": int(rng.choice([0, 0, 1])),
              "small_batch_span": int(rng.choice([100, 2560, 2560, 65536])), "stage_growth": int(rng.choice([0, 0, 2, 16])),
              "scan_impl": int(rng.choice([0, 1, 2])), "survivor_segments": int(rng.choice([1, 1, 2])),
-             "scan_gate": int(rng.choice([0, 1, 2]))}
+             "scan_gate": int(rng.choice([0, 1, 2])), "split_rows": int(rng.choice([0, 1, 1, 2, 2]))}
     gate = None
     try:
         for name, v in knobs.items():
