@@ -335,9 +335,12 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
     if (one_stage) {
         stages.push_back({0u, 0xFFFFFFFFu});
     } else {
-        // small batches are launch-bound (coarser stages), large ones rerank-bound (tighter thresholds)
+        // geometric growth of the early stages: 16 (coarser stages: a stage of launches less) below 32 768 queries, 8 (tighter
+        // thresholds: ~9 % fewer exact distances) from there on.  Up to round 4 the step to 8 came at 256 queries; re-swept on the
+        // round-5 kernels: 512 queries 1.70 -> 1.54 ms per call with 16, 2048 2.32 -> 2.23, 8192 3.83 -> 3.74, 16 384 5.64 -> 5.57,
+        // 65 536 17.05 -> 17.12
         const int gopt = g_stage_growth.load();
-        const uint64_t growth = gopt >= 2 ? (uint64_t)gopt : (rq_large_batch(nq) ? 8 : 16);
+        const uint64_t growth = gopt >= 2 ? (uint64_t)gopt : (nq >= 32768 ? 8 : 16);
         // the first stage runs with threshold f32::MAX (everything survives) until the ranker's heap is full; in a large
         // batch it also takes what would be the next stage (whose threshold -- the worst of the first topk -- lets most
         // of it through anyway): one stage of launches less for ~1 % more exact distances

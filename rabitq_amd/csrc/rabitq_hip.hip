@@ -644,7 +644,7 @@ rq_status rq_set_option(const char *name, int value) {
         g_stage_settle_pct = value;
         return RQ_OK;
     }
-    if (std::string(name) == "stage_growth") {  // geometric growth of the early stages (0 = default: 8, or 16 for small batches)
+    if (std::string(name) == "stage_growth") {  // geometric growth of the early stages (0 = default: 16 below 32 768 queries, 8 from there on)
         if (value != 0 && (value < 2 || value > 64)) return fail(RQ_ERR_INVALID, "stage_growth must be 0 or in [2, 64]");
         g_stage_growth = value;
         return RQ_OK;

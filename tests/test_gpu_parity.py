@@ -1772,7 +1772,7 @@ def test_split_rows_keep_results_exact(rq, oracle, d, kind, tiered, tmp_path):
             pr = ix.last_profile()
             assert pr["rerank_shadow_rejects"] <= pr["rerank_candidates"]
             if kind in ("gauss", "small_ints") and not heur:
-                assert pr["rerank_shadow_rejects"] > pr["rerank_candidates"] // 4, (pr["rerank_shadow_rejects"], pr["rerank_candidates"])
+                assert pr["rerank_shadow_rejects"] > pr["rerank_candidates"] // 8, (pr["rerank_shadow_rejects"], pr["rerank_candidates"])
         _compare_with_oracle(rq, oracle, oidx, gidx, queries[:40], 8, 10, False)    # small batch: the fused finish restores the words too
         ix.set_option("split_rows", 0)
         ix.set_option("rerank_shadow", 0)
@@ -1891,7 +1891,7 @@ def test_rerank_shadow_rows_keep_results_exact(rq, oracle, d, kind, shadow, tmp_
             pr = ix.last_profile()
             assert pr["rerank_shadow_rejects"] <= pr["rerank_candidates"]
             if kind in ("gauss", "small_ints") and not heur:
-                assert pr["rerank_shadow_rejects"] > pr["rerank_candidates"] // 4, (pr["rerank_shadow_rejects"], pr["rerank_candidates"])
+                assert pr["rerank_shadow_rejects"] > pr["rerank_candidates"] // 8, (pr["rerank_shadow_rejects"], pr["rerank_candidates"])
         ix.set_option("rerank_shadow", 0)      # the same index without shadow rows: the plain exact re-ranker
         plain = rq.RaBitQ.build(x, centres, P)
         ix.set_option("rerank_shadow", shadow)
