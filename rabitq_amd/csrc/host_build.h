@@ -749,6 +749,35 @@ struct JsonIn {
 };
 }  // namespace
 
+// Split rows <-> plain f32 rows on the host (dump / load / rq_get_array of an index that stores split rows: common.h), rows shared
+// among up to 16 threads: a 100M x 768 index is 7.7e10 words
+static void transcode_split_rows(float *plain, uint32_t *planes, uint64_t rows, uint32_t dim, bool to_planes) {
+    auto work = [=](uint64_t r0, uint64_t r1) {
+        for (uint64_t r = r0; r < r1; ++r) {
+            float *pr = plain + r * dim;
+            uint16_t *h = reinterpret_cast<uint16_t *>(planes + r * dim), *lo = h + dim;
+            if (to_planes) {
+                for (uint32_t e = 0; e < dim; ++e) {
+                    uint32_t bits;
+                    memcpy(&bits, pr + e, 4);
+                    h[e] = (uint16_t)((bits + 0x8000u) >> 16), lo[e] = (uint16_t)bits;
+                }
+            } else {
+                for (uint32_t e = 0; e < dim; ++e) {
+                    const uint32_t bits = rq_split_join(h[e], lo[e]);
+                    memcpy(pr + e, &bits, 4);
+                }
+            }
+        }
+    };
+    const uint64_t words = rows * dim;
+    const unsigned nt = words < (1u << 22) ? 1u : std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (nt <= 1) return work(0, rows);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, rows * t / nt, rows * (t + 1) / nt);
+    for (auto &x : th) x.join();
+}
+
 // rows [i0, i0 + m) of the cluster-ordered base between host memory (`buf`, m x dim) and whichever tier holds them
 // (to_index = false: index -> buf; true: buf -> index)
 static rq_status copy_base_rows(const rq_index *idx, uint64_t i0, uint64_t m, float *buf, bool to_index) {
@@ -761,17 +790,18 @@ static rq_status copy_base_rows(const rq_index *idx, uint64_t i0, uint64_t m, fl
             else HIPC(hipMemcpy(hp, idx->base.p + dev_row * dim, rows * dim * 4, hipMemcpyDeviceToHost));
             return RQ_OK;
         }
-        planes.resize(rows * dim);
-        if (to_index) {
-            for (uint64_t r = 0; r < rows; ++r)
-                for (uint32_t e = 0; e < dim; ++e)
-                    rq_row_put(RowRef{reinterpret_cast<const float *>(planes.data() + r * dim), true}, (uint32_t)dim, e, hp[r * dim + e]);
-            HIPC(hipMemcpy(idx->base.p + dev_row * dim, planes.data(), rows * dim * 4, hipMemcpyHostToDevice));
-        } else {
-            HIPC(hipMemcpy(planes.data(), idx->base.p + dev_row * dim, rows * dim * 4, hipMemcpyDeviceToHost));
-            for (uint64_t r = 0; r < rows; ++r)
-                for (uint32_t e = 0; e < dim; ++e)
-                    hp[r * dim + e] = rq_row_get(RowRef{reinterpret_cast<const float *>(planes.data() + r * dim), true}, (uint32_t)dim, e);
+        // (in pieces of at most 256 MiB: the staging buffer must not double a 280 GB tier)
+        const uint64_t piece = std::max<uint64_t>(1, (64ull << 20) / dim);
+        for (uint64_t r0 = 0; r0 < rows; r0 += piece) {
+            const uint64_t nr = std::min(piece, rows - r0);
+            planes.resize(nr * dim);
+            if (to_index) {
+                transcode_split_rows(hp + r0 * dim, planes.data(), nr, (uint32_t)dim, true);
+                HIPC(hipMemcpy(idx->base.p + (dev_row + r0) * dim, planes.data(), nr * dim * 4, hipMemcpyHostToDevice));
+            } else {
+                HIPC(hipMemcpy(planes.data(), idx->base.p + (dev_row + r0) * dim, nr * dim * 4, hipMemcpyDeviceToHost));
+                transcode_split_rows(hp + r0 * dim, planes.data(), nr, (uint32_t)dim, false);
+            }
         }
         return RQ_OK;
     };
@@ -805,11 +835,7 @@ static rq_status copy_base_rows(const rq_index *idx, uint64_t i0, uint64_t m, fl
                 if (to_index) memcpy(hrow, brow, (e - a2) * dim * 4);
                 else memcpy(brow, hrow, (e - a2) * dim * 4);
             } else {
-                for (uint64_t r = 0; r < e - a2; ++r)
-                    for (uint32_t el = 0; el < dim; ++el) {
-                        if (to_index) rq_row_put(RowRef{hrow + r * dim, true}, (uint32_t)dim, el, brow[r * dim + el]);
-                        else brow[r * dim + el] = rq_row_get(RowRef{hrow + r * dim, true}, (uint32_t)dim, el);
-                    }
+                transcode_split_rows(brow, reinterpret_cast<uint32_t *>(hrow), e - a2, (uint32_t)dim, to_index);
             }
         }
     }

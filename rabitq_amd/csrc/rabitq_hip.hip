@@ -19,6 +19,7 @@
 #include <mutex>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 #include <sys/stat.h>
 #include <dlfcn.h>
