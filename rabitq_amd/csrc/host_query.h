@@ -715,7 +715,7 @@ static rq_status run_pass(const rq_index *idx, Workspace &ws, const float *d_q, 
             if (idx->base_q8.p && (stage_no > 0 || qp.thr_init) && !(g_scan_dbg & 512))
                 accurate_filtered8_kernel<<<dim3(gx, nq), 256, (size_t)dim * sizeof(float) + (nprobe <= RQ_ACC8_LDS_PROBES ? (size_t)nprobe * 16 : 0), st>>>(
                     ws.surv.p, ws.surv_cnt.p, seg, idx->base.p, idx->base_q8.p, idx->list_q8.p, qpad, dim, rerank_order, ws.thr.p,
-                    probe_cluster, nprobe, ws.nshadow.p);
+                    probe_cluster, nprobe, ws.nshadow.p, k);
             else if (idx->base_h.p && (stage_no > 0 || qp.thr_init) && !(g_scan_dbg & 512))
                 accurate_filtered_kernel<<<dim3(gx, nq), 256, (size_t)dim * sizeof(float), st>>>(
                     ws.surv.p, ws.surv_cnt.p, seg, idx->base.p, idx->base_h.p, qpad, dim, rerank_order, ws.thr.p,

@@ -2467,7 +2467,8 @@ __global__ __launch_bounds__(256) void accurate_split_kernel(SurvRec *__restrict
     for (uint32_t c = threadIdx.x * 4; c < dim; c += 1024)
         *reinterpret_cast<float4 *>(acc_q + c) = *reinterpret_cast<const float4 *>(qpad + (uint64_t)b * dim + c);
     if (lt_lds)
-        for (uint32_t sl = threadIdx.x; sl < nprobe; sl += 256) ltl[sl] = base.lt[probe_row[sl]];
+        for (uint32_t sl = threadIdx.x; sl < nprobe; sl += 256)  // (a padded probe slot -- id 0xFFFFFFFF, "no list" -- has no survivors and no record)
+            ltl[sl] = probe_row[sl] < base.k ? base.lt[probe_row[sl]] : ListTier{0u, 0u, 0u, 0u};
     if (threadIdx.x == 0) qn = 0;
     __syncthreads();
     const float thr = thr_start ? thr_start[b] : __builtin_inff();
@@ -2676,7 +2677,7 @@ __global__ __launch_bounds__(256, RQ_ACC8_WAVES) void accurate_filtered8_kernel(
                                                                  const uint32_t *__restrict__ order,
                                                                  const float *__restrict__ thr_start,
                                                                  const uint32_t *__restrict__ probe_cluster, uint32_t nprobe,
-                                                                 uint32_t *__restrict__ nshadow) {
+                                                                 uint32_t *__restrict__ nshadow, uint32_t nlists) {
     extern __shared__ __attribute__((aligned(16))) float acc_q[];  // dim floats (the padded query), then -- when they fit -- the nprobe lists' (lo, s, err)
     __shared__ uint32_t queue[512];
     __shared__ uint32_t qn;
@@ -2698,7 +2699,8 @@ __global__ __launch_bounds__(256, RQ_ACC8_WAVES) void accurate_filtered8_kernel(
     for (uint32_t c = threadIdx.x * 4; c < dim; c += 1024)
         *reinterpret_cast<float4 *>(acc_q + c) = *reinterpret_cast<const float4 *>(qpad + (uint64_t)b * dim + c);
     if (par_lds)
-        for (uint32_t sl = threadIdx.x; sl < nprobe; sl += 256) lpar[sl] = list_q8[pc[sl]];
+        for (uint32_t sl = threadIdx.x; sl < nprobe; sl += 256)  // (a padded probe slot -- id 0xFFFFFFFF, "no list" -- has no survivors and no map)
+            lpar[sl] = pc[sl] < nlists ? list_q8[pc[sl]] : make_float4(0.0f, 1.0f, __builtin_inff(), __builtin_inff());
     if (threadIdx.x == 0) qn = 0;
     __syncthreads();
     const float thr = thr_start[b];

@@ -41,7 +41,8 @@ def make_case(rng, it, nmax):
     k = int(rng.choice([1, 2, 5, 16, 40, 120, 300]))
     if os.environ.get("BIG_K") and rng.random() < 0.25:   # many short lists: the wide probe-selection kernels, ranked groups over thousands of lists
         k = int(rng.choice([700, 2000, 4096, 6000]))
-    n = int(rng.integers(max(k, 200), nmax if d <= 256 else max(4000, nmax // 4)))
+    n_lo, n_hi = max(k, 200), nmax if d <= 256 else max(4000, nmax // 4)
+    n = int(rng.integers(n_lo, max(n_hi, n_lo + 200)))   # (BIG_K: more lists than the wide-vector cap on n)
     nq = int(rng.choice([1, 3, 9, 33, 64, 70, 260, 300, 700]))
     if os.environ.get("BIG_BATCHES") and rng.random() < 0.15:   # the large-batch regime (scalar-register coarse kernel, ranked groups, ...)
         nq = int(rng.choice([2100, 4100]))

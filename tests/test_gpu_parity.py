@@ -1209,6 +1209,47 @@ def test_seeded_probed_query(rq, nq):
     idx.close()
 
 
+@pytest.mark.parametrize("tiered", [False, True])
+def test_probed_query_with_padded_slots(rq, tiered):
+    """Caller-supplied probe lists may be padded (id 0xFFFFFFFF, distance +inf: rq_coarse_topk_device pads when fewer lists exist
+    than asked for): padded slots contribute nothing -- the answer is the one for the unpadded lists, bit for bit, through the
+    re-rankers that stage per-probe records in LDS (8-bit shadow maps; tier records of split rows)."""
+    import torch
+    from rabitq_amd import index as ix
+    dev = torch.device("cuda", 0)
+    n, d, k, probe, topk, nq = 30_000, 128, 24, 8, 10, 300
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.8, seed=61, centre_scale=0.6)
+    ix.set_option("base_device_mb", (n * d * 4 * 4 // 5) >> 20 if tiered else -1)
+    try:
+        idx = rq.RaBitQ.build(x, centres, synth.random_orthogonal(d, seed=62))
+    finally:
+        ix.set_option("base_device_mb", -1)
+    assert idx.split_rows == tiered
+    queries, _, _ = synth.mixture(nq, d, k, sigma=0.8, seed=63, centre_scale=0.6)
+    _, cl, cd = rq.ops.coarse_rank(idx, queries, probe)
+    q = torch.from_numpy(queries).to(dev)
+
+    def run(lists, dists):
+        pc = torch.from_numpy(np.ascontiguousarray(lists).view(np.int32)).to(dev)
+        pdd = torch.from_numpy(np.ascontiguousarray(dists, np.float32)).to(dev)
+        od = torch.empty((nq, topk), device=dev)
+        oi = torch.zeros((nq, topk), device=dev, dtype=torch.int32)
+        on = torch.zeros(nq, device=dev, dtype=torch.int32)
+        idx.query_batch_device_probed(q.data_ptr(), nq, d, pc.data_ptr(), pdd.data_ptr(), lists.shape[1], topk, od.data_ptr(),
+                                      oi.data_ptr(), on.data_ptr())
+        torch.cuda.synchronize()
+        return od.cpu().numpy().view(np.uint32), oi.cpu().numpy(), on.cpu().numpy()
+
+    want = run(cl[:, :6], cd[:, :6])
+    padded_l, padded_d = cl.copy(), cd.copy()
+    padded_l[:, 6:] = 0xFFFFFFFF
+    padded_d[:, 6:] = np.inf
+    got = run(padded_l, padded_d)
+    for a, b in zip(want, got):
+        assert np.array_equal(a, b)
+    idx.close()
+
+
 # ---- batches in flight: begin / end halves of the device batch call -----------------------------------
 def test_begin_end_batches_overlap_and_match_sync(rq):
     import torch
