@@ -190,10 +190,12 @@ OPTION_VALUES = {
     "dense_dir": [0, 1], "small_batch": [0, 1], "small_batch_span": [64, 2560, 100000], "stage_growth": [0, 2, 16],
     "survivor_segments": [0, 1, 2], "max_scan_blocks": [0, 1, 7], "shared_thresholds": [0, 1, 2], "assign_impl": [0, 1],
     "rerank_shadow": [0, 1, 2], "pair_split": [0, 1], "scan_debug": [0, 128, 512, 4096, 16384, 128 | 512 | 4096],
+    "split_rows": [0, 1, 2], "large_batch_from": [2, 256, 100000], "cluster_major_div": [2, 32, 1024], "stage_settle_pct": [25, 100, 400],
 }
 OPTION_DEFAULTS = {"scan_impl": 0, "scan_gate": 0, "coarse_impl": 0, "coarse_tiled_from": 4096, "group_rank": 1, "scan_tile_table": 1, "dense_dir": 1,
                    "small_batch": 0, "small_batch_span": 2560, "stage_growth": 0, "survivor_segments": 1, "max_scan_blocks": 0,
-                   "shared_thresholds": 1, "assign_impl": 0, "rerank_shadow": 2, "pair_split": 1, "scan_debug": 0}
+                   "shared_thresholds": 1, "assign_impl": 0, "rerank_shadow": 2, "pair_split": 1, "scan_debug": 0,
+                   "split_rows": 1, "large_batch_from": 256, "cluster_major_div": 32, "stage_settle_pct": 100}
 
 
 def test_every_option_value_keeps_golden_results(rq):
@@ -223,7 +225,7 @@ def test_every_option_value_keeps_golden_results(rq):
         for bad in (1, 2, 4, 64, 256, 1024, 8192, 128 | 64):
             with pytest.raises(rq.RabitqError):
                 ix.set_option("scan_debug", bad)
-        for name, bad in (("scan_gate", 3), ("scan_impl", 3), ("coarse_impl", 5), ("scan_dense", 1)):
+        for name, bad in (("scan_gate", 3), ("scan_impl", 3), ("coarse_impl", 5), ("scan_dense", 1), ("split_rows", 3), ("stage_settle_pct", 0)):
             with pytest.raises(rq.RabitqError):
                 ix.set_option(name, bad)
     finally:
