@@ -362,6 +362,8 @@ rq_status rq_set_profiling(int level);
  * settings return identical results; the option exists for tests and measurements.
  * "base_device_mb": HBM budget (MiB) of the raw vectors of indexes built / loaded from now on (-1 = automatic, the
  * default); vectors beyond it live in pinned host memory.  Results never depend on it.
+ * "pass_overlap": a call that needs several passes (more than 65 536 queries) keeps two of them in flight, each on a workspace
+ * and stream of its own (1, default), or runs them one after the other (0).  Results are identical.
  * "split_rows": indexes built / loaded from now on whose raw vectors leave no room for shadow rows -- tiered ones (both tiers),
  * and untiered ones where the shadow of "rerank_shadow" would not fit -- keep each raw vector as two 16-bit planes inside its own
  * 4*dim bytes (1, default: the upper halves of the f32 words rounded to nearest, then the lower halves; every word is restored

@@ -563,6 +563,7 @@ static std::atomic<int> g_group_rank{1};  // group_rank_kernel for cluster-major
 static std::atomic<int> g_shared_thr{1};  // rq_query_batch_sharded_device: thresholds shared between the shards (0 never, 1 world > 1, 2 always)
 static std::atomic<int> g_sb_span{2560};  // developer knob: stream positions a query's block scans itself at most (small-batch path)
 static std::atomic<int> g_seg_opt{1};  // per-query survivor segments in the final stage: 0 never, 1 once the index has shown that the default capacity overflows, 2 every large batch (tests)
+static std::atomic<int> g_pass_overlap{1};  // a call of several passes keeps two of them in flight (1, default) or runs them one after the other (0)
 static std::atomic<int> g_small_batch{0};  // small-batch path (kernels_small.h): 0 = whenever it applies (default), 1 = never (test hook)
 static std::atomic<int> g_dense_dir{1};  // dense run directories for the VALU stages of large batches (0 = always append + sort: test hook)
 

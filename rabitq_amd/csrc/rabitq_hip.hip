@@ -656,6 +656,11 @@ rq_status rq_set_option(const char *name, int value) {
         g_base_device_mb = value;
         return RQ_OK;
     }
+    if (std::string(name) == "pass_overlap") {  // a call of several passes: two in flight (1, default) or one after the other (0); results identical
+        if (value < 0 || value > 1) return fail(RQ_ERR_INVALID, "pass_overlap must be 0 or 1");
+        g_pass_overlap = value;
+        return RQ_OK;
+    }
     if (std::string(name) == "split_rows") {  // tiered indexes built / loaded from now on: raw vectors as two 16-bit planes (1, default) or plain f32 (0)
         if (value < 0 || value > 2) return fail(RQ_ERR_INVALID, "split_rows must be 0, 1 or 2");
         g_split_rows = value;

@@ -15,9 +15,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 KNOBS = {"max_scan_blocks": [0, 0, 5000, 60000], "scan_tile_table": [0, 1, 2], "group_rank": [0, 1, 2], "coarse_impl": [0, 1, 2, 3, 4],
          "dense_dir": [0, 1, 1], "stage_growth": [0, 0, 2, 4, 16], "scan_impl": [0, 0, 1, 2], "survivor_segments": [0, 1, 2],
-         "small_batch": [0, 1], "small_batch_span": [100, 2560, 65536], "scan_gate": [0, 0, 1, 2]}
+         "small_batch": [0, 1], "small_batch_span": [100, 2560, 65536], "scan_gate": [0, 0, 1, 2], "pass_overlap": [0, 1]}
 DEFAULTS = {"max_scan_blocks": 0, "scan_tile_table": 1, "group_rank": 1, "coarse_impl": 0, "dense_dir": 1, "stage_growth": 0,
-            "scan_impl": 0, "survivor_segments": 1, "small_batch": 0, "small_batch_span": 2560, "scan_gate": 0}
+            "scan_impl": 0, "survivor_segments": 1, "small_batch": 0, "small_batch_span": 2560, "scan_gate": 0, "pass_overlap": 1}
 
 
 def main(**over):

@@ -190,12 +190,12 @@ OPTION_VALUES = {
     "dense_dir": [0, 1], "small_batch": [0, 1], "small_batch_span": [64, 2560, 100000], "stage_growth": [0, 2, 16],
     "survivor_segments": [0, 1, 2], "max_scan_blocks": [0, 1, 7], "shared_thresholds": [0, 1, 2], "assign_impl": [0, 1],
     "rerank_shadow": [0, 1, 2], "pair_split": [0, 1], "scan_debug": [0, 128, 512, 4096, 16384, 128 | 512 | 4096],
-    "split_rows": [0, 1, 2], "large_batch_from": [2, 256, 100000], "cluster_major_div": [2, 32, 1024], "stage_settle_pct": [25, 100, 400],
+    "split_rows": [0, 1, 2], "pass_overlap": [0, 1], "large_batch_from": [2, 256, 100000], "cluster_major_div": [2, 32, 1024], "stage_settle_pct": [25, 100, 400],
 }
 OPTION_DEFAULTS = {"scan_impl": 0, "scan_gate": 0, "coarse_impl": 0, "coarse_tiled_from": 4096, "group_rank": 1, "scan_tile_table": 1, "dense_dir": 1,
                    "small_batch": 0, "small_batch_span": 2560, "stage_growth": 0, "survivor_segments": 1, "max_scan_blocks": 0,
                    "shared_thresholds": 1, "assign_impl": 0, "rerank_shadow": 2, "pair_split": 1, "scan_debug": 0,
-                   "split_rows": 1, "large_batch_from": 256, "cluster_major_div": 32, "stage_settle_pct": 100}
+                   "split_rows": 1, "pass_overlap": 1, "large_batch_from": 256, "cluster_major_div": 32, "stage_settle_pct": 100}
 
 
 def test_every_option_value_keeps_golden_results(rq):
@@ -1249,6 +1249,47 @@ def test_probed_query_with_padded_slots(rq, tiered):
     got = run(padded_l, padded_d)
     for a, b in zip(want, got):
         assert np.array_equal(a, b)
+    idx.close()
+
+
+def test_call_of_several_passes_overlaps_them_with_the_same_results(rq):
+    """A call of more than 65 536 queries runs as several passes; two of them are kept in flight (option pass_overlap = 1, the
+    default).  150 000 queries -- three passes -- give the bits of the same call with the passes one after the other, and of the
+    queries sent in two separate calls; the counters add up."""
+    import torch
+    from rabitq_amd import index as ix
+    dev = torch.device("cuda", 0)
+    n, d, k, probe, topk, nq = 60_000, 128, 48, 6, 10, 150_000
+    x, centres, _ = synth.mixture(n, d, k, sigma=0.8, seed=171, centre_scale=0.6)
+    idx = rq.RaBitQ.build(x, centres, synth.random_orthogonal(d, seed=172))
+    g = torch.Generator(device=dev)
+    g.manual_seed(173)
+    q = (torch.from_numpy(centres).to(dev)[torch.randint(0, k, (nq,), generator=g, device=dev)] +
+         0.8 * torch.randn(nq, d, generator=g, device=dev)).contiguous()
+
+    def run(lo, hi):
+        m = hi - lo
+        od = torch.empty((m, topk), device=dev)
+        oi = torch.zeros((m, topk), device=dev, dtype=torch.int32)
+        on = torch.zeros(m, device=dev, dtype=torch.int32)
+        rq.metrics_reset()
+        idx.query_batch_device(q[lo:hi].data_ptr(), m, d, probe, topk, od.data_ptr(), oi.data_ptr(), on.data_ptr())
+        torch.cuda.synchronize()
+        mt = rq.metrics()
+        return od.cpu().numpy().view(np.uint32), oi.cpu().numpy(), on.cpu().numpy(), (mt["rough"], mt["precise"], mt["query"])
+
+    try:
+        a = run(0, nq)
+        ix.set_option("pass_overlap", 0)
+        b = run(0, nq)
+        c1, c2 = run(0, 70_000), run(70_000, nq)
+    finally:
+        ix.set_option("pass_overlap", 1)
+    for u, v in zip(a[:3], b[:3]):
+        assert np.array_equal(u, v)
+    assert a[3] == b[3] and a[3] == tuple(s1 + s2 for s1, s2 in zip(c1[3], c2[3]))
+    for i in range(3):
+        assert np.array_equal(a[i], np.concatenate([c1[i], c2[i]]))
     idx.close()
 
 
