@@ -982,7 +982,18 @@ static rq_status query_device(rq_index *idx, const float *d_q, uint32_t nq, uint
     if (!use_ws && !ext_cluster && !ext_thr && g_pass_overlap.load()) {
         bool seg0 = false;
         const uint32_t cap_first = pass_capacity(idx, nq, false, &seg0);
-        if (pass_queries(idx, nq, probe, cap_first, seg0) < nq) {
+        const uint32_t first_nq = pass_queries(idx, nq, probe, cap_first, seg0);
+        // (only with room for a second workspace: an index that fills the HBM -- configs[3] -- runs its passes one after the other;
+        // rough size of a pass's buffers: survivor records + directories, per-pair records and operands, distances, ranker state)
+        bool room = false;
+        if (first_nq < nq) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const uint64_t need = (uint64_t)first_nq * ((uint64_t)cap_first * 48 + (uint64_t)npb * 320 + (uint64_t)idx->dim * 8 + (uint64_t)idx->k * 4 + 4096);
+                room = free_b > need + (6ull << 30);
+            }
+        }
+        if (first_nq < nq && room) {
             ws_release(idx, ws);  // (the passes take workspaces of their own from the pool, this one among them)
             rel.w = nullptr;
             struct Flight {
